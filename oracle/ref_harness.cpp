@@ -1,0 +1,246 @@
+// ref_harness.cpp -- thin extern "C" shim around the *compiled reference* headers.
+//
+// TEST INFRASTRUCTURE ONLY (see oracle/README.md).  This file contains no search logic of its
+// own: it #includes /root/reference/search/search_function.h (found through -I, the reference
+// sources are never copied into this repository) and exposes the reference's own functions
+// through a flat C ABI so that tests/golden/make_golden.py can capture golden vectors and
+// bench.py can time the reference on host cores (cpu_baseline.kind = "reference").
+// Built by oracle/Makefile into oracle/_ref/libgbnns_ref.so (git-ignored) only where
+// /root/reference exists.
+//
+// Flags (oracle/Makefile): -O2 -std=c++11 -fopenmp -mavx2 -mfma -ffp-contract=off -w, which
+// compiles the reference's intrinsics to exactly the operations written in its source
+// (SURVEY.md section 8c).
+
+#include "search_function.h"  // reference: pulls support_classes.h, support_func.h, visited_list_pool.h
+
+#include <cstdint>
+
+namespace {
+
+Metric* pick_metric(int metric) {
+    static L2Metric l2;
+    static Angular ang;
+    return metric == 1 ? (Metric*)&ang : (Metric*)&l2;
+}
+
+vector<vector<uint32_t>> csr_to_lists(const uint64_t* off, const uint32_t* nbr, uint64_t n) {
+    vector<vector<uint32_t>> g(n);
+    for (uint64_t i = 0; i < n; ++i) g[i].assign(nbr + off[i], nbr + off[i + 1]);
+    return g;
+}
+
+struct RefGraph {
+    vector<vector<uint32_t>> lists;
+};
+
+// getRealNearest takes `vector<float>& ds` (search_function.h:106), so the harness must own a
+// std::vector copy of the base set.  It is cached on (pointer, length) so that a caller timing
+// ref_search_batch can warm it first (ref_prepare_db_cache) and not pay for the copy.
+vector<float> ds_cache;
+const float* ds_key = nullptr;
+size_t ds_len = 0;
+
+void ensure_ds_cache(const float* db_ptr, uint64_t n, int d) {
+    if (ds_key != db_ptr || ds_len != (size_t)n * d) {
+        ds_cache.assign(db_ptr, db_ptr + (size_t)n * d);
+        ds_key = db_ptr;
+        ds_len = (size_t)n * d;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+float ref_l2(const float* a, const float* b, uint64_t d) {
+    L2Metric m;
+    return m.Dist(a, b, d);
+}
+
+float ref_negdot(const float* a, const float* b, uint64_t d) {
+    Angular m;
+    return m.Dist(a, b, d);
+}
+
+void* ref_graph_create(const uint64_t* off, const uint32_t* nbr, uint64_t n) {
+    RefGraph* g = new RefGraph;
+    g->lists = csr_to_lists(off, nbr, n);
+    return g;
+}
+
+void ref_graph_destroy(void* g) { delete (RefGraph*)g; }
+
+// GetLowQueryFromNet (support_func.h:645) per query, exactly as performNetTest calls it (:354-355).
+void ref_project(const float* l1, const float* l2, const float* l3, const float* q, float* out,
+                 uint64_t nq, int d, int dh, int dlow) {
+    Net net;
+    net.layerFirst.assign(l1, l1 + (size_t)dh * (d + 1));
+    net.layerSecond.assign(l2, l2 + (size_t)dh * (dh + 1));
+    net.layerFinal.assign(l3, l3 + (size_t)dlow * (dh + 1));
+    Angular ang;
+    L2Metric l2m;
+    vector<float> zeros(dlow);
+    for (uint64_t i = 0; i < nq; ++i) {
+        vector<float> low(dlow);
+        GetLowQueryFromNet(&net, q + i * d, low, zeros.data(), d, dh, dh, dlow, &ang, &l2m);
+        for (int j = 0; j < dlow; ++j) out[i * dlow + j] = low[j];
+    }
+}
+
+// getOneSearchResults (search_function.h:43) per query; result heap dumped in pop order.
+void ref_walk(const float* q, uint64_t nq, const float* db, uint64_t n, int d, void* graph,
+              int ef, int k, const uint32_t* entries, int n_entries, int metric,
+              uint32_t* out_ids, float* out_dists, int32_t* out_count, int32_t* out_hops,
+              int32_t* out_dist_calc, int threads) {
+    RefGraph* g = (RefGraph*)graph;
+    VisitedListPool* pool = new VisitedListPool(1, n);
+    Metric* m = pick_metric(metric);
+    const int stride = k < ef ? k : ef;
+    omp_set_num_threads(threads > 0 ? threads : 1);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < (int64_t)nq; ++i) {
+        vector<uint32_t> ep;
+        if (entries) ep.assign(entries + i * n_entries, entries + (i + 1) * n_entries);
+        else ep.push_back(0);
+        TripleResult r = getOneSearchResults(q + i * d, db, n, d, g->lists, g->lists, ef, k, ep, m,
+                                             pool, false, false, 50);
+        if (out_hops) out_hops[i] = r.hops;
+        if (out_dist_calc) out_dist_calc[i] = r.dist_calc;
+        int c = 0;
+        while (!r.topk.empty()) {
+            if (out_ids) out_ids[i * stride + c] = (uint32_t)r.topk.top().second;
+            if (out_dists) out_dists[i * stride + c] = r.topk.top().first;
+            r.topk.pop();
+            ++c;
+        }
+        if (out_count) out_count[i] = c;
+        for (int s = c; s < stride; ++s) {
+            if (out_ids) out_ids[i * stride + s] = 0xFFFFFFFFu;
+            if (out_dists) out_dists[i * stride + s] = INFINITY;
+        }
+    }
+    delete pool;
+}
+
+// The per-query body of performNetTest (search_function.h:348-385) / performTest (:153-186)
+// calling the reference's own functions; same modes as gbo_search_batch in gbnns_oracle.cpp.
+void ref_search_batch(int mode, const float* queries, const float* q_low_in, uint64_t nq,
+                      const float* db_ptr, const float* db_low, uint64_t n, int d, int dlow,
+                      int dh, const float* l1, const float* l2, const float* l3, void* graph,
+                      int ef, int k, const uint32_t* entries, int metric, uint32_t* out_ids,
+                      int32_t* out_hops, int32_t* out_dist_calc, int threads) {
+    RefGraph* g = (RefGraph*)graph;
+    VisitedListPool* pool = new VisitedListPool(1, n);
+    Metric* m = pick_metric(metric);
+    Net net;
+    if (mode == 0) {
+        net.layerFirst.assign(l1, l1 + (size_t)dh * (d + 1));
+        net.layerSecond.assign(l2, l2 + (size_t)dh * (dh + 1));
+        net.layerFinal.assign(l3, l3 + (size_t)dlow * (dh + 1));
+    }
+    if (mode != 2) ensure_ds_cache(db_ptr, n, d);
+    Angular ang;
+    L2Metric l2m;
+    vector<float> zeros(dlow > 0 ? dlow : 1);
+    omp_set_num_threads(threads > 0 ? threads : 1);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < (int64_t)nq; ++i) {
+        vector<uint32_t> ep(1, entries ? entries[i] : 0u);
+        const float* point_q = queries + i * d;
+        TripleResult r;
+        if (mode == 2) {
+            r = getOneSearchResults(point_q, db_ptr, n, d, g->lists, g->lists, ef, k, ep, m, pool,
+                                    false, false, 50);
+            while ((int)r.topk.size() > k) r.topk.pop();
+            out_ids[i] = r.topk.top().second;
+            if (out_hops) out_hops[i] = r.hops;
+            if (out_dist_calc) out_dist_calc[i] = r.dist_calc;
+            continue;
+        }
+        vector<float> low(dlow);
+        const float* ql;
+        if (mode == 0) {
+            GetLowQueryFromNet(&net, point_q, low, zeros.data(), d, dh, dh, dlow, &ang, &l2m);
+            ql = low.data();
+        } else {
+            ql = q_low_in + i * dlow;
+        }
+        r = getOneSearchResults(ql, db_low, n, dlow, g->lists, g->lists, ef, ef, ep, m, pool,
+                                false, false, 50);
+        out_ids[i] = getRealNearest(point_q, k, d, dlow, r.topk, ds_cache, m);
+        if (out_hops) out_hops[i] = r.hops;
+        if (out_dist_calc) out_dist_calc[i] = r.dist_calc + ef;
+    }
+    delete pool;
+}
+
+void ref_prepare_db_cache(const float* db_ptr, uint64_t n, int d) { ensure_ds_cache(db_ptr, n, d); }
+
+// hnswlikeGD (support_func.h:521) on a kNN graph given in CSR; result fetched in a second call.
+static vector<vector<uint32_t>> g_gd_result;
+
+uint64_t ref_hnswlike_gd(const uint64_t* koff, const uint32_t* knbr, const float* ds, int M,
+                         uint64_t n, int d, int metric, int reverse, int threads) {
+    vector<vector<uint32_t>> knn = csr_to_lists(koff, knbr, n);
+    omp_set_num_threads(threads > 0 ? threads : 1);
+    g_gd_result = hnswlikeGD(knn, ds, M, n, d, pick_metric(metric), reverse != 0, false);
+    uint64_t total = 0;
+    for (auto& l : g_gd_result) total += l.size();
+    return total;
+}
+
+void ref_hnswlike_gd_fetch(uint64_t* out_off, uint32_t* out_nbr) {
+    uint64_t p = 0;
+    for (size_t i = 0; i < g_gd_result.size(); ++i) {
+        out_off[i] = p;
+        for (uint32_t v : g_gd_result[i]) out_nbr[p++] = v;
+    }
+    out_off[g_gd_result.size()] = p;
+    g_gd_result.clear();
+}
+
+// Runs the reference's own harness end to end (performRealNetTests, search_function.h:411) so
+// that the result line it appends to `output_txt` can be compared with the drop-in's.
+void ref_perform_real_net_tests(int n, int d, int d_low, int n_q, int n_tr, const int* efs,
+                                int n_efs, void* graph, const float* db, const float* queries,
+                                const float* db_low, const float* l1, const float* l2,
+                                const float* l3, int d_hidden, const uint32_t* truth,
+                                const char* output_txt, const char* graph_name, int number_exper,
+                                int number_of_threads) {
+    RefGraph* g = (RefGraph*)graph;
+    vector<int> efv(efs, efs + n_efs);
+    vector<float> dbv(db, db + (size_t)n * d), qv(queries, queries + (size_t)n_q * d),
+        dblv(db_low, db_low + (size_t)n * d_low);
+    vector<uint32_t> tv(truth, truth + (size_t)n_q * n_tr);
+    Net net;
+    net.layerFirst.assign(l1, l1 + (size_t)d_hidden * (d + 1));
+    net.layerSecond.assign(l2, l2 + (size_t)d_hidden * (d_hidden + 1));
+    net.layerFinal.assign(l3, l3 + (size_t)d_low * (d_hidden + 1));
+    L2Metric l2m;
+    std::mt19937 rng(1);
+    performRealNetTests(n, d, d_low, n_q, n_tr, efv, rng, g->lists, g->lists, dbv, qv, dblv, &net,
+                        d_hidden, tv, output_txt, &l2m, graph_name, false, false, number_exper,
+                        number_of_threads);
+}
+
+void ref_perform_real_tests(int n, int d, int d_low, int n_q, int n_tr, const int* efs, int n_efs,
+                            void* graph, const float* db, const float* queries,
+                            const float* db_low, const float* queries_low, const uint32_t* truth,
+                            const char* output_txt, const char* graph_name, int number_exper,
+                            int number_of_threads) {
+    RefGraph* g = (RefGraph*)graph;
+    vector<int> efv(efs, efs + n_efs);
+    vector<float> dbv(db, db + (size_t)n * d), qv(queries, queries + (size_t)n_q * d),
+        dblv(db_low, db_low + (size_t)n * d_low),
+        qlv(queries_low, queries_low + (size_t)n_q * d_low);
+    vector<uint32_t> tv(truth, truth + (size_t)n_q * n_tr);
+    L2Metric l2m;
+    std::mt19937 rng(1);
+    performRealTests(n, d, d_low, n_q, n_tr, efv, rng, g->lists, g->lists, dbv, qv, dblv, qlv, tv,
+                     output_txt, &l2m, graph_name, false, false, number_exper, number_of_threads);
+}
+
+int ref_max_threads() { return omp_get_max_threads(); }
+
+}  // extern "C"
