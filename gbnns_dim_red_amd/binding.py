@@ -1,0 +1,314 @@
+"""ctypes binding of include/gbnns.h.
+
+Host buffers are numpy arrays; device buffers are torch CUDA(ROCm) tensors (torch is used only
+as the owner of device memory and streams -- no torch op is on the search path).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libgbnns_hip.so")
+
+METRIC_L2, METRIC_NEG_DOT = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+MODE_NET, MODE_LOWQ, MODE_PLAIN = 0, 1, 2
+
+# every symbol include/gbnns.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "gbnns_index_create", "gbnns_index_destroy", "gbnns_search_ex", "gbnns_search_batch",
+    "gbnns_project", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd",
+    "gbnns_free", "gbnns_device_count", "gbnns_version", "gbnns_last_error",
+]
+
+
+class GbnnsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gbnns status {code}: {msg}")
+        self.code = code
+
+
+class _IndexDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32), ("metric", C.c_int32),
+        ("mem_kind", C.c_int32), ("n", C.c_uint64), ("d", C.c_uint32), ("d_low", C.c_uint32),
+        ("d_hidden", C.c_uint32), ("reserved0", C.c_uint32), ("db", C.c_void_p),
+        ("db_low", C.c_void_p), ("graph_offsets", C.c_void_p), ("graph_nbrs", C.c_void_p),
+        ("net_l1", C.c_void_p), ("net_l2", C.c_void_p), ("net_l3", C.c_void_p),
+    ]
+
+
+class _SearchArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("mode", C.c_int32), ("ef", C.c_int32), ("k", C.c_int32),
+        ("mem_kind", C.c_int32), ("hash_capacity", C.c_int32), ("n_q", C.c_uint64),
+        ("queries", C.c_void_p), ("queries_low", C.c_void_p), ("entry_ids", C.c_void_p),
+        ("out_ids", C.c_void_p), ("out_hops", C.c_void_p), ("out_dist_calc", C.c_void_p),
+        ("out_cand", C.c_void_p), ("out_cand_dist", C.c_void_p), ("out_q_low", C.c_void_p),
+        ("out_edges", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
+class Profile(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("calls", C.c_uint32), ("project_ms", C.c_double),
+        ("walk_ms", C.c_double), ("walk_general_ms", C.c_double), ("rerank_ms", C.c_double),
+        ("total_ms", C.c_double), ("queries", C.c_uint64), ("general_queries", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "struct_size"}
+
+
+_lib = None
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Load libgbnns_hip.so.  Fails loudly when it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc, gfx950).  gbnns_dim_red_amd has no CPU fallback.")
+    lib = C.CDLL(_LIB_PATH)
+    lib.gbnns_last_error.restype = C.c_char_p
+    lib.gbnns_index_create.argtypes = [C.POINTER(_IndexDesc), C.POINTER(C.c_void_p)]
+    lib.gbnns_index_destroy.argtypes = [C.c_void_p]
+    lib.gbnns_search_ex.argtypes = [C.c_void_p, C.POINTER(_SearchArgs)]
+    lib.gbnns_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gbnns_project.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int,
+                                  C.c_void_p]
+    lib.gbnns_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.gbnns_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile), C.c_int]
+    lib.gbnns_build_graph_gd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                         C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.gbnns_free.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise GbnnsError(rc, load_library().gbnns_last_error().decode(errors="replace"))
+
+
+def version():
+    return load_library().gbnns_version()
+
+
+def device_count():
+    return load_library().gbnns_device_count()
+
+
+def _is_dev(x):
+    return hasattr(x, "data_ptr")
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if _is_dev(x):
+        return x.data_ptr()
+    return x.ctypes.data
+
+
+def _host(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _prep(x, dtype, torch_dtype_name):
+    """numpy -> contiguous numpy of dtype; torch tensor -> contiguous tensor (dtype checked)."""
+    if x is None:
+        return None
+    if _is_dev(x):
+        import torch
+        want = getattr(torch, torch_dtype_name)
+        if x.dtype != want:
+            raise TypeError(f"expected torch.{torch_dtype_name}, got {x.dtype}")
+        if not x.is_cuda:
+            raise TypeError("device buffers must be CUDA/ROCm tensors")
+        return x.contiguous()
+    return _host(x, dtype)
+
+
+def build_graph_gd(knn_offsets, knn_nbrs, ds, M, metric=METRIC_L2, reverse=True, threads=0):
+    """hnswlikeGD + reverse edges (support_func.h:521-575, 402-445) on host arrays -> CSR."""
+    lib = load_library()
+    koff, knbr, ds = _host(knn_offsets, np.uint64), _host(knn_nbrs, np.uint32), _host(ds, np.float32)
+    n, d = ds.shape
+    po, pn = C.c_void_p(), C.c_void_p()
+    _check(lib.gbnns_build_graph_gd(koff.ctypes.data, knbr.ctypes.data, ds.ctypes.data, n, d, M,
+                                    metric, int(reverse), threads, C.byref(po), C.byref(pn)))
+    try:
+        off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+        total = int(off[n])
+        nbr = (np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_uint32)), shape=(max(total, 1),))
+               [:total].copy())
+    finally:
+        lib.gbnns_free(po)
+        lib.gbnns_free(pn)
+    return off, nbr
+
+
+class Index:
+    """One dataset resident in HBM (gbnns_index).  db / db_low / net may be numpy arrays (copied
+    to the device) or torch CUDA tensors (borrowed; kept alive by this object)."""
+
+    def __init__(self, db, graph_offsets, graph_nbrs, db_low=None, net=None, metric=METRIC_L2,
+                 device=0):
+        lib = load_library()
+        self._lib = lib
+        self._h = C.c_void_p()
+        dev = _is_dev(db)
+        db = _prep(db, np.float32, "float32")
+        db_low = _prep(db_low, np.float32, "float32")
+        if db_low is not None and _is_dev(db_low) != dev:
+            raise TypeError("db and db_low must live in the same memory kind")
+        if net is not None:
+            net = tuple(_prep(x, np.float32, "float32") for x in net)
+            if any(_is_dev(x) != dev for x in net):
+                raise TypeError("net layers must live in the same memory kind as db")
+        off = _host(graph_offsets, np.uint64)
+        nbr = _host(graph_nbrs, np.uint32)
+        self.n, self.d = int(db.shape[0]), int(db.shape[1])
+        self.d_low = int(db_low.shape[1]) if db_low is not None else 0
+        self.d_hidden = int(net[0].shape[0]) if net is not None else 0
+        if off.shape[0] != self.n + 1:
+            raise ValueError("graph_offsets must have n+1 entries")
+        if net is not None:
+            shapes = [tuple(x.shape) for x in net]
+            want = [(self.d_hidden, self.d + 1), (self.d_hidden, self.d_hidden + 1),
+                    (self.d_low, self.d_hidden + 1)]
+            if shapes != want:
+                raise ValueError(f"net layer shapes {shapes} != {want}")
+        desc = _IndexDesc(
+            struct_size=C.sizeof(_IndexDesc), device=device, metric=metric,
+            mem_kind=MEM_DEVICE if dev else MEM_HOST, n=self.n, d=self.d, d_low=self.d_low,
+            d_hidden=self.d_hidden, db=_ptr(db), db_low=_ptr(db_low), graph_offsets=_ptr(off),
+            graph_nbrs=_ptr(nbr), net_l1=_ptr(net[0]) if net else None,
+            net_l2=_ptr(net[1]) if net else None, net_l3=_ptr(net[2]) if net else None)
+        _check(lib.gbnns_index_create(C.byref(desc), C.byref(self._h)))
+        self._keep = (db, db_low, net) if dev else None
+        self.metric = metric
+        self.device = device
+
+    def close(self):
+        if self._h:
+            self._lib.gbnns_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- search ------------------------------------------------------------------------------
+    def search(self, queries, ef, mode=MODE_NET, k=1, queries_low=None, entry_ids=None,
+               want=("hops", "dist_calc"), hash_capacity=0, stream=None, out=None):
+        """Runs one batch.  numpy queries -> synchronous call, numpy results.  torch CUDA queries
+        -> enqueued on `stream` (torch stream or None = current), torch results, no sync.
+        `want` may also name "cand", "cand_dist", "q_low", "edges".  Returns a dict with "ids" + wanted."""
+        dev = _is_dev(queries)
+        queries = _prep(queries, np.float32, "float32")
+        queries_low = _prep(queries_low, np.float32, "float32")
+        nq = int(queries.shape[0])
+        if queries.shape[1] != self.d:
+            raise ValueError("query dimension mismatch")
+        kk = ef if mode != MODE_PLAIN else max(1, min(k, ef))
+        res = {} if out is None else out
+        if dev:
+            import torch
+            tdev = queries.device
+            entry_ids = None if entry_ids is None else entry_ids.to(torch.int32).contiguous() \
+                if entry_ids.dtype != torch.int32 else entry_ids.contiguous()
+
+            def alloc(name, shape, dtype):
+                if name not in res:
+                    res[name] = torch.empty(shape, dtype=dtype, device=tdev)
+                return res[name]
+            i32, f32 = torch.int32, torch.float32
+            if stream is None:
+                stream = torch.cuda.current_stream(tdev)
+            sptr = stream.cuda_stream
+        else:
+            entry_ids = None if entry_ids is None else _host(entry_ids, np.uint32)
+
+            def alloc(name, shape, dtype):
+                if name not in res:
+                    res[name] = np.empty(shape, dtype=dtype)
+                return res[name]
+            i32, f32 = np.int32, np.float32
+            sptr = None
+        ids = alloc("ids", (nq,), i32 if dev else np.uint32)
+        a = _SearchArgs(struct_size=C.sizeof(_SearchArgs), mode=mode, ef=ef, k=kk,
+                        mem_kind=MEM_DEVICE if dev else MEM_HOST, hash_capacity=hash_capacity,
+                        n_q=nq, queries=_ptr(queries), queries_low=_ptr(queries_low),
+                        entry_ids=_ptr(entry_ids), out_ids=_ptr(ids), stream=sptr)
+        if "hops" in want:
+            a.out_hops = _ptr(alloc("hops", (nq,), i32))
+        if "dist_calc" in want:
+            a.out_dist_calc = _ptr(alloc("dist_calc", (nq,), i32))
+        if "cand" in want:
+            a.out_cand = _ptr(alloc("cand", (nq, kk), i32 if dev else np.uint32))
+        if "cand_dist" in want:
+            a.out_cand_dist = _ptr(alloc("cand_dist", (nq, kk), f32))
+        if "q_low" in want:
+            a.out_q_low = _ptr(alloc("q_low", (nq, self.d_low), f32))
+        if "edges" in want:
+            a.out_edges = _ptr(alloc("edges", (nq,), i32))
+        _check(self._lib.gbnns_search_ex(self._h, C.byref(a)))
+        self._last = (queries, queries_low, entry_ids)  # keep device inputs alive until next call
+        return res
+
+    def search_batch(self, queries, ef, entry_ids=None, want_cand=False):
+        """The plain 9-argument C entry point (NET mode, host buffers)."""
+        q = _host(queries, np.float32)
+        nq = q.shape[0]
+        ids = np.empty(nq, np.uint32)
+        hops = np.empty(nq, np.int32)
+        dc = np.empty(nq, np.int32)
+        cand = np.empty((nq, ef), np.uint32) if want_cand else None
+        ent = None if entry_ids is None else _host(entry_ids, np.uint32)
+        _check(self._lib.gbnns_search_batch(self._h, q.ctypes.data, nq, ef, _ptr(ent),
+                                            ids.ctypes.data, hops.ctypes.data, dc.ctypes.data,
+                                            _ptr(cand)))
+        r = dict(ids=ids, hops=hops, dist_calc=dc)
+        if want_cand:
+            r["cand"] = cand
+        return r
+
+    def project(self, x, stream=None):
+        """GetLowQueryFromNet over the rows of x -> [rows x d_low]."""
+        dev = _is_dev(x)
+        x = _prep(x, np.float32, "float32")
+        if dev:
+            import torch
+            out = torch.empty((x.shape[0], self.d_low), dtype=torch.float32, device=x.device)
+            if stream is None:
+                stream = torch.cuda.current_stream(x.device)
+            sptr = stream.cuda_stream
+        else:
+            out = np.empty((x.shape[0], self.d_low), np.float32)
+            sptr = None
+        _check(self._lib.gbnns_project(self._h, _ptr(x), x.shape[0], _ptr(out),
+                                       MEM_DEVICE if dev else MEM_HOST, sptr))
+        return out
+
+    # -- profiling -----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        _check(self._lib.gbnns_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset=True):
+        p = Profile()
+        _check(self._lib.gbnns_profile_read(self._h, C.byref(p), int(reset)))
+        return p.as_dict()

@@ -1,0 +1,639 @@
+// api.cpp -- host side of libgbnns_hip.so: the C ABI declared in include/gbnns.h.
+//
+// Owns device memory (index data in HBM, a growable per-index workspace), converts the reference's
+// host-side data structures to the device layouts, and sequences the kernels of one batch call on
+// one HIP stream:
+//     [MLP layer x3 + normalise] -> walk (LDS kernel) -> walk (general kernel, hand-over list)
+//     -> re-rank
+// There is no CPU fallback anywhere in this file: if HIP is unusable every entry point fails.
+
+#include "../../include/gbnns.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace gbnns;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? GBNNS_ERR_OOM : GBNNS_ERR_HIP,           \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,     \
+                        __LINE__);                                                           \
+    } while (0)
+
+inline uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return GBNNS_OK;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            bytes = 0;
+            if (e != hipSuccess) return fail(GBNNS_ERR_HIP, "hipFree: %s", hipGetErrorString(e));
+        }
+        const size_t want = need + need / 8;  // slack so slightly larger batches do not realloc
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(GBNNS_ERR_OOM, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        }
+        bytes = want;
+        return GBNNS_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+
+struct ProfCall {
+    hipEvent_t ev[5];  // begin, after project, after walk, after general, after rerank
+    uint64_t queries;
+    bool has_project, has_rerank;
+};
+
+}  // namespace
+
+struct gbnns_index {
+    int device = 0;
+    int metric = 0;
+    uint64_t n = 0;
+    uint32_t d = 0, d_low = 0, d_hidden = 0;
+    uint32_t d_pad = 0, dl_pad = 0;
+    const float* db = nullptr;      // [n x d_pad]
+    const float* db_low = nullptr;  // [n x dl_pad]
+    DevBuf db_own, db_low_own, ell, net;
+    uint32_t ell_stride = 0;
+    bool has_net = false;
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
+    uint32_t ws1 = 0, ws2 = 0, ws3 = 0;
+    // workspace
+    DevBuf q_in, q_low, h1, h2, cand, cand_dist, cnt, hops, dc, edges, out, entries, ovf_list, ctrl;
+    DevBuf g_bitmap, g_keys, g_tie;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfCall> pending;
+    gbnns_profile acc{};
+    // last-call statistics (host mode only)
+    uint32_t last_general = 0;
+};
+
+namespace {
+
+int upload(DevBuf& dst, const void* src, size_t rows, size_t row_floats, size_t pad_floats,
+           int mem_kind) {
+    // copies a [rows x row_floats] f32 matrix into a zero-padded [rows x pad_floats] device matrix
+    const size_t bytes = rows * pad_floats * sizeof(float);
+    int rc = dst.ensure(bytes ? bytes : 4);
+    if (rc) return rc;
+    const hipMemcpyKind kind = mem_kind == GBNNS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (pad_floats == row_floats) {
+        HIP_TRY(hipMemcpy(dst.p, src, bytes, kind));
+    } else {
+        HIP_TRY(hipMemset(dst.p, 0, bytes));
+        HIP_TRY(hipMemcpy2D(dst.p, pad_floats * 4, src, row_floats * 4, row_floats * 4, rows, kind));
+    }
+    return GBNNS_OK;
+}
+
+// [dout x (din+1)] rows = [W | b]  ->  W [dout x wstride] (zero padded) followed by bias [dout]
+void repack_layer(const float* layer, uint32_t din, uint32_t dout, uint32_t wstride,
+                  std::vector<float>& out) {
+    const size_t base = out.size();
+    out.resize(base + (size_t)dout * wstride + dout, 0.f);
+    float* w = out.data() + base;
+    float* b = w + (size_t)dout * wstride;
+    for (uint32_t o = 0; o < dout; ++o) {
+        const float* row = layer + (size_t)o * (din + 1);
+        std::memcpy(w + (size_t)o * wstride, row, (size_t)din * sizeof(float));
+        b[o] = row[din];
+    }
+}
+
+// CSR (host) -> padded adjacency.  Order inside each list is preserved.  A neighbour id that
+// repeats inside one list is dropped after its first occurrence: the reference would find it
+// already visited (search_function.h:25), so this changes nothing observable.
+int build_ell(const uint64_t* off, const uint32_t* nbr, uint64_t n, std::vector<uint32_t>& ell,
+              uint32_t& stride) {
+    uint64_t maxdeg = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (off[i + 1] < off[i]) return fail(GBNNS_ERR_INVALID, "graph_offsets not monotone at %llu",
+                                             (unsigned long long)i);
+        maxdeg = std::max<uint64_t>(maxdeg, off[i + 1] - off[i]);
+    }
+    if (maxdeg > (1u << 20)) return fail(GBNNS_ERR_UNSUPPORTED, "max degree %llu too large",
+                                         (unsigned long long)maxdeg);
+    stride = round_up((uint32_t)std::max<uint64_t>(maxdeg, 1), 16);
+    if ((double)n * stride * 4.0 > 200e9)
+        return fail(GBNNS_ERR_UNSUPPORTED, "padded adjacency would need %.1f GB", n * stride * 4e-9);
+    ell.assign((size_t)n * stride, kInvalidId);
+    std::vector<uint32_t> tmp;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t* src = nbr + off[i];
+        const uint32_t deg = (uint32_t)(off[i + 1] - off[i]);
+        uint32_t* dst = ell.data() + (size_t)i * stride;
+        bool dup = false;
+        for (uint32_t j = 0; j < deg; ++j) {
+            if (src[j] >= n) return fail(GBNNS_ERR_INVALID, "node %llu: neighbour id %u >= n",
+                                         (unsigned long long)i, src[j]);
+        }
+        if (deg > 1) {
+            tmp.assign(src, src + deg);
+            std::sort(tmp.begin(), tmp.end());
+            dup = std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end();
+        }
+        if (!dup) {
+            std::memcpy(dst, src, (size_t)deg * 4);
+        } else {
+            uint32_t m = 0;
+            for (uint32_t j = 0; j < deg; ++j) {
+                bool seen = false;
+                for (uint32_t l = 0; l < m && !seen; ++l) seen = dst[l] == src[j];
+                if (!seen) dst[m++] = src[j];
+            }
+        }
+    }
+    return GBNNS_OK;
+}
+
+uint32_t pow2_ceil(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+uint32_t log2_u32(uint32_t v) {
+    uint32_t b = 0;
+    while ((1u << b) < v) ++b;
+    return b;
+}
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+}  // namespace
+
+extern "C" {
+
+int gbnns_version(void) { return GBNNS_VERSION; }
+
+const char* gbnns_last_error(void) { return g_err.c_str(); }
+
+int gbnns_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+void gbnns_free(void* p) { std::free(p); }
+
+int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out) {
+    if (!desc || !out) return fail(GBNNS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (desc->struct_size != sizeof(gbnns_index_desc))
+        return fail(GBNNS_ERR_INVALID, "gbnns_index_desc.struct_size mismatch (%u != %zu)",
+                    desc->struct_size, sizeof(gbnns_index_desc));
+    if (desc->n == 0 || desc->n >= (1ull << 31)) return fail(GBNNS_ERR_INVALID, "n must be in [1, 2^31)");
+    if (desc->d == 0 || !desc->db) return fail(GBNNS_ERR_INVALID, "db / d missing");
+    if (!desc->graph_offsets || !desc->graph_nbrs) return fail(GBNNS_ERR_INVALID, "graph missing");
+    if (desc->metric != GBNNS_METRIC_L2 && desc->metric != GBNNS_METRIC_NEG_DOT)
+        return fail(GBNNS_ERR_INVALID, "unknown metric %d", desc->metric);
+    if (desc->mem_kind != GBNNS_MEM_HOST && desc->mem_kind != GBNNS_MEM_DEVICE)
+        return fail(GBNNS_ERR_INVALID, "unknown mem_kind %d", desc->mem_kind);
+    if ((desc->d_low != 0) != (desc->db_low != nullptr))
+        return fail(GBNNS_ERR_INVALID, "d_low and db_low must be given together");
+    const bool has_net = desc->net_l1 || desc->net_l2 || desc->net_l3;
+    if (has_net && !(desc->net_l1 && desc->net_l2 && desc->net_l3 && desc->d_hidden && desc->d_low))
+        return fail(GBNNS_ERR_INVALID, "net needs all three layers, d_hidden and d_low");
+
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(GBNNS_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (desc->device < 0 || desc->device >= count)
+        return fail(GBNNS_ERR_NO_DEVICE, "device %d out of range (%d devices)", desc->device, count);
+    HIP_TRY(hipSetDevice(desc->device));
+
+    gbnns_index* ix = new (std::nothrow) gbnns_index;
+    if (!ix) return fail(GBNNS_ERR_OOM, "host allocation failed");
+    ix->device = desc->device;
+    ix->metric = desc->metric;
+    ix->n = desc->n;
+    ix->d = desc->d;
+    ix->d_low = desc->d_low;
+    ix->d_hidden = desc->d_hidden;
+    ix->d_pad = round_up(desc->d, 4);
+    ix->dl_pad = round_up(desc->d_low, 4);
+    int rc = GBNNS_OK;
+
+    auto take = [&](const float* src, uint32_t dim, uint32_t pad, DevBuf& own, const float*& dst) -> int {
+        if (desc->mem_kind == GBNNS_MEM_DEVICE && pad == dim) {
+            dst = src;  // borrowed: rows already 16-B aligned
+            return GBNNS_OK;
+        }
+        int r = upload(own, src, ix->n, dim, pad, desc->mem_kind);
+        dst = own.as<float>();
+        return r;
+    };
+    rc = take(desc->db, ix->d, ix->d_pad, ix->db_own, ix->db);
+    if (!rc && desc->db_low) rc = take(desc->db_low, ix->d_low, ix->dl_pad, ix->db_low_own, ix->db_low);
+
+    if (!rc) {
+        std::vector<uint32_t> ell;
+        rc = build_ell(desc->graph_offsets, desc->graph_nbrs, ix->n, ell, ix->ell_stride);
+        if (!rc) rc = ix->ell.ensure(ell.size() * 4);
+        if (!rc) {
+            hipError_t e = hipMemcpy(ix->ell.p, ell.data(), ell.size() * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) rc = fail(GBNNS_ERR_HIP, "adjacency upload: %s", hipGetErrorString(e));
+        }
+    }
+
+    if (!rc && has_net) {
+        const uint32_t d = ix->d, dh = ix->d_hidden, dl = ix->d_low;
+        std::vector<float> l1, l2, l3;
+        const float *p1 = desc->net_l1, *p2 = desc->net_l2, *p3 = desc->net_l3;
+        if (desc->mem_kind == GBNNS_MEM_DEVICE) {
+            l1.resize((size_t)dh * (d + 1));
+            l2.resize((size_t)dh * (dh + 1));
+            l3.resize((size_t)dl * (dh + 1));
+            hipError_t e = hipMemcpy(l1.data(), p1, l1.size() * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(l2.data(), p2, l2.size() * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(l3.data(), p3, l3.size() * 4, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = fail(GBNNS_ERR_HIP, "net download: %s", hipGetErrorString(e));
+            p1 = l1.data();
+            p2 = l2.data();
+            p3 = l3.data();
+        }
+        if (!rc) {
+            ix->ws1 = round_up(d, 8);
+            ix->ws2 = round_up(dh, 8);
+            ix->ws3 = round_up(dh, 8);
+            std::vector<float> packed;
+            repack_layer(p1, d, dh, ix->ws1, packed);
+            const size_t o2 = packed.size();
+            repack_layer(p2, dh, dh, ix->ws2, packed);
+            const size_t o3 = packed.size();
+            repack_layer(p3, dh, dl, ix->ws3, packed);
+            rc = ix->net.ensure(packed.size() * 4);
+            if (!rc) {
+                hipError_t e = hipMemcpy(ix->net.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
+                if (e != hipSuccess) rc = fail(GBNNS_ERR_HIP, "net upload: %s", hipGetErrorString(e));
+            }
+            float* base = ix->net.as<float>();
+            ix->w1 = base;
+            ix->b1 = ix->w1 + (size_t)dh * ix->ws1;
+            ix->w2 = base + o2;
+            ix->b2 = ix->w2 + (size_t)dh * ix->ws2;
+            ix->w3 = base + o3;
+            ix->b3 = ix->w3 + (size_t)dl * ix->ws3;
+            ix->has_net = true;
+        }
+    }
+    if (!rc) rc = ix->ctrl.ensure(64);
+    if (!rc) {
+        hipError_t e = hipMemset(ix->ctrl.p, 0, 64);
+        if (e != hipSuccess) rc = fail(GBNNS_ERR_HIP, "ctrl init: %s", hipGetErrorString(e));
+    }
+    if (rc) {
+        gbnns_index_destroy(ix);
+        return rc;
+    }
+    *out = ix;
+    return GBNNS_OK;
+}
+
+int gbnns_index_destroy(gbnns_index* ix) {
+    if (!ix) return GBNNS_OK;
+    (void)hipSetDevice(ix->device);
+    for (auto& pc : ix->pending)
+        for (auto& e : pc.ev) (void)hipEventDestroy(e);
+    DevBuf* bufs[] = {&ix->db_own, &ix->db_low_own, &ix->ell, &ix->net, &ix->q_in, &ix->q_low,
+                      &ix->h1, &ix->h2, &ix->cand, &ix->cand_dist, &ix->cnt, &ix->hops, &ix->dc, &ix->edges,
+                      &ix->out, &ix->entries, &ix->ovf_list, &ix->ctrl, &ix->g_bitmap, &ix->g_keys,
+                      &ix->g_tie};
+    for (DevBuf* b : bufs) b->release();
+    delete ix;
+    return GBNNS_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// MLP over rows x [nx x xstride] (device) -> out [nx x dl_pad] (device); h1/h2 are scratch.
+int run_project(gbnns_index* ix, const float* x, uint32_t xstride, uint32_t nx, float* out,
+                hipStream_t s) {
+    int rc = ix->h1.ensure((size_t)nx * ix->d_hidden * 4);
+    if (!rc) rc = ix->h2.ensure((size_t)nx * ix->d_hidden * 4);
+    if (rc) return rc;
+    LayerParams p{};
+    p.x = x; p.xstride = xstride; p.w = ix->w1; p.wstride = ix->ws1; p.bias = ix->b1;
+    p.out = ix->h1.as<float>(); p.ostride = ix->d_hidden; p.nq = nx; p.din = ix->d;
+    p.dout = ix->d_hidden; p.relu = 1;
+    HIP_TRY(launch_mlp_layer(p, s));
+    p.x = ix->h1.as<float>(); p.xstride = ix->d_hidden; p.w = ix->w2; p.wstride = ix->ws2;
+    p.bias = ix->b2; p.out = ix->h2.as<float>(); p.din = ix->d_hidden;
+    HIP_TRY(launch_mlp_layer(p, s));
+    p.x = ix->h2.as<float>(); p.w = ix->w3; p.wstride = ix->ws3; p.bias = ix->b3; p.out = out;
+    p.ostride = ix->dl_pad; p.dout = ix->d_low; p.relu = 0;
+    HIP_TRY(launch_mlp_layer(p, s));
+    HIP_TRY(launch_normalize(out, ix->dl_pad, ix->d_low, nx, s));
+    return GBNNS_OK;
+}
+
+int prof_flush(gbnns_index* ix) {
+    for (auto& pc : ix->pending) {
+        HIP_TRY(hipEventSynchronize(pc.ev[4]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pc.ev[0], pc.ev[1]));
+        ix->acc.project_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, pc.ev[1], pc.ev[2]));
+        ix->acc.walk_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, pc.ev[2], pc.ev[3]));
+        ix->acc.walk_general_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, pc.ev[3], pc.ev[4]));
+        ix->acc.rerank_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, pc.ev[0], pc.ev[4]));
+        ix->acc.total_ms += ms;
+        ix->acc.calls += 1;
+        ix->acc.queries += pc.queries;
+        for (int i = 0; i < 5; ++i) (void)hipEventDestroy(pc.ev[i]);
+    }
+    ix->pending.clear();
+    return GBNNS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gbnns_profile_enable(gbnns_index* ix, int on) {
+    if (!ix) return fail(GBNNS_ERR_INVALID, "null index");
+    ix->profiling = on != 0;
+    return GBNNS_OK;
+}
+
+int gbnns_profile_read(gbnns_index* ix, gbnns_profile* out, int reset) {
+    if (!ix || !out) return fail(GBNNS_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ix->device));
+    int rc = prof_flush(ix);
+    if (rc) return rc;
+    uint32_t total = 0;  // ctrl[2]: queries the general kernel has processed since the last reset
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&total, ix->ctrl.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost));
+    ix->acc.general_queries = total;
+    ix->acc.struct_size = sizeof(gbnns_profile);
+    *out = ix->acc;
+    if (reset) {
+        ix->acc = gbnns_profile{};
+        HIP_TRY(hipMemset(ix->ctrl.as<uint32_t>() + 2, 0, 4));
+    }
+    return GBNNS_OK;
+}
+
+int gbnns_project(gbnns_index* ix, const float* x, uint64_t n_x, float* out, int mem_kind,
+                  void* stream) {
+    if (!ix || !x || !out) return fail(GBNNS_ERR_INVALID, "null argument");
+    if (!ix->has_net) return fail(GBNNS_ERR_INVALID, "index has no net");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t chunk = 1u << 16;
+    int rc = ix->q_low.ensure((size_t)std::min<uint64_t>(chunk, n_x) * ix->dl_pad * 4);
+    if (rc) return rc;
+    if (mem_kind == GBNNS_MEM_HOST) {
+        rc = ix->q_in.ensure((size_t)std::min<uint64_t>(chunk, n_x) * ix->d * 4);
+        if (rc) return rc;
+    }
+    for (uint64_t b = 0; b < n_x; b += chunk) {
+        const uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n_x - b);
+        const float* xin = x + b * ix->d;
+        if (mem_kind == GBNNS_MEM_HOST) {
+            HIP_TRY(hipMemcpyAsync(ix->q_in.p, xin, (size_t)m * ix->d * 4, hipMemcpyHostToDevice, s));
+            xin = ix->q_in.as<float>();
+        }
+        float* dst = ix->q_low.as<float>();
+        const bool direct = mem_kind == GBNNS_MEM_DEVICE && ix->dl_pad == ix->d_low;
+        if (direct) dst = out + b * ix->d_low;
+        rc = run_project(ix, xin, ix->d, m, dst, s);
+        if (rc) return rc;
+        if (!direct) {
+            const hipMemcpyKind kind = mem_kind == GBNNS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+            HIP_TRY(hipMemcpy2DAsync(out + b * ix->d_low, (size_t)ix->d_low * 4, dst, (size_t)ix->dl_pad * 4,
+                                     (size_t)ix->d_low * 4, m, kind, s));
+        }
+        if (mem_kind == GBNNS_MEM_HOST) HIP_TRY(hipStreamSynchronize(s));
+    }
+    return GBNNS_OK;
+}
+
+int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
+    if (!ix || !a) return fail(GBNNS_ERR_INVALID, "null argument");
+    if (a->struct_size != sizeof(gbnns_search_args))
+        return fail(GBNNS_ERR_INVALID, "gbnns_search_args.struct_size mismatch (%u != %zu)",
+                    a->struct_size, sizeof(gbnns_search_args));
+    if (a->mode < GBNNS_MODE_NET || a->mode > GBNNS_MODE_PLAIN) return fail(GBNNS_ERR_INVALID, "bad mode");
+    if (a->ef <= 0) return fail(GBNNS_ERR_INVALID, "ef must be >= 1");
+    if (a->mem_kind != GBNNS_MEM_HOST && a->mem_kind != GBNNS_MEM_DEVICE)
+        return fail(GBNNS_ERR_INVALID, "unknown mem_kind %d", a->mem_kind);
+    if (a->n_q == 0) return GBNNS_OK;
+    if (a->n_q >= (1ull << 31)) return fail(GBNNS_ERR_INVALID, "n_q too large");
+    if (!a->queries || !a->out_ids) return fail(GBNNS_ERR_INVALID, "queries / out_ids missing");
+    if (a->mode == GBNNS_MODE_NET && !ix->has_net) return fail(GBNNS_ERR_INVALID, "NET mode needs a net");
+    if (a->mode != GBNNS_MODE_PLAIN && !ix->db_low) return fail(GBNNS_ERR_INVALID, "mode needs db_low");
+    if (a->mode == GBNNS_MODE_LOWQ && !a->queries_low) return fail(GBNNS_ERR_INVALID, "queries_low missing");
+    if (a->hash_capacity != 0 && (a->hash_capacity < 128 || (a->hash_capacity & (a->hash_capacity - 1))))
+        return fail(GBNNS_ERR_INVALID, "hash_capacity must be a power of two >= 128");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = static_cast<hipStream_t>(a->stream);
+    const bool host = a->mem_kind == GBNNS_MEM_HOST;
+    const uint32_t nq = (uint32_t)a->n_q;
+    const int ef = a->ef;
+    const bool plain = a->mode == GBNNS_MODE_PLAIN;
+    const int k = plain ? std::max(1, std::min(a->k > 0 ? a->k : 1, ef)) : ef;
+    const uint32_t cstride = (uint32_t)k;
+    int rc;
+
+    // ---- workspace ----------------------------------------------------------------------
+    if ((rc = ix->cnt.ensure((size_t)nq * 4))) return rc;
+    if ((rc = ix->hops.ensure((size_t)nq * 4))) return rc;
+    if ((rc = ix->dc.ensure((size_t)nq * 4))) return rc;
+    if ((rc = ix->ovf_list.ensure((size_t)nq * 4))) return rc;
+    if (host || !a->out_cand)
+        if ((rc = ix->cand.ensure((size_t)nq * cstride * 4))) return rc;
+    if (a->out_cand_dist && host)
+        if ((rc = ix->cand_dist.ensure((size_t)nq * cstride * 4))) return rc;
+    if (host)
+        if ((rc = ix->out.ensure((size_t)nq * 4))) return rc;
+    if (host && a->out_edges)
+        if ((rc = ix->edges.ensure((size_t)nq * 4))) return rc;
+    const uint32_t bitmap_words = (uint32_t)((ix->n + 31) / 32);
+    if ((rc = ix->g_bitmap.ensure((size_t)kGeneralSlots * bitmap_words * 4))) return rc;
+    if ((rc = ix->g_keys.ensure((size_t)kGeneralSlots * ef * 8))) return rc;
+    if ((rc = ix->g_tie.ensure((size_t)kGeneralSlots * ix->n * 8))) return rc;
+
+    // ---- inputs -------------------------------------------------------------------------
+    const float* q_dev = a->queries;
+    if (host) {
+        if ((rc = ix->q_in.ensure((size_t)nq * ix->d * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->q_in.p, a->queries, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice, s));
+        q_dev = ix->q_in.as<float>();
+    }
+    const uint32_t* entries_dev = a->entry_ids;
+    if (a->entry_ids && host) {
+        if ((rc = ix->entries.ensure((size_t)nq * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->entries.p, a->entry_ids, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+        entries_dev = ix->entries.as<uint32_t>();
+    }
+    if (a->entry_ids && host) {
+        for (uint32_t i = 0; i < nq; ++i)
+            if (a->entry_ids[i] >= ix->n) return fail(GBNNS_ERR_INVALID, "entry id %u >= n", a->entry_ids[i]);
+    }
+
+    ProfCall pc{};
+    const bool prof = ix->profiling;
+    if (prof) {
+        for (int i = 0; i < 5; ++i) HIP_TRY(hipEventCreate(&pc.ev[i]));
+        pc.queries = nq;
+        HIP_TRY(hipEventRecord(pc.ev[0], s));
+    }
+
+    // ---- stage 1: queries in the walked space ------------------------------------------
+    WalkParams w{};
+    if (plain) {
+        w.q = q_dev; w.qstride = ix->d; w.db = ix->db; w.dstride = ix->d_pad; w.dim = ix->d;
+    } else {
+        if ((rc = ix->q_low.ensure((size_t)nq * ix->dl_pad * 4))) return rc;
+        float* ql = ix->q_low.as<float>();
+        if (a->mode == GBNNS_MODE_NET) {
+            if ((rc = run_project(ix, q_dev, ix->d, nq, ql, s))) return rc;
+            w.q = ql; w.qstride = ix->dl_pad;
+        } else if (host) {
+            HIP_TRY(hipMemcpyAsync(ql, a->queries_low, (size_t)nq * ix->d_low * 4, hipMemcpyHostToDevice, s));
+            w.q = ql; w.qstride = ix->d_low;
+        } else {
+            w.q = a->queries_low; w.qstride = ix->d_low;
+        }
+        w.db = ix->db_low; w.dstride = ix->dl_pad; w.dim = ix->d_low;
+        if (a->out_q_low && a->mode == GBNNS_MODE_NET) {
+            const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+            HIP_TRY(hipMemcpy2DAsync(a->out_q_low, (size_t)ix->d_low * 4, ql, (size_t)ix->dl_pad * 4,
+                                     (size_t)ix->d_low * 4, nq, kind, s));
+        }
+    }
+    if (prof) HIP_TRY(hipEventRecord(pc.ev[1], s));
+
+    // ---- stage 2: beam walk -----------------------------------------------------------
+    w.ell = ix->ell.as<uint32_t>(); w.ell_stride = ix->ell_stride; w.n = (uint32_t)ix->n; w.nq = nq;
+    w.ef = ef; w.k = k; w.entries = entries_dev;
+    w.cand = (!host && a->out_cand) ? a->out_cand : ix->cand.as<uint32_t>();
+    w.cand_dist = a->out_cand_dist ? (host ? ix->cand_dist.as<float>() : a->out_cand_dist) : nullptr;
+    w.cand_stride = cstride;
+    w.count = ix->cnt.as<int32_t>();
+    w.hops = (!host && a->out_hops) ? a->out_hops : ix->hops.as<int32_t>();
+    w.dist_calc = (!host && a->out_dist_calc) ? a->out_dist_calc : ix->dc.as<int32_t>();
+    w.edges = a->out_edges ? (host ? ix->edges.as<int32_t>() : a->out_edges) : nullptr;
+    uint32_t* out_dev = host ? ix->out.as<uint32_t>() : a->out_ids;
+    w.best = plain ? out_dev : nullptr;
+    uint32_t* ctrl = ix->ctrl.as<uint32_t>();
+    w.ovf_count = ctrl; w.g_cursor = ctrl + 1; w.g_total = ctrl + 2; w.ovf_list = ix->ovf_list.as<uint32_t>();
+    w.g_bitmap = ix->g_bitmap.as<uint32_t>(); w.g_keys = ix->g_keys.as<uint64_t>();
+    w.g_tie = ix->g_tie.as<uint64_t>(); w.bitmap_words = bitmap_words;
+
+    uint32_t cap;
+    if (a->hash_capacity) {
+        cap = (uint32_t)a->hash_capacity;
+    } else {
+        const uint32_t target = std::max<uint32_t>(512u, 32u * (uint32_t)ef);
+        cap = std::min<uint32_t>(pow2_ceil(target + target / 3 + 64), 16384u);
+    }
+    w.hash_bits = log2_u32(cap);
+    w.hash_limit = cap - cap / 4;
+    w.all_general = walk_fast_lds_bytes(w) > kMaxLds ? 1 : 0;
+
+    HIP_TRY(hipMemsetAsync(ctrl, 0, 8, s));
+    if (!w.all_general) HIP_TRY(launch_walk_fast(w, ix->metric, s));
+    if (prof) HIP_TRY(hipEventRecord(pc.ev[2], s));
+    HIP_TRY(launch_walk_general(w, ix->metric, s));
+    if (prof) HIP_TRY(hipEventRecord(pc.ev[3], s));
+
+    // ---- stage 3: re-rank in the original space ------------------------------------------
+    if (!plain) {
+        RerankParams r{};
+        r.q = q_dev; r.qstride = ix->d; r.db = ix->db; r.dstride = ix->d_pad; r.dim = ix->d;
+        r.cand = w.cand; r.cand_stride = cstride; r.count = w.count; r.nq = nq; r.out = out_dev;
+        HIP_TRY(launch_rerank(r, ix->metric, s));
+    }
+    if (prof) {
+        HIP_TRY(hipEventRecord(pc.ev[4], s));
+        ix->pending.push_back(pc);
+    }
+
+    // ---- outputs ----------------------------------------------------------------------
+    if (host) {
+        HIP_TRY(hipMemcpyAsync(a->out_ids, out_dev, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        if (a->out_hops) HIP_TRY(hipMemcpyAsync(a->out_hops, w.hops, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        if (a->out_dist_calc)
+            HIP_TRY(hipMemcpyAsync(a->out_dist_calc, w.dist_calc, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        if (a->out_edges) HIP_TRY(hipMemcpyAsync(a->out_edges, w.edges, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        if (a->out_cand)
+            HIP_TRY(hipMemcpyAsync(a->out_cand, w.cand, (size_t)nq * cstride * 4, hipMemcpyDeviceToHost, s));
+        if (a->out_cand_dist)
+            HIP_TRY(hipMemcpyAsync(a->out_cand_dist, w.cand_dist, (size_t)nq * cstride * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&ix->last_general, ctrl, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (w.all_general) ix->last_general = nq;
+    }
+    return GBNNS_OK;
+}
+
+int gbnns_search_batch(gbnns_index* index, const float* queries, size_t n_q, int ef,
+                       const uint32_t* entry_ids, uint32_t* out_ids, int32_t* out_hops,
+                       int32_t* out_dist_calc, uint32_t* out_cand) {
+    gbnns_search_args a{};
+    a.struct_size = sizeof a;
+    a.mode = GBNNS_MODE_NET;
+    a.ef = ef;
+    a.k = ef;
+    a.mem_kind = GBNNS_MEM_HOST;
+    a.n_q = n_q;
+    a.queries = queries;
+    a.entry_ids = entry_ids;
+    a.out_ids = out_ids;
+    a.out_hops = out_hops;
+    a.out_dist_calc = out_dist_calc;
+    a.out_cand = out_cand;
+    return gbnns_search_ex(index, &a);
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// kernels.h -- launch interface between the C-ABI host layer (api.cpp) and the gfx950 kernels
+// (kernels.hip).  Plain structs of device pointers and sizes; no HIP types besides hipStream_t.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gbnns {
+
+constexpr uint32_t kInvalidId = 0xFFFFFFFFu;
+constexpr int kWave = 64;
+constexpr int kTieCap = 64;            // LDS tie list of the fast walk kernel (one slot per lane)
+constexpr int kGeneralSlots = 64;      // persistent waves of the general walk kernel
+
+// Beam walk (search_function.h:43-102 + :15-40).  One query per wavefront.
+struct WalkParams {
+    const float* q;          // [nq x qstride] query vectors in the walked space
+    uint32_t qstride;        // floats
+    const float* db;         // [n x dstride] base vectors in the walked space (rows 16-B aligned)
+    uint32_t dstride;        // floats, multiple of 4
+    uint32_t dim;            // true dimension of the walked space
+    const uint32_t* ell;     // [n x ell_stride] padded adjacency, kInvalidId-terminated rows
+    uint32_t ell_stride;     // multiple of 16
+    uint32_t n;
+    uint32_t nq;
+    int32_t ef;
+    int32_t k;               // results kept (<= ef); cand_stride = min(k, ef)
+    const uint32_t* entries; // [nq] or nullptr (= node 0)
+    // LDS visited set of the fast kernel
+    uint32_t hash_bits;      // capacity = 1 << hash_bits
+    uint32_t hash_limit;     // max entries before a query is handed to the general kernel
+    // outputs
+    uint32_t* cand;          // [nq x cand_stride] pop order (worst -> best), kInvalidId pad
+    float* cand_dist;        // optional, same shape
+    uint32_t cand_stride;
+    int32_t* count;          // [nq] valid entries in cand
+    int32_t* hops;           // [nq]
+    int32_t* dist_calc;      // [nq]
+    int32_t* edges;          // optional [nq]: neighbour ids read (sum of degrees of expanded nodes)
+    uint32_t* best;          // optional [nq]: id of the best result (PLAIN mode answer)
+    // hand-over list (fast kernel appends, general kernel consumes)
+    uint32_t* ovf_count;     // [1]
+    uint32_t* ovf_list;      // [nq]
+    // general kernel workspace: per slot [bitmap words][keys ef][tie n]
+    uint32_t* g_cursor;      // [1] work-queue head
+    uint32_t* g_total;       // [1] running count of queries the general kernel processed
+    uint32_t* g_bitmap;      // [slots x bitmap_words]
+    uint64_t* g_keys;        // [slots x ef]
+    uint64_t* g_tie;         // [slots x n]
+    uint32_t bitmap_words;
+    int32_t all_general;     // 1: the general kernel takes every query (fast kernel skipped)
+};
+
+size_t walk_fast_lds_bytes(const WalkParams& p);
+hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s);
+hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s);
+
+// Re-rank (search_function.h:105-125).  One query per wavefront, one candidate per lane.
+struct RerankParams {
+    const float* q;          // [nq x qstride] original-space queries
+    uint32_t qstride;
+    const float* db;         // [n x dstride]
+    uint32_t dstride;        // floats, multiple of 4
+    uint32_t dim;
+    const uint32_t* cand;    // [nq x cand_stride] pop order
+    uint32_t cand_stride;
+    const int32_t* count;    // [nq]
+    uint32_t nq;
+    uint32_t* out;           // [nq]
+};
+hipError_t launch_rerank(const RerankParams& p, int metric, hipStream_t s);
+
+// MLP projection (support_func.h:624-658).  W is repacked by the host: [dout x wstride] weights
+// (zero padded, wstride multiple of 8) + separate bias[dout].
+struct LayerParams {
+    const float* x;          // [nq x xstride]
+    uint32_t xstride;
+    const float* w;          // [dout x wstride]
+    uint32_t wstride;
+    const float* bias;       // [dout]
+    float* out;              // [nq x ostride]
+    uint32_t ostride;
+    uint32_t nq, din, dout;
+    int32_t relu;
+};
+hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s);
+// y [nq x stride]: y /= sqrt(L2(y, 0)) over dim (4-lane order, d%4 tail ignored in the norm),
+// pad columns [dim, stride) are written as zero.
+hipError_t launch_normalize(float* y, uint32_t stride, uint32_t dim, uint32_t nq, hipStream_t s);
+
+// helpers
+hipError_t launch_fill_u32(uint32_t* p, uint32_t v, size_t count, hipStream_t s);
+
+}  // namespace gbnns

@@ -1,0 +1,756 @@
+// kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the two-stage graph search.
+//
+// Arithmetic contract: every distance / dot product is evaluated in IEEE binary32 with
+// the operation order of the reference's SSE/AVX source (support_func.h:107-163): separate mul and
+// add (this file is compiled with -ffp-contract=off), 4 resp. 8 independent running sums, the
+// reference's horizontal-sum order, correctly rounded sqrt and divide.  That makes every float the
+// kernels produce bit-identical to the reference built with strict flags, and therefore every
+// compare-driven decision (beam order, visited set, hops, dist_calc, final ids) identical.
+//
+// Wavefront = 64 lanes.  All walk/re-rank kernels use one 64-thread workgroup (= one wavefront)
+// per query, so cross-lane traffic goes through ballots/shuffles and wave-private LDS.
+
+#include "kernels.h"
+
+namespace gbnns {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// One wavefront per workgroup: the barrier degenerates to a wave-local fence that orders LDS /
+// global traffic between lanes of the wave.
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+// Monotone float -> u32 map (a < b  <=>  fkey(a) < fkey(b)); -0 and +0 map to the same key, as
+// they compare equal in the reference's std::pair<float,int> ordering.
+__device__ __forceinline__ uint32_t fkey(float x) {
+    x = x + 0.0f;
+    const uint32_t b = __float_as_uint(x);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+    const uint32_t b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+    return __uint_as_float(b);
+}
+
+// Result-list entry: [63:32] fkey(dist) | [31:1] id | [0] expanded.  Ascending u64 order ==
+// ascending (dist, id) pair order of the reference's result heap (search_function.h:50).
+__device__ __forceinline__ uint64_t make_key(uint32_t dk, uint32_t id) {
+    return ((uint64_t)dk << 32) | ((uint64_t)id << 1);
+}
+__device__ __forceinline__ uint32_t key_id(uint64_t k) { return (uint32_t)(k & 0xFFFFFFFFu) >> 1; }
+__device__ __forceinline__ uint32_t key_hi(uint64_t k) { return (uint32_t)(k >> 32); }
+
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    const uint32_t lo = __shfl((int)(uint32_t)v, src);
+    const uint32_t hi = __shfl((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// distances (support_func.h:107-128 L2Metric::Dist, :131-163 Angular::Dist)
+// `a` is read with 16-B vector loads (rows are padded to a multiple of 4 floats with zeros);
+// `b` likewise.  `dim` is the TRUE dimension: the L2 form drops dim%4 tail dims, the dot form
+// performs the optional 4-wide and masked steps exactly when the reference does (the zero
+// padding plays the role of masked_read's zeros).
+// ------------------------------------------------------------------------------------------
+
+template <typename PA, typename PB>
+__device__ __forceinline__ float l2_ordered(PA a, PB b, uint32_t dim) {
+    const uint32_t steps = dim >> 2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    uint32_t t = 0;
+    for (; t + 4 <= steps; t += 4) {
+        const float4 a0 = a[t], a1 = a[t + 1], a2 = a[t + 2], a3 = a[t + 3];
+        const float4 b0 = b[t], b1 = b[t + 1], b2 = b[t + 2], b3 = b[t + 3];
+        float e;
+        e = a0.x - b0.x; s0 = s0 + e * e;  e = a0.y - b0.y; s1 = s1 + e * e;
+        e = a0.z - b0.z; s2 = s2 + e * e;  e = a0.w - b0.w; s3 = s3 + e * e;
+        e = a1.x - b1.x; s0 = s0 + e * e;  e = a1.y - b1.y; s1 = s1 + e * e;
+        e = a1.z - b1.z; s2 = s2 + e * e;  e = a1.w - b1.w; s3 = s3 + e * e;
+        e = a2.x - b2.x; s0 = s0 + e * e;  e = a2.y - b2.y; s1 = s1 + e * e;
+        e = a2.z - b2.z; s2 = s2 + e * e;  e = a2.w - b2.w; s3 = s3 + e * e;
+        e = a3.x - b3.x; s0 = s0 + e * e;  e = a3.y - b3.y; s1 = s1 + e * e;
+        e = a3.z - b3.z; s2 = s2 + e * e;  e = a3.w - b3.w; s3 = s3 + e * e;
+    }
+    for (; t < steps; ++t) {
+        const float4 av = a[t];
+        const float4 bv = b[t];
+        float e;
+        e = av.x - bv.x; s0 = s0 + e * e;  e = av.y - bv.y; s1 = s1 + e * e;
+        e = av.z - bv.z; s2 = s2 + e * e;  e = av.w - bv.w; s3 = s3 + e * e;
+    }
+    return ((s0 + s1) + s2) + s3;
+}
+
+// Compile-time step count (d_low = 32 -> STEPS = 8): all row loads are issued up front.
+template <int STEPS, typename PA, typename PB>
+__device__ __forceinline__ float l2_ordered_fixed(PA a, PB b) {
+    float4 av[STEPS];
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) av[t] = a[t];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) {
+        const float4 bv = b[t];
+        float e;
+        e = av[t].x - bv.x; s0 = s0 + e * e;  e = av[t].y - bv.y; s1 = s1 + e * e;
+        e = av[t].z - bv.z; s2 = s2 + e * e;  e = av[t].w - bv.w; s3 = s3 + e * e;
+    }
+    return ((s0 + s1) + s2) + s3;
+}
+
+template <typename PA, typename PB>
+__device__ __forceinline__ float negdot_ordered(PA a, PB b, uint32_t dim) {
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f, c6 = 0.f, c7 = 0.f;
+    const uint32_t n8 = dim >> 3;
+    for (uint32_t s = 0; s < n8; ++s) {
+        const float4 a0 = a[2 * s], a1 = a[2 * s + 1];
+        const float4 b0 = b[2 * s], b1 = b[2 * s + 1];
+        c0 = c0 + a0.x * b0.x; c1 = c1 + a0.y * b0.y; c2 = c2 + a0.z * b0.z; c3 = c3 + a0.w * b0.w;
+        c4 = c4 + a1.x * b1.x; c5 = c5 + a1.y * b1.y; c6 = c6 + a1.z * b1.z; c7 = c7 + a1.w * b1.w;
+    }
+    float m0 = c4 + c0, m1 = c5 + c1, m2 = c6 + c2, m3 = c7 + c3;
+    uint32_t t = 2 * n8;
+    uint32_t rem = dim & 7;
+    if (rem >= 4) {
+        const float4 av = a[t], bv = b[t];
+        m0 = m0 + av.x * bv.x; m1 = m1 + av.y * bv.y; m2 = m2 + av.z * bv.z; m3 = m3 + av.w * bv.w;
+        ++t;
+        rem -= 4;
+    }
+    if (rem > 0) {  // masked step: padding lanes hold zeros, 0*0 = +0 is still added
+        const float4 av = a[t], bv = b[t];
+        m0 = m0 + av.x * bv.x; m1 = m1 + av.y * bv.y; m2 = m2 + av.z * bv.z; m3 = m3 + av.w * bv.w;
+    }
+    return -((m0 + m1) + (m2 + m3));
+}
+
+template <int METRIC, typename PA, typename PB>
+__device__ __forceinline__ float metric_dist(PA a, PB b, uint32_t dim) {
+    if constexpr (METRIC == 1) return negdot_ordered(a, b, dim);
+    else return l2_ordered(a, b, dim);
+}
+
+// ------------------------------------------------------------------------------------------
+// sorted result list (search_function.h:50 topResults) -- ascending u64 keys, capacity ef
+// ------------------------------------------------------------------------------------------
+
+// Inserts `nk`; when the list is full the largest key is evicted (returned through `evicted`).
+// One top-down pass: every chunk of 64 keys is read once, keys >= nk are rewritten one slot up.
+template <typename KP>
+__device__ __forceinline__ int list_insert(KP keys, int& size, int ef, uint64_t nk,
+                                           uint64_t& evicted, bool& did_evict, int lane) {
+    did_evict = (size == ef);
+    evicted = did_evict ? keys[size - 1] : 0ull;
+    const int top = did_evict ? size - 1 : size;  // keys [0, top) may have to move
+    int pos = 0;
+    for (int base = (top - 1) & ~63; base >= 0; base -= 64) {
+        const int idx = base + lane;
+        const uint64_t v = (idx < top) ? keys[idx] : ~0ull;
+        const bool lt = v < nk;
+        const uint64_t m = __ballot(lt);
+        if (idx < top && !lt) keys[idx + 1] = v;
+        if (m) {
+            pos = base + __popcll(m);
+            break;
+        }
+    }
+    if (lane == 0) keys[pos] = nk;
+    if (!did_evict) ++size;
+    wave_sync();
+    return pos;
+}
+
+// ------------------------------------------------------------------------------------------
+// the beam walk
+// ------------------------------------------------------------------------------------------
+
+struct WalkState {
+    int size;       // entries in the result list
+    int tsize;      // entries in the tie list
+    int first_un;   // every list entry below this index is expanded
+    int hops;
+    int dist_calc;
+    int edges;      // neighbour ids read (for the algorithmic-bytes figure)
+};
+
+// Tie list: result-list entries that were evicted UNEXPANDED while their distance still equals
+// the current worst distance.  The reference keeps every evicted entry in its unbounded candidate
+// heap (search_function.h:55,65-69) and expands such an entry when it surfaces, because the stop
+// test is strict (`cand.dist > worst.dist`, :67).  Entries whose distance exceeds the worst
+// distance can never be expanded again (the worst distance only decreases), so only exact ties
+// need to be kept; the list is flushed whenever the worst distance strictly decreases.
+
+// Picks the next node to expand (closest unexpanded; ties -> LARGEST id, because the candidate
+// heap is keyed (-dist, id)).  Returns false when nothing is left (the reference's loop exit).
+template <typename KP, typename TP>
+__device__ __forceinline__ bool select_candidate(KP keys, TP tie, WalkState& st, uint32_t& node,
+                                                 int lane) {
+    int p = -1, best = -1;
+    uint32_t hi_p = 0;
+    for (int base = st.first_un & ~63; base < st.size; base += 64) {
+        const int idx = base + lane;
+        const uint64_t kv = (idx < st.size) ? keys[idx] : ~0ull;
+        const bool un = (idx < st.size) && !(kv & 1ull);
+        if (p < 0) {
+            const uint64_t m = __ballot(un);
+            if (!m) continue;
+            const int pl = __ffsll((unsigned long long)m) - 1;
+            p = base + pl;
+            hi_p = (uint32_t)__shfl((int)key_hi(kv), pl);
+        }
+        const bool same = (idx < st.size) && key_hi(kv) == hi_p;
+        const uint64_t ms = __ballot(same && un && idx >= p);
+        if (ms) best = base + 63 - __clzll((long long)ms);
+        const uint64_t mall = __ballot(same);
+        if (!((mall >> 63) & 1ull)) break;  // run of equal distances ends inside this chunk
+    }
+    st.first_un = (p < 0) ? st.size : p;
+
+    if (st.tsize > 0) {
+        const uint32_t worst_hi = key_hi(keys[st.size - 1]);
+        if (p < 0 || hi_p == worst_hi) {
+            // all tie entries sit at the worst distance: the largest id among them competes
+            uint32_t tbest = 0;  // id + 1 of the largest tie id, 0 = none
+            int tpos = -1;
+            for (int base = 0; base < st.tsize; base += 64) {
+                const int idx = base + lane;
+                uint32_t v = (idx < st.tsize) ? key_id(tie[idx]) + 1u : 0u;
+                int w = idx;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {  // wave arg-max (ids are distinct)
+                    const uint32_t ov = (uint32_t)__shfl_xor((int)v, off);
+                    const int ow = __shfl_xor(w, off);
+                    if (ov > v) { v = ov; w = ow; }
+                }
+                if (v > tbest) { tbest = v; tpos = w; }
+            }
+            const uint32_t tmax = tbest - 1u;
+            const uint32_t lid = (best >= 0) ? key_id(keys[best]) : 0u;
+            if (tpos >= 0 && (best < 0 || tmax > lid)) {
+                node = tmax;
+                if (lane == 0) tie[tpos] = tie[st.tsize - 1];  // unordered remove
+                st.tsize -= 1;
+                wave_sync();
+                return true;
+            }
+        }
+    }
+    if (best < 0) return false;
+    node = key_id(keys[best]);
+    if (lane == 0) keys[best] = keys[best] | 1ull;
+    wave_sync();
+    return true;
+}
+
+// Result of offering one (dist, id) to the result list with the reference's rule
+// (search_function.h:31-37): insert when worst.dist > dist || size < ef (strict, distance only),
+// then evict the largest pair if size > ef.  Returns false if the tie list overflowed.
+template <typename KP, typename TP>
+__device__ __forceinline__ bool offer(KP keys, TP tie, int tie_cap, WalkState& st, int ef,
+                                      uint32_t dk, uint32_t id, int lane) {
+    if (st.size >= ef && !(dk < key_hi(keys[st.size - 1]))) return true;
+    uint64_t ev;
+    bool did;
+    const int pos = list_insert(keys, st.size, ef, make_key(dk, id), ev, did, lane);
+    if (pos < st.first_un) st.first_un = pos;
+    if (did) {
+        const uint32_t nw = key_hi(keys[st.size - 1]);
+        if (key_hi(ev) == nw) {
+            if (!(ev & 1ull)) {
+                if (st.tsize >= tie_cap) return false;
+                if (lane == 0) tie[st.tsize] = ev;
+                st.tsize += 1;
+                wave_sync();
+            }
+        } else {
+            st.tsize = 0;
+        }
+    }
+    return true;
+}
+
+// Writes the trimmed result list in POP order (worst -> best), as the reference's heap would be
+// drained by getRealNearest (search_function.h:109-122).
+template <typename KP>
+__device__ __forceinline__ void write_results(const WalkParams& p, uint32_t qi, KP keys,
+                                              const WalkState& st, int lane) {
+    const int kept = st.size < p.k ? st.size : p.k;
+    for (int r = lane; r < (int)p.cand_stride; r += 64) {
+        uint32_t id = kInvalidId;
+        float dv = __builtin_inff();
+        if (r < kept) {
+            const uint64_t kv = keys[kept - 1 - r];
+            id = key_id(kv);
+            dv = fkey_inv(key_hi(kv));
+        }
+        p.cand[(size_t)qi * p.cand_stride + r] = id;
+        if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + r] = dv;
+    }
+    if (lane == 0) {
+        p.count[qi] = kept;
+        p.hops[qi] = st.hops;
+        p.dist_calc[qi] = st.dist_calc;
+        if (p.edges) p.edges[qi] = st.edges;
+        if (p.best) p.best[qi] = key_id(keys[0]);
+    }
+}
+
+template <int METRIC, int STEPS, typename QP>
+__device__ __forceinline__ float walk_dist(QP qs, const float* row, uint32_t dim) {
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+    if constexpr (METRIC == 0 && STEPS > 0) return l2_ordered_fixed<STEPS>(r4, qs);  // row loads first
+    else return metric_dist<METRIC>(qs, r4, dim);
+}
+
+// ---- fast kernel: result list, tie list, visited hash set and the query all live in LDS -------
+//
+// LDS layout (dynamic): [keys: ef_pad x u64][tie: kTieCap x u64][q: dstride x f32][hash: cap x u32]
+// The visited set is an open-addressing hash set of node ids (exact: an id is "visited" iff it
+// was inserted).  A query that would exceed hash_limit entries, or whose tie list overflows, is
+// appended to the hand-over list and re-run from scratch by the general kernel.
+
+template <int METRIC, int STEPS>
+__global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id();
+    const uint32_t qi = blockIdx.x;
+    const int ef = p.ef;
+    const int ef_pad = (ef + 63) & ~63;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* tie = keys + ef_pad;
+    float* qf = reinterpret_cast<float*>(tie + kTieCap);
+    uint32_t* hash = reinterpret_cast<uint32_t*>(qf + p.dstride);
+    const float4* qs = reinterpret_cast<const float4*>(qf);
+    const uint32_t cap = 1u << p.hash_bits;
+    const uint32_t hmask = cap - 1u;
+    const uint32_t hshift = 32u - p.hash_bits;
+
+    for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
+    for (uint32_t i = lane; i < p.dstride; i += 64)
+        qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
+    wave_sync();
+
+    WalkState st;
+    st.size = 0; st.tsize = 0; st.first_un = 0; st.hops = 0; st.dist_calc = 1; st.edges = 0;
+
+    const uint32_t entry = p.entries ? p.entries[qi] : 0u;
+    {
+        const float d0 = walk_dist<METRIC, STEPS>(qs, p.db + (size_t)entry * p.dstride, p.dim);
+        if (lane == 0) {
+            keys[0] = make_key(fkey(d0), entry);
+            hash[(entry * 0x9E3779B1u) >> hshift] = entry;
+        }
+        st.size = 1;
+        wave_sync();
+    }
+
+    bool handed_over = false;
+    uint32_t node;
+    while (select_candidate(keys, tie, st, node, lane)) {
+        const uint32_t* row = p.ell + (size_t)node * p.ell_stride;
+        for (uint32_t c = 0; c < p.ell_stride; c += 64) {
+            const uint32_t nb = (c + lane < p.ell_stride) ? row[c + lane] : kInvalidId;
+            const bool valid = nb != kInvalidId;
+            const uint64_t mv = __ballot(valid);
+            if (!mv) break;
+            if ((uint32_t)st.dist_calc + 64u > p.hash_limit) { handed_over = true; break; }
+            st.edges += __popcll(mv);
+            bool fresh = false;
+            if (valid) {
+                uint32_t h = (nb * 0x9E3779B1u) >> hshift;
+                while (true) {
+                    const uint32_t old = atomicCAS(&hash[h], kInvalidId, nb);
+                    if (old == kInvalidId) { fresh = true; break; }
+                    if (old == nb) break;
+                    h = (h + 1u) & hmask;
+                }
+            }
+            uint32_t dk = 0xFFFFFFFFu;
+            if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, p.db + (size_t)nb * p.dstride, p.dim));
+            const uint64_t mf = __ballot(fresh);
+            st.dist_calc += __popcll(mf);
+            // reference order: neighbours are offered one by one in list order
+            const uint32_t worst0 = key_hi(keys[st.size - 1]);
+            uint64_t m = __ballot(fresh && (st.size < ef || dk < worst0));
+            while (m) {
+                const int l = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                const uint32_t dl = (uint32_t)__shfl((int)dk, l);
+                const uint32_t il = (uint32_t)__shfl((int)nb, l);
+                if (!offer(keys, tie, kTieCap, st, ef, dl, il, lane)) { handed_over = true; break; }
+            }
+            if (handed_over) break;
+        }
+        if (handed_over) break;
+        st.hops += 1;
+    }
+
+    if (handed_over) {
+        if (lane == 0) {
+            const uint32_t slot = atomicAdd(p.ovf_count, 1u);
+            p.ovf_list[slot] = qi;
+        }
+        return;
+    }
+    write_results(p, qi, keys, st, lane);
+}
+
+// ---- general kernel: exact for every input (any ef, any number of ties, any visited count) ----
+//
+// Persistent wavefronts pull query indices from the hand-over list.  Visited set = one bit per
+// node in a per-slot global bitmap (cleared per query); result list and tie list in global
+// memory (tie capacity n: every node can be in it at most once).
+
+template <int METRIC>
+__global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id();
+    const uint32_t slot = blockIdx.x;
+    float* qf = reinterpret_cast<float*>(smem);
+    const float4* qs = reinterpret_cast<const float4*>(qf);
+    uint32_t* bitmap = p.g_bitmap + (size_t)slot * p.bitmap_words;
+    uint64_t* keys = p.g_keys + (size_t)slot * (size_t)p.ef;
+    uint64_t* tie = p.g_tie + (size_t)slot * (size_t)p.n;
+    const int ef = p.ef;
+    const uint32_t total = p.all_general ? p.nq : *p.ovf_count;
+    if (slot == 0 && lane == 0 && total) atomicAdd(p.g_total, total);
+
+    while (true) {
+        uint32_t w = 0;
+        if (lane == 0) w = atomicAdd(p.g_cursor, 1u);
+        w = (uint32_t)__shfl((int)w, 0);
+        if (w >= total) break;
+        const uint32_t qi = p.all_general ? w : p.ovf_list[w];
+
+        for (uint32_t i = lane; i < p.bitmap_words; i += 64) bitmap[i] = 0u;
+        for (uint32_t i = lane; i < p.dstride; i += 64)
+            qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
+        wave_sync();
+
+        WalkState st;
+        st.size = 0; st.tsize = 0; st.first_un = 0; st.hops = 0; st.dist_calc = 1; st.edges = 0;
+        const uint32_t entry = p.entries ? p.entries[qi] : 0u;
+        {
+            const float d0 =
+                metric_dist<METRIC>(qs, reinterpret_cast<const float4*>(p.db + (size_t)entry * p.dstride),
+                                    p.dim);
+            if (lane == 0) {
+                keys[0] = make_key(fkey(d0), entry);
+                bitmap[entry >> 5] = 1u << (entry & 31u);
+            }
+            st.size = 1;
+            wave_sync();
+        }
+        uint32_t node;
+        while (select_candidate(keys, tie, st, node, lane)) {
+            const uint32_t* row = p.ell + (size_t)node * p.ell_stride;
+            for (uint32_t c = 0; c < p.ell_stride; c += 64) {
+                const uint32_t nb = (c + lane < p.ell_stride) ? row[c + lane] : kInvalidId;
+                const bool valid = nb != kInvalidId;
+                const uint64_t mv = __ballot(valid);
+                if (!mv) break;
+                st.edges += __popcll(mv);
+                bool fresh = false;
+                if (valid) {
+                    const uint32_t bit = 1u << (nb & 31u);
+                    fresh = !(atomicOr(&bitmap[nb >> 5], bit) & bit);
+                }
+                uint32_t dk = 0xFFFFFFFFu;
+                if (fresh)
+                    dk = fkey(metric_dist<METRIC>(
+                        qs, reinterpret_cast<const float4*>(p.db + (size_t)nb * p.dstride), p.dim));
+                const uint64_t mf = __ballot(fresh);
+                st.dist_calc += __popcll(mf);
+                const uint32_t worst0 = key_hi(keys[st.size - 1]);
+                uint64_t m = __ballot(fresh && (st.size < ef || dk < worst0));
+                while (m) {
+                    const int l = __ffsll((unsigned long long)m) - 1;
+                    m &= m - 1;
+                    const uint32_t dl = (uint32_t)__shfl((int)dk, l);
+                    const uint32_t il = (uint32_t)__shfl((int)nb, l);
+                    offer(keys, tie, (int)p.n, st, ef, dl, il, lane);
+                }
+            }
+            st.hops += 1;
+        }
+        write_results(p, qi, keys, st, lane);
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// re-rank (search_function.h:105-125 getRealNearest)
+// ------------------------------------------------------------------------------------------
+// One candidate per lane; each lane streams its own row with 16-B loads against the query staged
+// in LDS.  Winner = strict minimum in pop order  <=>  min over (distance, pop index).
+
+template <int METRIC>
+__global__ __launch_bounds__(64) void rerank_kernel(RerankParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id();
+    const uint32_t qi = blockIdx.x;
+    float* qf = reinterpret_cast<float*>(smem);
+    const float4* qs = reinterpret_cast<const float4*>(qf);
+    for (uint32_t i = lane; i < p.dstride; i += 64)
+        qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
+    wave_sync();
+    const int cnt = p.count[qi];
+    const uint32_t* cand = p.cand + (size_t)qi * p.cand_stride;
+    uint64_t bestk = ~0ull;
+    for (int base = 0; base < cnt; base += 64) {
+        const int r = base + lane;
+        if (r < cnt) {
+            const uint32_t id = cand[r];
+            const float dv = metric_dist<METRIC>(
+                reinterpret_cast<const float4*>(p.db + (size_t)id * p.dstride), qs, p.dim);
+            const uint64_t kv = ((uint64_t)fkey(dv) << 32) | (uint32_t)r;
+            bestk = kv < bestk ? kv : bestk;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = shfl_u64(bestk, lane ^ off);
+        bestk = o < bestk ? o : bestk;
+    }
+    if (lane == 0) p.out[qi] = (cnt > 0) ? cand[(uint32_t)(bestk & 0xFFFFFFFFu)] : kInvalidId;
+}
+
+// ------------------------------------------------------------------------------------------
+// MLP projection (support_func.h:624-633 computeNetLayer over a batch)
+// ------------------------------------------------------------------------------------------
+// out[q][o] = act( dot8(W[o,:], x[q,:]) + b[o] ) with dot8 = the 8-running-sum order of
+// Angular::Dist.  Block = 256 threads = 32 queries x 64 neurons; thread = 2 queries x 4 neurons,
+// 8 running sums each; x / W tiles of 32 k-values staged through LDS (rows padded to 36 floats so
+// the 16-B fragment reads of 16 consecutive rows hit distinct bank groups).
+
+constexpr int kTQ = 32, kTO = 64, kKC = 32, kLd = kKC + 4;
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void mlp_layer_kernel(LayerParams p) {
+    __shared__ __attribute__((aligned(16))) float xs[kTQ * kLd];
+    __shared__ __attribute__((aligned(16))) float ws[kTO * kLd];
+    const int t = threadIdx.x;
+    const int tq = t >> 4;   // 0..15 -> queries 2*tq, 2*tq+1
+    const int to = t & 15;   // neurons to + 16*j
+    const uint32_t qbase = blockIdx.x * kTQ;
+    const uint32_t obase = blockIdx.y * kTO;
+    const uint32_t kmain = (p.din >> 3) << 3;
+
+    float acc[2][4][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[a][b][l] = 0.f;
+
+    for (uint32_t k0 = 0; k0 < kmain; k0 += kKC) {
+        const uint32_t kc = (kmain - k0 < (uint32_t)kKC) ? (kmain - k0) : (uint32_t)kKC;
+        for (int e = t; e < kTQ * kKC; e += 256) {
+            const int r = e / kKC, c = e % kKC;
+            const uint32_t qg = qbase + r;
+            xs[r * kLd + c] = (qg < p.nq && (uint32_t)c < kc) ? p.x[(size_t)qg * p.xstride + k0 + c] : 0.f;
+        }
+        for (int e = t; e < kTO * kKC; e += 256) {
+            const int r = e / kKC, c = e % kKC;
+            const uint32_t og = obase + r;
+            ws[r * kLd + c] = (og < p.dout && (uint32_t)c < kc) ? p.w[(size_t)og * p.wstride + k0 + c] : 0.f;
+        }
+        __syncthreads();
+        for (uint32_t s = 0; s < kc; s += 8) {
+            float4 xv[2][2], wv[4][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float4* xp = reinterpret_cast<const float4*>(&xs[(2 * tq + a) * kLd + s]);
+                xv[a][0] = xp[0];
+                xv[a][1] = xp[1];
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float4* wp = reinterpret_cast<const float4*>(&ws[(to + 16 * b) * kLd + s]);
+                wv[b][0] = wp[0];
+                wv[b][1] = wp[1];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    acc[a][b][0] = acc[a][b][0] + wv[b][0].x * xv[a][0].x;
+                    acc[a][b][1] = acc[a][b][1] + wv[b][0].y * xv[a][0].y;
+                    acc[a][b][2] = acc[a][b][2] + wv[b][0].z * xv[a][0].z;
+                    acc[a][b][3] = acc[a][b][3] + wv[b][0].w * xv[a][0].w;
+                    acc[a][b][4] = acc[a][b][4] + wv[b][1].x * xv[a][1].x;
+                    acc[a][b][5] = acc[a][b][5] + wv[b][1].y * xv[a][1].y;
+                    acc[a][b][6] = acc[a][b][6] + wv[b][1].z * xv[a][1].z;
+                    acc[a][b][7] = acc[a][b][7] + wv[b][1].w * xv[a][1].w;
+                }
+        }
+        __syncthreads();
+    }
+
+    const uint32_t rem8 = p.din & 7;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const uint32_t qg = qbase + 2 * tq + a;
+        if (qg >= p.nq) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t og = obase + to + 16 * b;
+            if (og >= p.dout) continue;
+            float m[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = acc[a][b][j + 4] + acc[a][b][j];
+            uint32_t kk = kmain, rem = rem8;
+            const float* xr = p.x + (size_t)qg * p.xstride;
+            const float* wr = p.w + (size_t)og * p.wstride;
+            if (rem >= 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = m[j] + wr[kk + j] * xr[kk + j];
+                kk += 4;
+                rem -= 4;
+            }
+            if (rem > 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xv = ((uint32_t)j < rem) ? xr[kk + j] : 0.f;
+                    const float wv = ((uint32_t)j < rem) ? wr[kk + j] : 0.f;
+                    m[j] = m[j] + wv * xv;
+                }
+            }
+            const float dist = -((m[0] + m[1]) + (m[2] + m[3]));  // Angular::Dist
+            float v = 0.f;
+            v = v - dist;               // support_func.h:627
+            v = v + p.bias[og];         // :628
+            if (RELU && v < 0.f) v = 0.f;  // :629-631
+            p.out[(size_t)qg * p.ostride + og] = v;
+        }
+    }
+}
+
+// support_func.h:636-642 normalizeVector: norm = sqrt(L2Metric.Dist(y, zeros)); y[i] /= norm.
+__global__ __launch_bounds__(256) void normalize_kernel(float* y, uint32_t stride, uint32_t dim,
+                                                        uint32_t nq) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float* r = y + (size_t)q * stride;
+    const uint32_t steps = dim >> 2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (uint32_t t = 0; t < steps; ++t) {
+        const float e0 = r[4 * t + 0] - 0.f, e1 = r[4 * t + 1] - 0.f;
+        const float e2 = r[4 * t + 2] - 0.f, e3 = r[4 * t + 3] - 0.f;
+        s0 = s0 + e0 * e0; s1 = s1 + e1 * e1; s2 = s2 + e2 * e2; s3 = s3 + e3 * e3;
+    }
+    float norm = ((s0 + s1) + s2) + s3;
+    norm = __fsqrt_rn(norm);
+    for (uint32_t i = 0; i < dim; ++i) r[i] = __fdiv_rn(r[i], norm);
+    for (uint32_t i = dim; i < stride; ++i) r[i] = 0.f;
+}
+
+__global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += step) p[i] = v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+
+size_t walk_fast_lds_bytes(const WalkParams& p) {
+    const size_t ef_pad = ((size_t)p.ef + 63) & ~(size_t)63;
+    return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)p.dstride * 4 + ((size_t)4 << p.hash_bits);
+}
+
+template <typename K>
+static hipError_t set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return hipSuccess;
+}
+
+template <int METRIC, int STEPS>
+static hipError_t launch_fast_t(const WalkParams& p, hipStream_t s) {
+    const size_t lds = walk_fast_lds_bytes(p);
+    hipError_t e = set_lds(walk_fast_kernel<METRIC, STEPS>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((walk_fast_kernel<METRIC, STEPS>), dim3(p.nq), dim3(64), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s) {
+    if (p.nq == 0) return hipSuccess;
+    if (metric == 1) return launch_fast_t<1, 0>(p, s);
+    if (p.dstride == p.dim) {
+        switch (p.dim) {
+            case 32: return launch_fast_t<0, 8>(p, s);
+            case 48: return launch_fast_t<0, 12>(p, s);
+            case 64: return launch_fast_t<0, 16>(p, s);
+            default: break;
+        }
+    }
+    return launch_fast_t<0, 0>(p, s);
+}
+
+hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s) {
+    if (p.nq == 0) return hipSuccess;
+    const size_t lds = (size_t)p.dstride * 4;
+    if (metric == 1) {
+        hipError_t e = set_lds(walk_general_kernel<1>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((walk_general_kernel<1>), dim3(kGeneralSlots), dim3(64), lds, s, p);
+    } else {
+        hipError_t e = set_lds(walk_general_kernel<0>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((walk_general_kernel<0>), dim3(kGeneralSlots), dim3(64), lds, s, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rerank(const RerankParams& p, int metric, hipStream_t s) {
+    if (p.nq == 0) return hipSuccess;
+    const size_t lds = (size_t)p.dstride * 4;
+    if (metric == 1) {
+        hipError_t e = set_lds(rerank_kernel<1>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((rerank_kernel<1>), dim3(p.nq), dim3(64), lds, s, p);
+    } else {
+        hipError_t e = set_lds(rerank_kernel<0>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((rerank_kernel<0>), dim3(p.nq), dim3(64), lds, s, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s) {
+    if (p.nq == 0 || p.dout == 0) return hipSuccess;
+    const dim3 grid((p.nq + kTQ - 1) / kTQ, (p.dout + kTO - 1) / kTO);
+    if (p.relu) hipLaunchKernelGGL((mlp_layer_kernel<true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((mlp_layer_kernel<false>), grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_normalize(float* y, uint32_t stride, uint32_t dim, uint32_t nq, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(normalize_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, y, stride, dim, nq);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_u32(uint32_t* p, uint32_t v, size_t count, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, v, count);
+    return hipGetLastError();
+}
+
+}  // namespace gbnns

@@ -1,0 +1,153 @@
+/* gbnns.h -- C ABI of libgbnns_hip.so: the MI355X (gfx950) implementation of the two-stage
+ * graph-based ANN search of Shekhale/gbnns_dim_red.
+ *
+ * The reference has no FFI: its "interface" for this path is the set of free functions in
+ * search/search_function.h that search/final_test.cpp calls.  Each entry point below names the
+ * reference code it replaces (paths relative to the reference repository root).  The C++ drop-in
+ * headers in gbnns_dim_red_amd/search/ keep the reference's names and signatures and call these
+ * functions; INTEGRATION.md shows the binding.
+ *
+ * Conventions: plain pointers and sizes only; every function returns a gbnns_status (0 = OK) and
+ * never throws; gbnns_last_error() gives a thread-local message for the last failure.  A handle
+ * may be used by one host thread at a time; distinct handles are independent.  All vectors are
+ * IEEE binary32, row-major; ids are uint32 (n < 2^31).  There is NO CPU fallback: without a
+ * usable gfx950 device gbnns_index_create fails with GBNNS_ERR_NO_DEVICE.
+ */
+#ifndef GBNNS_H_
+#define GBNNS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GBNNS_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    GBNNS_OK = 0,
+    GBNNS_ERR_INVALID = 1,     /* bad argument / inconsistent sizes / id out of range */
+    GBNNS_ERR_NO_DEVICE = 2,   /* no HIP device, or device ordinal out of range */
+    GBNNS_ERR_HIP = 3,         /* a HIP runtime call failed (message in gbnns_last_error) */
+    GBNNS_ERR_OOM = 4,         /* host or device allocation failed */
+    GBNNS_ERR_UNSUPPORTED = 5  /* valid request outside what this build implements */
+} gbnns_status;
+
+/* support_func.h:87-163: the Metric* slot.  L2 = L2Metric::Dist (:107-128, drops d%4 tail
+ * dims); NEG_DOT = Angular::Dist (:131-163, negative dot product). */
+typedef enum { GBNNS_METRIC_L2 = 0, GBNNS_METRIC_NEG_DOT = 1 } gbnns_metric;
+
+typedef enum { GBNNS_MEM_HOST = 0, GBNNS_MEM_DEVICE = 1 } gbnns_mem_kind;
+
+/* Which per-query body of the reference harness one batch call reproduces:
+ *   NET   search_function.h:353-362  MLP projection -> walk(ef,k=ef) in low-dim space -> re-rank
+ *   LOWQ  search_function.h:158-164  same with caller-supplied low-dim queries (performTest)
+ *   PLAIN search_function.h:174-181  walk(ef,k) directly in the space of `db`, answer = best */
+typedef enum { GBNNS_MODE_NET = 0, GBNNS_MODE_LOWQ = 1, GBNNS_MODE_PLAIN = 2 } gbnns_mode;
+
+typedef struct gbnns_index gbnns_index;
+
+/* Everything final_test.cpp:50-76 loads for one dataset.  The callee copies HOST buffers to HBM
+ * (caller keeps ownership and may free them after create returns); DEVICE buffers (mem_kind =
+ * GBNNS_MEM_DEVICE, pointers valid on `device`) are borrowed and must outlive the index.  The
+ * graph is always given in host memory as CSR (neighbour order preserved: it drives tie
+ * behaviour through visit order); it is converted once to the device layout. */
+typedef struct {
+    uint32_t struct_size;          /* = sizeof(gbnns_index_desc) */
+    int32_t device;                /* HIP device ordinal */
+    int32_t metric;                /* gbnns_metric, used by walk and re-rank */
+    int32_t mem_kind;              /* gbnns_mem_kind of db, db_low, net_* */
+    uint64_t n;                    /* base vectors */
+    uint32_t d;                    /* original dimension */
+    uint32_t d_low;                /* low dimension (0: PLAIN mode only) */
+    uint32_t d_hidden;             /* MLP width (0: no net -> NET mode unavailable) */
+    uint32_t reserved0;
+    const float* db;               /* [n x d]          final_test.cpp:50 */
+    const float* db_low;           /* [n x d_low]      final_test.cpp:56; may be NULL */
+    const uint64_t* graph_offsets; /* [n + 1] host     final_test.cpp:61-63 (loadEdges) */
+    const uint32_t* graph_nbrs;    /* [offsets[n]] host */
+    const float* net_l1;           /* [d_hidden x (d+1)]        rows = [W | b], final_test.cpp:73-76 */
+    const float* net_l2;           /* [d_hidden x (d_hidden+1)] */
+    const float* net_l3;           /* [d_low x (d_hidden+1)]    */
+} gbnns_index_desc;
+
+/* Replaces the data/graph/net set-up half of final_test.cpp main (:50-76) + the per-call
+ * VisitedListPool allocation (search_function.h:331). */
+int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out);
+int gbnns_index_destroy(gbnns_index* index);
+
+typedef struct {
+    uint32_t struct_size;      /* = sizeof(gbnns_search_args) */
+    int32_t mode;              /* gbnns_mode */
+    int32_t ef;                /* beam width (= recheck_size in NET/LOWQ, search_function.h:432-434) */
+    int32_t k;                 /* PLAIN: heap is trimmed to k, answer = its top (reference uses 1) */
+    int32_t mem_kind;          /* gbnns_mem_kind of every buffer below */
+    int32_t hash_capacity;     /* 0 = auto; else power of two: entries of the per-query LDS visited set */
+    uint64_t n_q;
+    const float* queries;      /* [n_q x d] */
+    const float* queries_low;  /* LOWQ: [n_q x d_low], else NULL */
+    const uint32_t* entry_ids; /* [n_q] entry node per query, NULL = node 0 (search_function.h:417-427) */
+    uint32_t* out_ids;         /* [n_q] answers (ans[i], search_function.h:361) */
+    int32_t* out_hops;         /* optional [n_q]  TripleResult.hops */
+    int32_t* out_dist_calc;    /* optional [n_q]  TripleResult.dist_calc (walk only, without the
+                                  "+ recheck_size" the harness adds at :362) */
+    uint32_t* out_cand;        /* optional [n_q x min(k,ef)] result heap in POP order (worst->best),
+                                  0xFFFFFFFF padded; k = ef in NET/LOWQ */
+    float* out_cand_dist;      /* optional, same shape: low-dim distances of out_cand (+inf pad) */
+    float* out_q_low;          /* optional NET: [n_q x d_low] projected queries */
+    int32_t* out_edges;        /* optional [n_q]: neighbour ids read by the walk (sum of the degrees of
+                                  the expanded nodes) -- feeds the algorithmic-bytes figure */
+    void* stream;              /* hipStream_t to enqueue on (NULL = default stream) */
+} gbnns_search_args;
+
+/* Replaces the timed query loop of performNetTest (search_function.h:346-387) / performTest
+ * (:151-188): one call = the whole batch.  With HOST buffers the call copies in, runs and
+ * copies out synchronously (what the drop-in harness times).  With DEVICE buffers everything is
+ * enqueued on args->stream and the call returns without synchronising. */
+int gbnns_search_ex(gbnns_index* index, const gbnns_search_args* args);
+
+/* Convenience form of the above: NET mode, host buffers, synchronous. */
+int gbnns_search_batch(gbnns_index* index, const float* queries, size_t n_q, int ef,
+                       const uint32_t* entry_ids, uint32_t* out_ids, int32_t* out_hops,
+                       int32_t* out_dist_calc, uint32_t* out_cand);
+
+/* GetLowQueryFromNet (support_func.h:645-658) over a batch: x [n_x x d] -> out [n_x x d_low].
+ * Also what produces `<name>_base_angular_optimal.fvecs` from the base set. */
+int gbnns_project(gbnns_index* index, const float* x, uint64_t n_x, float* out, int mem_kind,
+                  void* stream);
+
+/* Per-kernel device timing (hipEvent pairs on the launch stream), accumulated since the last
+ * reset.  Reading synchronises the recorded events. */
+typedef struct {
+    uint32_t struct_size;
+    uint32_t calls;               /* search calls accumulated */
+    double project_ms;            /* MLP layers + normalise */
+    double walk_ms;               /* LDS-resident beam-walk kernel */
+    double walk_general_ms;       /* exact general-case kernel (queries the LDS kernel handed over) */
+    double rerank_ms;             /* original-space re-rank kernel */
+    double total_ms;              /* first launch .. last launch of each call */
+    uint64_t queries;             /* queries processed */
+    uint64_t general_queries;     /* of which were (re)run by the general kernel */
+} gbnns_profile;
+
+int gbnns_profile_enable(gbnns_index* index, int on);
+int gbnns_profile_read(gbnns_index* index, gbnns_profile* out, int reset);
+
+/* hnswlikeGD (support_func.h:521-575, need_const_degree = false) + addReverseEdgesForGD
+ * (:402-445): prunes a kNN graph (CSR, host) over `ds` [n x d] (host) into the search graph, as
+ * prepare_graph.cpp:70 does with M = 30, reverse = true.  Host code (OpenMP); returns malloc'ed
+ * CSR arrays the caller releases with gbnns_free. */
+int gbnns_build_graph_gd(const uint64_t* knn_offsets, const uint32_t* knn_nbrs, const float* ds,
+                         uint64_t n, uint32_t d, int M, int metric, int reverse, int threads,
+                         uint64_t** out_offsets, uint32_t** out_nbrs);
+void gbnns_free(void* p);
+
+int gbnns_device_count(void);
+int gbnns_version(void);
+const char* gbnns_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GBNNS_H_ */

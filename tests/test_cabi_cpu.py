@@ -1,0 +1,88 @@
+"""CPU-side checks of the C-ABI library: it builds, loads, exports every declared symbol, refuses
+to run without a GPU (no CPU fallback), and its host-side graph builder matches the reference."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import datagen
+import golden_util as gu
+import gbnns_dim_red_amd as g
+from gbnns_dim_red_amd import binding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    g.build_library()
+    return g.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "gbnns.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(gbnns_[a-z_]+)\s*\(", header, re.M))
+    assert declared == set(binding.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert g.version() == 100
+
+
+def test_struct_sizes_match_header(lib):
+    # 8-byte aligned C layouts as declared in include/gbnns.h
+    assert ctypes.sizeof(binding._IndexDesc) == 96
+    assert ctypes.sizeof(binding._SearchArgs) == 120
+    assert ctypes.sizeof(binding.Profile) == 64
+
+
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback(lib):
+    db = np.zeros((4, 8), np.float32)
+    off = np.arange(5, dtype=np.uint64)
+    nbr = np.array([1, 2, 3, 0], np.uint32)
+    with pytest.raises(g.GbnnsError) as e:
+        g.Index(db, off, nbr)
+    assert e.value.code == 2  # GBNNS_ERR_NO_DEVICE
+
+
+def test_argument_validation(lib):
+    h = ctypes.c_void_p()
+    assert lib.gbnns_index_create(None, ctypes.byref(h)) == 1
+    d = binding._IndexDesc(struct_size=3)
+    assert lib.gbnns_index_create(ctypes.byref(d), ctypes.byref(h)) == 1
+    assert b"struct_size" in lib.gbnns_last_error()
+
+
+def test_graph_builder_matches_reference_golden(lib):
+    gd = gu.load("tail_toy")
+    # db_low bytes are pinned by sha in the golden; regenerate through the fixture's q_low path is
+    # GPU-only, so here the builder is checked on the original-space vectors against the oracle
+    # restatement (itself pinned to the reference) ...
+    import oracle
+    orc = oracle.Oracle()
+    c = gd.case
+    db_low = orc.project(c.net, c.base)
+    assert datagen.sha(db_low) == gd.meta["db_low_sha"]
+    koff, knbr = datagen.dense_to_csr(gd["knn"])
+    for threads in (1, 3):
+        off, nbr = g.build_graph_gd(koff, knbr, db_low, gd.meta["gd_M"], threads=threads)
+        # ... and directly against the graph the compiled reference produced
+        assert np.array_equal(off, gd["graph_off"])
+        assert np.array_equal(nbr, gd["graph_nbr"])
+
+
+@pytest.mark.parametrize("M,rev", [(8, True), (14, False), (5, True), (2, True)])
+def test_graph_builder_vs_oracle(lib, orc, M, rev):
+    c = datagen.Case("b", 78, 1200, 8, 24, 12, 16)
+    knn = datagen.knn_bruteforce(c.base, 18)
+    koff, knbr = datagen.dense_to_csr(knn)
+    a = g.build_graph_gd(koff, knbr, c.base, M, reverse=rev, threads=4)
+    b = orc.hnswlike_gd(koff, knbr, c.base, M, reverse=rev, threads=2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -1,0 +1,260 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every call goes through the C ABI
+(libgbnns_hip.so via gbnns_dim_red_amd.binding); expectations come from the committed golden
+vectors (captured from the compiled reference) and from the CPU oracle on seeded inputs.
+
+Bar: bit-exact -- ids, hops, dist_calc, candidate lists, and the IEEE bit patterns of projected
+queries and of candidate distances.
+"""
+import numpy as np
+import pytest
+
+import datagen
+import golden_util as gu
+import oracle as orc_mod
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import gbnns_dim_red_amd as g
+    g.load_library()  # raises if the HIP library was not built: no fallback
+    return g
+
+
+def _index(g, gd, orc, metric=None):
+    c = gd.case
+    db_low = orc.project(c.net, c.base, threads=8)
+    off, nbr = gd.graph
+    ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net,
+                 metric=gd.metric if metric is None else metric)
+    return ix, db_low
+
+
+@pytest.mark.parametrize("name", gu.CASE_NAMES)
+def test_golden_two_stage(g, orc, name):
+    gd = gu.load(name)
+    c = gd.case
+    ix, db_low = _index(g, gd, orc)
+    # the device projection of the base set reproduces the reference's db_low bytes
+    assert datagen.sha(ix.project(c.base)) == gd.meta["db_low_sha"]
+    for ef in gd.efs:
+        r = ix.search(c.queries, ef, mode=g.MODE_NET,
+                      want=("hops", "dist_calc", "cand", "cand_dist", "q_low"))
+        assert np.array_equal(gu.bits(r["q_low"]), gd["q_low_bits"]), (name, ef)
+        assert np.array_equal(r["cand"], gd[f"walk_ids_{ef}"]), (name, ef)
+        assert np.array_equal(gu.bits(r["cand_dist"]), gd[f"walk_dist_bits_{ef}"]), (name, ef)
+        assert np.array_equal(r["hops"], gd[f"walk_hops_{ef}"]), (name, ef)
+        assert np.array_equal(r["dist_calc"], gd[f"walk_dc_{ef}"]), (name, ef)
+        assert np.array_equal(r["ids"], gd[f"net_ans_{ef}"]), (name, ef)
+        # the 9-argument entry point
+        rb = ix.search_batch(c.queries, ef, want_cand=True)
+        assert np.array_equal(rb["ids"], gd[f"net_ans_{ef}"])
+        assert np.array_equal(rb["cand"], gd[f"walk_ids_{ef}"])
+        # precomputed low-dim queries (performTest path)
+        q_low = gd["q_low_bits"].view(np.float32)
+        r1 = ix.search(c.queries, ef, mode=g.MODE_LOWQ, queries_low=q_low)
+        assert np.array_equal(r1["ids"], gd[f"net_ans_{ef}"])
+        assert np.array_equal(r1["hops"], gd[f"walk_hops_{ef}"])
+        # random entry points
+        re_ = ix.search(c.queries, ef, mode=g.MODE_LOWQ, queries_low=q_low,
+                        entry_ids=gd["entries"], want=("hops", "dist_calc", "cand"))
+        assert np.array_equal(re_["cand"], gd[f"walk_e_ids_{ef}"])
+        assert np.array_equal(re_["hops"], gd[f"walk_e_hops_{ef}"])
+        assert np.array_equal(re_["dist_calc"], gd[f"walk_e_dc_{ef}"])
+        # plain walk in the original space (performRealTests baseline, d == d_low branch)
+        p = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=1)
+        assert np.array_equal(p["ids"], gd[f"plain_ans_{ef}"])
+        assert np.array_equal(p["hops"], gd[f"plain_hops_{ef}"])
+        assert np.array_equal(p["dist_calc"], gd[f"plain_dc_{ef}"])
+    ix.close()
+
+
+def test_golden_tie_heavy_lattice(g):
+    gd = gu.load("ties_toy")
+    c = gd.case
+    for tag, (off, nbr) in dict(gd=gd.graph, rnd=(gd["rgraph_off"], gd["rgraph_nbr"])).items():
+        ix = g.Index(c.base, off, nbr)
+        for ef in gd.efs:
+            r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=gd["entries"],
+                          want=("hops", "dist_calc", "cand", "cand_dist"))
+            assert np.array_equal(r["cand"], gd[f"lat_{tag}_ids_{ef}"]), (tag, ef)
+            assert np.array_equal(gu.bits(r["cand_dist"]), gd[f"lat_{tag}_dist_bits_{ef}"])
+            assert np.array_equal(r["hops"], gd[f"lat_{tag}_hops_{ef}"]), (tag, ef)
+            assert np.array_equal(r["dist_calc"], gd[f"lat_{tag}_dc_{ef}"]), (tag, ef)
+        ix.close()
+
+
+def _oracle_case(orc, seed, n, nq, d, dlow, dh, kind="clustered", deg=(4, 28)):
+    c = datagen.Case("x", seed, n, nq, d, dlow, dh, kind=kind)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    off, nbr = datagen.random_graph(rng, n, *deg)
+    db_low = orc.project(c.net, c.base, threads=8)
+    ent = rng.integers(0, n, size=nq).astype(np.uint32)
+    return c, off, nbr, db_low, ent
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_oracle_parity_medium(g, orc, metric):
+    c, off, nbr, db_low, ent = _oracle_case(orc, 501 + metric, 20000, 600, 64, 32, 48)
+    ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net, metric=metric)
+    q_low = orc.project(c.net, c.queries)
+    for ef in (1, 7, 64, 180, 1000):
+        w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, metric=metric, threads=8)
+        s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low,
+                             net=c.net, entries=ent, metric=metric, threads=8)
+        r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"))
+        assert np.array_equal(r["cand"], w["ids"]), ef
+        assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), ef
+        assert np.array_equal(r["hops"], w["hops"]), ef
+        assert np.array_equal(r["dist_calc"], w["dist_calc"]), ef
+        assert np.array_equal(r["ids"], s["ids"]), ef
+    ix.close()
+
+
+def test_general_kernel_paths(g, orc):
+    """Force the hand-over paths: (a) a visited set too small for the walk, (b) a tie list that
+    overflows (lattice data, exact distance ties everywhere), (c) ef beyond the LDS list."""
+    c, off, nbr, db_low, ent = _oracle_case(orc, 601, 8000, 300, 32, 16, 24)
+    ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+    ix.profile_enable(True)
+    q_low = orc.project(c.net, c.queries)
+    for ef in (16, 200):
+        w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, threads=8)
+        r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand"),
+                      hash_capacity=128)
+        assert np.array_equal(r["cand"], w["ids"])
+        assert np.array_equal(r["hops"], w["hops"])
+        assert np.array_equal(r["dist_calc"], w["dist_calc"])
+    assert ix.profile_read()["general_queries"] > 0
+    ix.close()
+
+    # (b) lattice: huge tie classes, walk straight on the lattice in PLAIN mode
+    cl = datagen.Case("lat", 602, 6000, 200, 12, 4, 8, kind="lattice")
+    rng = np.random.Generator(np.random.PCG64(9))
+    off, nbr = datagen.random_graph(rng, cl.n, 8, 40)
+    ix = g.Index(cl.base, off, nbr)
+    ix.profile_enable(True)
+    for ef in (1, 3, 10, 100):
+        w = orc.walk(cl.queries, cl.base, off, nbr, ef, threads=8)
+        r = ix.search(cl.queries, ef, mode=g.MODE_PLAIN, k=ef, want=("hops", "dist_calc", "cand"))
+        assert np.array_equal(r["cand"], w["ids"]), ef
+        assert np.array_equal(r["hops"], w["hops"]), ef
+        assert np.array_equal(r["dist_calc"], w["dist_calc"]), ef
+    prof = ix.profile_read()
+    ix.close()
+    # (c) ef larger than anything the LDS kernel can hold
+    c2, off2, nbr2, db_low2, ent2 = _oracle_case(orc, 603, 30000, 40, 16, 8, 8)
+    ix = g.Index(c2.base, off2, nbr2, db_low=db_low2, net=c2.net)
+    q_low2 = orc.project(c2.net, c2.queries)
+    ef = 25000
+    w = orc.walk(q_low2, db_low2, off2, nbr2, ef, threads=8)
+    r = ix.search(c2.queries, ef, want=("hops", "dist_calc", "cand"))
+    assert np.array_equal(r["cand"], w["ids"])
+    assert np.array_equal(r["hops"], w["hops"])
+    ix.close()
+    assert prof["general_queries"] >= 0
+
+
+def test_edge_cases(g, orc):
+    # isolated entry node, self loops, duplicate neighbours inside a list, ragged degrees
+    n, d = 300, 8
+    c = datagen.Case("e", 701, n, 50, d, 4, 8)
+    lists = [[] for _ in range(n)]
+    rng = np.random.Generator(np.random.PCG64(5))
+    for i in range(1, n):
+        k = int(rng.integers(0, 70))
+        li = list(rng.integers(0, n, size=k))
+        if i % 7 == 0:
+            li = li + li[:3] + [i]  # duplicates + self loop
+        lists[i] = li
+    lists[0] = []  # node 0 (default entry) has no neighbours
+    off, nbr = datagen.lists_to_csr([np.asarray(l, np.uint32) for l in lists])
+    ix = g.Index(c.base, off, nbr)
+    ent = rng.integers(0, n, size=c.nq).astype(np.uint32)
+    for ef in (1, 5, 64):
+        for entries in (None, ent):
+            w = orc.walk(c.queries, c.base, off, nbr, ef, entries=entries)
+            r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=entries,
+                          want=("hops", "dist_calc", "cand"))
+            assert np.array_equal(r["cand"], w["ids"])
+            assert np.array_equal(r["hops"], w["hops"])
+            assert np.array_equal(r["dist_calc"], w["dist_calc"])
+    # empty batch is a no-op; bad entry id and bad ef are rejected
+    assert ix.search(c.queries[:0], 4, mode=g.MODE_PLAIN)["ids"].shape == (0,)
+    with pytest.raises(g.GbnnsError):
+        ix.search(c.queries, 4, mode=g.MODE_PLAIN, entry_ids=np.full(c.nq, n, np.uint32))
+    with pytest.raises(g.GbnnsError):
+        ix.search(c.queries, 0, mode=g.MODE_PLAIN)
+    with pytest.raises(g.GbnnsError):
+        ix.search(c.queries, 4, mode=g.MODE_NET)  # index has no net
+    ix.close()
+    with pytest.raises(g.GbnnsError):
+        g.Index(c.base, off, np.where(nbr == 3, n + 5, nbr).astype(np.uint32))  # id out of range
+
+
+def test_device_buffers_match_host_buffers(g, orc):
+    import torch
+    c, off, nbr, db_low, ent = _oracle_case(orc, 801, 12000, 500, 48, 16, 32)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ix_h = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+    ix_d = g.Index(t(c.base), off, nbr, db_low=t(db_low), net=tuple(t(x) for x in c.net))
+    for ef in (8, 64):
+        rh = ix_h.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand"))
+        rd = ix_d.search(t(c.queries), ef, entry_ids=t(ent.astype(np.int32)),
+                         want=("hops", "dist_calc", "cand"))
+        torch.cuda.synchronize()
+        assert np.array_equal(rd["ids"].cpu().numpy().view(np.uint32), rh["ids"])
+        assert np.array_equal(rd["cand"].cpu().numpy().view(np.uint32), rh["cand"])
+        assert np.array_equal(rd["hops"].cpu().numpy(), rh["hops"])
+        assert np.array_equal(rd["dist_calc"].cpu().numpy(), rh["dist_calc"])
+    pl = ix_d.project(t(c.queries))
+    torch.cuda.synchronize()
+    assert np.array_equal(gu.bits(pl.cpu().numpy()), gu.bits(orc.project(c.net, c.queries)))
+    ix_h.close()
+    ix_d.close()
+
+
+def test_full_size_properties(g):
+    """SIFT1M-shaped workload at full size (n = 1e6, 10k queries, 128->32, ef = 64): too big for
+    the oracle to enumerate in seconds, so checked through size-independent properties --
+    determinism, candidate lists sorted worst->best with exact recomputed distances, answer is
+    the argmin of exact original-space distances over its candidate list, shard invariance."""
+    import torch
+    from gbnns_dim_red_amd import synth
+    ds = synth.make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=1234,
+                            device="cuda:0")
+    ix = ds.index()
+    q = ds.queries
+    r1 = ix.search(q, 64, want=("hops", "dist_calc", "cand", "cand_dist", "q_low"))
+    r2 = ix.search(q, 64, want=("hops", "dist_calc", "cand", "cand_dist", "q_low"))
+    torch.cuda.synchronize()
+    for k in ("ids", "cand", "hops", "dist_calc"):
+        assert torch.equal(r1[k], r2[k]), k
+    cand = r1["cand"].long()
+    assert (cand >= 0).all() and (cand < ds.n).all()
+    # distances reported == exact recomputation (torch fp32 sum of squares is NOT the 4-lane
+    # order, so compare with a tolerance of a few ulp; the bit-exact check is the golden suite)
+    ql = r1["q_low"]
+    dd = ((ds.db_low[cand] - ql[:, None, :]) ** 2).sum(-1)
+    assert torch.allclose(dd, r1["cand_dist"], rtol=1e-5, atol=1e-7)
+    # pop order: worst -> best, no duplicates
+    cd = r1["cand_dist"]
+    assert (cd[:, :-1] >= cd[:, 1:]).all()
+    assert (torch.sort(cand, dim=1).values.diff(dim=1) != 0).all()
+    # answer = argmin over the candidate list of the exact original-space distance
+    do = ((ds.base[cand] - q[:, None, :]) ** 2).sum(-1)
+    best = do.min(dim=1).values
+    got = ((ds.base[r1["ids"].long()] - q) ** 2).sum(-1)
+    assert torch.allclose(got, best, rtol=1e-5, atol=1e-6)
+    # shard invariance: any split of the batch gives the same per-query results
+    parts = [ix.search(q[a:b].contiguous(), 64)["ids"].clone() for a, b in ((0, 3333), (3333, 10000))]
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat(parts), r1["ids"])
+    # recall of the synthetic workload is what bench.py reports against
+    rec = (r1["ids"].long() == ds.gt).float().mean().item()
+    assert rec > 0.9, rec
+    ix.close()
