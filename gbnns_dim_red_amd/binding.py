@@ -18,7 +18,7 @@ MODE_NET, MODE_LOWQ, MODE_PLAIN = 0, 1, 2
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "gbnns_index_create", "gbnns_index_destroy", "gbnns_search_ex", "gbnns_search_batch",
-    "gbnns_project", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd",
+    "gbnns_project", "gbnns_rerank", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd",
     "gbnns_free", "gbnns_device_count", "gbnns_version", "gbnns_last_error",
 ]
 
@@ -86,6 +86,8 @@ def load_library():
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gbnns_project.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int,
                                   C.c_void_p]
+    lib.gbnns_rerank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
+                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.gbnns_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.gbnns_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile), C.c_int]
     lib.gbnns_build_graph_gd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -302,6 +304,16 @@ class Index:
             sptr = None
         _check(self._lib.gbnns_project(self._h, _ptr(x), x.shape[0], _ptr(out),
                                        MEM_DEVICE if dev else MEM_HOST, sptr))
+        return out
+
+    def rerank(self, queries, cand, count=None):
+        """getRealNearest over a batch (host buffers): cand [nq x stride] in pop order."""
+        q = _host(queries, np.float32)
+        cand = _host(cand, np.uint32)
+        count = None if count is None else _host(count, np.int32)
+        out = np.empty(q.shape[0], np.uint32)
+        _check(self._lib.gbnns_rerank(self._h, q.ctypes.data, q.shape[0], cand.ctypes.data,
+                                      cand.shape[1], _ptr(count), out.ctypes.data, MEM_HOST, None))
         return out
 
     # -- profiling -----------------------------------------------------------------------------

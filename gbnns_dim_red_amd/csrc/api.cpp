@@ -457,6 +457,51 @@ int gbnns_project(gbnns_index* ix, const float* x, uint64_t n_x, float* out, int
     return GBNNS_OK;
 }
 
+int gbnns_rerank(gbnns_index* ix, const float* queries, uint64_t n_q, const uint32_t* cand,
+                 uint32_t cand_stride, const int32_t* count, uint32_t* out_ids, int mem_kind,
+                 void* stream) {
+    if (!ix || !queries || !cand || !out_ids) return fail(GBNNS_ERR_INVALID, "null argument");
+    if (n_q == 0) return GBNNS_OK;
+    if (cand_stride == 0 || n_q >= (1ull << 31)) return fail(GBNNS_ERR_INVALID, "bad sizes");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t nq = (uint32_t)n_q;
+    const bool host = mem_kind == GBNNS_MEM_HOST;
+    int rc;
+    RerankParams r{};
+    r.db = ix->db; r.dstride = ix->d_pad; r.dim = ix->d; r.qstride = ix->d; r.cand_stride = cand_stride;
+    r.nq = nq;
+    if ((rc = ix->cnt.ensure((size_t)nq * 4))) return rc;
+    int32_t* cnt_dev = ix->cnt.as<int32_t>();
+    if (host) {
+        if ((rc = ix->q_in.ensure((size_t)nq * ix->d * 4))) return rc;
+        if ((rc = ix->cand.ensure((size_t)nq * cand_stride * 4))) return rc;
+        if ((rc = ix->out.ensure((size_t)nq * 4))) return rc;
+        for (uint64_t i = 0; i < n_q; ++i) {
+            const uint32_t c = count ? (uint32_t)std::max(count[i], 0) : cand_stride;
+            if (c > cand_stride) return fail(GBNNS_ERR_INVALID, "count[%llu] > stride", (unsigned long long)i);
+            for (uint32_t j = 0; j < c; ++j)
+                if (cand[i * cand_stride + j] >= ix->n)
+                    return fail(GBNNS_ERR_INVALID, "candidate id %u >= n", cand[i * cand_stride + j]);
+        }
+        HIP_TRY(hipMemcpyAsync(ix->q_in.p, queries, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ix->cand.p, cand, (size_t)nq * cand_stride * 4, hipMemcpyHostToDevice, s));
+        if (count) HIP_TRY(hipMemcpyAsync(cnt_dev, count, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+        r.q = ix->q_in.as<float>(); r.cand = ix->cand.as<uint32_t>(); r.out = ix->out.as<uint32_t>();
+    } else {
+        r.q = queries; r.cand = cand; r.out = out_ids;
+        if (count) cnt_dev = const_cast<int32_t*>(count);
+    }
+    if (!count) HIP_TRY(launch_fill_u32(reinterpret_cast<uint32_t*>(cnt_dev), cand_stride, nq, s));
+    r.count = cnt_dev;
+    HIP_TRY(launch_rerank(r, ix->metric, s));
+    if (host) {
+        HIP_TRY(hipMemcpyAsync(out_ids, r.out, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return GBNNS_OK;
+}
+
 int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     if (!ix || !a) return fail(GBNNS_ERR_INVALID, "null argument");
     if (a->struct_size != sizeof(gbnns_search_args))

@@ -229,6 +229,8 @@ __device__ __forceinline__ bool select_candidate(KP keys, TP tie, WalkState& st,
                     const int ow = __shfl_xor(w, off);
                     if (ov > v) { v = ov; w = ow; }
                 }
+                v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+                w = __builtin_amdgcn_readfirstlane(w);
                 if (v > tbest) { tbest = v; tpos = w; }
             }
             const uint32_t tmax = tbest - 1u;
@@ -400,6 +402,189 @@ __global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
         return;
     }
     write_results(p, qi, keys, st, lane);
+}
+
+// ---- register kernel (ef <= 64): the result list lives in registers, one entry per lane -------
+//
+// Lane i holds the i-th smallest (dist, id) entry as two dwords: hi = fkey(dist), lo = id<<1 |
+// expanded.  Empty lanes hold all-ones (which reads as "expanded", so they are never selected).
+// Insertion is a u64 compare + popcount for the position and one wave-wide DPP shift
+// (v_mov_b32 wave_shr:1) for the move -- no LDS traffic, a dozen instructions per insert instead
+// of five dependent LDS round trips.  LDS keeps only the visited hash set, the query and the tie
+// list: [tie: kTieCap x u64][q: dstride x f32][hash: cap x u32].
+
+__device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+
+template <int METRIC, int STEPS>
+__global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id();
+    const uint32_t qi = blockIdx.x;
+    const int ef = p.ef;
+    uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
+    float* qf = reinterpret_cast<float*>(tie + kTieCap);
+    uint32_t* hash = reinterpret_cast<uint32_t*>(qf + p.dstride);
+    const float4* qs = reinterpret_cast<const float4*>(qf);
+    const uint32_t cap = 1u << p.hash_bits;
+    const uint32_t hmask = cap - 1u;
+    const uint32_t hshift = 32u - p.hash_bits;
+
+    for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
+    for (uint32_t i = lane; i < p.dstride; i += 64)
+        qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
+    wave_sync();
+
+    uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;  // this lane's list entry (empty)
+    int size = 1, tsize = 0, hops = 0, dist_calc = 1, edges = 0;
+    uint32_t worst;                                // hi of lane size-1 (wave-uniform)
+    const uint32_t entry = p.entries ? p.entries[qi] : 0u;
+    {
+        const float d0 = walk_dist<METRIC, STEPS>(qs, p.db + (size_t)entry * p.dstride, p.dim);
+        worst = fkey(d0);
+        if (lane == 0) {
+            hi = worst;
+            lo = entry << 1;
+            hash[(entry * 0x9E3779B1u) >> hshift] = entry;
+        }
+        wave_sync();
+    }
+
+    bool handed_over = false;
+    while (true) {
+        // ---- next node to expand: closest unexpanded entry, ties -> largest id -------------
+        const bool un = !(lo & 1u);
+        const uint64_t mu = __ballot(un);
+        int best = -1;
+        uint32_t hi_p = 0;
+        if (mu) {
+            const int pl = __ffsll((unsigned long long)mu) - 1;
+            hi_p = readlane_u32(hi, pl);
+            const uint64_t ms = __ballot(un && hi == hi_p);
+            best = 63 - __clzll((long long)ms);
+        }
+        uint32_t node;
+        bool from_tie = false;
+        if (tsize > 0 && (best < 0 || hi_p == worst)) {
+            // tie entries all sit at the worst distance: the largest id among them competes
+            uint32_t v = (lane < tsize) ? key_id(tie[lane]) + 1u : 0u;
+            int w = lane;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t ov = (uint32_t)__shfl_xor((int)v, off);
+                const int ow = __shfl_xor(w, off);
+                if (ov > v) { v = ov; w = ow; }
+            }
+            // every lane now holds the same (v, w); tell the compiler so (keeps loop state scalar)
+            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            w = __builtin_amdgcn_readfirstlane(w);
+            const uint32_t lid = (best >= 0) ? (readlane_u32(lo, best) >> 1) : 0u;
+            if (best < 0 || v - 1u > lid) {
+                from_tie = true;
+                node = v - 1u;
+                if (lane == 0) tie[w] = tie[tsize - 1];
+                tsize -= 1;
+                wave_sync();
+            }
+        }
+        if (!from_tie) {
+            if (best < 0) break;
+            node = readlane_u32(lo, best) >> 1;
+            if (lane == best) lo |= 1u;
+        }
+
+        // ---- expand: neighbours in list order -----------------------------------------------
+        const uint32_t* row = p.ell + (size_t)node * p.ell_stride;
+        for (uint32_t c = 0; c < p.ell_stride; c += 64) {
+            const uint32_t nb = (c + lane < p.ell_stride) ? row[c + lane] : kInvalidId;
+            const bool valid = nb != kInvalidId;
+            const uint64_t mv = __ballot(valid);
+            if (!mv) break;
+            if ((uint32_t)dist_calc + 64u > p.hash_limit) { handed_over = true; break; }
+            edges += __popcll(mv);
+            bool fresh = false;
+            if (valid) {
+                uint32_t h = (nb * 0x9E3779B1u) >> hshift;
+                while (true) {
+                    const uint32_t old = atomicCAS(&hash[h], kInvalidId, nb);
+                    if (old == kInvalidId) { fresh = true; break; }
+                    if (old == nb) break;
+                    h = (h + 1u) & hmask;
+                }
+            }
+            uint32_t dk = 0xFFFFFFFFu;
+            if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, p.db + (size_t)nb * p.dstride, p.dim));
+            const uint64_t mf = __ballot(fresh);
+            dist_calc += __popcll(mf);
+            uint64_t m = __ballot(fresh && (size < ef || dk < worst));
+            while (m) {
+                const int l = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                const uint32_t dl = readlane_u32(dk, l);
+                if (size >= ef && !(dl < worst)) continue;  // search_function.h:31, current worst
+                const uint32_t nlo = readlane_u32(nb, l) << 1;
+                const uint64_t key = ((uint64_t)hi << 32) | lo;
+                const uint64_t nk = ((uint64_t)dl << 32) | nlo;
+                const bool lt = key < nk;
+                const int pos = __popcll(__ballot(lt));
+                const bool full = size >= ef;
+                const uint32_t ev_hi = readlane_u32(hi, ef - 1);
+                const uint32_t ev_lo = readlane_u32(lo, ef - 1);
+                const uint32_t slo = dpp_wave_shr1(lo);
+                const uint32_t shi = dpp_wave_shr1(hi);
+                if (!lt && lane < ef) { lo = slo; hi = shi; }
+                if (lane == pos) { lo = nlo; hi = dl; }
+                if (!full) size += 1;
+                worst = readlane_u32(hi, size - 1);
+                if (full) {
+                    if (ev_hi == worst) {           // evicted at a distance that is still the worst
+                        if (!(ev_lo & 1u)) {
+                            if (tsize >= kTieCap) { handed_over = true; break; }
+                            if (lane == 0) tie[tsize] = ((uint64_t)ev_hi << 32) | ev_lo;
+                            tsize += 1;
+                            wave_sync();
+                        }
+                    } else {
+                        tsize = 0;                  // worst distance decreased: old ties are dead
+                    }
+                }
+            }
+            if (handed_over) break;
+        }
+        if (handed_over) break;
+        hops += 1;
+    }
+
+    if (handed_over) {
+        if (lane == 0) {
+            const uint32_t slot = atomicAdd(p.ovf_count, 1u);
+            p.ovf_list[slot] = qi;
+        }
+        return;
+    }
+    // results in POP order (worst -> best): sorted index i goes to position kept-1-i
+    const int kept = size < p.k ? size : p.k;
+    if (lane < (int)p.cand_stride) {
+        const int r = kept - 1 - lane;
+        if (lane < kept) {
+            p.cand[(size_t)qi * p.cand_stride + r] = lo >> 1;
+            if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + r] = fkey_inv(hi);
+        } else {
+            p.cand[(size_t)qi * p.cand_stride + lane] = kInvalidId;
+            if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + lane] = __builtin_inff();
+        }
+    }
+    if (lane == 0) {
+        p.count[qi] = kept;
+        p.hops[qi] = hops;
+        p.dist_calc[qi] = dist_calc;
+        if (p.edges) p.edges[qi] = edges;
+        if (p.best) p.best[qi] = lo >> 1;
+    }
 }
 
 // ---- general kernel: exact for every input (any ef, any number of ties, any visited count) ----
@@ -666,7 +851,7 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t count) {
 // ------------------------------------------------------------------------------------------
 
 size_t walk_fast_lds_bytes(const WalkParams& p) {
-    const size_t ef_pad = ((size_t)p.ef + 63) & ~(size_t)63;
+    const size_t ef_pad = p.ef <= 64 ? 0 : (((size_t)p.ef + 63) & ~(size_t)63);  // ef <= 64: list in registers
     return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)p.dstride * 4 + ((size_t)4 << p.hash_bits);
 }
 
@@ -681,6 +866,12 @@ static hipError_t set_lds(K kernel, size_t bytes) {
 template <int METRIC, int STEPS>
 static hipError_t launch_fast_t(const WalkParams& p, hipStream_t s) {
     const size_t lds = walk_fast_lds_bytes(p);
+    if (p.ef <= 64) {
+        hipError_t e = set_lds(walk_reg_kernel<METRIC, STEPS>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((walk_reg_kernel<METRIC, STEPS>), dim3(p.nq), dim3(64), lds, s, p);
+        return hipGetLastError();
+    }
     hipError_t e = set_lds(walk_fast_kernel<METRIC, STEPS>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((walk_fast_kernel<METRIC, STEPS>), dim3(p.nq), dim3(64), lds, s, p);

@@ -1,0 +1,343 @@
+// search_function.h -- drop-in for the reference's search/search_function.h on MI355X.
+//
+// Same free functions, parameter order and types as the reference, so search/final_test.cpp
+// compiles against this header unchanged apart from its data paths:
+//   TripleResult (:7-12), getOneSearchResults (:43-47), getRealNearest (:105-107),
+//   performTest (:128-134), performRealTests (:291-295), performNetTest (:319-325),
+//   performRealNetTests (:411-415).
+// What differs is where the work happens: the per-query loop inside the StopW region of
+// performTest / performNetTest (:151-188, :346-387) is ONE gbnns_search_ex call for the whole
+// batch (host buffers in, answers out, inside the same timed region); scoring and the result
+// line are produced exactly as the reference does (:389-407).
+//
+// Not available on the device path (the process exits with a message instead of silently doing
+// something else): use_second_graph = true / llf (auxiliary "long link" graph, :73-80) and more
+// than one entry point per query -- final_test.cpp uses neither.
+// makeStep (:15-40) is an internal step of the walk and has no host-visible counterpart.
+#pragma once
+
+#include <queue>
+#include <tuple>
+
+#include "support_classes.h"
+#include "visited_list_pool.h"
+
+using namespace std;
+
+struct TripleResult {
+    priority_queue<pair<float, int>> topk;
+    int hops;
+    int dist_calc;
+    int degree;
+};
+
+// ---- device index cache ----------------------------------------------------------------------
+// The reference passes raw vectors to every call; the device copy is created on first use and
+// reused while the same buffers are passed again (performRealNetTests calls performNetTest once
+// per ef with identical data).
+typedef std::tuple<const void*, const void*, const void*, const void*, size_t, size_t, size_t, int> GbnnsKey;
+
+inline std::map<GbnnsKey, gbnns_index*>& gbnnsCache() {
+    static std::map<GbnnsKey, gbnns_index*> cache;
+    return cache;
+}
+
+inline gbnns_index* gbnnsIndexFor(vector<vector<uint32_t>>& graph, const float* db, size_t n, size_t d,
+                                  const float* db_low, size_t d_low, const Net* net, size_t d_hidden,
+                                  Metric* metric) {
+    const GbnnsKey key(db, db_low, &graph, net, n, d, d_low, metric->gbnnsMetric());
+    auto it = gbnnsCache().find(key);
+    if (it != gbnnsCache().end()) return it->second;
+    const GbnnsCsr csr = gbnnsToCsr(graph);
+    gbnns_index_desc desc = {};
+    desc.struct_size = sizeof desc;
+    desc.metric = metric->gbnnsMetric();
+    desc.mem_kind = GBNNS_MEM_HOST;
+    desc.n = n;
+    desc.d = (uint32_t)d;
+    desc.db = db;
+    if (db_low) {
+        desc.d_low = (uint32_t)d_low;
+        desc.db_low = db_low;
+    }
+    desc.graph_offsets = csr.offsets.data();
+    desc.graph_nbrs = csr.nbrs.data();
+    if (net) {
+        desc.d_hidden = (uint32_t)d_hidden;
+        desc.net_l1 = net->layerFirst.data();
+        desc.net_l2 = net->layerSecond.data();
+        desc.net_l3 = net->layerFinal.data();
+    }
+    const char* dev = getenv("GBNNS_DEVICE");
+    desc.device = dev ? atoi(dev) : 0;
+    gbnns_index* ix = nullptr;
+    if (gbnns_index_create(&desc, &ix)) gbnnsDie("gbnns_index_create");
+    gbnnsCache()[key] = ix;
+    return ix;
+}
+
+inline void gbnnsRequireDevicePath(bool use_second_graph, bool llf) {
+    if (use_second_graph || llf) {
+        std::cerr << "gbnns: use_second_graph / llf are not implemented on the MI355X path" << std::endl;
+        exit(2);
+    }
+}
+
+inline vector<uint32_t> gbnnsEntries(const vector<vector<uint32_t>>& inter_points, size_t n_q) {
+    vector<uint32_t> e(n_q, 0);
+    for (size_t i = 0; i < n_q && i < inter_points.size(); ++i) {
+        if (inter_points[i].size() != 1) {
+            std::cerr << "gbnns: exactly one entry point per query is supported" << std::endl;
+            exit(2);
+        }
+        e[i] = inter_points[i][0];
+    }
+    return e;
+}
+
+// One batch on the device.  mode NET / LOWQ: two-stage with ef = recheck_size;
+// mode PLAIN: walk in the space of the index's `db` with (ef, k), answer = best.
+inline void gbnnsBatch(gbnns_index* ix, int mode, const float* queries, const float* queries_low,
+                       size_t n_q, int ef, int k, const vector<uint32_t>& entries, vector<uint32_t>& ans,
+                       vector<int32_t>& hops, vector<int32_t>& dist_calc) {
+    gbnns_search_args a = {};
+    a.struct_size = sizeof a;
+    a.mode = mode;
+    a.ef = ef;
+    a.k = k;
+    a.mem_kind = GBNNS_MEM_HOST;
+    a.n_q = n_q;
+    a.queries = queries;
+    a.queries_low = queries_low;
+    a.entry_ids = entries.data();
+    a.out_ids = ans.data();
+    a.out_hops = hops.data();
+    a.out_dist_calc = dist_calc.data();
+    if (gbnns_search_ex(ix, &a)) gbnnsDie("gbnns_search_ex");
+}
+
+// ---- per-query entry points (single-query device calls; the batch functions below are the fast
+// path) ------------------------------------------------------------------------------------------
+
+TripleResult getOneSearchResults(const float* query, const float* db, uint32_t N, uint32_t d,
+                                 vector<vector<uint32_t>>& main_graph, vector<vector<uint32_t>>& auxiliary_graph,
+                                 int ef, int k, vector<uint32_t>& inter_points, Metric* metric,
+                                 VisitedListPool* visitedlistpool, bool use_second_graph, bool llf,
+                                 uint32_t hops_bound) {
+    (void)auxiliary_graph; (void)visitedlistpool; (void)hops_bound;
+    gbnnsRequireDevicePath(use_second_graph, llf);
+    if (inter_points.size() != 1) {
+        std::cerr << "gbnns: exactly one entry point per query is supported" << std::endl;
+        exit(2);
+    }
+    gbnns_index* ix = gbnnsIndexFor(main_graph, db, N, d, nullptr, 0, nullptr, 0, metric);
+    const int kept = k < ef ? k : ef;
+    vector<uint32_t> cand(kept);
+    vector<float> cdist(kept);
+    uint32_t best = 0;
+    int32_t hops = 0, dc = 0;
+    gbnns_search_args a = {};
+    a.struct_size = sizeof a;
+    a.mode = GBNNS_MODE_PLAIN;
+    a.ef = ef;
+    a.k = kept;
+    a.mem_kind = GBNNS_MEM_HOST;
+    a.n_q = 1;
+    a.queries = query;
+    a.entry_ids = inter_points.data();
+    a.out_ids = &best;
+    a.out_hops = &hops;
+    a.out_dist_calc = &dc;
+    a.out_cand = cand.data();
+    a.out_cand_dist = cdist.data();
+    if (gbnns_search_ex(ix, &a)) gbnnsDie("gbnns_search_ex");
+    TripleResult r;
+    for (int i = 0; i < kept; ++i)
+        if (cand[i] != 0xFFFFFFFFu) r.topk.emplace(cdist[i], (int)cand[i]);
+    r.hops = hops;
+    r.dist_calc = dc;
+    r.degree = 0;
+    return r;
+}
+
+int getRealNearest(const float* point_q, int k, int d, int d_low, priority_queue<pair<float, int>>& topk,
+                   vector<float>& ds, Metric* metric) {
+    (void)k; (void)d_low;
+    vector<uint32_t> ids;
+    while (!topk.empty()) {  // pop order: worst -> best, as the reference walks the heap (:109-122)
+        ids.push_back((uint32_t)topk.top().second);
+        topk.pop();
+    }
+    static vector<vector<uint32_t>> no_graph;  // re-rank needs no adjacency
+    if (no_graph.size() != ds.size() / d) no_graph.assign(ds.size() / d, vector<uint32_t>());
+    gbnns_index* ix = gbnnsIndexFor(no_graph, ds.data(), ds.size() / d, d, nullptr, 0, nullptr, 0, metric);
+    uint32_t out = 0;
+    const int32_t count = (int32_t)ids.size();
+    if (gbnns_rerank(ix, point_q, 1, ids.data(), (uint32_t)ids.size(), &count, &out, GBNNS_MEM_HOST, nullptr))
+        gbnnsDie("gbnns_rerank");
+    return (int)out;
+}
+
+// ---- scoring + result line (search_function.h:190-209 / :389-407) ------------------------------
+inline void gbnnsScore(const vector<uint32_t>& ans, vector<float>& ds, vector<uint32_t>& truth, int d,
+                       int n_q, int n_tr, Metric* metric, float& acc) {
+    for (int i = 0; i < n_q; ++i) {
+        acc += ans[i] == truth[(size_t)i * n_tr];
+        // SIFT duplicate rule: the 2nd ground-truth id also counts when it is an exact duplicate
+        const float* first = ds.data() + (size_t)d * truth[(size_t)i * n_tr];
+        const float* second = ds.data() + (size_t)d * truth[(size_t)i * n_tr + 1];
+        const float dist = metric->Dist(first, second, d);
+        if (dist == 0 and truth[(size_t)i * n_tr] != truth[(size_t)i * n_tr + 1])
+            acc += ans[i] == truth[(size_t)i * n_tr + 1];
+    }
+}
+
+inline void gbnnsReport(std::ofstream& outfile, const string& graph_name, float acc, long long hops,
+                        long long dist_calc, float work_time, int num_exp, int n_q) {
+    // same expression shapes as the reference: float / int, integer / integer, float / double
+    const long long denom = (long long)num_exp * n_q;
+    cout << "graph_type " << graph_name << " acc " << acc / (num_exp * n_q) << " hops " << hops / denom
+         << " dist_calc " << dist_calc / denom << " work_time " << work_time / (num_exp * 1e6 * n_q) << endl;
+    outfile << "graph_type " << graph_name << " acc " << acc / (num_exp * n_q) << " hops " << hops / denom
+            << " dist_calc " << dist_calc / denom << " work_time " << work_time / (num_exp * 1e6 * n_q) << endl;
+}
+
+// ---- batch harness ---------------------------------------------------------------------------
+
+void performTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>>& kl_graph, vector<float>& ds,
+                 vector<float>& queries, vector<float>& ds_low, vector<float>& queries_low,
+                 vector<uint32_t>& truth, int n, int d, int d_low, int n_q, int n_tr, int ef, int k,
+                 string graph_name, Metric* metric, const char* output_txt,
+                 vector<vector<uint32_t>> inter_points, bool use_second_graph, bool llf, uint32_t hops_bound,
+                 int dist_calc_boost, int recheck_size, int number_exper, int number_of_threads) {
+    (void)kl_graph; (void)hops_bound; (void)number_of_threads;
+    gbnnsRequireDevicePath(use_second_graph, llf);
+    std::ofstream outfile;
+    outfile.open(output_txt, std::ios_base::app);
+
+    // which device call reproduces the reference's branch (:158-182)
+    gbnns_index* ix;
+    int mode, run_ef, run_k;
+    const float* q_main = queries.data();
+    const float* q_low = nullptr;
+    if (d != d_low && recheck_size > 0) {
+        ix = gbnnsIndexFor(knn_graph, ds.data(), n, d, ds_low.data(), d_low, nullptr, 0, metric);
+        mode = GBNNS_MODE_LOWQ; run_ef = recheck_size; run_k = recheck_size;
+        q_low = queries_low.data();
+    } else if (d != d_low) {
+        ix = gbnnsIndexFor(knn_graph, ds_low.data(), n, d_low, nullptr, 0, nullptr, 0, metric);
+        mode = GBNNS_MODE_PLAIN; run_ef = ef; run_k = k;
+        q_main = queries_low.data();
+    } else {
+        ix = gbnnsIndexFor(knn_graph, ds.data(), n, d, nullptr, 0, nullptr, 0, metric);
+        mode = GBNNS_MODE_PLAIN; run_ef = ef; run_k = k;
+    }
+    const vector<uint32_t> entries = gbnnsEntries(inter_points, n_q);
+
+    long long hops = 0;
+    long long dist_calc = 0 + (long long)dist_calc_boost * n_q;
+    float acc = 0;
+    float work_time = 0;
+    int num_exp = 0;
+    vector<int32_t> q_hops(n_q), q_dc(n_q);
+    for (int v = 0; v < number_exper; ++v) {
+        num_exp += 1;
+        vector<uint32_t> ans(n_q);
+        StopW stopw = StopW();
+        gbnnsBatch(ix, mode, q_main, q_low, n_q, run_ef, run_k, entries, ans, q_hops, q_dc);
+        work_time += stopw.getElapsedTimeMicro();
+        for (int i = 0; i < n_q; ++i) {
+            hops += q_hops[i];
+            dist_calc += q_dc[i] + (mode == GBNNS_MODE_LOWQ ? recheck_size : 0);
+        }
+        gbnnsScore(ans, ds, truth, d, n_q, n_tr, metric, acc);
+    }
+    gbnnsReport(outfile, graph_name, acc, hops, dist_calc, work_time, num_exp, n_q);
+}
+
+inline vector<vector<uint32_t>> gbnnsInterPoints(int n, int n_q, std::mt19937& random_gen, const string& graph_name) {
+    // "hnsw*" graphs start from node 0, everything else from a uniformly random node (:297-307)
+    vector<vector<uint32_t>> inter_points(n_q);
+    const int mult = graph_name.substr(0, 4) == "hnsw" ? 0 : 1;
+    uniform_int_distribution<int> uniform_distr(0, n - 1);
+    for (int j = 0; j < n_q; ++j) inter_points[j].push_back(uniform_distr(random_gen) * mult);
+    return inter_points;
+}
+
+void performRealTests(int n, int d, int d_low, int n_q, int n_tr, vector<int> efs, std::mt19937 random_gen,
+                      vector<vector<uint32_t>>& main_graph, vector<vector<uint32_t>>& kl, vector<float>& db,
+                      vector<float>& queries, vector<float>& db_low, vector<float>& queries_low,
+                      vector<uint32_t>& truth, const char* output_txt, Metric* metric, string graph_name,
+                      bool use_second_graph, bool llf, int number_exper, int number_of_threads) {
+    const vector<vector<uint32_t>> inter_points = gbnnsInterPoints(n, n_q, random_gen, graph_name);
+    const uint32_t hops_bound = 50;
+    for (size_t i = 0; i < efs.size(); ++i)
+        performTest(main_graph, kl, db, queries, db_low, queries_low, truth, n, d, d_low, n_q, n_tr, efs[i], 1,
+                    graph_name, metric, output_txt, inter_points, use_second_graph, llf, hops_bound, 0, efs[i],
+                    number_exper, number_of_threads);
+}
+
+void performNetTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>>& kl_graph, vector<float>& ds,
+                    vector<float>& queries, vector<float>& ds_low, const Net* net, size_t d_hidden,
+                    vector<uint32_t>& truth, int n, int d, int d_low, int n_q, int n_tr, int ef, int k,
+                    string graph_name, Metric* metric, const char* output_txt,
+                    vector<vector<uint32_t>> inter_points, bool use_second_graph, bool llf, uint32_t hops_bound,
+                    int dist_calc_boost, int recheck_size, int number_exper, int number_of_threads) {
+    (void)kl_graph; (void)hops_bound; (void)number_of_threads;
+    gbnnsRequireDevicePath(use_second_graph, llf);
+    std::ofstream outfile;
+    outfile.open(output_txt, std::ios_base::app);
+
+    // branches of the reference's loop body (:353-381)
+    const bool two_stage = d != d_low && recheck_size > 0;
+    const bool low_only = d != d_low && !two_stage;
+    gbnns_index* ix = (d != d_low)
+                          ? gbnnsIndexFor(knn_graph, ds.data(), n, d, ds_low.data(), d_low, net, d_hidden, metric)
+                          : gbnnsIndexFor(knn_graph, ds.data(), n, d, nullptr, 0, nullptr, 0, metric);
+    gbnns_index* ix_low = low_only ? gbnnsIndexFor(knn_graph, ds_low.data(), n, d_low, nullptr, 0, nullptr, 0, metric)
+                                   : nullptr;
+    const vector<uint32_t> entries = gbnnsEntries(inter_points, n_q);
+
+    long long hops = 0;
+    long long dist_calc = 0 + (long long)dist_calc_boost * n_q;
+    float acc = 0;
+    float work_time = 0;
+    int num_exp = 0;
+    vector<int32_t> q_hops(n_q), q_dc(n_q);
+    vector<float> q_low;
+    for (int v = 0; v < number_exper; ++v) {
+        num_exp += 1;
+        vector<uint32_t> ans(n_q);
+        StopW stopw = StopW();
+        if (two_stage) {
+            gbnnsBatch(ix, GBNNS_MODE_NET, queries.data(), nullptr, n_q, recheck_size, recheck_size, entries, ans,
+                       q_hops, q_dc);
+        } else if (low_only) {
+            q_low.resize((size_t)n_q * d_low);
+            if (gbnns_project(ix, queries.data(), n_q, q_low.data(), GBNNS_MEM_HOST, nullptr)) gbnnsDie("gbnns_project");
+            gbnnsBatch(ix_low, GBNNS_MODE_PLAIN, q_low.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc);
+        } else {
+            gbnnsBatch(ix, GBNNS_MODE_PLAIN, queries.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc);
+        }
+        work_time += stopw.getElapsedTimeMicro();
+        for (int i = 0; i < n_q; ++i) {
+            hops += q_hops[i];
+            dist_calc += q_dc[i] + (two_stage ? recheck_size : 0);
+        }
+        gbnnsScore(ans, ds, truth, d, n_q, n_tr, metric, acc);
+    }
+    gbnnsReport(outfile, graph_name, acc, hops, dist_calc, work_time, num_exp, n_q);
+}
+
+void performRealNetTests(int n, int d, int d_low, int n_q, int n_tr, vector<int> efs, std::mt19937 random_gen,
+                         vector<vector<uint32_t>>& main_graph, vector<vector<uint32_t>>& kl, vector<float>& db,
+                         vector<float>& queries, vector<float>& db_low, const Net* net, size_t d_hidden,
+                         vector<uint32_t>& truth, const char* output_txt, Metric* metric, string graph_name,
+                         bool use_second_graph, bool llf, int number_exper, int number_of_threads) {
+    const vector<vector<uint32_t>> inter_points = gbnnsInterPoints(n, n_q, random_gen, graph_name);
+    const uint32_t hops_bound = 50;
+    for (size_t i = 0; i < efs.size(); ++i)
+        performNetTest(main_graph, kl, db, queries, db_low, net, d_hidden, truth, n, d, d_low, n_q, n_tr, efs[i], 1,
+                       graph_name, metric, output_txt, inter_points, use_second_graph, llf, hops_bound, 0, efs[i],
+                       number_exper, number_of_threads);
+}

@@ -117,6 +117,14 @@ int gbnns_search_batch(gbnns_index* index, const float* queries, size_t n_q, int
 int gbnns_project(gbnns_index* index, const float* x, uint64_t n_x, float* out, int mem_kind,
                   void* stream);
 
+/* getRealNearest (search_function.h:105-125) over a batch: for query i, cand[i*stride ..] holds
+ * count[i] (NULL: stride) candidate ids in POP order (worst -> best in the low-dim space); the
+ * answer is the strict minimum of the exact distance in the space of `db`, earlier entries
+ * winning ties. */
+int gbnns_rerank(gbnns_index* index, const float* queries, uint64_t n_q, const uint32_t* cand,
+                 uint32_t cand_stride, const int32_t* count, uint32_t* out_ids, int mem_kind,
+                 void* stream);
+
 /* Per-kernel device timing (hipEvent pairs on the launch stream), accumulated since the last
  * reset.  Reading synchronises the recorded events. */
 typedef struct {

@@ -1,0 +1,83 @@
+"""The C++ drop-in (gbnns_dim_red_amd/search/final_test) end to end on the GPU: files in the
+reference's formats in, result lines out, compared with the lines the reference's own harness
+(performRealNetTests / performRealTests, compiled reference) printed for the same inputs."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "gbnns_dim_red_amd", "search", "final_test")
+
+
+def write_xvecs(path, a):
+    a = np.ascontiguousarray(a)
+    n, d = a.shape
+    rec = np.empty((n, d + 1), np.uint32)
+    rec[:, 0] = d
+    rec[:, 1:] = a.view(np.uint32)
+    rec.tofile(path)
+
+
+def write_edges(path, off, nbr):
+    with open(path, "wb") as f:
+        for i in range(len(off) - 1):
+            row = nbr[int(off[i]):int(off[i + 1])]
+            np.array([len(row)], np.uint32).tofile(f)
+            row.astype(np.uint32).tofile(f)
+
+
+@pytest.mark.parametrize("name", ["sift_toy", "tail_toy", "ties_toy"])
+def test_final_test_result_lines(tmp_path, orc, name):
+    assert os.path.exists(BIN), "build() must produce the drop-in driver"
+    gd = gu.load(name)
+    c = gd.case
+    ds = "toy"
+    data = tmp_path / "data"
+    models = tmp_path / "models"
+    data.mkdir()
+    models.mkdir()
+    db_low = orc.project(c.net, c.base, threads=4)
+    write_xvecs(data / f"{ds}_base.fvecs", c.base)
+    write_xvecs(data / f"{ds}_query.fvecs", c.queries)
+    write_xvecs(data / f"{ds}_groundtruth.ivecs", gd["truth"])
+    write_xvecs(data / f"{ds}_base_angular_optimal.fvecs", db_low)
+    off, nbr = gd.graph
+    write_edges(models / "hnsw_toygraph.ivecs", off, nbr)
+    write_edges(models / "hnsw_toygraph_angular_optimal.ivecs", off, nbr)
+    for i, layer in enumerate(c.net, 1):
+        write_xvecs(models / f"{ds}_net_as_matrix_angular_optimal_{i}.fvecs", layer)
+    efs = ",".join(str(e) for e in gd.efs)
+    params = tmp_path / "params.txt"
+    params.write_text("\n".join([
+        f"{ds} n {c.n}", f"{ds} n_q {c.nq}", f"{ds} n_tr {gd['truth'].shape[1]}", f"{ds} d {c.d}",
+        f"{ds} d_low {c.dlow}", f"{ds} d_hidden {c.dh}", f"{ds} efs {efs}", f"{ds} efs_hnsw {efs}",
+        f"{ds} hnsw_name toygraph", "other n 5", "# comment line with three tokens"]) + "\n")
+    env = dict(os.environ, GBNNS_NUM_EXPER="2")
+    p = subprocess.run([BIN, ds, str(data), str(models), str(tmp_path), str(params)], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = open(tmp_path / f"final_results_{ds}.txt").read().splitlines()
+    got = sorted(ln.split(" work_time ")[0] for ln in lines)
+    assert got == sorted(gd.meta["result_lines"])
+    # the same lines were echoed to stdout, and every one carries a positive work_time
+    for ln in lines:
+        assert ln in p.stdout
+        assert float(ln.split(" work_time ")[1]) > 0
+
+
+def test_final_test_rejects_bad_files(tmp_path):
+    # wrong dimension in an fvecs file -> "file error" + exit(1), as the reference does
+    (tmp_path / "params.txt").write_text("toy n 2\ntoy n_q 1\ntoy n_tr 2\ntoy d 4\ntoy d_low 2\n"
+                                         "toy d_hidden 4\ntoy efs 1\ntoy efs_hnsw 1\ntoy hnsw_name g\n")
+    write_xvecs(tmp_path / "toy_base.fvecs", np.zeros((2, 3), np.float32))
+    p = subprocess.run([BIN, "toy", str(tmp_path), str(tmp_path), str(tmp_path),
+                        str(tmp_path / "params.txt")], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "file error" in p.stdout
+    p = subprocess.run([BIN], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and "Need to specify parameters" in p.stdout
