@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hash-capacity", type=int, default=0, help="0 = library default (tuning knob)")
     ap.add_argument("--sweep", action="store_true", help="also time every reference ef (stderr)")
     ap.add_argument("--cache-dir", default=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"))
     args = ap.parse_args()
@@ -109,7 +110,7 @@ def main():
 
     def step():
         nonlocal gathered
-        r = ix.search(q, ef, want=want, out=out)
+        r = ix.search(q, ef, want=want, out=out, hash_capacity=args.hash_capacity)
         if world > 1:
             # the path's only exchange step: all-gather of the int32 answer ids over RCCL/xGMI
             gathered = torch.empty(world * args.nq, dtype=r["ids"].dtype, device=dev)
@@ -145,6 +146,10 @@ def main():
     # ---- algorithmic bytes of the dominant kernel (the beam walk), SURVEY.md section 8d ------
     dc = res["dist_calc"].double()
     hops = res["hops"].double()
+    if rank == 0:
+        qs = torch.tensor([0.5, 0.9, 0.99, 0.999, 1.0], dtype=torch.float64, device=dev)
+        log("dist_calc quantiles 50/90/99/99.9/max:", [int(v) for v in torch.quantile(dc, qs).tolist()],
+            "hops max", int(hops.max().item()))
     edges = res["edges"].double()
     d_low, d = ds.d_low, ds.d
     walk_bytes = (dc * 4 * d_low + edges * 4 + hops * 8 + 4 * d_low + 4 * ef).sum().item()

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -109,6 +110,13 @@ struct gbnns_index {
     gbnns_profile acc{};
     // last-call statistics (host mode only)
     uint32_t last_general = 0;
+    // visited-set sizing feedback: stats of the previous call arrive asynchronously in pinned memory
+    uint32_t* h_stats = nullptr;       // [4] copy of ctrl after the walk kernels
+    hipEvent_t stats_ev = nullptr;
+    bool stats_pending = false;
+    int stats_ef = 0;
+    uint32_t stats_cap = 0;
+    std::map<int, uint32_t> cap_for_ef;
 };
 
 namespace {
@@ -338,6 +346,8 @@ int gbnns_index_destroy(gbnns_index* ix) {
     (void)hipSetDevice(ix->device);
     for (auto& pc : ix->pending)
         for (auto& e : pc.ev) (void)hipEventDestroy(e);
+    if (ix->stats_ev) (void)hipEventDestroy(ix->stats_ev);
+    if (ix->h_stats) (void)hipHostFree(ix->h_stats);
     DevBuf* bufs[] = {&ix->db_own, &ix->db_low_own, &ix->ell, &ix->net, &ix->q_in, &ix->q_low,
                       &ix->h1, &ix->h2, &ix->cand, &ix->cand_dist, &ix->cnt, &ix->hops, &ix->dc, &ix->edges,
                       &ix->out, &ix->entries, &ix->ovf_list, &ix->ctrl, &ix->g_bitmap, &ix->g_keys,
@@ -409,15 +419,15 @@ int gbnns_profile_read(gbnns_index* ix, gbnns_profile* out, int reset) {
     HIP_TRY(hipSetDevice(ix->device));
     int rc = prof_flush(ix);
     if (rc) return rc;
-    uint32_t total = 0;  // ctrl[2]: queries the general kernel has processed since the last reset
+    uint32_t total = 0;  // ctrl[3]: queries the general kernel has processed since the last reset
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&total, ix->ctrl.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&total, ix->ctrl.as<uint32_t>() + 3, 4, hipMemcpyDeviceToHost));
     ix->acc.general_queries = total;
     ix->acc.struct_size = sizeof(gbnns_profile);
     *out = ix->acc;
     if (reset) {
         ix->acc = gbnns_profile{};
-        HIP_TRY(hipMemset(ix->ctrl.as<uint32_t>() + 2, 0, 4));
+        HIP_TRY(hipMemset(ix->ctrl.as<uint32_t>() + 3, 0, 4));
     }
     return GBNNS_OK;
 }
@@ -611,26 +621,55 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     uint32_t* out_dev = host ? ix->out.as<uint32_t>() : a->out_ids;
     w.best = plain ? out_dev : nullptr;
     uint32_t* ctrl = ix->ctrl.as<uint32_t>();
-    w.ovf_count = ctrl; w.g_cursor = ctrl + 1; w.g_total = ctrl + 2; w.ovf_list = ix->ovf_list.as<uint32_t>();
+    w.ovf_count = ctrl; w.g_cursor = ctrl + 1; w.max_dc = ctrl + 2; w.g_total = ctrl + 3; w.ovf_list = ix->ovf_list.as<uint32_t>();
     w.g_bitmap = ix->g_bitmap.as<uint32_t>(); w.g_keys = ix->g_keys.as<uint64_t>();
     w.g_tie = ix->g_tie.as<uint64_t>(); w.bitmap_words = bitmap_words;
 
+    // Visited-set capacity.  First guess 32*ef entries at <= 75% load; afterwards the batch
+    // statistics of earlier calls (max dist_calc, hand-overs) size it: smallest power of two whose
+    // limit (7/8 load) still leaves 12.5% headroom over the largest walk seen; doubled whenever a
+    // call handed queries over.  Smaller tables -> more wavefronts per CU (LDS-bound occupancy).
+    if (ix->stats_pending && hipEventQuery(ix->stats_ev) == hipSuccess) {
+        ix->stats_pending = false;
+        const uint32_t ovf = ix->h_stats[0], maxdc = ix->h_stats[2];
+        uint32_t c = ix->stats_cap;
+        if (ovf > 0) {
+            c = std::min<uint32_t>(c * 2, 16384u);
+        } else {
+            while (c > 256 && maxdc + maxdc / 8 + 64 <= (c / 2) - (c / 2) / 8) c /= 2;
+        }
+        ix->cap_for_ef[ix->stats_ef] = c;  // stats_ef = ef * 4 + mode
+    }
     uint32_t cap;
-    if (a->hash_capacity) {
+    const bool auto_cap = a->hash_capacity == 0;
+    if (!auto_cap) {
         cap = (uint32_t)a->hash_capacity;
+    } else if (ix->cap_for_ef.count(ef * 4 + a->mode)) {
+        cap = ix->cap_for_ef[ef * 4 + a->mode];
     } else {
         const uint32_t target = std::max<uint32_t>(512u, 32u * (uint32_t)ef);
         cap = std::min<uint32_t>(pow2_ceil(target + target / 3 + 64), 16384u);
     }
     w.hash_bits = log2_u32(cap);
-    w.hash_limit = cap - cap / 4;
+    w.hash_limit = cap - cap / 8;
     w.all_general = walk_fast_lds_bytes(w) > kMaxLds ? 1 : 0;
 
-    HIP_TRY(hipMemsetAsync(ctrl, 0, 8, s));
+    HIP_TRY(hipMemsetAsync(ctrl, 0, 12, s));
     if (!w.all_general) HIP_TRY(launch_walk_fast(w, ix->metric, s));
     if (prof) HIP_TRY(hipEventRecord(pc.ev[2], s));
     HIP_TRY(launch_walk_general(w, ix->metric, s));
     if (prof) HIP_TRY(hipEventRecord(pc.ev[3], s));
+    if (auto_cap && !w.all_general && !ix->stats_pending) {
+        if (!ix->h_stats) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ix->h_stats), 16, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&ix->stats_ev, hipEventDisableTiming));
+        }
+        HIP_TRY(hipMemcpyAsync(ix->h_stats, ctrl, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(ix->stats_ev, s));
+        ix->stats_pending = true;
+        ix->stats_ef = ef * 4 + a->mode;
+        ix->stats_cap = cap;
+    }
 
     // ---- stage 3: re-rank in the original space ------------------------------------------
     if (!plain) {

@@ -44,6 +44,7 @@ struct WalkParams {
     // general kernel workspace: per slot [bitmap words][keys ef][tie n]
     uint32_t* g_cursor;      // [1] work-queue head
     uint32_t* g_total;       // [1] running count of queries the general kernel processed
+    uint32_t* max_dc;        // [1] max dist_calc over the batch (feeds the host's visited-set sizing)
     uint32_t* g_bitmap;      // [slots x bitmap_words]
     uint64_t* g_keys;        // [slots x ef]
     uint64_t* g_tie;         // [slots x n]

@@ -299,6 +299,7 @@ __device__ __forceinline__ void write_results(const WalkParams& p, uint32_t qi, 
         p.count[qi] = kept;
         p.hops[qi] = st.hops;
         p.dist_calc[qi] = st.dist_calc;
+        atomicMax(p.max_dc, (uint32_t)st.dist_calc);
         if (p.edges) p.edges[qi] = st.edges;
         if (p.best) p.best[qi] = key_id(keys[0]);
     }
@@ -455,6 +456,11 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
     }
 
     bool handed_over = false;
+    // Adjacency prefetch: right after a node is picked, the row of the entry that will be picked
+    // next IF this expansion inserts nothing closer is requested too.  The load stays in flight
+    // behind this hop's vector gathers (loads retire in order), so a correct guess removes one of
+    // the two dependent memory round trips of the next hop; a wrong guess costs one 128-B row.
+    uint32_t pf_node = kInvalidId, pf_val = kInvalidId;
     while (true) {
         // ---- next node to expand: closest unexpanded entry, ties -> largest id -------------
         const bool un = !(lo & 1u);
@@ -497,12 +503,36 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
             if (lane == best) lo |= 1u;
         }
 
-        // ---- expand: neighbours in list order -----------------------------------------------
+        // ---- adjacency row of `node` (prefetched or loaded now) + prefetch for the next hop -----
         const uint32_t* row = p.ell + (size_t)node * p.ell_stride;
+        uint32_t nb0;
+        if (node == pf_node) nb0 = pf_val;
+        else nb0 = ((uint32_t)lane < p.ell_stride) ? row[lane] : kInvalidId;
+        // consume nb0 BEFORE issuing the prefetch: the wait for a (conditionally issued) row load
+        // must not also cover the younger prefetch load
+        const uint64_t mv0 = __ballot(nb0 != kInvalidId);
+        {
+            const bool un2 = !(lo & 1u);
+            const uint64_t mu2 = __ballot(un2);
+            pf_node = kInvalidId;
+            if (mu2) {
+                const int pl2 = __ffsll((unsigned long long)mu2) - 1;
+                const uint32_t hp2 = readlane_u32(hi, pl2);
+                const uint64_t ms2 = __ballot(un2 && hi == hp2);
+                pf_node = readlane_u32(lo, 63 - __clzll((long long)ms2)) >> 1;
+                pf_val = ((uint32_t)lane < p.ell_stride) ? p.ell[(size_t)pf_node * p.ell_stride + lane] : kInvalidId;
+            }
+        }
+
+        // ---- expand: neighbours in list order -----------------------------------------------
         for (uint32_t c = 0; c < p.ell_stride; c += 64) {
-            const uint32_t nb = (c + lane < p.ell_stride) ? row[c + lane] : kInvalidId;
+            uint32_t nb = nb0;
+            uint64_t mv = mv0;
+            if (c) {
+                nb = (c + lane < p.ell_stride) ? row[c + lane] : kInvalidId;
+                mv = __ballot(nb != kInvalidId);
+            }
             const bool valid = nb != kInvalidId;
-            const uint64_t mv = __ballot(valid);
             if (!mv) break;
             if ((uint32_t)dist_calc + 64u > p.hash_limit) { handed_over = true; break; }
             edges += __popcll(mv);
@@ -582,6 +612,7 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
         p.count[qi] = kept;
         p.hops[qi] = hops;
         p.dist_calc[qi] = dist_calc;
+        atomicMax(p.max_dc, (uint32_t)dist_calc);
         if (p.edges) p.edges[qi] = edges;
         if (p.best) p.best[qi] = lo >> 1;
     }

@@ -14,7 +14,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("walk_fast_kernel", "walk_general_kernel", "rerank_kernel", "mlp_layer_kernel",
+    for key in ("walk_reg_kernel", "walk_fast_kernel", "walk_general_kernel", "rerank_kernel", "mlp_layer_kernel",
                 "normalize_kernel", "fill_u32_kernel"):
         if key in name:
             return key
