@@ -197,18 +197,6 @@ int build_ell(const uint64_t* off, const uint32_t* nbr, uint64_t n, std::vector<
     return GBNNS_OK;
 }
 
-uint32_t pow2_ceil(uint32_t v) {
-    uint32_t p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
-
-uint32_t log2_u32(uint32_t v) {
-    uint32_t b = 0;
-    while ((1u << b) < v) ++b;
-    return b;
-}
-
 constexpr size_t kMaxLds = 160 * 1024;
 
 }  // namespace
@@ -328,9 +316,9 @@ int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out) {
             ix->has_net = true;
         }
     }
-    if (!rc) rc = ix->ctrl.ensure(64);
+    if (!rc) rc = ix->ctrl.ensure(128);
     if (!rc) {
-        hipError_t e = hipMemset(ix->ctrl.p, 0, 64);
+        hipError_t e = hipMemset(ix->ctrl.p, 0, 128);
         if (e != hipSuccess) rc = fail(GBNNS_ERR_HIP, "ctrl init: %s", hipGetErrorString(e));
     }
     if (rc) {
@@ -407,6 +395,16 @@ int prof_flush(gbnns_index* ix) {
 }  // namespace
 
 extern "C" {
+
+// Diagnostic (not in gbnns.h): copies the 8 stamp sums of a GBNNS_STAMPS build and clears them.
+int gbnns_debug_read_stamps(gbnns_index* ix, unsigned long long* out8) {
+    if (!ix || !out8) return fail(GBNNS_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out8, ix->ctrl.as<uint32_t>() + 8, 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ix->ctrl.as<uint32_t>() + 8, 0, 64));
+    return GBNNS_OK;
+}
 
 int gbnns_profile_enable(gbnns_index* ix, int on) {
     if (!ix) return fail(GBNNS_ERR_INVALID, "null index");
@@ -527,8 +525,8 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     if (a->mode == GBNNS_MODE_NET && !ix->has_net) return fail(GBNNS_ERR_INVALID, "NET mode needs a net");
     if (a->mode != GBNNS_MODE_PLAIN && !ix->db_low) return fail(GBNNS_ERR_INVALID, "mode needs db_low");
     if (a->mode == GBNNS_MODE_LOWQ && !a->queries_low) return fail(GBNNS_ERR_INVALID, "queries_low missing");
-    if (a->hash_capacity != 0 && (a->hash_capacity < 128 || (a->hash_capacity & (a->hash_capacity - 1))))
-        return fail(GBNNS_ERR_INVALID, "hash_capacity must be a power of two >= 128");
+    if (a->hash_capacity != 0 && a->hash_capacity < 128)
+        return fail(GBNNS_ERR_INVALID, "hash_capacity must be 0 (auto) or >= 128");
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = static_cast<hipStream_t>(a->stream);
     const bool host = a->mem_kind == GBNNS_MEM_HOST;
@@ -625,35 +623,47 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.g_bitmap = ix->g_bitmap.as<uint32_t>(); w.g_keys = ix->g_keys.as<uint64_t>();
     w.g_tie = ix->g_tie.as<uint64_t>(); w.bitmap_words = bitmap_words;
 
-    // Visited-set capacity.  First guess 32*ef entries at <= 75% load; afterwards the batch
-    // statistics of earlier calls (max dist_calc, hand-overs) size it: smallest power of two whose
-    // limit (7/8 load) still leaves 12.5% headroom over the largest walk seen; doubled whenever a
-    // call handed queries over.  Smaller tables -> more wavefronts per CU (LDS-bound occupancy).
+    // Visited-set capacity.  The walk kernel's occupancy is LDS-bound, and a 10k-query batch is only
+    // a few "rounds" deep (queries / (256 CUs x resident wavefronts)), so the table is sized from
+    // the LDS budget: take the number of entries the walks need (first guess 43*ef; afterwards
+    // 9/7 x the largest dist_calc of earlier batches, doubled whenever a batch handed queries
+    // over), find how many wavefronts per CU that allows, then give each wavefront the whole
+    // 160 KB / wavefronts share (capacity need not be a power of two: slot = mulhi(hash, cap)).
     if (ix->stats_pending && hipEventQuery(ix->stats_ev) == hipSuccess) {
         ix->stats_pending = false;
         const uint32_t ovf = ix->h_stats[0], maxdc = ix->h_stats[2];
-        uint32_t c = ix->stats_cap;
-        if (ovf > 0) {
-            c = std::min<uint32_t>(c * 2, 16384u);
-        } else {
-            while (c > 256 && maxdc + maxdc / 8 + 64 <= (c / 2) - (c / 2) / 8) c /= 2;
-        }
-        ix->cap_for_ef[ix->stats_ef] = c;  // stats_ef = ef * 4 + mode
+        uint32_t need = (maxdc + maxdc / 8 + 64) / 7 * 8 + 8;
+        if (ovf > 0) need = std::max<uint32_t>(need, ix->stats_cap * 2);
+        ix->cap_for_ef[ix->stats_ef] = need;  // stats_ef = ef * 4 + mode
     }
+    const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride);
     uint32_t cap;
     const bool auto_cap = a->hash_capacity == 0;
     if (!auto_cap) {
         cap = (uint32_t)a->hash_capacity;
-    } else if (ix->cap_for_ef.count(ef * 4 + a->mode)) {
-        cap = ix->cap_for_ef[ef * 4 + a->mode];
     } else {
-        const uint32_t target = std::max<uint32_t>(512u, 32u * (uint32_t)ef);
-        cap = std::min<uint32_t>(pow2_ceil(target + target / 3 + 64), 16384u);
+        uint32_t need;
+        if (ix->cap_for_ef.count(ef * 4 + a->mode)) {
+            need = ix->cap_for_ef[ef * 4 + a->mode];
+        } else {
+            const uint32_t target = std::max<uint32_t>(512u, 32u * (uint32_t)ef);
+            need = target + target / 3 + 64;
+        }
+        const size_t gran = 512;  // LDS allocation granularity
+        const size_t want = (lds_fixed + (size_t)need * 4 + gran - 1) / gran * gran;
+        size_t slots = std::min<size_t>(32, kMaxLds / want);
+        if (slots == 0) {
+            cap = need;  // does not fit LDS at all: the general kernel takes the batch
+        } else {
+            const size_t share = kMaxLds / slots / gran * gran;
+            cap = (uint32_t)((share - lds_fixed) / 4);
+        }
     }
-    w.hash_bits = log2_u32(cap);
+    w.hash_cap = cap;
     w.hash_limit = cap - cap / 8;
     w.all_general = walk_fast_lds_bytes(w) > kMaxLds ? 1 : 0;
 
+    w.stamps = reinterpret_cast<unsigned long long*>(ctrl + 8);  // ctrl[8..23], diagnostic builds
     HIP_TRY(hipMemsetAsync(ctrl, 0, 12, s));
     if (!w.all_general) HIP_TRY(launch_walk_fast(w, ix->metric, s));
     if (prof) HIP_TRY(hipEventRecord(pc.ev[2], s));

@@ -27,7 +27,7 @@ struct WalkParams {
     int32_t k;               // results kept (<= ef); cand_stride = min(k, ef)
     const uint32_t* entries; // [nq] or nullptr (= node 0)
     // LDS visited set of the fast kernel
-    uint32_t hash_bits;      // capacity = 1 << hash_bits
+    uint32_t hash_cap;       // entries of the LDS visited set (any size >= 128)
     uint32_t hash_limit;     // max entries before a query is handed to the general kernel
     // outputs
     uint32_t* cand;          // [nq x cand_stride] pop order (worst -> best), kInvalidId pad
@@ -50,9 +50,11 @@ struct WalkParams {
     uint64_t* g_tie;         // [slots x n]
     uint32_t bitmap_words;
     int32_t all_general;     // 1: the general kernel takes every query (fast kernel skipped)
+    unsigned long long* stamps;  // diagnostic builds only (GBNNS_STAMPS): [8] segment cycle sums
 };
 
 size_t walk_fast_lds_bytes(const WalkParams& p);
+size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride);  // everything but the visited set
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s);
 

@@ -12,6 +12,10 @@
 
 #include "kernels.h"
 
+#ifndef GBNNS_EXP
+#define GBNNS_EXP 0  // >0: throw-away marginal-cost experiments, never shipped
+#endif
+
 namespace gbnns {
 
 namespace {
@@ -331,9 +335,7 @@ __global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
     float* qf = reinterpret_cast<float*>(tie + kTieCap);
     uint32_t* hash = reinterpret_cast<uint32_t*>(qf + p.dstride);
     const float4* qs = reinterpret_cast<const float4*>(qf);
-    const uint32_t cap = 1u << p.hash_bits;
-    const uint32_t hmask = cap - 1u;
-    const uint32_t hshift = 32u - p.hash_bits;
+    const uint32_t cap = p.hash_cap;  // any size: slot = mulhi(id * C, cap)
 
     for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
     for (uint32_t i = lane; i < p.dstride; i += 64)
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
         const float d0 = walk_dist<METRIC, STEPS>(qs, p.db + (size_t)entry * p.dstride, p.dim);
         if (lane == 0) {
             keys[0] = make_key(fkey(d0), entry);
-            hash[(entry * 0x9E3779B1u) >> hshift] = entry;
+            hash[__umulhi(entry * 0x9E3779B1u, cap)] = entry;
         }
         st.size = 1;
         wave_sync();
@@ -367,12 +369,12 @@ __global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
             st.edges += __popcll(mv);
             bool fresh = false;
             if (valid) {
-                uint32_t h = (nb * 0x9E3779B1u) >> hshift;
+                uint32_t h = __umulhi(nb * 0x9E3779B1u, cap);
                 while (true) {
                     const uint32_t old = atomicCAS(&hash[h], kInvalidId, nb);
                     if (old == kInvalidId) { fresh = true; break; }
                     if (old == nb) break;
-                    h = (h + 1u) & hmask;
+                    h = (h + 1u == cap) ? 0u : h + 1u;
                 }
             }
             uint32_t dk = 0xFFFFFFFFu;
@@ -414,6 +416,8 @@ __global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
 // of five dependent LDS round trips.  LDS keeps only the visited hash set, the query and the tie
 // list: [tie: kTieCap x u64][q: dstride x f32][hash: cap x u32].
 
+constexpr int kRegTieCap = 16;       // tie list of the register kernel (LDS, 128 B)
+
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
 }
@@ -421,19 +425,63 @@ __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
 
+#ifdef GBNNS_STAMPS
+// Diagnostic build only (make STAMPS=1): per-segment cycle sums of the hop loop, accumulated in
+// scalar registers and added to p.stamps[] once per wave.  Never enabled in the shipped library.
+#define STAMP(var)                                                                        \
+    unsigned long long var;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);
+#define STAMP_ADD(i, a, b) seg[i] += (b) - (a);
+#else
+#define STAMP(var)
+#define STAMP_ADD(i, a, b)
+#endif
+
+// Row distance split in two halves so the 16-B row loads can be issued early (before the visited
+// test) and consumed late: load_row<STEPS>() then l2_from_regs<STEPS>().
+template <int STEPS>
+struct RowRegs {
+    float4 v[STEPS > 0 ? STEPS : 1];
+};
+
+template <int STEPS>
+__device__ __forceinline__ void load_row(RowRegs<STEPS>& r, const float* row) {
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) r.v[t] = r4[t];
+}
+
+template <int STEPS, typename QP>
+__device__ __forceinline__ float l2_from_regs(const RowRegs<STEPS>& r, QP qs) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) {
+        const float4 bv = qs[t];
+        float e;
+        e = r.v[t].x - bv.x; s0 = s0 + e * e;  e = r.v[t].y - bv.y; s1 = s1 + e * e;
+        e = r.v[t].z - bv.z; s2 = s2 + e * e;  e = r.v[t].w - bv.w; s3 = s3 + e * e;
+    }
+    return ((s0 + s1) + s2) + s3;
+}
+
 template <int METRIC, int STEPS>
 __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef GBNNS_STAMPS
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    STAMP(t_begin)
+#endif
+    constexpr bool kEarlyLoad = (METRIC == 0 && STEPS > 0);  // speculative row loads
     const int lane = lane_id();
     const uint32_t qi = blockIdx.x;
     const int ef = p.ef;
     uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
-    float* qf = reinterpret_cast<float*>(tie + kTieCap);
+    float* qf = reinterpret_cast<float*>(tie + kRegTieCap);
     uint32_t* hash = reinterpret_cast<uint32_t*>(qf + p.dstride);
     const float4* qs = reinterpret_cast<const float4*>(qf);
-    const uint32_t cap = 1u << p.hash_bits;
-    const uint32_t hmask = cap - 1u;
-    const uint32_t hshift = 32u - p.hash_bits;
+    const uint32_t cap = p.hash_cap;  // any size: slot = mulhi(id * C, cap)
 
     for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
     for (uint32_t i = lane; i < p.dstride; i += 64)
@@ -450,60 +498,85 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
         if (lane == 0) {
             hi = worst;
             lo = entry << 1;
-            hash[(entry * 0x9E3779B1u) >> hshift] = entry;
+            hash[__umulhi(entry * 0x9E3779B1u, cap)] = entry;
         }
         wave_sync();
     }
 
-    bool handed_over = false;
-    // Adjacency prefetch: right after a node is picked, the row of the entry that will be picked
-    // next IF this expansion inserts nothing closer is requested too.  The load stays in flight
-    // behind this hop's vector gathers (loads retire in order), so a correct guess removes one of
-    // the two dependent memory round trips of the next hop; a wrong guess costs one 128-B row.
+    int status = 0;  // 0 = walking, 1 = finished, 2 = handed over to the general kernel
+    // Adjacency prefetch: when a node is picked, the row of the entry that will be picked next IF
+    // this expansion inserts nothing closer is requested too.  The load stays in flight behind this
+    // hop's vector gathers (loads retire in order), so a correct guess removes one of the two
+    // dependent memory round trips of the next hop; a wrong guess costs one 128-B row.
     uint32_t pf_node = kInvalidId, pf_val = kInvalidId;
     while (true) {
+        STAMP(t0)
         // ---- next node to expand: closest unexpanded entry, ties -> largest id -------------
-        const bool un = !(lo & 1u);
-        const uint64_t mu = __ballot(un);
-        int best = -1;
-        uint32_t hi_p = 0;
-        if (mu) {
-            const int pl = __ffsll((unsigned long long)mu) - 1;
-            hi_p = readlane_u32(hi, pl);
-            const uint64_t ms = __ballot(un && hi == hi_p);
-            best = 63 - __clzll((long long)ms);
+        const uint64_t mu = __ballot(!(lo & 1u));
+        uint32_t node = 0, pred = kInvalidId;
+        bool picked = false;
+        if (mu != 0 && tsize == 0) {
+            // common case: the two closest unexpanded entries have different distances
+            const int p1 = __ffsll((unsigned long long)mu) - 1;
+            const uint64_t mu2 = mu & (mu - 1);
+            if (mu2) {
+                const int p2 = __ffsll((unsigned long long)mu2) - 1;
+                if (readlane_u32(hi, p1) != readlane_u32(hi, p2)) {
+                    picked = true;
+                    node = readlane_u32(lo, p1) >> 1;
+                    pred = readlane_u32(lo, p2) >> 1;
+                    if (lane == p1) lo |= 1u;
+                }
+            } else {
+                picked = true;
+                node = readlane_u32(lo, p1) >> 1;
+                if (lane == p1) lo |= 1u;
+            }
         }
-        uint32_t node;
-        bool from_tie = false;
-        if (tsize > 0 && (best < 0 || hi_p == worst)) {
-            // tie entries all sit at the worst distance: the largest id among them competes
-            uint32_t v = (lane < tsize) ? key_id(tie[lane]) + 1u : 0u;
-            int w = lane;
+        if (!picked) {
+            // rare: equal-distance run among the unexpanded entries, a non-empty tie list, or the end
+            const bool un = !(lo & 1u);
+            int best = -1;
+            uint32_t hi_p = 0;
+            if (mu) {
+                const int pl = __ffsll((unsigned long long)mu) - 1;
+                hi_p = readlane_u32(hi, pl);
+                const uint64_t ms = __ballot(un && hi == hi_p);
+                best = 63 - __clzll((long long)ms);
+            }
+            bool from_tie = false;
+            if (tsize > 0 && (best < 0 || hi_p == worst)) {
+                // tie entries all sit at the worst distance: the largest id among them competes
+                uint32_t v = (lane < tsize) ? key_id(tie[lane]) + 1u : 0u;
+                int w = lane;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t ov = (uint32_t)__shfl_xor((int)v, off);
-                const int ow = __shfl_xor(w, off);
-                if (ov > v) { v = ov; w = ow; }
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint32_t ov = (uint32_t)__shfl_xor((int)v, off);
+                    const int ow = __shfl_xor(w, off);
+                    if (ov > v) { v = ov; w = ow; }
+                }
+                // every lane now holds the same (v, w); tell the compiler so (keeps loop state scalar)
+                v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+                w = __builtin_amdgcn_readfirstlane(w);
+                const uint32_t lid = (best >= 0) ? (readlane_u32(lo, best) >> 1) : 0u;
+                if (best < 0 || v - 1u > lid) {
+                    from_tie = true;
+                    node = v - 1u;
+                    if (lane == 0) tie[w] = tie[tsize - 1];
+                    tsize -= 1;
+                    wave_sync();
+                }
             }
-            // every lane now holds the same (v, w); tell the compiler so (keeps loop state scalar)
-            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-            w = __builtin_amdgcn_readfirstlane(w);
-            const uint32_t lid = (best >= 0) ? (readlane_u32(lo, best) >> 1) : 0u;
-            if (best < 0 || v - 1u > lid) {
-                from_tie = true;
-                node = v - 1u;
-                if (lane == 0) tie[w] = tie[tsize - 1];
-                tsize -= 1;
-                wave_sync();
+            if (!from_tie) {
+                if (best < 0) { status = 1; break; }
+                node = readlane_u32(lo, best) >> 1;
+                if (lane == best) lo |= 1u;
             }
         }
-        if (!from_tie) {
-            if (best < 0) break;
-            node = readlane_u32(lo, best) >> 1;
-            if (lane == best) lo |= 1u;
-        }
+        STAMP(t1)
+        STAMP_ADD(0, t0, t1)
 
-        // ---- adjacency row of `node` (prefetched or loaded now) + prefetch for the next hop -----
+        // ---- adjacency row of `node` (prefetched or loaded now), then the prefetch for the next hop
         const uint32_t* row = p.ell + (size_t)node * p.ell_stride;
         uint32_t nb0;
         if (node == pf_node) nb0 = pf_val;
@@ -511,20 +584,15 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
         // consume nb0 BEFORE issuing the prefetch: the wait for a (conditionally issued) row load
         // must not also cover the younger prefetch load
         const uint64_t mv0 = __ballot(nb0 != kInvalidId);
-        {
-            const bool un2 = !(lo & 1u);
-            const uint64_t mu2 = __ballot(un2);
-            pf_node = kInvalidId;
-            if (mu2) {
-                const int pl2 = __ffsll((unsigned long long)mu2) - 1;
-                const uint32_t hp2 = readlane_u32(hi, pl2);
-                const uint64_t ms2 = __ballot(un2 && hi == hp2);
-                pf_node = readlane_u32(lo, 63 - __clzll((long long)ms2)) >> 1;
-                pf_val = ((uint32_t)lane < p.ell_stride) ? p.ell[(size_t)pf_node * p.ell_stride + lane] : kInvalidId;
-            }
-        }
+        STAMP(t2)
+        STAMP_ADD(1, t1, t2)
+        pf_node = pred;
+        if (pred != kInvalidId)
+            pf_val = ((uint32_t)lane < p.ell_stride) ? p.ell[(size_t)pred * p.ell_stride + lane] : kInvalidId;
+        STAMP(t3)
+        STAMP_ADD(2, t2, t3)
 
-        // ---- expand: neighbours in list order -----------------------------------------------
+        // ---- expand: neighbours in list order, 64 per pass --------------------------------------
         for (uint32_t c = 0; c < p.ell_stride; c += 64) {
             uint32_t nb = nb0;
             uint64_t mv = mv0;
@@ -532,64 +600,114 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
                 nb = (c + lane < p.ell_stride) ? row[c + lane] : kInvalidId;
                 mv = __ballot(nb != kInvalidId);
             }
-            const bool valid = nb != kInvalidId;
             if (!mv) break;
-            if ((uint32_t)dist_calc + 64u > p.hash_limit) { handed_over = true; break; }
+            if ((uint32_t)dist_calc + 64u > p.hash_limit) { status = 2; break; }
+            const bool valid = nb != kInvalidId;
             edges += __popcll(mv);
+            // row loads go out before the visited test: its LDS round trips overlap the memory latency
+            // (rows of already-visited neighbours are fetched in vain -- we are not bandwidth bound)
+            RowRegs<STEPS> rr;
+            if constexpr (kEarlyLoad) {
+                if (valid) load_row<STEPS>(rr, p.db + (size_t)nb * p.dstride);
+            }
+#if GBNNS_EXP == 1  // marginal cost of the row gather: issue it twice
+            RowRegs<STEPS> rr2;
+            if constexpr (kEarlyLoad) {
+                if (valid) load_row<STEPS>(rr2, p.db + (size_t)(nb ^ 1u) * p.dstride);
+            }
+#endif
             bool fresh = false;
             if (valid) {
-                uint32_t h = (nb * 0x9E3779B1u) >> hshift;
+                uint32_t h = __umulhi(nb * 0x9E3779B1u, cap);
                 while (true) {
                     const uint32_t old = atomicCAS(&hash[h], kInvalidId, nb);
                     if (old == kInvalidId) { fresh = true; break; }
                     if (old == nb) break;
-                    h = (h + 1u) & hmask;
+                    h = (h + 1u == cap) ? 0u : h + 1u;
                 }
             }
+#if GBNNS_EXP == 2  // marginal cost of the visited test: probe again (finds every id present)
+            if (valid) {
+                uint32_t h = __umulhi(nb * 0x9E3779B1u, cap);
+                while (true) {
+                    const uint32_t old = atomicCAS(&hash[h], kInvalidId, nb);
+                    if (old == kInvalidId || old == nb) break;
+                    h = (h + 1u == cap) ? 0u : h + 1u;
+                }
+            }
+#endif
+            STAMP(t4)
+            STAMP_ADD(3, t3, t4)
             uint32_t dk = 0xFFFFFFFFu;
-            if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, p.db + (size_t)nb * p.dstride, p.dim));
-            const uint64_t mf = __ballot(fresh);
-            dist_calc += __popcll(mf);
+#if GBNNS_EXP == 1
+            if constexpr (kEarlyLoad) {
+                if (fresh) { float x = l2_from_regs<STEPS>(rr2, qs); asm volatile("" ::"v"(x)); }
+            }
+#endif
+#if GBNNS_EXP == 3  // marginal cost of the distance arithmetic: evaluate it twice
+            if constexpr (kEarlyLoad) {
+                if (fresh) { RowRegs<STEPS> r3 = rr; asm volatile("" : "+v"(r3.v[0].x)); float x = l2_from_regs<STEPS>(r3, qs); asm volatile("" ::"v"(x)); }
+            }
+#endif
+            if constexpr (kEarlyLoad) {
+                if (fresh) dk = fkey(l2_from_regs<STEPS>(rr, qs));
+            } else {
+                if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, p.db + (size_t)nb * p.dstride, p.dim));
+            }
+            dist_calc += __popcll(__ballot(fresh));
             uint64_t m = __ballot(fresh && (size < ef || dk < worst));
+            STAMP(t5)
+            STAMP_ADD(4, t4, t5)
+            // reference order: survivors are offered one by one in list order (search_function.h:31-37)
             while (m) {
                 const int l = __ffsll((unsigned long long)m) - 1;
                 m &= m - 1;
                 const uint32_t dl = readlane_u32(dk, l);
-                if (size >= ef && !(dl < worst)) continue;  // search_function.h:31, current worst
+                const bool full = size >= ef;
+                if (full && !(dl < worst)) continue;  // re-test against the CURRENT worst
                 const uint32_t nlo = readlane_u32(nb, l) << 1;
                 const uint64_t key = ((uint64_t)hi << 32) | lo;
                 const uint64_t nk = ((uint64_t)dl << 32) | nlo;
                 const bool lt = key < nk;
                 const int pos = __popcll(__ballot(lt));
-                const bool full = size >= ef;
-                const uint32_t ev_hi = readlane_u32(hi, ef - 1);
-                const uint32_t ev_lo = readlane_u32(lo, ef - 1);
+                const uint32_t ev_lo = readlane_u32(lo, ef - 1);  // evicted entry when full (its hi == worst)
                 const uint32_t slo = dpp_wave_shr1(lo);
                 const uint32_t shi = dpp_wave_shr1(hi);
                 if (!lt && lane < ef) { lo = slo; hi = shi; }
                 if (lane == pos) { lo = nlo; hi = dl; }
-                if (!full) size += 1;
-                worst = readlane_u32(hi, size - 1);
-                if (full) {
-                    if (ev_hi == worst) {           // evicted at a distance that is still the worst
-                        if (!(ev_lo & 1u)) {
-                            if (tsize >= kTieCap) { handed_over = true; break; }
-                            if (lane == 0) tie[tsize] = ((uint64_t)ev_hi << 32) | ev_lo;
-                            tsize += 1;
-                            wave_sync();
-                        }
-                    } else {
+                if (!full) {
+                    size += 1;
+                    worst = readlane_u32(hi, size - 1);
+                } else {
+                    const uint32_t nw = readlane_u32(hi, ef - 1);
+                    if (nw != worst) {
                         tsize = 0;                  // worst distance decreased: old ties are dead
+                    } else if (!(ev_lo & 1u)) {     // evicted unexpanded at a distance that is still the worst
+                        if (tsize >= kRegTieCap) { status = 2; break; }
+                        if (lane == 0) tie[tsize] = ((uint64_t)worst << 32) | ev_lo;
+                        tsize += 1;
+                        wave_sync();
                     }
+                    worst = nw;
                 }
             }
-            if (handed_over) break;
+            STAMP(t6)
+            STAMP_ADD(5, t5, t6)
+            if (status) break;
         }
-        if (handed_over) break;
+        if (status) break;
         hops += 1;
     }
+#ifdef GBNNS_STAMPS
+    {
+        STAMP(t_end)
+        seg[6] = t_end - t_begin;
+        if (lane == 0 && p.stamps)
+            for (int i = 0; i < 7; ++i) atomicAdd(p.stamps + i, seg[i]);
+    }
+#endif
 
-    if (handed_over) {
+    if (status == 2) {
         if (lane == 0) {
             const uint32_t slot = atomicAdd(p.ovf_count, 1u);
             p.ovf_list[slot] = qi;
@@ -882,8 +1000,16 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t count) {
 // ------------------------------------------------------------------------------------------
 
 size_t walk_fast_lds_bytes(const WalkParams& p) {
-    const size_t ef_pad = p.ef <= 64 ? 0 : (((size_t)p.ef + 63) & ~(size_t)63);  // ef <= 64: list in registers
-    return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)p.dstride * 4 + ((size_t)4 << p.hash_bits);
+    if (p.ef <= 64)  // register kernel: list in registers
+        return (size_t)kRegTieCap * 8 + (size_t)p.dstride * 4 + (size_t)p.hash_cap * 4;
+    const size_t ef_pad = ((size_t)p.ef + 63) & ~(size_t)63;
+    return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)p.dstride * 4 + (size_t)p.hash_cap * 4;
+}
+
+size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride) {
+    if (ef <= 64) return (size_t)kRegTieCap * 8 + (size_t)dstride * 4;
+    const size_t ef_pad = ((size_t)ef + 63) & ~(size_t)63;
+    return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)dstride * 4;
 }
 
 template <typename K>

@@ -83,7 +83,8 @@ typedef struct {
     int32_t ef;                /* beam width (= recheck_size in NET/LOWQ, search_function.h:432-434) */
     int32_t k;                 /* PLAIN: heap is trimmed to k, answer = its top (reference uses 1) */
     int32_t mem_kind;          /* gbnns_mem_kind of every buffer below */
-    int32_t hash_capacity;     /* 0 = auto; else power of two: entries of the per-query LDS visited set */
+    int32_t hash_capacity;     /* 0 = auto (sized from the LDS budget and earlier batches); else entries
+                                  (>= 128) of the per-query LDS visited set */
     uint64_t n_q;
     const float* queries;      /* [n_q x d] */
     const float* queries_low;  /* LOWQ: [n_q x d_low], else NULL */
