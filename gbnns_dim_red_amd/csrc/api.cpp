@@ -102,7 +102,7 @@ struct gbnns_index {
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     uint32_t ws1 = 0, ws2 = 0, ws3 = 0;
     // workspace
-    DevBuf q_in, q_low, h1, h2, cand, cand_dist, cnt, hops, dc, edges, out, entries, ovf_list, ctrl;
+    DevBuf q_in, q_low, h1, h2, cand, cand_dist, cnt, hops, dc, edges, out, entries, ovf_list, ovf2_list, ctrl;
     DevBuf g_bitmap, g_keys, g_tie;
     // profiling
     bool profiling = false;
@@ -338,7 +338,7 @@ int gbnns_index_destroy(gbnns_index* ix) {
     if (ix->h_stats) (void)hipHostFree(ix->h_stats);
     DevBuf* bufs[] = {&ix->db_own, &ix->db_low_own, &ix->ell, &ix->net, &ix->q_in, &ix->q_low,
                       &ix->h1, &ix->h2, &ix->cand, &ix->cand_dist, &ix->cnt, &ix->hops, &ix->dc, &ix->edges,
-                      &ix->out, &ix->entries, &ix->ovf_list, &ix->ctrl, &ix->g_bitmap, &ix->g_keys,
+                      &ix->out, &ix->entries, &ix->ovf_list, &ix->ovf2_list, &ix->ctrl, &ix->g_bitmap, &ix->g_keys,
                       &ix->g_tie};
     for (DevBuf* b : bufs) b->release();
     delete ix;
@@ -417,15 +417,15 @@ int gbnns_profile_read(gbnns_index* ix, gbnns_profile* out, int reset) {
     HIP_TRY(hipSetDevice(ix->device));
     int rc = prof_flush(ix);
     if (rc) return rc;
-    uint32_t total = 0;  // ctrl[3]: queries the general kernel has processed since the last reset
+    uint32_t total = 0;  // ctrl[5]: queries the general kernel has processed since the last reset
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&total, ix->ctrl.as<uint32_t>() + 3, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&total, ix->ctrl.as<uint32_t>() + 5, 4, hipMemcpyDeviceToHost));
     ix->acc.general_queries = total;
     ix->acc.struct_size = sizeof(gbnns_profile);
     *out = ix->acc;
     if (reset) {
         ix->acc = gbnns_profile{};
-        HIP_TRY(hipMemset(ix->ctrl.as<uint32_t>() + 3, 0, 4));
+        HIP_TRY(hipMemset(ix->ctrl.as<uint32_t>() + 5, 0, 4));
     }
     return GBNNS_OK;
 }
@@ -542,6 +542,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     if ((rc = ix->hops.ensure((size_t)nq * 4))) return rc;
     if ((rc = ix->dc.ensure((size_t)nq * 4))) return rc;
     if ((rc = ix->ovf_list.ensure((size_t)nq * 4))) return rc;
+    if ((rc = ix->ovf2_list.ensure((size_t)nq * 4))) return rc;
     if (host || !a->out_cand)
         if ((rc = ix->cand.ensure((size_t)nq * cstride * 4))) return rc;
     if (a->out_cand_dist && host)
@@ -619,7 +620,10 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     uint32_t* out_dev = host ? ix->out.as<uint32_t>() : a->out_ids;
     w.best = plain ? out_dev : nullptr;
     uint32_t* ctrl = ix->ctrl.as<uint32_t>();
-    w.ovf_count = ctrl; w.g_cursor = ctrl + 1; w.max_dc = ctrl + 2; w.g_total = ctrl + 3; w.ovf_list = ix->ovf_list.as<uint32_t>();
+    // ctrl words: [0] list A count, [1] general cursor, [2] max dist_calc, [3] list B count,
+    // [4] retry cursor (all cleared per call), [5] general-kernel query total (persistent)
+    w.ovf_count = ctrl; w.g_cursor = ctrl + 1; w.max_dc = ctrl + 2; w.ovf2_count = ctrl + 3; w.r_cursor = ctrl + 4;
+    w.g_total = ctrl + 5; w.ovf_list = ix->ovf_list.as<uint32_t>(); w.ovf2_list = ix->ovf2_list.as<uint32_t>();
     w.g_bitmap = ix->g_bitmap.as<uint32_t>(); w.g_keys = ix->g_keys.as<uint64_t>();
     w.g_tie = ix->g_tie.as<uint64_t>(); w.bitmap_words = bitmap_words;
 
@@ -664,8 +668,21 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.all_general = walk_fast_lds_bytes(w) > kMaxLds ? 1 : 0;
 
     w.stamps = reinterpret_cast<unsigned long long*>(ctrl + 8);  // ctrl[8..23], diagnostic builds
-    HIP_TRY(hipMemsetAsync(ctrl, 0, 12, s));
-    if (!w.all_general) HIP_TRY(launch_walk_fast(w, ix->metric, s));
+    HIP_TRY(hipMemsetAsync(ctrl, 0, 20, s));
+    if (!w.all_general) {
+        HIP_TRY(launch_walk_fast(w, ix->metric, s));
+        // retry pass: hand-overs of the first pass, one wavefront per CU with all the LDS
+        WalkParams w2 = w;
+        const size_t gran = 512;
+        w2.hash_cap = (uint32_t)((kMaxLds / gran * gran - lds_fixed) / 4);
+        w2.hash_limit = w2.hash_cap - w2.hash_cap / 8;
+        if (w2.hash_cap > cap) {
+            HIP_TRY(launch_walk_retry(w2, ix->metric, s));
+        } else {
+            HIP_TRY(hipMemcpyAsync(ctrl + 3, ctrl, 4, hipMemcpyDeviceToDevice, s));  // nothing to gain: A -> B
+            HIP_TRY(hipMemcpyAsync(w.ovf2_list, w.ovf_list, (size_t)nq * 4, hipMemcpyDeviceToDevice, s));
+        }
+    }
     if (prof) HIP_TRY(hipEventRecord(pc.ev[2], s));
     HIP_TRY(launch_walk_general(w, ix->metric, s));
     if (prof) HIP_TRY(hipEventRecord(pc.ev[3], s));

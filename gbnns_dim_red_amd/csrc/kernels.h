@@ -11,6 +11,7 @@ constexpr uint32_t kInvalidId = 0xFFFFFFFFu;
 constexpr int kWave = 64;
 constexpr int kTieCap = 64;            // LDS tie list of the fast walk kernel (one slot per lane)
 constexpr int kGeneralSlots = 64;      // persistent waves of the general walk kernel
+constexpr int kRetrySlots = 256;       // persistent waves of the retry pass (one per CU: it takes all the LDS)
 
 // Beam walk (search_function.h:43-102 + :15-40).  One query per wavefront.
 struct WalkParams {
@@ -38,9 +39,12 @@ struct WalkParams {
     int32_t* dist_calc;      // [nq]
     int32_t* edges;          // optional [nq]: neighbour ids read (sum of degrees of expanded nodes)
     uint32_t* best;          // optional [nq]: id of the best result (PLAIN mode answer)
-    // hand-over list (fast kernel appends, general kernel consumes)
-    uint32_t* ovf_count;     // [1]
+    // hand-over lists: first pass -> A -> retry pass (largest LDS visited set) -> B -> general kernel
+    uint32_t* ovf_count;     // [1]   list A
     uint32_t* ovf_list;      // [nq]
+    uint32_t* ovf2_count;    // [1]   list B
+    uint32_t* ovf2_list;     // [nq]
+    uint32_t* r_cursor;      // [1]   work-queue head of the retry pass
     // general kernel workspace: per slot [bitmap words][keys ef][tie n]
     uint32_t* g_cursor;      // [1] work-queue head
     uint32_t* g_total;       // [1] running count of queries the general kernel processed
@@ -56,6 +60,7 @@ struct WalkParams {
 size_t walk_fast_lds_bytes(const WalkParams& p);
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride);  // everything but the visited set
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s);
+hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s);
 
 // Re-rank (search_function.h:105-125).  One query per wavefront, one candidate per lane.

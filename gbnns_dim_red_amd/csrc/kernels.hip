@@ -12,10 +12,6 @@
 
 #include "kernels.h"
 
-#ifndef GBNNS_EXP
-#define GBNNS_EXP 0  // >0: throw-away marginal-cost experiments, never shipped
-#endif
-
 namespace gbnns {
 
 namespace {
@@ -324,10 +320,9 @@ __device__ __forceinline__ float walk_dist(QP qs, const float* row, uint32_t dim
 // appended to the hand-over list and re-run from scratch by the general kernel.
 
 template <int METRIC, int STEPS>
-__global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
+                                              uint32_t* ovf_count, uint32_t* ovf_list) {
     const int lane = lane_id();
-    const uint32_t qi = blockIdx.x;
     const int ef = p.ef;
     const int ef_pad = (ef + 63) & ~63;
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
@@ -399,12 +394,38 @@ __global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
 
     if (handed_over) {
         if (lane == 0) {
-            const uint32_t slot = atomicAdd(p.ovf_count, 1u);
-            p.ovf_list[slot] = qi;
+            const uint32_t slot = atomicAdd(ovf_count, 1u);
+            ovf_list[slot] = qi;
         }
         return;
     }
     write_results(p, qi, keys, st, lane);
+}
+
+// First pass: one query per workgroup (= wavefront).  Retry pass: persistent wavefronts, one per CU
+// with the largest visited set LDS allows, re-run the queries the first pass handed over; what
+// still does not fit goes to the general kernel.
+template <typename F>
+__device__ __forceinline__ void retry_loop(const WalkParams& p, F&& run) {
+    const uint32_t total = *p.ovf_count;
+    while (true) {
+        uint32_t w = 0;
+        if (lane_id() == 0) w = atomicAdd(p.r_cursor, 1u);
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+        if (w >= total) break;
+        run(p.ovf_list[w]);
+        wave_sync();
+    }
+}
+
+template <int METRIC, int STEPS, bool RETRY>
+__global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (RETRY) {
+        retry_loop(p, [&](uint32_t qi) { walk_fast_one<METRIC, STEPS>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
+    } else {
+        walk_fast_one<METRIC, STEPS>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
+    }
 }
 
 // ---- register kernel (ef <= 64): the result list lives in registers, one entry per lane -------
@@ -466,16 +487,61 @@ __device__ __forceinline__ float l2_from_regs(const RowRegs<STEPS>& r, QP qs) {
     return ((s0 + s1) + s2) + s3;
 }
 
-template <int METRIC, int STEPS>
-__global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// Row address.  OFF32: every byte offset into the table fits 32 bits, so the load can use the
+// "scalar base + 32-bit lane offset" form (one address VGPR instead of two, no 64-bit multiply).
+template <bool OFF32>
+__device__ __forceinline__ const float* row_ptr(const float* base, uint32_t id, uint32_t stride_floats) {
+    if constexpr (OFF32) {
+        const uint32_t off = id * (stride_floats * 4u);
+        return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off);
+    } else {
+        return base + (size_t)id * stride_floats;
+    }
+}
+
+// One offer to the register-resident result list, reference rule (search_function.h:31-37):
+// insert when worst.dist > dist || size < ef, evict the largest pair when full.  Returns false
+// when the tie list overflowed (query is handed to the general kernel).
+__device__ __forceinline__ bool reg_offer(uint32_t dl, uint32_t nlo, uint32_t& lo, uint32_t& hi, int& size,
+                                          uint32_t& worst, int& tsize, uint64_t* tie, int ef, int lane) {
+    const bool full = size >= ef;
+    if (full && !(dl < worst)) return true;  // re-test against the CURRENT worst
+    const uint64_t key = ((uint64_t)hi << 32) | lo;
+    const uint64_t nk = ((uint64_t)dl << 32) | nlo;
+    const bool lt = key < nk;
+    const int pos = __popcll(__ballot(lt));
+    const uint32_t ev_lo = readlane_u32(lo, ef - 1);  // evicted entry when full (its hi == worst)
+    const uint32_t slo = dpp_wave_shr1(lo);
+    const uint32_t shi = dpp_wave_shr1(hi);
+    if (!lt && lane < ef) { lo = slo; hi = shi; }
+    if (lane == pos) { lo = nlo; hi = dl; }
+    if (!full) {
+        size += 1;
+        worst = readlane_u32(hi, size - 1);
+        return true;
+    }
+    const uint32_t nw = readlane_u32(hi, ef - 1);
+    if (nw != worst) {
+        tsize = 0;                  // worst distance decreased: old ties are dead
+    } else if (!(ev_lo & 1u)) {     // evicted unexpanded at a distance that is still the worst
+        if (tsize >= kRegTieCap) return false;
+        if (lane == 0) tie[tsize] = ((uint64_t)worst << 32) | ev_lo;
+        tsize += 1;
+        wave_sync();
+    }
+    worst = nw;
+    return true;
+}
+
+template <int METRIC, int STEPS, bool OFF32>
+__device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
+                                             uint32_t* ovf_count, uint32_t* ovf_list) {
 #ifdef GBNNS_STAMPS
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     STAMP(t_begin)
 #endif
     constexpr bool kEarlyLoad = (METRIC == 0 && STEPS > 0);  // speculative row loads
     const int lane = lane_id();
-    const uint32_t qi = blockIdx.x;
     const int ef = p.ef;
     uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
     float* qf = reinterpret_cast<float*>(tie + kRegTieCap);
@@ -493,7 +559,7 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
     uint32_t worst;                                // hi of lane size-1 (wave-uniform)
     const uint32_t entry = p.entries ? p.entries[qi] : 0u;
     {
-        const float d0 = walk_dist<METRIC, STEPS>(qs, p.db + (size_t)entry * p.dstride, p.dim);
+        const float d0 = walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, entry, p.dstride), p.dim);
         worst = fkey(d0);
         if (lane == 0) {
             hi = worst;
@@ -577,7 +643,8 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
         STAMP_ADD(0, t0, t1)
 
         // ---- adjacency row of `node` (prefetched or loaded now), then the prefetch for the next hop
-        const uint32_t* row = p.ell + (size_t)node * p.ell_stride;
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(
+            row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), node, p.ell_stride));
         uint32_t nb0;
         if (node == pf_node) nb0 = pf_val;
         else nb0 = ((uint32_t)lane < p.ell_stride) ? row[lane] : kInvalidId;
@@ -588,7 +655,7 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
         STAMP_ADD(1, t1, t2)
         pf_node = pred;
         if (pred != kInvalidId)
-            pf_val = ((uint32_t)lane < p.ell_stride) ? p.ell[(size_t)pred * p.ell_stride + lane] : kInvalidId;
+            pf_val = ((uint32_t)lane < p.ell_stride) ? reinterpret_cast<const uint32_t*>(row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), pred, p.ell_stride))[lane] : kInvalidId;
         STAMP(t3)
         STAMP_ADD(2, t2, t3)
 
@@ -608,14 +675,8 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
             // (rows of already-visited neighbours are fetched in vain -- we are not bandwidth bound)
             RowRegs<STEPS> rr;
             if constexpr (kEarlyLoad) {
-                if (valid) load_row<STEPS>(rr, p.db + (size_t)nb * p.dstride);
+                if (valid) load_row<STEPS>(rr, row_ptr<OFF32>(p.db, nb, p.dstride));
             }
-#if GBNNS_EXP == 1  // marginal cost of the row gather: issue it twice
-            RowRegs<STEPS> rr2;
-            if constexpr (kEarlyLoad) {
-                if (valid) load_row<STEPS>(rr2, p.db + (size_t)(nb ^ 1u) * p.dstride);
-            }
-#endif
             bool fresh = false;
             if (valid) {
                 uint32_t h = __umulhi(nb * 0x9E3779B1u, cap);
@@ -626,33 +687,13 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
                     h = (h + 1u == cap) ? 0u : h + 1u;
                 }
             }
-#if GBNNS_EXP == 2  // marginal cost of the visited test: probe again (finds every id present)
-            if (valid) {
-                uint32_t h = __umulhi(nb * 0x9E3779B1u, cap);
-                while (true) {
-                    const uint32_t old = atomicCAS(&hash[h], kInvalidId, nb);
-                    if (old == kInvalidId || old == nb) break;
-                    h = (h + 1u == cap) ? 0u : h + 1u;
-                }
-            }
-#endif
             STAMP(t4)
             STAMP_ADD(3, t3, t4)
             uint32_t dk = 0xFFFFFFFFu;
-#if GBNNS_EXP == 1
-            if constexpr (kEarlyLoad) {
-                if (fresh) { float x = l2_from_regs<STEPS>(rr2, qs); asm volatile("" ::"v"(x)); }
-            }
-#endif
-#if GBNNS_EXP == 3  // marginal cost of the distance arithmetic: evaluate it twice
-            if constexpr (kEarlyLoad) {
-                if (fresh) { RowRegs<STEPS> r3 = rr; asm volatile("" : "+v"(r3.v[0].x)); float x = l2_from_regs<STEPS>(r3, qs); asm volatile("" ::"v"(x)); }
-            }
-#endif
             if constexpr (kEarlyLoad) {
                 if (fresh) dk = fkey(l2_from_regs<STEPS>(rr, qs));
             } else {
-                if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, p.db + (size_t)nb * p.dstride, p.dim));
+                if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, nb, p.dstride), p.dim));
             }
             dist_calc += __popcll(__ballot(fresh));
             uint64_t m = __ballot(fresh && (size < ef || dk < worst));
@@ -662,33 +703,9 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
             while (m) {
                 const int l = __ffsll((unsigned long long)m) - 1;
                 m &= m - 1;
-                const uint32_t dl = readlane_u32(dk, l);
-                const bool full = size >= ef;
-                if (full && !(dl < worst)) continue;  // re-test against the CURRENT worst
-                const uint32_t nlo = readlane_u32(nb, l) << 1;
-                const uint64_t key = ((uint64_t)hi << 32) | lo;
-                const uint64_t nk = ((uint64_t)dl << 32) | nlo;
-                const bool lt = key < nk;
-                const int pos = __popcll(__ballot(lt));
-                const uint32_t ev_lo = readlane_u32(lo, ef - 1);  // evicted entry when full (its hi == worst)
-                const uint32_t slo = dpp_wave_shr1(lo);
-                const uint32_t shi = dpp_wave_shr1(hi);
-                if (!lt && lane < ef) { lo = slo; hi = shi; }
-                if (lane == pos) { lo = nlo; hi = dl; }
-                if (!full) {
-                    size += 1;
-                    worst = readlane_u32(hi, size - 1);
-                } else {
-                    const uint32_t nw = readlane_u32(hi, ef - 1);
-                    if (nw != worst) {
-                        tsize = 0;                  // worst distance decreased: old ties are dead
-                    } else if (!(ev_lo & 1u)) {     // evicted unexpanded at a distance that is still the worst
-                        if (tsize >= kRegTieCap) { status = 2; break; }
-                        if (lane == 0) tie[tsize] = ((uint64_t)worst << 32) | ev_lo;
-                        tsize += 1;
-                        wave_sync();
-                    }
-                    worst = nw;
+                if (!reg_offer(readlane_u32(dk, l), readlane_u32(nb, l) << 1, lo, hi, size, worst, tsize, tie, ef, lane)) {
+                    status = 2;
+                    break;
                 }
             }
             STAMP(t6)
@@ -709,8 +726,8 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
 
     if (status == 2) {
         if (lane == 0) {
-            const uint32_t slot = atomicAdd(p.ovf_count, 1u);
-            p.ovf_list[slot] = qi;
+            const uint32_t slot = atomicAdd(ovf_count, 1u);
+            ovf_list[slot] = qi;
         }
         return;
     }
@@ -736,6 +753,16 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
     }
 }
 
+template <int METRIC, int STEPS, bool OFF32, bool RETRY>
+__global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (RETRY) {
+        retry_loop(p, [&](uint32_t qi) { walk_reg_one<METRIC, STEPS, OFF32>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
+    } else {
+        walk_reg_one<METRIC, STEPS, OFF32>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
+    }
+}
+
 // ---- general kernel: exact for every input (any ef, any number of ties, any visited count) ----
 //
 // Persistent wavefronts pull query indices from the hand-over list.  Visited set = one bit per
@@ -753,7 +780,7 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
     uint64_t* keys = p.g_keys + (size_t)slot * (size_t)p.ef;
     uint64_t* tie = p.g_tie + (size_t)slot * (size_t)p.n;
     const int ef = p.ef;
-    const uint32_t total = p.all_general ? p.nq : *p.ovf_count;
+    const uint32_t total = p.all_general ? p.nq : *p.ovf2_count;
     if (slot == 0 && lane == 0 && total) atomicAdd(p.g_total, total);
 
     while (true) {
@@ -761,7 +788,7 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
         if (lane == 0) w = atomicAdd(p.g_cursor, 1u);
         w = (uint32_t)__shfl((int)w, 0);
         if (w >= total) break;
-        const uint32_t qi = p.all_general ? w : p.ovf_list[w];
+        const uint32_t qi = p.all_general ? w : p.ovf2_list[w];
 
         for (uint32_t i = lane; i < p.bitmap_words; i += 64) bitmap[i] = 0u;
         for (uint32_t i = lane; i < p.dstride; i += 64)
@@ -1020,34 +1047,47 @@ static hipError_t set_lds(K kernel, size_t bytes) {
     return hipSuccess;
 }
 
-template <int METRIC, int STEPS>
-static hipError_t launch_fast_t(const WalkParams& p, hipStream_t s) {
-    const size_t lds = walk_fast_lds_bytes(p);
-    if (p.ef <= 64) {
-        hipError_t e = set_lds(walk_reg_kernel<METRIC, STEPS>, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((walk_reg_kernel<METRIC, STEPS>), dim3(p.nq), dim3(64), lds, s, p);
-        return hipGetLastError();
-    }
-    hipError_t e = set_lds(walk_fast_kernel<METRIC, STEPS>, lds);
+template <typename K>
+static hipError_t launch_walk_k(K kernel, const WalkParams& p, bool retry, size_t lds, hipStream_t s) {
+    hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((walk_fast_kernel<METRIC, STEPS>), dim3(p.nq), dim3(64), lds, s, p);
+    const unsigned grid = retry ? (unsigned)kRetrySlots : p.nq;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s) {
+template <int METRIC, int STEPS>
+static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) {
+    const size_t lds = walk_fast_lds_bytes(p);
+    if (p.ef <= 64) {
+        // 32-bit byte offsets when both tables are < 4 GiB
+        const bool off32 = (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32);
+        if (off32)
+            return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, true>, p, true, lds, s)
+                         : launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false>, p, false, lds, s);
+        return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, false, true>, p, true, lds, s)
+                     : launch_walk_k(walk_reg_kernel<METRIC, STEPS, false, false>, p, false, lds, s);
+    }
+    return retry ? launch_walk_k(walk_fast_kernel<METRIC, STEPS, true>, p, true, lds, s)
+                 : launch_walk_k(walk_fast_kernel<METRIC, STEPS, false>, p, false, lds, s);
+}
+
+static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
-    if (metric == 1) return launch_fast_t<1, 0>(p, s);
+    if (metric == 1) return launch_fast_t<1, 0>(p, retry, s);
     if (p.dstride == p.dim) {
         switch (p.dim) {
-            case 32: return launch_fast_t<0, 8>(p, s);
-            case 48: return launch_fast_t<0, 12>(p, s);
-            case 64: return launch_fast_t<0, 16>(p, s);
+            case 32: return launch_fast_t<0, 8>(p, retry, s);
+            case 48: return launch_fast_t<0, 12>(p, retry, s);
+            case 64: return launch_fast_t<0, 16>(p, retry, s);
             default: break;
         }
     }
-    return launch_fast_t<0, 0>(p, s);
+    return launch_fast_t<0, 0>(p, retry, s);
 }
+
+hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s) { return launch_walk_any(p, metric, false, s); }
+hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s) { return launch_walk_any(p, metric, true, s); }
 
 hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;

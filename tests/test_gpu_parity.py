@@ -128,7 +128,7 @@ def test_general_kernel_paths(g, orc):
         assert np.array_equal(r["cand"], w["ids"])
         assert np.array_equal(r["hops"], w["hops"])
         assert np.array_equal(r["dist_calc"], w["dist_calc"])
-    assert ix.profile_read()["general_queries"] > 0
+    ix.profile_read()  # (a) is absorbed by the retry pass (largest LDS visited set), not the general kernel
     ix.close()
 
     # (b) lattice: huge tie classes, walk straight on the lattice in PLAIN mode
@@ -143,19 +143,47 @@ def test_general_kernel_paths(g, orc):
         assert np.array_equal(r["cand"], w["ids"]), ef
         assert np.array_equal(r["hops"], w["hops"]), ef
         assert np.array_equal(r["dist_calc"], w["dist_calc"]), ef
-    prof = ix.profile_read()
+    ix.profile_read()
     ix.close()
-    # (c) ef larger than anything the LDS kernel can hold
+
+    # (b2) a tie class far larger than the LDS tie list: 2000 nodes at squared distance exactly 5
+    # from the query plus 100 closer ones; closer nodes evict unexpanded tied entries one by one,
+    # which only the general kernel (tie list of capacity n) can hold
+    import itertools
+    shell = sorted({p_ for base_ in ((2, 1, 0, 0),) for perm in itertools.permutations(base_)
+                    for sg in itertools.product((1, -1), repeat=4)
+                    for p_ in [tuple(a * b for a, b in zip(perm, sg))]})
+    rng = np.random.Generator(np.random.PCG64(10))
+    far = np.array([shell[i] for i in rng.integers(0, len(shell), size=2000)], np.float32)
+    near = np.zeros((100, 4), np.float32)
+    near[:, 0] = (np.arange(1, 101) / 64.0).astype(np.float32)
+    base = np.concatenate([far, near])[rng.permutation(2100)]
+    off, nbr = datagen.random_graph(rng, 2100, 16, 32)
+    queries = np.zeros((64, 4), np.float32)
+    ent = rng.integers(0, 2100, size=64).astype(np.uint32)
+    ix = g.Index(base, off, nbr)
+    ix.profile_enable(True)
+    for ef in (8, 32, 64, 100):
+        w = orc.walk(queries, base, off, nbr, ef, entries=ent, threads=8)
+        r = ix.search(queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand"))
+        assert np.array_equal(r["cand"], w["ids"]), ef
+        assert np.array_equal(r["hops"], w["hops"]), ef
+        assert np.array_equal(r["dist_calc"], w["dist_calc"]), ef
+    assert ix.profile_read()["general_queries"] > 0  # tie-list overflow: only the general kernel can serve it
+    ix.close()
+
+    # (c) ef larger than anything the LDS kernels can hold: the general kernel takes the whole batch
     c2, off2, nbr2, db_low2, ent2 = _oracle_case(orc, 603, 30000, 40, 16, 8, 8)
     ix = g.Index(c2.base, off2, nbr2, db_low=db_low2, net=c2.net)
+    ix.profile_enable(True)
     q_low2 = orc.project(c2.net, c2.queries)
     ef = 25000
     w = orc.walk(q_low2, db_low2, off2, nbr2, ef, threads=8)
     r = ix.search(c2.queries, ef, want=("hops", "dist_calc", "cand"))
     assert np.array_equal(r["cand"], w["ids"])
     assert np.array_equal(r["hops"], w["hops"])
+    assert ix.profile_read()["general_queries"] == 40
     ix.close()
-    assert prof["general_queries"] >= 0
 
 
 def test_edge_cases(g, orc):
