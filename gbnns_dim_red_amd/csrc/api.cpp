@@ -141,7 +141,7 @@ int upload(DevBuf& dst, const void* src, size_t rows, size_t row_floats, size_t 
 void repack_layer(const float* layer, uint32_t din, uint32_t dout, uint32_t wstride,
                   std::vector<float>& out) {
     const size_t base = out.size();
-    out.resize(base + (size_t)dout * wstride + dout, 0.f);
+    out.resize(base + (size_t)dout * wstride + round_up(dout, 4), 0.f);  // keeps the next layer 16-B aligned
     float* w = out.data() + base;
     float* b = w + (size_t)dout * wstride;
     for (uint32_t o = 0; o < dout; ++o) {

@@ -995,6 +995,119 @@ __global__ __launch_bounds__(256) void mlp_layer_kernel(LayerParams p) {
     }
 }
 
+// Same tile and arithmetic as mlp_layer_kernel, for 16-B aligned operands (xstride % 4 == 0):
+// 16-B global loads, and the next k-chunk is fetched into registers while the current one is
+// being consumed from LDS (the generic kernel exposes one global round trip per chunk).
+template <bool RELU>
+__global__ __launch_bounds__(256) void mlp_layer_vec_kernel(LayerParams p) {
+    __shared__ __attribute__((aligned(16))) float xs[kTQ * kLd];
+    __shared__ __attribute__((aligned(16))) float ws[kTO * kLd];
+    const int t = threadIdx.x;
+    const int tq = t >> 4;   // 0..15 -> queries 2*tq, 2*tq+1
+    const int to = t & 15;   // neurons to + 16*j
+    const uint32_t qbase = blockIdx.x * kTQ;
+    const uint32_t obase = blockIdx.y * kTO;
+    const uint32_t kmain = (p.din >> 3) << 3;
+    // staging role of this thread: one float4 of the x tile, two of the w tile
+    const int srow = t >> 3, sc4 = (t & 7) * 4;
+    const uint32_t xq = qbase + srow;
+    const uint32_t wo0 = obase + srow, wo1 = obase + srow + 32;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto fetch = [&](uint32_t k0, float4& fx, float4& fw0, float4& fw1) {
+        const bool kin = k0 + sc4 < kmain;  // kmain is a multiple of 8 and sc4 of 4: whole float4 in or out
+        fx = (kin && xq < p.nq) ? *reinterpret_cast<const float4*>(p.x + (size_t)xq * p.xstride + k0 + sc4) : zero4;
+        fw0 = (kin && wo0 < p.dout) ? *reinterpret_cast<const float4*>(p.w + (size_t)wo0 * p.wstride + k0 + sc4) : zero4;
+        fw1 = (kin && wo1 < p.dout) ? *reinterpret_cast<const float4*>(p.w + (size_t)wo1 * p.wstride + k0 + sc4) : zero4;
+    };
+
+    float acc[2][4][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[a][b][l] = 0.f;
+
+    float4 fx, fw0, fw1;
+    fetch(0, fx, fw0, fw1);
+    for (uint32_t k0 = 0; k0 < kmain; k0 += kKC) {
+        const uint32_t kc = (kmain - k0 < (uint32_t)kKC) ? (kmain - k0) : (uint32_t)kKC;
+        *reinterpret_cast<float4*>(&xs[srow * kLd + sc4]) = fx;
+        *reinterpret_cast<float4*>(&ws[srow * kLd + sc4]) = fw0;
+        *reinterpret_cast<float4*>(&ws[(srow + 32) * kLd + sc4]) = fw1;
+        __syncthreads();
+        if (k0 + kKC < kmain) fetch(k0 + kKC, fx, fw0, fw1);  // in flight during the compute below
+        for (uint32_t s = 0; s < kc; s += 8) {
+            float4 xv[2][2], wv[4][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float4* xp = reinterpret_cast<const float4*>(&xs[(2 * tq + a) * kLd + s]);
+                xv[a][0] = xp[0];
+                xv[a][1] = xp[1];
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float4* wp = reinterpret_cast<const float4*>(&ws[(to + 16 * b) * kLd + s]);
+                wv[b][0] = wp[0];
+                wv[b][1] = wp[1];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    acc[a][b][0] = acc[a][b][0] + wv[b][0].x * xv[a][0].x;
+                    acc[a][b][1] = acc[a][b][1] + wv[b][0].y * xv[a][0].y;
+                    acc[a][b][2] = acc[a][b][2] + wv[b][0].z * xv[a][0].z;
+                    acc[a][b][3] = acc[a][b][3] + wv[b][0].w * xv[a][0].w;
+                    acc[a][b][4] = acc[a][b][4] + wv[b][1].x * xv[a][1].x;
+                    acc[a][b][5] = acc[a][b][5] + wv[b][1].y * xv[a][1].y;
+                    acc[a][b][6] = acc[a][b][6] + wv[b][1].z * xv[a][1].z;
+                    acc[a][b][7] = acc[a][b][7] + wv[b][1].w * xv[a][1].w;
+                }
+        }
+        __syncthreads();
+    }
+
+    const uint32_t rem8 = p.din & 7;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const uint32_t qg = qbase + 2 * tq + a;
+        if (qg >= p.nq) continue;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t og = obase + to + 16 * b;
+            if (og >= p.dout) continue;
+            float m[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = acc[a][b][j + 4] + acc[a][b][j];
+            uint32_t kk = kmain, rem = rem8;
+            const float* xr = p.x + (size_t)qg * p.xstride;
+            const float* wr = p.w + (size_t)og * p.wstride;
+            if (rem >= 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = m[j] + wr[kk + j] * xr[kk + j];
+                kk += 4;
+                rem -= 4;
+            }
+            if (rem > 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xv = ((uint32_t)j < rem) ? xr[kk + j] : 0.f;
+                    const float wv = ((uint32_t)j < rem) ? wr[kk + j] : 0.f;
+                    m[j] = m[j] + wv * xv;
+                }
+            }
+            const float dist = -((m[0] + m[1]) + (m[2] + m[3]));  // Angular::Dist
+            float v = 0.f;
+            v = v - dist;               // support_func.h:627
+            v = v + p.bias[og];         // :628
+            if (RELU && v < 0.f) v = 0.f;  // :629-631
+            p.out[(size_t)qg * p.ostride + og] = v;
+        }
+    }
+}
+
 // support_func.h:636-642 normalizeVector: norm = sqrt(L2Metric.Dist(y, zeros)); y[i] /= norm.
 __global__ __launch_bounds__(256) void normalize_kernel(float* y, uint32_t stride, uint32_t dim,
                                                         uint32_t nq) {
@@ -1122,8 +1235,15 @@ hipError_t launch_rerank(const RerankParams& p, int metric, hipStream_t s) {
 hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s) {
     if (p.nq == 0 || p.dout == 0) return hipSuccess;
     const dim3 grid((p.nq + kTQ - 1) / kTQ, (p.dout + kTO - 1) / kTO);
-    if (p.relu) hipLaunchKernelGGL((mlp_layer_kernel<true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((mlp_layer_kernel<false>), grid, dim3(256), 0, s, p);
+    const bool aligned = p.xstride % 4 == 0 && p.wstride % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
+    if (aligned) {
+        if (p.relu) hipLaunchKernelGGL((mlp_layer_vec_kernel<true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((mlp_layer_vec_kernel<false>), grid, dim3(256), 0, s, p);
+    } else {
+        if (p.relu) hipLaunchKernelGGL((mlp_layer_kernel<true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((mlp_layer_kernel<false>), grid, dim3(256), 0, s, p);
+    }
     return hipGetLastError();
 }
 
