@@ -194,7 +194,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "walk_fast_kernel",
+            "kernel": "walk_reg_kernel" if ef <= 64 else "walk_fast_kernel",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -209,6 +209,15 @@ def main():
                        "rerank_GBps": round(rerank_bytes / (rerank_ms * 1e-3) / 1e9, 1) if rerank_ms > 0 else None,
                        "general_queries": prof["general_queries"]},
     }
+
+    # ---- PCIe-inclusive rate (host buffers in, ids out: what the C++ drop-in times); never `value`
+    if world == 1:
+        qh = q.cpu().numpy()
+        ix.search(qh, ef, want=())
+        t1 = time.perf_counter()
+        for _ in range(5):
+            ix.search(qh, ef, want=())
+        result["host_buffers_qps"] = round(5 * args.nq / (time.perf_counter() - t1), 1)
 
     # ---- CPU baseline (rank 0, N = 1 only): the compiled reference if present, else the port ----
     if world == 1 and not args.no_cpu_baseline:

@@ -14,7 +14,12 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("walk_reg_kernel", "walk_fast_kernel", "walk_general_kernel", "rerank_kernel", "mlp_layer_kernel",
+    for key in ("walk_reg_kernel", "walk_fast_kernel"):
+        if key in name:
+            # last template argument = RETRY (the persistent second pass over handed-over queries)
+            args = name[name.find("<") + 1:name.rfind(">")].replace(" ", "").split(",")
+            return key + ("/retry" if args and args[-1] in ("true", "1") else "")
+    for key in ("walk_general_kernel", "rerank_kernel", "mlp_layer_vec_kernel", "mlp_layer_kernel",
                 "normalize_kernel", "fill_u32_kernel"):
         if key in name:
             return key
@@ -63,12 +68,14 @@ def main():
                 line.append("%s=%.4g" % (c, m))
                 res.setdefault(k, {})[c] = m
             print("%-24s %s" % (k, "  ".join(line)))
-    w = res.get("walk_fast_kernel", {})
+    dom = "walk_reg_kernel" if "walk_reg_kernel" in res else "walk_fast_kernel"
+    w = res.get(dom, {})
     if "FETCH_SIZE" in w:
         fetch_kib, write_kib = w["FETCH_SIZE"], w.get("WRITE_SIZE", 0.0)
         raw = (fetch_kib + write_kib) * 1024
         corr = (2 * fetch_kib + write_kib) * 1024
-        print("\nwalk_fast_kernel HBM bytes per launch: raw %.4g B (FETCH+WRITE), fetch-x2-corrected %.4g B" % (raw, corr))
+        print("\n%s HBM bytes per launch: raw %.4g B (FETCH+WRITE), fetch-x2-corrected %.4g B" % (dom, raw, corr))
+        res["dominant_kernel"] = dom
         res["walk_fast_hbm_bytes_per_launch_raw"] = raw
         res["walk_fast_hbm_bytes_per_launch"] = corr
     json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
