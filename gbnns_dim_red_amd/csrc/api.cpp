@@ -663,6 +663,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
             cap = (uint32_t)((share - lds_fixed) / 4);
         }
     }
+    cap &= ~3u;  // whole 4-slot buckets
     w.hash_cap = cap;
     w.hash_limit = cap - cap / 8;
     w.all_general = walk_fast_lds_bytes(w) > kMaxLds ? 1 : 0;
@@ -674,7 +675,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         // retry pass: hand-overs of the first pass, one wavefront per CU with all the LDS
         WalkParams w2 = w;
         const size_t gran = 512;
-        w2.hash_cap = (uint32_t)((kMaxLds / gran * gran - lds_fixed) / 4);
+        w2.hash_cap = (uint32_t)((kMaxLds / gran * gran - lds_fixed) / 4) & ~3u;
         w2.hash_limit = w2.hash_cap - w2.hash_cap / 8;
         if (w2.hash_cap > cap) {
             HIP_TRY(launch_walk_retry(w2, ix->metric, s));

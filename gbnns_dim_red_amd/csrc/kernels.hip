@@ -138,6 +138,28 @@ __device__ __forceinline__ float metric_dist(PA a, PB b, uint32_t dim) {
 }
 
 // ------------------------------------------------------------------------------------------
+// visited set (visited_list_pool.h): exact hash set of node ids in LDS, 4-slot buckets
+// ------------------------------------------------------------------------------------------
+// Returns true when `id` was not in the set (and is now).  A bucket (16 B) is read with one
+// ds_read_b128: the id is present iff it is found in a bucket of its probe sequence before a
+// bucket with an empty slot; a new id claims the first empty slot of that bucket with a CAS (a
+// lane of the same wavefront may win the slot in the same instruction: then the bucket is read
+// again).  Ids offered concurrently are distinct (rows are de-duplicated at index creation).
+__device__ __forceinline__ bool visited_claim(uint32_t* hash, uint32_t nbuckets, uint32_t id) {
+    uint32_t b = __umulhi(id * 0x9E3779B1u, nbuckets);
+    while (true) {
+        const uint4 e = *reinterpret_cast<const uint4*>(hash + 4u * b);
+        if (e.x == id || e.y == id || e.z == id || e.w == id) return false;
+        const int slot = e.x == kInvalidId ? 0 : e.y == kInvalidId ? 1 : e.z == kInvalidId ? 2 : e.w == kInvalidId ? 3 : -1;
+        if (slot >= 0) {
+            if (atomicCAS(hash + 4u * b + slot, kInvalidId, id) == kInvalidId) return true;
+            continue;  // lost the slot to another lane: look at the bucket again
+        }
+        b = (b + 1u == nbuckets) ? 0u : b + 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // sorted result list (search_function.h:50 topResults) -- ascending u64 keys, capacity ef
 // ------------------------------------------------------------------------------------------
 
@@ -345,7 +367,7 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
         const float d0 = walk_dist<METRIC, STEPS>(qs, p.db + (size_t)entry * p.dstride, p.dim);
         if (lane == 0) {
             keys[0] = make_key(fkey(d0), entry);
-            hash[__umulhi(entry * 0x9E3779B1u, cap)] = entry;
+            hash[4u * __umulhi(entry * 0x9E3779B1u, cap >> 2)] = entry;  // first slot of its bucket
         }
         st.size = 1;
         wave_sync();
@@ -364,13 +386,7 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
             st.edges += __popcll(mv);
             bool fresh = false;
             if (valid) {
-                uint32_t h = __umulhi(nb * 0x9E3779B1u, cap);
-                while (true) {
-                    const uint32_t old = atomicCAS(&hash[h], kInvalidId, nb);
-                    if (old == kInvalidId) { fresh = true; break; }
-                    if (old == nb) break;
-                    h = (h + 1u == cap) ? 0u : h + 1u;
-                }
+                fresh = visited_claim(hash, cap >> 2, nb);
             }
             uint32_t dk = 0xFFFFFFFFu;
             if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, p.db + (size_t)nb * p.dstride, p.dim));
@@ -502,6 +518,10 @@ __device__ __forceinline__ const float* row_ptr(const float* base, uint32_t id, 
 // One offer to the register-resident result list, reference rule (search_function.h:31-37):
 // insert when worst.dist > dist || size < ef, evict the largest pair when full.  Returns false
 // when the tie list overflowed (query is handed to the general kernel).
+// Lanes >= ef are scratch (they receive what falls off the end); readers mask them out.
+// The placement is decided per lane without a scalar round trip: a lane whose key is >= the new
+// key takes its left neighbour's entry, unless that neighbour's key is < the new key -- then it
+// is the insertion point and takes the new key.
 __device__ __forceinline__ bool reg_offer(uint32_t dl, uint32_t nlo, uint32_t& lo, uint32_t& hi, int& size,
                                           uint32_t& worst, int& tsize, uint64_t* tie, int ef, int lane) {
     const bool full = size >= ef;
@@ -509,12 +529,15 @@ __device__ __forceinline__ bool reg_offer(uint32_t dl, uint32_t nlo, uint32_t& l
     const uint64_t key = ((uint64_t)hi << 32) | lo;
     const uint64_t nk = ((uint64_t)dl << 32) | nlo;
     const bool lt = key < nk;
-    const int pos = __popcll(__ballot(lt));
+    // left neighbour's `lt` (lane 0 has none: treated as "smaller", which makes lane 0 an insertion point)
+    const uint32_t lt_left = (uint32_t)__builtin_amdgcn_update_dpp(1, lt ? 1 : 0, 0x138, 0xf, 0xf, false);
     const uint32_t ev_lo = readlane_u32(lo, ef - 1);  // evicted entry when full (its hi == worst)
     const uint32_t slo = dpp_wave_shr1(lo);
     const uint32_t shi = dpp_wave_shr1(hi);
-    if (!lt && lane < ef) { lo = slo; hi = shi; }
-    if (lane == pos) { lo = nlo; hi = dl; }
+    if (!lt) {
+        lo = lt_left ? nlo : slo;
+        hi = lt_left ? dl : shi;
+    }
     if (!full) {
         size += 1;
         worst = readlane_u32(hi, size - 1);
@@ -564,11 +587,12 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         if (lane == 0) {
             hi = worst;
             lo = entry << 1;
-            hash[__umulhi(entry * 0x9E3779B1u, cap)] = entry;
+            hash[4u * __umulhi(entry * 0x9E3779B1u, cap >> 2)] = entry;  // first slot of its bucket
         }
         wave_sync();
     }
 
+    const uint64_t efmask = ef >= 64 ? ~0ull : ((1ull << ef) - 1ull);  // lanes that hold list entries
     int status = 0;  // 0 = walking, 1 = finished, 2 = handed over to the general kernel
     // Adjacency prefetch: when a node is picked, the row of the entry that will be picked next IF
     // this expansion inserts nothing closer is requested too.  The load stays in flight behind this
@@ -578,7 +602,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     while (true) {
         STAMP(t0)
         // ---- next node to expand: closest unexpanded entry, ties -> largest id -------------
-        const uint64_t mu = __ballot(!(lo & 1u));
+        const uint64_t mu = __ballot(!(lo & 1u)) & efmask;
         uint32_t node = 0, pred = kInvalidId;
         bool picked = false;
         if (mu != 0 && tsize == 0) {
@@ -607,7 +631,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             if (mu) {
                 const int pl = __ffsll((unsigned long long)mu) - 1;
                 hi_p = readlane_u32(hi, pl);
-                const uint64_t ms = __ballot(un && hi == hi_p);
+                const uint64_t ms = __ballot(un && hi == hi_p) & efmask;
                 best = 63 - __clzll((long long)ms);
             }
             bool from_tie = false;
@@ -679,13 +703,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             }
             bool fresh = false;
             if (valid) {
-                uint32_t h = __umulhi(nb * 0x9E3779B1u, cap);
-                while (true) {
-                    const uint32_t old = atomicCAS(&hash[h], kInvalidId, nb);
-                    if (old == kInvalidId) { fresh = true; break; }
-                    if (old == nb) break;
-                    h = (h + 1u == cap) ? 0u : h + 1u;
-                }
+                fresh = visited_claim(hash, cap >> 2, nb);
             }
             STAMP(t4)
             STAMP_ADD(3, t3, t4)

@@ -11,17 +11,19 @@ ix = ds.index()
 lib = g.load_library()
 lib.gbnns_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 names = ["select", "row wait", "prefetch issue", "visited (hash)", "gather+dist", "inserts", "TOTAL wave life"]
+NQ = int(os.environ.get("NQ", len(ds.queries)))
+qsub = ds.queries[:NQ].contiguous()
 for ef in (int(a) for a in (sys.argv[1:] or ["64"])):
     for _ in range(3):
-        r = ix.search(ds.queries, ef, want=("hops",))
+        r = ix.search(qsub, ef, want=("hops",))
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * 8)()
     lib.gbnns_debug_read_stamps(ix._h, buf)
-    r = ix.search(ds.queries, ef, want=("hops",))
+    r = ix.search(qsub, ef, want=("hops",))
     torch.cuda.synchronize()
     lib.gbnns_debug_read_stamps(ix._h, buf)
     hops = r["hops"].double().sum().item()
     tot = buf[6]
-    print(f"ef={ef}: hops/query {hops/len(ds.queries):.1f}, wave life {tot/len(ds.queries):.0f} cycles/query, {tot/hops:.0f} cycles/hop")
+    print(f"nq={NQ} ef={ef}: hops/query {hops/NQ:.1f}, wave life {tot/NQ:.0f} cycles/query, {tot/hops:.0f} cycles/hop")
     for i in range(6):
         print(f"   {names[i]:16s} {buf[i]/hops:8.0f} cycles/hop  {100.0*buf[i]/tot:5.1f} %")
