@@ -286,3 +286,70 @@ def test_full_size_properties(g):
     rec = (r1["ids"].long() == ds.gt).float().mean().item()
     assert rec > 0.9, rec
     ix.close()
+
+
+@pytest.mark.parametrize("shape", [
+    # BASELINE.json configurations at a size the oracle enumerates in seconds
+    dict(name="gist", n=20000, nq=100, d=960, dlow=64, dh=128, efs=(200, 400), metric=0),
+    dict(name="glove", n=30000, nq=300, d=200, dlow=32, dh=64, efs=(64, 300), metric=1),
+    dict(name="deep", n=40000, nq=400, d=96, dlow=32, dh=64, efs=(40, 120), metric=0),
+    dict(name="deep48", n=20000, nq=200, d=96, dlow=48, dh=64, efs=(40, 200), metric=0),  # reference's own deep row
+])
+def test_config_shapes_vs_oracle(g, orc, shape):
+    c = datagen.Case(shape["name"], 900 + len(shape["name"]), shape["n"], shape["nq"], shape["d"],
+                     shape["dlow"], shape["dh"])
+    db_low = orc.project(c.net, c.base, threads=8)
+    # a real search graph: exact kNN in the low-dim space -> GD pruning by the product's builder
+    import torch
+    knn = _knn_gpu(torch.from_numpy(db_low).cuda(), 24).cpu().numpy().astype(np.uint32)
+    koff, knbr = datagen.dense_to_csr(knn)
+    off, nbr = g.build_graph_gd(koff, knbr, db_low, 12, threads=8)
+    ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net, metric=shape["metric"])
+    assert datagen.sha(ix.project(c.base)) == datagen.sha(db_low)
+    for ef in shape["efs"]:
+        s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low,
+                             net=c.net, metric=shape["metric"], threads=8)
+        r = ix.search(c.queries, ef, want=("hops", "dist_calc"))
+        assert np.array_equal(r["ids"], s["ids"]), (shape["name"], ef)
+        assert np.array_equal(r["hops"], s["hops"]), (shape["name"], ef)
+        assert np.array_equal(r["dist_calc"] + ef, s["dist_calc"]), (shape["name"], ef)
+    ix.close()
+
+
+def _knn_gpu(x, k):
+    import torch
+    sq = (x * x).sum(1)
+    out = []
+    for s in range(0, x.shape[0], 4096):
+        dm = sq[s:s + 4096, None] + sq[None, :] - 2.0 * (x[s:s + 4096] @ x.t())
+        dm[torch.arange(dm.shape[0], device=x.device), torch.arange(s, s + dm.shape[0], device=x.device)] = float("inf")
+        out.append(dm.topk(k, dim=1, largest=False).indices)
+    return torch.cat(out)
+
+
+def test_small_and_degenerate_indexes(g, orc):
+    # n = 1 (entry is the only node), ef larger than the reachable set, one-query batches
+    one = np.ones((1, 8), np.float32)
+    ix = g.Index(one, np.array([0, 0], np.uint64), np.zeros(0, np.uint32))
+    r = ix.search(np.zeros((3, 8), np.float32), 5, mode=g.MODE_PLAIN, k=5, want=("hops", "dist_calc", "cand"))
+    assert r["ids"].tolist() == [0, 0, 0] and r["hops"].tolist() == [1, 1, 1] and r["dist_calc"].tolist() == [1, 1, 1]
+    assert (r["cand"][:, 0] == 0).all() and (r["cand"][:, 1:] == 0xFFFFFFFF).all()
+    ix.close()
+    c = datagen.Case("s", 950, 50, 7, 16, 8, 8)
+    rng = np.random.Generator(np.random.PCG64(3))
+    off, nbr = datagen.random_graph(rng, c.n, 1, 4)
+    db_low = orc.project(c.net, c.base)
+    ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+    for ef in (1, 64, 65, 500):  # 500 > n: the list never fills
+        w = orc.walk(orc.project(c.net, c.queries), db_low, off, nbr, ef)
+        s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net)
+        r = ix.search(c.queries, ef, want=("hops", "dist_calc", "cand"))
+        assert np.array_equal(r["cand"], w["ids"]) and np.array_equal(r["ids"], s["ids"])
+        assert np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"])
+        r1 = ix.search(c.queries[:1], ef)
+        assert r1["ids"][0] == s["ids"][0]
+    # standalone re-rank entry point == getRealNearest over the same lists
+    w = orc.walk(orc.project(c.net, c.queries), db_low, off, nbr, 16)
+    assert np.array_equal(ix.rerank(c.queries, w["ids"], w["count"]),
+                          orc.rerank(c.queries, w["ids"], w["count"], c.base))
+    ix.close()
