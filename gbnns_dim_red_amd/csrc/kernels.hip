@@ -454,6 +454,7 @@ __global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
 // list: [tie: kTieCap x u64][q: dstride x f32][hash: cap x u32].
 
 constexpr int kRegTieCap = 16;       // tie list of the register kernel (LDS, 128 B)
+constexpr int kRegListMaxEf = 256;   // largest ef served by the register-list kernels (4 registers per lane)
 
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
@@ -515,35 +516,87 @@ __device__ __forceinline__ const float* row_ptr(const float* base, uint32_t id, 
     }
 }
 
+// Register-resident result list: entry of rank i lives in register i / 64 of lane i % 64
+// (R registers per lane, ef <= 64 * R).  Empty slots hold all-ones, which reads as "expanded".
+template <int R>
+struct RegList {
+    uint32_t lo[R], hi[R];
+
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int r = 0; r < R; ++r) lo[r] = hi[r] = 0xFFFFFFFFu;
+    }
+    // wave-uniform rank -> value (all R readlanes are issued, a scalar select keeps the right one)
+    __device__ __forceinline__ uint32_t lo_at(int rank) const {
+        uint32_t v = readlane_u32(lo[0], rank & 63);
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            const uint32_t t = readlane_u32(lo[r], rank & 63);
+            if ((rank >> 6) == r) v = t;
+        }
+        return v;
+    }
+    __device__ __forceinline__ uint32_t hi_at(int rank) const {
+        uint32_t v = readlane_u32(hi[0], rank & 63);
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            const uint32_t t = readlane_u32(hi[r], rank & 63);
+            if ((rank >> 6) == r) v = t;
+        }
+        return v;
+    }
+    __device__ __forceinline__ void mark_expanded(int rank, int lane) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((rank >> 6) == r && lane == (rank & 63)) lo[r] |= 1u;
+    }
+    // lanes of register r that hold list entries (rank < ef)
+    __device__ __forceinline__ static uint64_t lane_mask(int r, int ef) {
+        const int left = ef - r * 64;
+        return left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
+    }
+};
+
 // One offer to the register-resident result list, reference rule (search_function.h:31-37):
 // insert when worst.dist > dist || size < ef, evict the largest pair when full.  Returns false
 // when the tie list overflowed (query is handed to the general kernel).
-// Lanes >= ef are scratch (they receive what falls off the end); readers mask them out.
+// Lanes of rank >= ef are scratch (they receive what falls off the end); readers mask them out.
 // The placement is decided per lane without a scalar round trip: a lane whose key is >= the new
 // key takes its left neighbour's entry, unless that neighbour's key is < the new key -- then it
-// is the insertion point and takes the new key.
-__device__ __forceinline__ bool reg_offer(uint32_t dl, uint32_t nlo, uint32_t& lo, uint32_t& hi, int& size,
-                                          uint32_t& worst, int& tsize, uint64_t* tie, int ef, int lane) {
+// is the insertion point and takes the new key.  Register r+1's lane 0 has register r's lane 63
+// as its left neighbour (carried through scalar registers).
+template <int R>
+__device__ __forceinline__ bool reg_offer(uint32_t dl, uint32_t nlo, RegList<R>& L, int& size, uint32_t& worst,
+                                          int& tsize, uint64_t* tie, int ef, int lane) {
     const bool full = size >= ef;
     if (full && !(dl < worst)) return true;  // re-test against the CURRENT worst
-    const uint64_t key = ((uint64_t)hi << 32) | lo;
     const uint64_t nk = ((uint64_t)dl << 32) | nlo;
-    const bool lt = key < nk;
-    // left neighbour's `lt` (lane 0 has none: treated as "smaller", which makes lane 0 an insertion point)
-    const uint32_t lt_left = (uint32_t)__builtin_amdgcn_update_dpp(1, lt ? 1 : 0, 0x138, 0xf, 0xf, false);
-    const uint32_t ev_lo = readlane_u32(lo, ef - 1);  // evicted entry when full (its hi == worst)
-    const uint32_t slo = dpp_wave_shr1(lo);
-    const uint32_t shi = dpp_wave_shr1(hi);
-    if (!lt) {
-        lo = lt_left ? nlo : slo;
-        hi = lt_left ? dl : shi;
+    const uint32_t ev_lo = L.lo_at(ef - 1);  // evicted entry when full (its hi == worst)
+    uint32_t c_lt = 1u, c_lo = 0u, c_hi = 0u;  // left neighbour of lane 0 (rank 0: "smaller" -> insertion point)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint64_t key = ((uint64_t)L.hi[r] << 32) | L.lo[r];
+        const bool lt = key < nk;
+        const uint32_t lt_i = lt ? 1u : 0u;
+        const uint32_t lt_left = (uint32_t)__builtin_amdgcn_update_dpp((int)c_lt, (int)lt_i, 0x138, 0xf, 0xf, false);
+        const uint32_t slo = (uint32_t)__builtin_amdgcn_update_dpp((int)c_lo, (int)L.lo[r], 0x138, 0xf, 0xf, false);
+        const uint32_t shi = (uint32_t)__builtin_amdgcn_update_dpp((int)c_hi, (int)L.hi[r], 0x138, 0xf, 0xf, false);
+        if (r + 1 < R) {
+            c_lt = readlane_u32(lt_i, 63);
+            c_lo = readlane_u32(L.lo[r], 63);
+            c_hi = readlane_u32(L.hi[r], 63);
+        }
+        if (!lt) {
+            L.lo[r] = lt_left ? nlo : slo;
+            L.hi[r] = lt_left ? dl : shi;
+        }
     }
     if (!full) {
         size += 1;
-        worst = readlane_u32(hi, size - 1);
+        worst = L.hi_at(size - 1);
         return true;
     }
-    const uint32_t nw = readlane_u32(hi, ef - 1);
+    const uint32_t nw = L.hi_at(ef - 1);
     if (nw != worst) {
         tsize = 0;                  // worst distance decreased: old ties are dead
     } else if (!(ev_lo & 1u)) {     // evicted unexpanded at a distance that is still the worst
@@ -556,7 +609,7 @@ __device__ __forceinline__ bool reg_offer(uint32_t dl, uint32_t nlo, uint32_t& l
     return true;
 }
 
-template <int METRIC, int STEPS, bool OFF32>
+template <int METRIC, int STEPS, bool OFF32, int R>
 __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                              uint32_t* ovf_count, uint32_t* ovf_list) {
 #ifdef GBNNS_STAMPS
@@ -577,7 +630,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
     wave_sync();
 
-    uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;  // this lane's list entry (empty)
+    RegList<R> L;  // this lane's R list entries
+    L.clear();
     int size = 1, tsize = 0, hops = 0, dist_calc = 1, edges = 0;
     uint32_t worst;                                // hi of lane size-1 (wave-uniform)
     const uint32_t entry = p.entries ? p.entries[qi] : 0u;
@@ -585,14 +639,13 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         const float d0 = walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, entry, p.dstride), p.dim);
         worst = fkey(d0);
         if (lane == 0) {
-            hi = worst;
-            lo = entry << 1;
+            L.hi[0] = worst;
+            L.lo[0] = entry << 1;
             hash[4u * __umulhi(entry * 0x9E3779B1u, cap >> 2)] = entry;  // first slot of its bucket
         }
         wave_sync();
     }
 
-    const uint64_t efmask = ef >= 64 ? ~0ull : ((1ull << ef) - 1ull);  // lanes that hold list entries
     int status = 0;  // 0 = walking, 1 = finished, 2 = handed over to the general kernel
     // Adjacency prefetch: when a node is picked, the row of the entry that will be picked next IF
     // this expansion inserts nothing closer is requested too.  The load stays in flight behind this
@@ -602,37 +655,46 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     while (true) {
         STAMP(t0)
         // ---- next node to expand: closest unexpanded entry, ties -> largest id -------------
-        const uint64_t mu = __ballot(!(lo & 1u)) & efmask;
+        uint64_t mu[R];
+        int p1 = -1, p2 = -1;  // ranks of the two closest unexpanded entries
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            mu[r] = __ballot(!(L.lo[r] & 1u)) & RegList<R>::lane_mask(r, ef);
+            uint64_t m = mu[r];
+            if (p1 < 0 && m) {
+                p1 = r * 64 + __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+            }
+            if (p1 >= 0 && p2 < 0 && m) p2 = r * 64 + __ffsll((unsigned long long)m) - 1;
+        }
         uint32_t node = 0, pred = kInvalidId;
         bool picked = false;
-        if (mu != 0 && tsize == 0) {
+        if (p1 >= 0 && tsize == 0) {
             // common case: the two closest unexpanded entries have different distances
-            const int p1 = __ffsll((unsigned long long)mu) - 1;
-            const uint64_t mu2 = mu & (mu - 1);
-            if (mu2) {
-                const int p2 = __ffsll((unsigned long long)mu2) - 1;
-                if (readlane_u32(hi, p1) != readlane_u32(hi, p2)) {
+            if (p2 >= 0) {
+                if (L.hi_at(p1) != L.hi_at(p2)) {
                     picked = true;
-                    node = readlane_u32(lo, p1) >> 1;
-                    pred = readlane_u32(lo, p2) >> 1;
-                    if (lane == p1) lo |= 1u;
+                    node = L.lo_at(p1) >> 1;
+                    pred = L.lo_at(p2) >> 1;
+                    L.mark_expanded(p1, lane);
                 }
             } else {
                 picked = true;
-                node = readlane_u32(lo, p1) >> 1;
-                if (lane == p1) lo |= 1u;
+                node = L.lo_at(p1) >> 1;
+                L.mark_expanded(p1, lane);
             }
         }
         if (!picked) {
             // rare: equal-distance run among the unexpanded entries, a non-empty tie list, or the end
-            const bool un = !(lo & 1u);
             int best = -1;
             uint32_t hi_p = 0;
-            if (mu) {
-                const int pl = __ffsll((unsigned long long)mu) - 1;
-                hi_p = readlane_u32(hi, pl);
-                const uint64_t ms = __ballot(un && hi == hi_p) & efmask;
-                best = 63 - __clzll((long long)ms);
+            if (p1 >= 0) {
+                hi_p = L.hi_at(p1);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint64_t ms = __ballot(!(L.lo[r] & 1u) && L.hi[r] == hi_p) & RegList<R>::lane_mask(r, ef);
+                    if (ms) best = r * 64 + 63 - __clzll((long long)ms);
+                }
             }
             bool from_tie = false;
             if (tsize > 0 && (best < 0 || hi_p == worst)) {
@@ -648,7 +710,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                 // every lane now holds the same (v, w); tell the compiler so (keeps loop state scalar)
                 v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
                 w = __builtin_amdgcn_readfirstlane(w);
-                const uint32_t lid = (best >= 0) ? (readlane_u32(lo, best) >> 1) : 0u;
+                const uint32_t lid = (best >= 0) ? (L.lo_at(best) >> 1) : 0u;
                 if (best < 0 || v - 1u > lid) {
                     from_tie = true;
                     node = v - 1u;
@@ -659,8 +721,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             }
             if (!from_tie) {
                 if (best < 0) { status = 1; break; }
-                node = readlane_u32(lo, best) >> 1;
-                if (lane == best) lo |= 1u;
+                node = L.lo_at(best) >> 1;
+                L.mark_expanded(best, lane);
             }
         }
         STAMP(t1)
@@ -721,7 +783,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             while (m) {
                 const int l = __ffsll((unsigned long long)m) - 1;
                 m &= m - 1;
-                if (!reg_offer(readlane_u32(dk, l), readlane_u32(nb, l) << 1, lo, hi, size, worst, tsize, tie, ef, lane)) {
+                if (!reg_offer<R>(readlane_u32(dk, l), readlane_u32(nb, l) << 1, L, size, worst, tsize, tie, ef, lane)) {
                     status = 2;
                     break;
                 }
@@ -749,16 +811,19 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         }
         return;
     }
-    // results in POP order (worst -> best): sorted index i goes to position kept-1-i
+    // results in POP order (worst -> best): rank i goes to position kept-1-i
     const int kept = size < p.k ? size : p.k;
-    if (lane < (int)p.cand_stride) {
-        const int r = kept - 1 - lane;
-        if (lane < kept) {
-            p.cand[(size_t)qi * p.cand_stride + r] = lo >> 1;
-            if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + r] = fkey_inv(hi);
-        } else {
-            p.cand[(size_t)qi * p.cand_stride + lane] = kInvalidId;
-            if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + lane] = __builtin_inff();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int rank = r * 64 + lane;
+        if (rank < (int)p.cand_stride) {
+            if (rank < kept) {
+                p.cand[(size_t)qi * p.cand_stride + (kept - 1 - rank)] = L.lo[r] >> 1;
+                if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + (kept - 1 - rank)] = fkey_inv(L.hi[r]);
+            } else {
+                p.cand[(size_t)qi * p.cand_stride + rank] = kInvalidId;
+                if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + rank] = __builtin_inff();
+            }
         }
     }
     if (lane == 0) {
@@ -767,17 +832,17 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         p.dist_calc[qi] = dist_calc;
         atomicMax(p.max_dc, (uint32_t)dist_calc);
         if (p.edges) p.edges[qi] = edges;
-        if (p.best) p.best[qi] = lo >> 1;
+        if (p.best) p.best[qi] = L.lo[0] >> 1;
     }
 }
 
-template <int METRIC, int STEPS, bool OFF32, bool RETRY>
+template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R>
 __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if constexpr (RETRY) {
-        retry_loop(p, [&](uint32_t qi) { walk_reg_one<METRIC, STEPS, OFF32>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
+        retry_loop(p, [&](uint32_t qi) { walk_reg_one<METRIC, STEPS, OFF32, R>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
     } else {
-        walk_reg_one<METRIC, STEPS, OFF32>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
+        walk_reg_one<METRIC, STEPS, OFF32, R>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
     }
 }
 
@@ -1158,14 +1223,14 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t count) {
 // ------------------------------------------------------------------------------------------
 
 size_t walk_fast_lds_bytes(const WalkParams& p) {
-    if (p.ef <= 64)  // register kernel: list in registers
+    if (p.ef <= kRegListMaxEf)  // register kernels: list in registers
         return (size_t)kRegTieCap * 8 + (size_t)p.dstride * 4 + (size_t)p.hash_cap * 4;
     const size_t ef_pad = ((size_t)p.ef + 63) & ~(size_t)63;
     return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)p.dstride * 4 + (size_t)p.hash_cap * 4;
 }
 
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride) {
-    if (ef <= 64) return (size_t)kRegTieCap * 8 + (size_t)dstride * 4;
+    if (ef <= kRegListMaxEf) return (size_t)kRegTieCap * 8 + (size_t)dstride * 4;
     const size_t ef_pad = ((size_t)ef + 63) & ~(size_t)63;
     return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)dstride * 4;
 }
@@ -1187,18 +1252,26 @@ static hipError_t launch_walk_k(K kernel, const WalkParams& p, bool retry, size_
     return hipGetLastError();
 }
 
+template <int METRIC, int STEPS, int R>
+static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipStream_t s) {
+    // 32-bit byte offsets when both tables are < 4 GiB
+    const bool off32 = (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32);
+    if (off32)
+        return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, true, R>, p, true, lds, s)
+                     : launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, R>, p, false, lds, s);
+    return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, false, true, R>, p, true, lds, s)
+                 : launch_walk_k(walk_reg_kernel<METRIC, STEPS, false, false, R>, p, false, lds, s);
+}
+
+// ef <= 64: one list register per lane (all row-length specialisations); ef <= 128 / 256: two / four
+// registers (generic or 128-B-row distance); beyond that the list lives in LDS.
 template <int METRIC, int STEPS>
 static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) {
     const size_t lds = walk_fast_lds_bytes(p);
-    if (p.ef <= 64) {
-        // 32-bit byte offsets when both tables are < 4 GiB
-        const bool off32 = (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32);
-        if (off32)
-            return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, true>, p, true, lds, s)
-                         : launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false>, p, false, lds, s);
-        return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, false, true>, p, true, lds, s)
-                     : launch_walk_k(walk_reg_kernel<METRIC, STEPS, false, false>, p, false, lds, s);
-    }
+    constexpr int kWideSteps = (STEPS == 8) ? 8 : 0;
+    if (p.ef <= 64) return launch_reg_t<METRIC, STEPS, 1>(p, retry, lds, s);
+    if (p.ef <= 128) return launch_reg_t<METRIC, kWideSteps, 2>(p, retry, lds, s);
+    if (p.ef <= kRegListMaxEf) return launch_reg_t<METRIC, kWideSteps, 4>(p, retry, lds, s);
     return retry ? launch_walk_k(walk_fast_kernel<METRIC, STEPS, true>, p, true, lds, s)
                  : launch_walk_k(walk_fast_kernel<METRIC, STEPS, false>, p, false, lds, s);
 }
