@@ -176,6 +176,7 @@ def make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=123
                  queries=queries, net=net, db_low=db_low, graph_off=goff, graph_nbr=gnbr,
                  gt=gt2[:, 0].contiguous(), gt2=gt2, timings=timings)
     if path:
+        os.makedirs(cache_dir, exist_ok=True)
         tmp = path + f".tmp{os.getpid()}"
         torch.save(dict(base=base, queries=queries, net=list(net), db_low=db_low,
                         graph_off=torch.from_numpy(goff.astype(np.int64)),

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Kernel times on the other BASELINE.json configuration shapes (synthetic data, one GPU).
+Not the contract bench (that is bench.py / SIFT1M): a survey of where the time goes per shape."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gbnns_dim_red_amd import synth
+
+CONFIGS = {
+    "sift": dict(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, efs=[64, 128]),
+    "gist": dict(n=1_000_000, nq=1_000, d=960, d_low=64, d_hidden=1024, efs=[200, 400]),
+    "glove": dict(n=1_200_000, nq=10_000, d=200, d_low=32, d_hidden=256, efs=[64, 300]),
+    "deep": dict(n=10_000_000, nq=125_000, d=96, d_low=32, d_hidden=128, efs=[40, 120]),
+}
+ap = argparse.ArgumentParser()
+ap.add_argument("configs", nargs="*", default=["gist", "glove"])
+ap.add_argument("--scale", type=float, default=1.0, help="scale n (and nq for deep) down for a quick look")
+a = ap.parse_args()
+for name in a.configs:
+    c = dict(CONFIGS[name])
+    efs = c.pop("efs")
+    c["n"] = int(c["n"] * a.scale)
+    t0 = time.time()
+    ds = synth.make_dataset(device="cuda:0", cache_dir=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"), **c)
+    ix = ds.index()
+    print(f"== {name}: n={ds.n} nq={ds.nq} {ds.d}->{ds.d_low} (h {ds.d_hidden}) built in {time.time()-t0:.1f}s", flush=True)
+    for ef in efs:
+        for _ in range(3):
+            r = ix.search(ds.queries, ef, want=("hops", "dist_calc"))
+        torch.cuda.synchronize()
+        ix.profile_read(reset=True); ix.profile_enable(True)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            r = ix.search(ds.queries, ef, want=("hops", "dist_calc"))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 5
+        p = ix.profile_read(reset=True); ix.profile_enable(False)
+        rec = (r["ids"].long() == ds.gt).float().mean().item()
+        k = {x: round(p[x + "_ms"] / p["calls"], 4) for x in ("project", "walk", "walk_general", "rerank")}
+        rr_bytes = ds.nq * ef * 4.0 * ds.d
+        print(json.dumps(dict(config=name, ef=ef, recall=round(rec, 4), qps=round(ds.nq / dt), ms=round(dt * 1e3, 3),
+                              kernels_ms=k, rerank_GBps=round(rr_bytes / (k["rerank"] * 1e-3) / 1e9, 1),
+                              hops=round(r["hops"].float().mean().item(), 1),
+                              dist_calc=round(r["dist_calc"].float().mean().item(), 1),
+                              general=p["general_queries"])), flush=True)
+    ix.close()
+    del ds
+    torch.cuda.empty_cache()
