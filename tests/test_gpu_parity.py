@@ -353,3 +353,55 @@ def test_small_and_degenerate_indexes(g, orc):
     assert np.array_equal(ix.rerank(c.queries, w["ids"], w["count"]),
                           orc.rerank(c.queries, w["ids"], w["count"], c.base))
     ix.close()
+
+
+def test_randomised_small_cases(g, orc):
+    """Many tiny seeded configurations (dimension tails, ragged degrees incl. 0 and > 64, every mode,
+    both metrics, random ef / k / entry points): ids, hops, dist_calc and candidate lists must equal
+    the oracle's in every one."""
+    rng = np.random.Generator(np.random.PCG64(20261003))
+    for case in range(120):
+        n = int(rng.integers(2, 1500))
+        nq = int(rng.integers(1, 40))
+        d = int(rng.integers(1, 71))
+        dlow = int(rng.integers(1, 41))
+        dh = int(rng.integers(1, 50))
+        metric = int(rng.integers(0, 2))
+        kind = "lattice" if case % 5 == 0 else "clustered"
+        c = datagen.Case("r", 3000 + case, n, nq, d, dlow, dh, kind=kind)
+        deg_hi = int(rng.choice([3, 12, 33, 70, 130]))
+        off, nbr = datagen.random_graph(rng, n, 0, min(deg_hi, n - 1))
+        ent = rng.integers(0, n, size=nq).astype(np.uint32)
+        ef = int(rng.choice([1, 2, 5, 17, 64, 65, 100, 129, 257, 400]))
+        mode = int(rng.integers(0, 3))
+        tag = (case, n, nq, d, dlow, dh, metric, kind, deg_hi, ef, mode)
+        if mode == 2:
+            k = int(rng.integers(1, ef + 1))
+            ix = g.Index(c.base, off, nbr, metric=metric)
+            w = orc.walk(c.queries, c.base, off, nbr, ef, k=k, entries=ent, metric=metric)
+            r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=k, entry_ids=ent, want=("hops", "dist_calc", "cand"))
+            assert np.array_equal(r["cand"], w["ids"]), tag
+            assert np.array_equal(r["hops"], w["hops"]), tag
+            assert np.array_equal(r["dist_calc"], w["dist_calc"]), tag
+            best = w["ids"][np.arange(nq), w["count"] - 1]
+            assert np.array_equal(r["ids"], best), tag
+        else:
+            db_low = orc.project(c.net, c.base)
+            if not np.isfinite(db_low).all():
+                continue  # a zero-norm projection (0/0): outside the arithmetic contract
+            q_low = orc.project(c.net, c.queries)
+            if not np.isfinite(q_low).all():
+                continue
+            ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net, metric=metric)
+            s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net,
+                                 entries=ent, metric=metric)
+            if mode == 0:
+                r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "q_low"))
+                assert np.array_equal(gu.bits(r["q_low"]), gu.bits(q_low)), tag
+            else:
+                r = ix.search(c.queries, ef, mode=g.MODE_LOWQ, queries_low=q_low, entry_ids=ent,
+                              want=("hops", "dist_calc"))
+            assert np.array_equal(r["ids"], s["ids"]), tag
+            assert np.array_equal(r["hops"], s["hops"]), tag
+            assert np.array_equal(r["dist_calc"] + ef, s["dist_calc"]), tag
+        ix.close()
