@@ -210,6 +210,25 @@ def main():
                        "general_queries": prof["general_queries"]},
     }
 
+    # ---- opt-in matrix-core projection (not bit-exact): how fast, and how many answers change --------
+    if world == 1:
+        for _ in range(3):
+            rm = ix.search(q, ef, want=(), flags=g.FLAG_MFMA_PROJECT)
+        torch.cuda.synchronize()
+        ix.profile_read(reset=True)
+        ix.profile_enable(True)
+        for _ in range(10):
+            rm = ix.search(q, ef, want=(), flags=g.FLAG_MFMA_PROJECT)
+        torch.cuda.synchronize()
+        pm = ix.profile_read(reset=True)
+        ix.profile_enable(False)
+        result["mfma_project_option"] = {
+            "project_ms": round(pm["project_ms"] / max(pm["calls"], 1), 4),
+            "answers_changed": int((rm["ids"] != res["ids"]).sum().item()),
+            "recall_at_1": round(recall_of(rm["ids"]), 4),
+            "note": "f32 MFMA fma-chain rounding; off by default, default path is bit-exact",
+        }
+
     # ---- PCIe-inclusive rate (host buffers in, ids out: what the C++ drop-in times); never `value`
     if world == 1:
         qh = q.cpu().numpy()

@@ -14,6 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "lib", "libgbnns_hip.so")
 METRIC_L2, METRIC_NEG_DOT = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 MODE_NET, MODE_LOWQ, MODE_PLAIN = 0, 1, 2
+FLAG_MFMA_PROJECT = 1
 
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -46,7 +47,8 @@ class _SearchArgs(C.Structure):
         ("queries", C.c_void_p), ("queries_low", C.c_void_p), ("entry_ids", C.c_void_p),
         ("out_ids", C.c_void_p), ("out_hops", C.c_void_p), ("out_dist_calc", C.c_void_p),
         ("out_cand", C.c_void_p), ("out_cand_dist", C.c_void_p), ("out_q_low", C.c_void_p),
-        ("out_edges", C.c_void_p), ("stream", C.c_void_p),
+        ("out_edges", C.c_void_p), ("stream", C.c_void_p), ("flags", C.c_uint32),
+        ("reserved1", C.c_uint32),
     ]
 
 
@@ -216,7 +218,7 @@ class Index:
 
     # -- search ------------------------------------------------------------------------------
     def search(self, queries, ef, mode=MODE_NET, k=1, queries_low=None, entry_ids=None,
-               want=("hops", "dist_calc"), hash_capacity=0, stream=None, out=None):
+               want=("hops", "dist_calc"), hash_capacity=0, stream=None, out=None, flags=0):
         """Runs one batch.  numpy queries -> synchronous call, numpy results.  torch CUDA queries
         -> enqueued on `stream` (torch stream or None = current), torch results, no sync.
         `want` may also name "cand", "cand_dist", "q_low", "edges".  Returns a dict with "ids" + wanted."""
@@ -255,7 +257,7 @@ class Index:
         a = _SearchArgs(struct_size=C.sizeof(_SearchArgs), mode=mode, ef=ef, k=kk,
                         mem_kind=MEM_DEVICE if dev else MEM_HOST, hash_capacity=hash_capacity,
                         n_q=nq, queries=_ptr(queries), queries_low=_ptr(queries_low),
-                        entry_ids=_ptr(entry_ids), out_ids=_ptr(ids), stream=sptr)
+                        entry_ids=_ptr(entry_ids), out_ids=_ptr(ids), stream=sptr, flags=flags)
         if "hops" in want:
             a.out_hops = _ptr(alloc("hops", (nq,), i32))
         if "dist_calc" in want:

@@ -351,14 +351,14 @@ namespace {
 
 // MLP over rows x [nx x xstride] (device) -> out [nx x dl_pad] (device); h1/h2 are scratch.
 int run_project(gbnns_index* ix, const float* x, uint32_t xstride, uint32_t nx, float* out,
-                hipStream_t s) {
+                hipStream_t s, bool mfma = false) {
     int rc = ix->h1.ensure((size_t)nx * ix->d_hidden * 4);
     if (!rc) rc = ix->h2.ensure((size_t)nx * ix->d_hidden * 4);
     if (rc) return rc;
     LayerParams p{};
     p.x = x; p.xstride = xstride; p.w = ix->w1; p.wstride = ix->ws1; p.bias = ix->b1;
     p.out = ix->h1.as<float>(); p.ostride = ix->d_hidden; p.nq = nx; p.din = ix->d;
-    p.dout = ix->d_hidden; p.relu = 1;
+    p.dout = ix->d_hidden; p.relu = 1; p.mfma = mfma ? 1 : 0;
     HIP_TRY(launch_mlp_layer(p, s));
     p.x = ix->h1.as<float>(); p.xstride = ix->d_hidden; p.w = ix->w2; p.wstride = ix->ws2;
     p.bias = ix->b2; p.out = ix->h2.as<float>(); p.din = ix->d_hidden;
@@ -590,7 +590,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         if ((rc = ix->q_low.ensure((size_t)nq * ix->dl_pad * 4))) return rc;
         float* ql = ix->q_low.as<float>();
         if (a->mode == GBNNS_MODE_NET) {
-            if ((rc = run_project(ix, q_dev, ix->d, nq, ql, s))) return rc;
+            if ((rc = run_project(ix, q_dev, ix->d, nq, ql, s, (a->flags & GBNNS_FLAG_MFMA_PROJECT) != 0))) return rc;
             w.q = ql; w.qstride = ix->dl_pad;
         } else if (host) {
             HIP_TRY(hipMemcpyAsync(ql, a->queries_low, (size_t)nq * ix->d_low * 4, hipMemcpyHostToDevice, s));

@@ -90,6 +90,7 @@ struct LayerParams {
     uint32_t ostride;
     uint32_t nq, din, dout;
     int32_t relu;
+    int32_t mfma;            // 1: matrix-core variant (k-ordered fma chain: not bit-exact, opt-in)
 };
 hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s);
 // y [nq x stride]: y /= sqrt(L2(y, 0)) over dim (4-lane order, d%4 tail ignored in the norm),

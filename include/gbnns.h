@@ -100,7 +100,16 @@ typedef struct {
     int32_t* out_edges;        /* optional [n_q]: neighbour ids read by the walk (sum of the degrees of
                                   the expanded nodes) -- feeds the algorithmic-bytes figure */
     void* stream;              /* hipStream_t to enqueue on (NULL = default stream) */
+    uint32_t flags;            /* GBNNS_FLAG_* */
+    uint32_t reserved1;
 } gbnns_search_args;
+
+/* Throughput option, off by default: run the MLP projection on the matrix cores (f32 MFMA).  The
+ * dot products then round differently from support_func.h:131-163 (one fma chain instead of 8
+ * separately rounded sums), so projected queries differ in the last ulp and an answer can differ
+ * where two candidates are nearly tied; everything downstream is unchanged.  bench.py reports the
+ * number of changed answers.  Without this flag results are bit-identical to the reference. */
+#define GBNNS_FLAG_MFMA_PROJECT 1u
 
 /* Replaces the timed query loop of performNetTest (search_function.h:346-387) / performTest
  * (:151-188): one call = the whole batch.  With HOST buffers the call copies in, runs and
