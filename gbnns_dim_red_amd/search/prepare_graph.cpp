@@ -1,0 +1,50 @@
+// prepare_graph.cpp -- the reference's graph-preparation driver (search/prepare_graph.cpp):
+// loads the low-dimensional base set and its kNN lists, prunes them with hnswlikeGD(M = 30,
+// reverse edges) and writes the adjacency the search walks (prepare_graph.cpp:64-74).
+//
+//   ./prepare_graph <dataset> <lat_name> [data_dir] [models_dir] [params_file]
+//
+// Files (reference naming): <data_dir>/<dataset>_base_<lat_name>.fvecs,
+// <models_dir>/<dataset>_knn_1k_<lat_name>.ivecs  ->  <models_dir>/<dataset>_gd_knn_<lat_name>.ivecs
+// GBNNS_GD_M overrides M.  Host-only program (the builder is host code, as in the reference).
+#include "search_function.h"
+
+static string pickPath(int argc, char** argv, int pos, const char* env, const string& fallback) {
+    if (argc > pos) return argv[pos];
+    const char* e = getenv(env);
+    return e ? string(e) : fallback;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        cout << " Need to specify parameters" << endl;
+        return 1;
+    }
+    const string datasetName = argv[1];
+    const string fileLatName = argv[2];
+    const string dataDir = pickPath(argc, argv, 3, "GBNNS_DATA_DIR", "data/" + datasetName);
+    const string modelsDir = pickPath(argc, argv, 4, "GBNNS_MODELS_DIR", "models/" + datasetName);
+    const string paramsPath = pickPath(argc, argv, 5, "GBNNS_PARAMS", "parameters_of_databases.txt");
+    cout << datasetName << endl;
+
+    std::map<string, string> params = readSearchParams(paramsPath, datasetName);
+    const size_t n = atoi(params["n"].c_str());
+    const size_t d_low = atoi(params["d_low"].c_str());
+    if (n == 0 || d_low == 0) {
+        cout << "dataset '" << datasetName << "' not found in " << paramsPath << endl;
+        return 1;
+    }
+    cout << n << " " << d_low << endl;
+
+    L2Metric l2 = L2Metric();
+    std::vector<float> db_low = loadXvecs<float>(dataDir + "/" + datasetName + "_base_" + fileLatName + ".fvecs", d_low, n);
+    vector<vector<uint32_t>> knn_low =
+        loadEdges(modelsDir + "/" + datasetName + "_knn_1k_" + fileLatName + ".ivecs", n, "knn_low");
+
+    int M = 30;
+    if (const char* e = getenv("GBNNS_GD_M")) M = atoi(e);
+    vector<vector<uint32_t>> gd_knn_low = hnswlikeGD(knn_low, db_low.data(), M, n, d_low, &l2, true, false);
+    cout << "GD_knn " << findGraphAverageDegree(gd_knn_low) << endl;
+    writeEdges(modelsDir + "/" + datasetName + "_gd_knn_" + fileLatName + ".ivecs", gd_knn_low);
+    return 0;
+}

@@ -3,7 +3,7 @@
 //   Net (:45-49), Metric / L2Metric / Angular (:87-163), findGraphAverageDegree (:166),
 //   readXvec / writeXvec / loadXvecs (:176-228), writeEdges / loadEdges (:205-249),
 //   splitString / addMapFromStr / readSearchParams / getVectorFromString (:578-621),
-//   GetLowQueryFromNet (:645-658).
+//   hnswlikeGD (:521-575), GetLowQueryFromNet (:645-658).
 // Like the reference's header it holds non-inline definitions: include it from one .cpp only.
 //
 // The Metric classes here are plain scalar code in the reference's operation order (4 running
@@ -197,6 +197,31 @@ inline GbnnsCsr gbnnsToCsr(const vector<vector<uint32_t>>& graph) {
 inline void gbnnsDie(const char* what) {
     std::cerr << "gbnns: " << what << ": " << gbnns_last_error() << std::endl;
     exit(2);
+}
+
+// hnswlikeGD (reference support_func.h:521-575): prunes a kNN graph into the search graph (the
+// "GD" rule + the M/2 nearest + optional reverse edges).  Same signature; the work is done by the
+// library's host builder gbnns_build_graph_gd (OpenMP, reference operation order).
+// need_const_degree = true (getConstantDegreeForGD, :466-485) is not implemented.
+vector<vector<uint32_t>> hnswlikeGD(vector<vector<uint32_t>>& graph, const float* ds, int M, size_t N, size_t d,
+                                    Metric* metric, bool reverse, bool need_const_degree) {
+    if (need_const_degree) {
+        std::cerr << "gbnns: hnswlikeGD(need_const_degree = true) is not implemented" << std::endl;
+        exit(2);
+    }
+    const GbnnsCsr knn = gbnnsToCsr(graph);
+    uint64_t* off = nullptr;
+    uint32_t* nbr = nullptr;
+    if (gbnns_build_graph_gd(knn.offsets.data(), knn.nbrs.data(), ds, N, (uint32_t)d, M, metric->gbnnsMetric(),
+                             reverse ? 1 : 0, 0, &off, &nbr)) {
+        std::cerr << "gbnns: gbnns_build_graph_gd failed (bad ids, M < 2 or out of memory)" << std::endl;
+        exit(2);
+    }
+    vector<vector<uint32_t>> out(N);
+    for (size_t i = 0; i < N; ++i) out[i].assign(nbr + off[i], nbr + off[i + 1]);
+    gbnns_free(off);
+    gbnns_free(nbr);
+    return out;
 }
 
 // GetLowQueryFromNet: one query through the 3-layer net on the device (gbnns_project).  Same
