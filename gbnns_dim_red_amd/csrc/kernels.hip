@@ -609,6 +609,53 @@ __device__ __forceinline__ bool reg_offer(uint32_t dl, uint32_t nlo, RegList<R>&
     return true;
 }
 
+// Batch merge of one hop's survivors into a one-register list (ef <= 64).  Offering the survivors
+// one by one (reg_offer) is a long serial chain; here every survivor's final position and every
+// list entry's shift are counted in one pass over the survivors (independent compares), the new
+// list is scattered through a 512-B LDS buffer, and the result equals the sequential rule
+// (search_function.h:31-37) whenever no dropped element (evicted entry or rejected survivor) ties
+// the new worst distance: an element the sequential rule rejects has dist >= the worst distance of
+// its moment >= the final worst distance, so it lies outside the top-ef by (dist, id) unless it
+// TIES the final worst distance -- and an accepted element is only ever displaced by smaller keys.
+// On such a tie (returns false, list untouched) the caller falls back to the sequential offers.
+__device__ __forceinline__ bool reg_merge(uint64_t m, uint32_t dk, uint32_t nb, RegList<1>& L, int& size,
+                                          uint32_t& worst, int& tsize, uint64_t* stage, int ef, int lane) {
+    const int ns = __popcll(m);
+    const uint64_t key = ((uint64_t)L.hi[0] << 32) | L.lo[0];
+    const uint64_t skey = ((uint64_t)dk << 32) | ((uint64_t)nb << 1);
+    const bool is_entry = lane < size;
+    const bool is_surv = (m >> lane) & 1ull;
+    const uint64_t entry_mask = size >= 64 ? ~0ull : ((1ull << size) - 1ull);
+    int shift = 0, rank = 0, pos_l = 0;
+    uint64_t mm = m;
+    while (mm) {
+        const int sl = __ffsll((unsigned long long)mm) - 1;
+        mm &= mm - 1;
+        const uint64_t ks = ((uint64_t)readlane_u32(dk, sl) << 32) | ((uint64_t)readlane_u32(nb, sl) << 1);
+        shift += key > ks ? 1 : 0;
+        rank += skey > ks ? 1 : 0;
+        const int cnt = __popcll(__ballot(key < ks) & entry_mask);
+        pos_l = lane == sl ? cnt : pos_l;
+    }
+    // a lane plays two roles: it holds list entry `lane` and (maybe) the survivor of neighbour `lane`
+    const int dst_e = lane + shift, dst_s = pos_l + rank;
+    const int new_size = size + ns < ef ? size + ns : ef;
+    if (is_entry && dst_e < ef) stage[dst_e] = key;
+    if (is_surv && dst_s < ef) stage[dst_s] = skey;
+    wave_sync();
+    const uint64_t nkey = lane < new_size ? stage[lane] : ~0ull;
+    const uint32_t nw = readlane_u32((uint32_t)(nkey >> 32), new_size - 1);
+    // boundary tie: a dropped element at exactly the new worst distance -> order matters, go sequential
+    if (__ballot((is_entry && dst_e >= ef && L.hi[0] == nw) || (is_surv && dst_s >= ef && dk == nw))) return false;
+    L.lo[0] = (uint32_t)nkey;
+    L.hi[0] = (uint32_t)(nkey >> 32);
+    if (size + ns > ef) tsize = 0;  // something was evicted and (no tie) the worst distance decreased
+    size = new_size;
+    worst = nw;
+    wave_sync();
+    return true;
+}
+
 template <int METRIC, int STEPS, bool OFF32, int R>
 __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                              uint32_t* ovf_count, uint32_t* ovf_list) {
@@ -620,7 +667,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     const int lane = lane_id();
     const int ef = p.ef;
     uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
-    float* qf = reinterpret_cast<float*>(tie + kRegTieCap);
+    uint64_t* stage = tie + kRegTieCap;  // [64] scatter buffer of the batch merge
+    float* qf = reinterpret_cast<float*>(stage + 64);
     uint32_t* hash = reinterpret_cast<uint32_t*>(qf + p.dstride);
     const float4* qs = reinterpret_cast<const float4*>(qf);
     const uint32_t cap = p.hash_cap;  // any size: slot = mulhi(id * C, cap)
@@ -779,7 +827,11 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             uint64_t m = __ballot(fresh && (size < ef || dk < worst));
             STAMP(t5)
             STAMP_ADD(4, t4, t5)
-            // reference order: survivors are offered one by one in list order (search_function.h:31-37)
+            // several survivors: merge them in one pass (falls through to the sequential offers on a
+            // boundary tie); reference order = one by one in list order (search_function.h:31-37)
+            if constexpr (R == 1) {
+                if ((m & (m - 1)) != 0 && reg_merge(m, dk, nb, L, size, worst, tsize, stage, ef, lane)) m = 0;
+            }
             while (m) {
                 const int l = __ffsll((unsigned long long)m) - 1;
                 m &= m - 1;
@@ -1307,13 +1359,13 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t count) {
 
 size_t walk_fast_lds_bytes(const WalkParams& p) {
     if (p.ef <= kRegListMaxEf)  // register kernels: list in registers
-        return (size_t)kRegTieCap * 8 + (size_t)p.dstride * 4 + (size_t)p.hash_cap * 4;
+        return (size_t)kRegTieCap * 8 + 512 + (size_t)p.dstride * 4 + (size_t)p.hash_cap * 4;
     const size_t ef_pad = ((size_t)p.ef + 63) & ~(size_t)63;
     return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)p.dstride * 4 + (size_t)p.hash_cap * 4;
 }
 
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride) {
-    if (ef <= kRegListMaxEf) return (size_t)kRegTieCap * 8 + (size_t)dstride * 4;
+    if (ef <= kRegListMaxEf) return (size_t)kRegTieCap * 8 + 512 + (size_t)dstride * 4;  // tie list + merge buffer + query
     const size_t ef_pad = ((size_t)ef + 63) & ~(size_t)63;
     return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)dstride * 4;
 }
