@@ -705,31 +705,53 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         // ---- next node to expand: closest unexpanded entry, ties -> largest id -------------
         uint64_t mu[R];
         int p1 = -1, p2 = -1;  // ranks of the two closest unexpanded entries
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            mu[r] = __ballot(!(L.lo[r] & 1u)) & RegList<R>::lane_mask(r, ef);
-            uint64_t m = mu[r];
-            if (p1 < 0 && m) {
-                p1 = r * 64 + __ffsll((unsigned long long)m) - 1;
-                m &= m - 1;
-            }
-            if (p1 >= 0 && p2 < 0 && m) p2 = r * 64 + __ffsll((unsigned long long)m) - 1;
-        }
         uint32_t node = 0, pred = kInvalidId;
         bool picked = false;
-        if (p1 >= 0 && tsize == 0) {
-            // common case: the two closest unexpanded entries have different distances
-            if (p2 >= 0) {
-                if (L.hi_at(p1) != L.hi_at(p2)) {
+        if constexpr (R == 1) {
+            // one list register: straight branches to the rare path (the kernel is instruction-issue
+            // bound -- a flag-and-merge formulation costs ~20 more scalar instructions per hop)
+            mu[0] = __ballot(!(L.lo[0] & 1u)) & RegList<R>::lane_mask(0, ef);
+            if (mu[0] == 0 || tsize != 0) goto slow_select;
+            {
+                const int q1 = __ffsll((unsigned long long)mu[0]) - 1;
+                const uint64_t m2 = mu[0] & (mu[0] - 1);
+                p1 = q1;
+                if (m2) {
+                    const int q2 = __ffsll((unsigned long long)m2) - 1;
+                    if (readlane_u32(L.hi[0], q1) == readlane_u32(L.hi[0], q2)) goto slow_select;
+                    pred = readlane_u32(L.lo[0], q2) >> 1;
+                }
+                node = readlane_u32(L.lo[0], q1) >> 1;
+                if (lane == q1) L.lo[0] |= 1u;
+                goto have_node;
+            }
+        slow_select:
+            p1 = mu[0] ? __ffsll((unsigned long long)mu[0]) - 1 : -1;
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                mu[r] = __ballot(!(L.lo[r] & 1u)) & RegList<R>::lane_mask(r, ef);
+                uint64_t m = mu[r];
+                if (p1 < 0 && m) {
+                    p1 = r * 64 + __ffsll((unsigned long long)m) - 1;
+                    m &= m - 1;
+                }
+                if (p1 >= 0 && p2 < 0 && m) p2 = r * 64 + __ffsll((unsigned long long)m) - 1;
+            }
+            if (p1 >= 0 && tsize == 0) {
+                // common case: the two closest unexpanded entries have different distances
+                if (p2 >= 0) {
+                    if (L.hi_at(p1) != L.hi_at(p2)) {
+                        picked = true;
+                        node = L.lo_at(p1) >> 1;
+                        pred = L.lo_at(p2) >> 1;
+                        L.mark_expanded(p1, lane);
+                    }
+                } else {
                     picked = true;
                     node = L.lo_at(p1) >> 1;
-                    pred = L.lo_at(p2) >> 1;
                     L.mark_expanded(p1, lane);
                 }
-            } else {
-                picked = true;
-                node = L.lo_at(p1) >> 1;
-                L.mark_expanded(p1, lane);
             }
         }
         if (!picked) {
@@ -773,6 +795,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                 L.mark_expanded(best, lane);
             }
         }
+    have_node:
         STAMP(t1)
         STAMP_ADD(0, t0, t1)
 

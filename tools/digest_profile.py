@@ -14,11 +14,14 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("walk_reg_kernel", "walk_fast_kernel"):
+    for key, idx in (("walk_reg_kernel", 3), ("walk_fast_kernel", 2)):
         if key in name:
-            # last template argument = RETRY (the persistent second pass over handed-over queries)
+            # template argument `idx` = RETRY (the persistent second pass over handed-over queries);
+            # walk_reg_kernel<METRIC, STEPS, OFF32, RETRY, R>, walk_fast_kernel<METRIC, STEPS, RETRY>
             args = name[name.find("<") + 1:name.rfind(">")].replace(" ", "").split(",")
-            return key + ("/retry" if args and args[-1] in ("true", "1") else "")
+            retry = len(args) > idx and args[idx] in ("true", "1")
+            regs = "/R%s" % args[4] if key == "walk_reg_kernel" and len(args) > 4 and args[4] != "1" else ""
+            return key + regs + ("/retry" if retry else "")
     for key in ("walk_general_kernel", "rerank_kernel", "mlp_layer_vec_kernel", "mlp_layer_kernel",
                 "normalize_kernel", "fill_u32_kernel"):
         if key in name:
