@@ -145,18 +145,31 @@ __device__ __forceinline__ float metric_dist(PA a, PB b, uint32_t dim) {
 // bucket with an empty slot; a new id claims the first empty slot of that bucket with a CAS (a
 // lane of the same wavefront may win the slot in the same instruction: then the bucket is read
 // again).  Ids offered concurrently are distinct (rows are de-duplicated at index creation).
-__device__ __forceinline__ bool visited_claim(uint32_t* hash, uint32_t nbuckets, uint32_t id) {
+__device__ __forceinline__ bool visited_claim(uint32_t* hash, uint32_t nbuckets, uint32_t id, bool valid) {
+    // Wave-uniform loop over "some lane still probing" (scalar branch, no per-lane loop masks);
+    // ids are < 2^31 (gbnns_index_create), so only an empty slot (0xFFFFFFFF) has its sign bit set,
+    // and slots of a bucket fill in order: the number of occupied slots is 4 + the sum of the signs.
     uint32_t b = __umulhi(id * 0x9E3779B1u, nbuckets);
-    while (true) {
-        const uint4 e = *reinterpret_cast<const uint4*>(hash + 4u * b);
-        if (e.x == id || e.y == id || e.z == id || e.w == id) return false;
-        const int slot = e.x == kInvalidId ? 0 : e.y == kInvalidId ? 1 : e.z == kInvalidId ? 2 : e.w == kInvalidId ? 3 : -1;
-        if (slot >= 0) {
-            if (atomicCAS(hash + 4u * b + slot, kInvalidId, id) == kInvalidId) return true;
-            continue;  // lost the slot to another lane: look at the bucket again
+    bool fresh = false, active = valid;
+    do {
+        if (active) {
+            const uint4 e = *reinterpret_cast<const uint4*>(hash + 4u * b);
+            const uint32_t differ = min(min(e.x ^ id, e.y ^ id), min(e.z ^ id, e.w ^ id));
+            const int full = 4 + ((int)e.x >> 31) + ((int)e.y >> 31) + ((int)e.z >> 31) + ((int)e.w >> 31);
+            const bool absent = differ != 0u;
+            const bool claim = absent & (full < 4);
+            // One CAS for every probing lane, no nested divergence: lanes that do not claim compare
+            // against a value no slot ever holds (ids < 2^31) and change nothing.  A lane of this
+            // wavefront may win the slot in the same instruction: the loser looks at the bucket again.
+            const uint32_t old = atomicCAS(hash + 4u * b + ((uint32_t)full & 3u), claim ? kInvalidId : 0xFFFFFFFEu, id);
+            const bool won = claim & (old == kInvalidId);
+            fresh = won;
+            active = absent & !won;
+            const uint32_t nx = (b + 1u == nbuckets) ? 0u : b + 1u;
+            b = (full >= 4) ? nx : b;
         }
-        b = (b + 1u == nbuckets) ? 0u : b + 1u;
-    }
+    } while (__ballot(active));
+    return fresh;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -384,10 +397,7 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
             if (!mv) break;
             if ((uint32_t)st.dist_calc + 64u > p.hash_limit) { handed_over = true; break; }
             st.edges += __popcll(mv);
-            bool fresh = false;
-            if (valid) {
-                fresh = visited_claim(hash, cap >> 2, nb);
-            }
+            const bool fresh = visited_claim(hash, cap >> 2, nb, valid);
             uint32_t dk = 0xFFFFFFFFu;
             if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, p.db + (size_t)nb * p.dstride, p.dim));
             const uint64_t mf = __ballot(fresh);
@@ -612,47 +622,61 @@ __device__ __forceinline__ bool reg_offer(uint32_t dl, uint32_t nlo, RegList<R>&
 // Batch merge of one hop's survivors into a one-register list (ef <= 64).  Offering the survivors
 // one by one (reg_offer) is a long serial chain; here every survivor's final position and every
 // list entry's shift are counted in one pass over the survivors (independent compares), the new
-// list is scattered through a 512-B LDS buffer, and the result equals the sequential rule
+// list is scattered through a small LDS buffer, and the result equals the sequential rule
 // (search_function.h:31-37) whenever no dropped element (evicted entry or rejected survivor) ties
 // the new worst distance: an element the sequential rule rejects has dist >= the worst distance of
 // its moment >= the final worst distance, so it lies outside the top-ef by (dist, id) unless it
 // TIES the final worst distance -- and an accepted element is only ever displaced by smaller keys.
 // On such a tie (returns false, list untouched) the caller falls back to the sequential offers.
-__device__ __forceinline__ bool reg_merge(uint64_t m, uint32_t dk, uint32_t nb, RegList<1>& L, int& size,
+__device__ __forceinline__ uint64_t clear_bit64(uint64_t m, int bit) {  // wave-uniform operands
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));
+    return m;
+}
+
+constexpr int kRegStageSlots = 66;   // merge scatter buffer: ranks 0..ef (ef <= 64), padded to 16 B
+
+__device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk, uint32_t nb, RegList<1>& L, int& size,
                                           uint32_t& worst, int& tsize, uint64_t* stage, int ef, int lane) {
     const int ns = __popcll(m);
     const uint64_t key = ((uint64_t)L.hi[0] << 32) | L.lo[0];
-    const uint64_t skey = ((uint64_t)dk << 32) | ((uint64_t)nb << 1);
+    const uint32_t slo = nb << 1;
+    const uint64_t skey = ((uint64_t)dk << 32) | slo;
     const bool is_entry = lane < size;
-    const bool is_surv = (m >> lane) & 1ull;
     const uint64_t entry_mask = size >= 64 ? ~0ull : ((1ull << size) - 1ull);
-    int shift = 0, rank = 0, pos_l = 0;
-    uint64_t mm = m;
-    while (mm) {
-        const int sl = __ffsll((unsigned long long)mm) - 1;
-        mm &= mm - 1;
-        const uint64_t ks = ((uint64_t)readlane_u32(dk, sl) << 32) | ((uint64_t)readlane_u32(nb, sl) << 1);
-        shift += key > ks ? 1 : 0;
-        rank += skey > ks ? 1 : 0;
-        const int cnt = __popcll(__ballot(key < ks) & entry_mask);
-        pos_l = lane == sl ? cnt : pos_l;
-    }
     // a lane plays two roles: it holds list entry `lane` and (maybe) the survivor of neighbour `lane`
-    const int dst_e = lane + shift, dst_s = pos_l + rank;
-    const int new_size = size + ns < ef ? size + ns : ef;
-    if (is_entry && dst_e < ef) stage[dst_e] = key;
-    if (is_surv && dst_s < ef) stage[dst_s] = skey;
+    uint32_t shift = 0, rank = 0, pos_l = 0;
+    uint64_t mm = m;
+    do {
+        const int sl = __ffsll((unsigned long long)mm) - 1;
+        mm = clear_bit64(mm, sl);
+        const uint64_t ks = ((uint64_t)readlane_u32(dk, sl) << 32) | readlane_u32(slo, sl);
+        // keys are distinct (a survivor was never visited), so "entry < ks" is "!(entry > ks)"
+        const bool gt = key > ks;
+        shift += gt ? 1u : 0u;
+        rank += skey > ks ? 1u : 0u;
+        const uint32_t below = (uint32_t)__popcll(~__ballot(gt) & entry_mask);
+        pos_l = lane == sl ? below : pos_l;
+    } while (mm);
+    const int dst_e = lane + (int)shift, dst_s = (int)(pos_l + rank);
+    const int total = size + ns;
+    const int new_size = total < ef ? total : ef;
+    // rank ef (the first element that falls off) is staged too: it decides the boundary-tie test
+    if (is_entry && dst_e <= ef) stage[dst_e] = key;
+    if (is_surv && dst_s <= ef) stage[dst_s] = skey;
     wave_sync();
     const uint64_t nkey = lane < new_size ? stage[lane] : ~0ull;
     const uint32_t nw = readlane_u32((uint32_t)(nkey >> 32), new_size - 1);
-    // boundary tie: a dropped element at exactly the new worst distance -> order matters, go sequential
-    if (__ballot((is_entry && dst_e >= ef && L.hi[0] == nw) || (is_surv && dst_s >= ef && dk == nw))) return false;
+    if (total > ef) {
+        // dropped elements are the merged ranks >= ef, ascending: one of them ties the new worst
+        // distance iff the first one does -> order matters, go sequential (list untouched)
+        const uint32_t first_dropped = (uint32_t)__builtin_amdgcn_readfirstlane((int)(stage[ef] >> 32));
+        if (first_dropped == nw) return false;
+        tsize = 0;  // something was evicted and (no tie) the worst distance decreased
+    }
     L.lo[0] = (uint32_t)nkey;
     L.hi[0] = (uint32_t)(nkey >> 32);
-    if (size + ns > ef) tsize = 0;  // something was evicted and (no tie) the worst distance decreased
     size = new_size;
     worst = nw;
-    wave_sync();
     return true;
 }
 
@@ -667,8 +691,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     const int lane = lane_id();
     const int ef = p.ef;
     uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
-    uint64_t* stage = tie + kRegTieCap;  // [64] scatter buffer of the batch merge
-    float* qf = reinterpret_cast<float*>(stage + 64);
+    uint64_t* stage = tie + kRegTieCap;  // scatter buffer of the batch merge
+    float* qf = reinterpret_cast<float*>(stage + kRegStageSlots);
     uint32_t* hash = reinterpret_cast<uint32_t*>(qf + p.dstride);
     const float4* qs = reinterpret_cast<const float4*>(qf);
     const uint32_t cap = p.hash_cap;  // any size: slot = mulhi(id * C, cap)
@@ -831,29 +855,37 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             // row loads go out before the visited test: its LDS round trips overlap the memory latency
             // (rows of already-visited neighbours are fetched in vain -- we are not bandwidth bound)
             RowRegs<STEPS> rr;
+            uint32_t roff = 0;  // row byte offset, kept live past the loads (see below)
             if constexpr (kEarlyLoad) {
-                if (valid) load_row<STEPS>(rr, row_ptr<OFF32>(p.db, nb, p.dstride));
+                if constexpr (OFF32) {
+                    roff = nb * (p.dstride * 4u);
+                    if (valid) load_row<STEPS>(rr, reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff));
+                } else {
+                    if (valid) load_row<STEPS>(rr, row_ptr<OFF32>(p.db, nb, p.dstride));
+                }
             }
-            bool fresh = false;
-            if (valid) {
-                fresh = visited_claim(hash, cap >> 2, nb);
-            }
+            const bool fresh = visited_claim(hash, cap >> 2, nb, valid);
             STAMP(t4)
             STAMP_ADD(3, t3, t4)
             uint32_t dk = 0xFFFFFFFFu;
             if constexpr (kEarlyLoad) {
                 if (fresh) dk = fkey(l2_from_regs<STEPS>(rr, qs));
+                // The address register must not double as a load destination: if it does, the next
+                // hop's address computation has to wait for every load in flight (vmcnt(0)), which
+                // serialises the adjacency prefetch with the gather (tools/check_isa.sh).
+                asm volatile("" ::"v"(roff));
             } else {
                 if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, nb, p.dstride), p.dim));
             }
             dist_calc += __popcll(__ballot(fresh));
-            uint64_t m = __ballot(fresh && (size < ef || dk < worst));
+            const bool offer_it = fresh && (size < ef || dk < worst);
+            uint64_t m = __ballot(offer_it);
             STAMP(t5)
             STAMP_ADD(4, t4, t5)
             // several survivors: merge them in one pass (falls through to the sequential offers on a
             // boundary tie); reference order = one by one in list order (search_function.h:31-37)
             if constexpr (R == 1) {
-                if ((m & (m - 1)) != 0 && reg_merge(m, dk, nb, L, size, worst, tsize, stage, ef, lane)) m = 0;
+                if ((m & (m - 1)) != 0 && reg_merge(m, offer_it, dk, nb, L, size, worst, tsize, stage, ef, lane)) m = 0;
             }
             while (m) {
                 const int l = __ffsll((unsigned long long)m) - 1;
@@ -1382,13 +1414,13 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t count) {
 
 size_t walk_fast_lds_bytes(const WalkParams& p) {
     if (p.ef <= kRegListMaxEf)  // register kernels: list in registers
-        return (size_t)kRegTieCap * 8 + 512 + (size_t)p.dstride * 4 + (size_t)p.hash_cap * 4;
+        return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (size_t)p.dstride * 4 + (size_t)p.hash_cap * 4;
     const size_t ef_pad = ((size_t)p.ef + 63) & ~(size_t)63;
     return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)p.dstride * 4 + (size_t)p.hash_cap * 4;
 }
 
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride) {
-    if (ef <= kRegListMaxEf) return (size_t)kRegTieCap * 8 + 512 + (size_t)dstride * 4;  // tie list + merge buffer + query
+    if (ef <= kRegListMaxEf) return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (size_t)dstride * 4;  // tie list + merge buffer + query
     const size_t ef_pad = ((size_t)ef + 63) & ~(size_t)63;
     return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)dstride * 4;
 }
