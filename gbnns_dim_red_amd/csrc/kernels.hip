@@ -702,6 +702,14 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
     wave_sync();
 
+    // the query stays in registers (every lane holds all of it): the occupancy scan shows the walk is
+    // issue-bound from ~14 wavefronts/CU, so the registers cost nothing and each hop saves 8 LDS reads
+    RowRegs<STEPS> qreg;
+    if constexpr (kEarlyLoad) {
+#pragma unroll
+        for (int t = 0; t < STEPS; ++t) qreg.v[t] = qs[t];
+    }
+
     RegList<R> L;  // this lane's R list entries
     L.clear();
     int size = 1, tsize = 0, hops = 0, dist_calc = 1, edges = 0;
@@ -869,7 +877,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             STAMP_ADD(3, t3, t4)
             uint32_t dk = 0xFFFFFFFFu;
             if constexpr (kEarlyLoad) {
-                if (fresh) dk = fkey(l2_from_regs<STEPS>(rr, qs));
+                if (fresh) dk = fkey(l2_from_regs<STEPS>(rr, qreg.v));
                 // The address register must not double as a load destination: if it does, the next
                 // hop's address computation has to wait for every load in flight (vmcnt(0)), which
                 // serialises the adjacency prefetch with the gather (tools/check_isa.sh).
