@@ -33,6 +33,11 @@ __device__ __forceinline__ uint32_t fkey(float x) {
     const uint32_t b = __float_as_uint(x);
     return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
 }
+// same map for a value that cannot be -0 (a sum of squares): no canonicalising add
+__device__ __forceinline__ uint32_t fkey_sumsq(float x) {
+    const uint32_t b = __float_as_uint(x);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
 __device__ __forceinline__ float fkey_inv(uint32_t k) {
     const uint32_t b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
     return __uint_as_float(b);
@@ -514,6 +519,42 @@ __device__ __forceinline__ float l2_from_regs(const RowRegs<STEPS>& r, QP qs) {
     return ((s0 + s1) + s2) + s3;
 }
 
+// 128-byte rows (8 steps): the same arithmetic, hand-scheduled.  The compiler emits the two packed
+// chains (x,y) and (z,w) one after the other, every dependent pair separated by an s_nop (a packed
+// f32 result needs one wait state before it is read); interleaving the chains fills those slots
+// with useful instructions: ~49 instead of ~77 issue slots per distance.  Operation order and
+// rounding are those of l2_from_regs (v_pk_add/v_pk_mul are exact IEEE f32 per half, no fma).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define GBNNS_L2_STEP(T)                                                        \
+    "v_pk_add_f32 %[ta], %[a" #T "], %[qa" #T "] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+    "v_pk_add_f32 %[tb], %[b" #T "], %[qb" #T "] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+    "v_pk_mul_f32 %[ta], %[ta], %[ta]\n\t"                                     \
+    "v_pk_mul_f32 %[tb], %[tb], %[tb]\n\t"                                     \
+    "v_pk_add_f32 %[sa], %[sa], %[ta]\n\t"                                     \
+    "v_pk_add_f32 %[sb], %[sb], %[tb]\n\t"
+
+template <typename QP>
+__device__ __forceinline__ float l2_from_regs8(const RowRegs<8>& r, QP qs) {
+    f32x2 sa, sb, ta, tb;  // sa = (s0, s1), sb = (s2, s3)
+#define GBNNS_PAIRS(T)                                                                          \
+    [a##T] "v"(f32x2{r.v[T].x, r.v[T].y}), [b##T] "v"(f32x2{r.v[T].z, r.v[T].w}),                \
+    [qa##T] "v"(f32x2{qs[T].x, qs[T].y}), [qb##T] "v"(f32x2{qs[T].z, qs[T].w})
+    asm("v_pk_add_f32 %[ta], %[a0], %[qa0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %[tb], %[b0], %[qb0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[sa], %[ta], %[ta]\n\t"   // 0 + e*e == e*e
+        "v_pk_mul_f32 %[sb], %[tb], %[tb]\n\t"
+        GBNNS_L2_STEP(1) GBNNS_L2_STEP(2) GBNNS_L2_STEP(3)
+        : [sa] "=&v"(sa), [sb] "=&v"(sb), [ta] "=&v"(ta), [tb] "=&v"(tb)
+        : GBNNS_PAIRS(0), GBNNS_PAIRS(1), GBNNS_PAIRS(2), GBNNS_PAIRS(3));
+    asm(GBNNS_L2_STEP(4) GBNNS_L2_STEP(5) GBNNS_L2_STEP(6) GBNNS_L2_STEP(7)
+        : [sa] "+v"(sa), [sb] "+v"(sb), [ta] "=&v"(ta), [tb] "=&v"(tb)
+        : GBNNS_PAIRS(4), GBNNS_PAIRS(5), GBNNS_PAIRS(6), GBNNS_PAIRS(7));
+#undef GBNNS_PAIRS
+    return ((sa.x + sa.y) + sb.x) + sb.y;
+}
+#undef GBNNS_L2_STEP
+
 // Row address.  OFF32: every byte offset into the table fits 32 bits, so the load can use the
 // "scalar base + 32-bit lane offset" form (one address VGPR instead of two, no 64-bit multiply).
 template <bool OFF32>
@@ -877,7 +918,11 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             STAMP_ADD(3, t3, t4)
             uint32_t dk = 0xFFFFFFFFu;
             if constexpr (kEarlyLoad) {
-                if (fresh) dk = fkey(l2_from_regs<STEPS>(rr, qreg.v));
+                if constexpr (STEPS == 8) {
+                    if (fresh) dk = fkey_sumsq(l2_from_regs8(rr, qreg.v));
+                } else {
+                    if (fresh) dk = fkey(l2_from_regs<STEPS>(rr, qreg.v));
+                }
                 // The address register must not double as a load destination: if it does, the next
                 // hop's address computation has to wait for every load in flight (vmcnt(0)), which
                 // serialises the adjacency prefetch with the gather (tools/check_isa.sh).
