@@ -468,6 +468,11 @@ __global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
 // of five dependent LDS round trips.  LDS keeps only the visited hash set, the query and the tie
 // list: [tie: kTieCap x u64][q: dstride x f32][hash: cap x u32].
 
+__device__ __forceinline__ uint64_t clear_bit64(uint64_t m, int bit) {  // wave-uniform operands
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));
+    return m;
+}
+
 constexpr int kRegTieCap = 16;       // tie list of the register kernel (LDS, 128 B)
 constexpr int kRegListMaxEf = 256;   // largest ef served by the register-list kernels (4 registers per lane)
 
@@ -669,11 +674,6 @@ __device__ __forceinline__ bool reg_offer(uint32_t dl, uint32_t nlo, RegList<R>&
 // its moment >= the final worst distance, so it lies outside the top-ef by (dist, id) unless it
 // TIES the final worst distance -- and an accepted element is only ever displaced by smaller keys.
 // On such a tie (returns false, list untouched) the caller falls back to the sequential offers.
-__device__ __forceinline__ uint64_t clear_bit64(uint64_t m, int bit) {  // wave-uniform operands
-    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));
-    return m;
-}
-
 constexpr int kRegStageSlots = 66;   // merge scatter buffer: ranks 0..ef (ef <= 64), padded to 16 B
 
 __device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk, uint32_t nb, RegList<1>& L, int& size,
@@ -721,7 +721,7 @@ __device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk,
     return true;
 }
 
-template <int METRIC, int STEPS, bool OFF32, int R>
+template <int METRIC, int STEPS, bool OFF32, int R, bool ONE_CHUNK = false>
 __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                              uint32_t* ovf_count, uint32_t* ovf_list) {
 #ifdef GBNNS_STAMPS
@@ -784,10 +784,14 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             // one list register: straight branches to the rare path (the kernel is instruction-issue
             // bound -- a flag-and-merge formulation costs ~20 more scalar instructions per hop)
             mu[0] = __ballot(!(L.lo[0] & 1u)) & RegList<R>::lane_mask(0, ef);
-            if (mu[0] == 0 || tsize != 0) goto slow_select;
+            // one select + one branch; the empty asm keeps the compiler from folding it back into
+            // `mu == 0 || tsize != 0`, which it evaluates with five 64-bit mask instructions
+            uint64_t fastm = tsize == 0 ? mu[0] : 0ull;
+            asm("" : "+s"(fastm));
+            if (fastm == 0) goto slow_select;
             {
-                const int q1 = __ffsll((unsigned long long)mu[0]) - 1;
-                const uint64_t m2 = mu[0] & (mu[0] - 1);
+                const int q1 = __ffsll((unsigned long long)fastm) - 1;
+                const uint64_t m2 = clear_bit64(fastm, q1);
                 p1 = q1;
                 if (m2) {
                     const int q2 = __ffsll((unsigned long long)m2) - 1;
@@ -890,7 +894,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         STAMP_ADD(2, t2, t3)
 
         // ---- expand: neighbours in list order, 64 per pass --------------------------------------
-        for (uint32_t c = 0; c < p.ell_stride; c += 64) {
+        // ONE_CHUNK (rows of at most 64 slots): a single pass, the loop and its bookkeeping fold away
+        for (uint32_t c = 0; c < (ONE_CHUNK ? 64u : p.ell_stride); c += 64) {
             uint32_t nb = nb0;
             uint64_t mv = mv0;
             if (c) {
@@ -996,13 +1001,13 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     }
 }
 
-template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R>
+template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R, bool ONE_CHUNK = false>
 __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if constexpr (RETRY) {
         retry_loop(p, [&](uint32_t qi) { walk_reg_one<METRIC, STEPS, OFF32, R>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
     } else {
-        walk_reg_one<METRIC, STEPS, OFF32, R>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
+        walk_reg_one<METRIC, STEPS, OFF32, R, ONE_CHUNK>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
     }
 }
 
@@ -1499,6 +1504,11 @@ template <int METRIC, int STEPS, int R>
 static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipStream_t s) {
     // 32-bit byte offsets when both tables are < 4 GiB
     const bool off32 = (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32);
+    if constexpr (R == 1) {
+        // the common shape (ef <= 64, adjacency rows of at most 64 slots) gets a loop-free expansion
+        if (off32 && !retry && p.ell_stride <= 64)
+            return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
+    }
     if (off32)
         return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, true, R>, p, true, lds, s)
                      : launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, R>, p, false, lds, s);
