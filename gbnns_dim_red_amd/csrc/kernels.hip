@@ -468,6 +468,13 @@ __global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
 // of five dependent LDS round trips.  LDS keeps only the visited hash set, the query and the tie
 // list: [tie: kTieCap x u64][q: dstride x f32][hash: cap x u32].
 
+// vdst[lane `l`] = val (wave-uniform val and l).  The lane select goes through M0: two different
+// SGPR operands would exceed the constant-bus limit of gfx9-class VALU instructions.  Nothing else in
+// these kernels uses M0.
+__device__ __forceinline__ uint32_t writelane_u32(uint32_t vdst, uint32_t val, int l) {
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(vdst) : "s"(val), "s"(l) : "m0");
+    return vdst;
+}
 __device__ __forceinline__ uint64_t clear_bit64(uint64_t m, int bit) {  // wave-uniform operands
     asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));
     return m;
@@ -685,7 +692,8 @@ __device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk,
     const bool is_entry = lane < size;
     const uint64_t entry_mask = size >= 64 ? ~0ull : ((1ull << size) - 1ull);
     // a lane plays two roles: it holds list entry `lane` and (maybe) the survivor of neighbour `lane`
-    uint32_t shift = 0, rank = 0, pos_l = 0;
+    uint32_t shift = 0;   // entry: survivors with a smaller key
+    uint32_t dst_su = 0;  // survivor: its rank in the merged list, deposited by v_writelane
     uint64_t mm = m;
     do {
         const int sl = __ffsll((unsigned long long)mm) - 1;
@@ -694,11 +702,11 @@ __device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk,
         // keys are distinct (a survivor was never visited), so "entry < ks" is "!(entry > ks)"
         const bool gt = key > ks;
         shift += gt ? 1u : 0u;
-        rank += skey > ks ? 1u : 0u;
-        const uint32_t below = (uint32_t)__popcll(~__ballot(gt) & entry_mask);
-        pos_l = lane == sl ? below : pos_l;
+        const uint32_t below = (uint32_t)__popcll(~__ballot(gt) & entry_mask);  // entries before it
+        const uint32_t before = (uint32_t)__popcll(__ballot(skey < ks) & m);     // survivors before it
+        dst_su = writelane_u32(dst_su, below + before, sl);
     } while (mm);
-    const int dst_e = lane + (int)shift, dst_s = (int)(pos_l + rank);
+    const int dst_e = lane + (int)shift, dst_s = (int)dst_su;
     const int total = size + ns;
     const int new_size = total < ef ? total : ef;
     // rank ef (the first element that falls off) is staged too: it decides the boundary-tie test
