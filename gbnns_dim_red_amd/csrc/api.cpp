@@ -316,9 +316,9 @@ int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out) {
             ix->has_net = true;
         }
     }
-    if (!rc) rc = ix->ctrl.ensure(128);
+    if (!rc) rc = ix->ctrl.ensure(512);
     if (!rc) {
-        hipError_t e = hipMemset(ix->ctrl.p, 0, 128);
+        hipError_t e = hipMemset(ix->ctrl.p, 0, 512);
         if (e != hipSuccess) rc = fail(GBNNS_ERR_HIP, "ctrl init: %s", hipGetErrorString(e));
     }
     if (rc) {
@@ -396,13 +396,13 @@ int prof_flush(gbnns_index* ix) {
 
 extern "C" {
 
-// Diagnostic (not in gbnns.h): copies the 8 stamp sums of a GBNNS_STAMPS build and clears them.
-int gbnns_debug_read_stamps(gbnns_index* ix, unsigned long long* out8) {
-    if (!ix || !out8) return fail(GBNNS_ERR_INVALID, "null argument");
+// Diagnostic (not in gbnns.h): copies the 32 stamp/histogram sums of a GBNNS_STAMPS build and clears them.
+int gbnns_debug_read_stamps(gbnns_index* ix, unsigned long long* out32) {
+    if (!ix || !out32) return fail(GBNNS_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(ix->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out8, ix->ctrl.as<uint32_t>() + 8, 64, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(ix->ctrl.as<uint32_t>() + 8, 0, 64));
+    HIP_TRY(hipMemcpy(out32, ix->ctrl.as<uint32_t>() + 8, 256, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ix->ctrl.as<uint32_t>() + 8, 0, 256));
     return GBNNS_OK;
 }
 
@@ -668,7 +668,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.hash_limit = cap - cap / 8;
     w.all_general = walk_fast_lds_bytes(w) > kMaxLds ? 1 : 0;
 
-    w.stamps = reinterpret_cast<unsigned long long*>(ctrl + 8);  // ctrl[8..23], diagnostic builds
+    w.stamps = reinterpret_cast<unsigned long long*>(ctrl + 8);  // ctrl[8..71], diagnostic builds
     HIP_TRY(hipMemsetAsync(ctrl, 0, 20, s));
     if (!w.all_general) {
         HIP_TRY(launch_walk_fast(w, ix->metric, s));

@@ -150,13 +150,15 @@ __device__ __forceinline__ float metric_dist(PA a, PB b, uint32_t dim) {
 // bucket with an empty slot; a new id claims the first empty slot of that bucket with a CAS (a
 // lane of the same wavefront may win the slot in the same instruction: then the bucket is read
 // again).  Ids offered concurrently are distinct (rows are de-duplicated at index creation).
-__device__ __forceinline__ bool visited_claim(uint32_t* hash, uint32_t nbuckets, uint32_t id, bool valid) {
+__device__ __forceinline__ bool visited_claim(uint32_t* hash, uint32_t nbuckets, uint32_t id, bool valid,
+                                              unsigned int* dbg_iters = nullptr) {
     // Wave-uniform loop over "some lane still probing" (scalar branch, no per-lane loop masks);
     // ids are < 2^31 (gbnns_index_create), so only an empty slot (0xFFFFFFFF) has its sign bit set,
     // and slots of a bucket fill in order: the number of occupied slots is 4 + the sum of the signs.
     uint32_t b = __umulhi(id * 0x9E3779B1u, nbuckets);
     bool fresh = false, active = valid;
     do {
+        if (dbg_iters) *dbg_iters += 1;  // diagnostic builds only (constant-folded away otherwise)
         if (active) {
             const uint4 e = *reinterpret_cast<const uint4*>(hash + 4u * b);
             const uint32_t differ = min(min(e.x ^ id, e.y ^ id), min(e.z ^ id, e.w ^ id));
@@ -174,6 +176,76 @@ __device__ __forceinline__ bool visited_claim(uint32_t* hash, uint32_t nbuckets,
             b = (full >= 4) ? nx : b;
         }
     } while (__ballot(active));
+    return fresh;
+}
+
+// Hand-scheduled form of visited_claim for the register-list kernels (the walk is instruction-issue
+// bound and the compiler's version of the probe loop spends half of its ~50 instructions per iteration
+// on lane-mask bookkeeping).  Same table, same protocol; returns the wave-uniform mask of the lanes
+// whose id was new.  `lds_base` = LDS byte address of the table.  A lane that loses the slot race
+// to another lane of the wavefront retries the following slots of the bucket straight away (the
+// occupant cannot be its own id: ids offered together are distinct) and only re-reads the bucket
+// when they run out.  e0..e3 need a contiguous register quad, hence the fixed v[92:95].
+__device__ __forceinline__ uint64_t visited_claim_mask(uint32_t lds_base, uint32_t nbuckets, uint32_t id, uint64_t valid) {
+    const uint32_t end = lds_base + (nbuckets << 4);
+    const uint32_t mulc = 0x9E3779B1u;
+    uint32_t basev = lds_base, neg1 = 0xFFFFFFFFu, addr;
+    uint64_t fresh, act, sv;
+    uint32_t t0, t1, t2;
+    asm volatile(
+        "v_mul_lo_u32 %[t0], %[id], %[mulc]\n\t"
+        "s_mov_b64 %[fresh], 0\n\t"
+        "v_mul_hi_u32 %[t0], %[t0], %[nb]\n\t"      // bucket = mulhi(id * C, nbuckets)
+        "v_lshl_add_u32 %[addr], %[t0], 4, %[basev]\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[valid]\n"
+        "1:\n\t"
+        "ds_read_b128 v[92:95], %[addr]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_xor_b32 %[t0], v92, %[id]\n\t"
+        "v_xor_b32 %[t1], v93, %[id]\n\t"
+        "v_xor_b32 %[t2], v94, %[id]\n\t"
+        "v_min3_u32 %[t0], %[t0], %[t1], %[t2]\n\t"
+        "v_xor_b32 %[t2], v95, %[id]\n\t"
+        "v_ashrrev_i32 v92, 31, v92\n\t"
+        "v_ashrrev_i32 v93, 31, v93\n\t"
+        "v_ashrrev_i32 v94, 31, v94\n\t"
+        "v_min_u32 %[t0], %[t0], %[t2]\n\t"          // 0 <=> id is in the bucket
+        "v_ashrrev_i32 %[t2], 31, v95\n\t"
+        "v_add3_u32 %[t1], v92, v93, v94\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[t0]\n\t"
+        "v_add3_u32 %[t1], %[t1], %[t2], 4\n\t"       // occupied slots (they fill in order)
+        "s_and_b64 exec, exec, vcc\n\t"                // lanes that found their id are done
+        "s_cbranch_execz 9f\n\t"
+        "s_mov_b64 %[act], exec\n\t"
+        "v_lshl_add_u32 %[t2], %[t1], 2, %[addr]\n"    // first empty slot
+        "2:\n\t"
+        "v_cmp_gt_u32 vcc, 4, %[t1]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"                // lanes with a slot left to try
+        "s_cbranch_execz 3f\n\t"
+        "ds_cmpst_rtn_b32 %[t0], %[t2], %[neg1], %[id]\n\t"
+        "v_add_u32 %[t1], 1, %[t1]\n\t"
+        "v_add_u32 %[t2], 4, %[t2]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u32 vcc, -1, %[t0]\n\t"              // won the slot
+        "s_or_b64 %[fresh], %[fresh], vcc\n\t"
+        "s_andn2_b64 %[act], %[act], vcc\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"              // losers: next slot
+        "s_cbranch_execnz 2b\n"
+        "3:\n\t"
+        "s_mov_b64 exec, %[act]\n\t"                   // still absent and unplaced: their bucket is full
+        "s_cbranch_execz 9f\n\t"
+        "v_add_u32 %[addr], 16, %[addr]\n\t"
+        "v_cmp_eq_u32 vcc, %[end], %[addr]\n\t"
+        "v_cndmask_b32 %[addr], %[addr], %[basev], vcc\n\t"
+        "s_branch 1b\n"
+        "9:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [t2] "=&v"(t2), [addr] "=&v"(addr)
+        : [id] "v"(id), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [neg1] "v"(neg1), [mulc] "s"(mulc),
+          [nb] "s"(nbuckets)
+        : "vcc", "memory", "v92", "v93", "v94", "v95");
     return fresh;
 }
 
@@ -567,6 +639,58 @@ __device__ __forceinline__ float l2_from_regs8(const RowRegs<8>& r, QP qs) {
 }
 #undef GBNNS_L2_STEP
 
+// Pair form of the same distance: the two lanes 2i / 2i+1 hold the lower / upper 64 bytes of row i
+// (four 16-B steps each) and the matching half of the query.  Every lane squares its four steps; the
+// even lane runs the reference's chain over steps 0..3, hands its four running sums to the odd lane
+// (DPP quad_perm 0,0,2,2), which continues the chain over steps 4..7 and folds ((s0+s1)+s2)+s3:
+// the odd lane ends up with exactly the value l2_from_regs8 computes (same operations, same order).
+// Why: a lane that streams a whole 128-B row alone costs the CU's vector-memory path one cache-line
+// access per 16-B load; two lanes per row halve that (tools/ubench/gather_cost.hip: 36 -> 51 G rows/s
+// at ~16 rows per instruction), and the walk was bound by exactly that path.
+// Uses v[88:95] as scratch (contiguous pairs are needed for the packed sums).
+#define GBNNS_P_SUB(T)                                                                  \
+    "v_pk_add_f32 %[pa" #T "], %[a" #T "], %[qa" #T "] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
+    "v_pk_add_f32 %[pb" #T "], %[b" #T "], %[qb" #T "] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define GBNNS_P_MUL(T)                                           \
+    "v_pk_mul_f32 %[pa" #T "], %[pa" #T "], %[pa" #T "]\n\t" \
+    "v_pk_mul_f32 %[pb" #T "], %[pb" #T "], %[pb" #T "]\n\t"
+#define GBNNS_P_ACC(T)                                         \
+    "v_pk_add_f32 v[88:89], v[88:89], %[pa" #T "]\n\t"      \
+    "v_pk_add_f32 v[90:91], v[90:91], %[pb" #T "]\n\t"
+template <typename QP>
+__device__ __forceinline__ float l2_pair_from_regs(const RowRegs<4>& r, QP qh) {
+    f32x2 pa0, pb0, pa1, pb1, pa2, pb2, pa3, pb3;  // squared differences of this lane's four steps
+    float d;
+#define GBNNS_Q(T)                                                                               \
+    [a##T] "v"(f32x2{r.v[T].x, r.v[T].y}), [b##T] "v"(f32x2{r.v[T].z, r.v[T].w}),                \
+    [qa##T] "v"(f32x2{qh[T].x, qh[T].y}), [qb##T] "v"(f32x2{qh[T].z, qh[T].w})
+    asm(GBNNS_P_SUB(0) GBNNS_P_SUB(1) GBNNS_P_MUL(0) GBNNS_P_MUL(1) GBNNS_P_SUB(2) GBNNS_P_SUB(3) GBNNS_P_MUL(2) GBNNS_P_MUL(3)
+        "v_pk_add_f32 v[92:93], %[pa0], %[pa1]\n\t"      // even lane: steps 0..3 (0 + e*e == e*e)
+        "v_pk_add_f32 v[94:95], %[pb0], %[pb1]\n\t"
+        "v_pk_add_f32 v[92:93], v[92:93], %[pa2]\n\t"
+        "v_pk_add_f32 v[94:95], v[94:95], %[pb2]\n\t"
+        "v_pk_add_f32 v[92:93], v[92:93], %[pa3]\n\t"
+        "v_pk_add_f32 v[94:95], v[94:95], %[pb3]\n\t"
+        "s_nop 1\n\t"                                    // VALU write -> DPP read of the same register
+        "v_mov_b32_dpp v88, v92 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v89, v93 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v90, v94 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v91, v95 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        GBNNS_P_ACC(0) GBNNS_P_ACC(1) GBNNS_P_ACC(2) GBNNS_P_ACC(3)   // odd lane: steps 4..7 on top
+        "v_add_f32 %[d], v88, v89\n\t"
+        "v_add_f32 %[d], %[d], v90\n\t"
+        "v_add_f32 %[d], %[d], v91"
+        : [d] "=&v"(d), [pa0] "=&v"(pa0), [pb0] "=&v"(pb0), [pa1] "=&v"(pa1), [pb1] "=&v"(pb1), [pa2] "=&v"(pa2),
+          [pb2] "=&v"(pb2), [pa3] "=&v"(pa3), [pb3] "=&v"(pb3)
+        : GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
+        : "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+#undef GBNNS_Q
+    return d;
+}
+#undef GBNNS_P_SUB
+#undef GBNNS_P_MUL
+#undef GBNNS_P_ACC
+
 // Row address.  OFF32: every byte offset into the table fits 32 bits, so the load can use the
 // "scalar base + 32-bit lane offset" form (one address VGPR instead of two, no 64-bit multiply).
 template <bool OFF32>
@@ -734,10 +858,19 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                                              uint32_t* ovf_count, uint32_t* ovf_list) {
 #ifdef GBNNS_STAMPS
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned int probe_iters = 0;  // (the hand-scheduled probe does not count its iterations)
+    unsigned int hist[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0..7] survivors per hop (0,1,2,3,4,5-8,9-16,17+), [8] merges, [9] merge fallbacks, [10] sequential offers, [11] fast selects
     STAMP(t_begin)
 #endif
     constexpr bool kEarlyLoad = (METRIC == 0 && STEPS > 0);  // speculative row loads
+    // 128-byte rows: two lanes per neighbour (lane = 2 * slot + half), 32 adjacency slots per pass
+    constexpr bool kPair = (METRIC == 0 && STEPS == 8);
+    constexpr int kQSteps = kPair ? 4 : STEPS;               // 16-B steps of the row one lane holds
+    constexpr uint32_t kChunk = kPair ? 32u : 64u;           // adjacency slots per pass
+    constexpr uint64_t kSlotLanes = kPair ? 0x5555555555555555ull : ~0ull;  // lanes that own a slot
     const int lane = lane_id();
+    const uint32_t slot = kPair ? (uint32_t)lane >> 1 : (uint32_t)lane;    // adjacency slot of this lane
+    const uint32_t half = kPair ? (uint32_t)lane & 1u : 0u;
     const int ef = p.ef;
     uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
     uint64_t* stage = tie + kRegTieCap;  // scatter buffer of the batch merge
@@ -745,6 +878,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     uint32_t* hash = reinterpret_cast<uint32_t*>(qf + p.dstride);
     const float4* qs = reinterpret_cast<const float4*>(qf);
     const uint32_t cap = p.hash_cap;  // any size: slot = mulhi(id * C, cap)
+    const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
 
     for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
     for (uint32_t i = lane; i < p.dstride; i += 64)
@@ -753,10 +887,10 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
 
     // the query stays in registers (every lane holds all of it): the occupancy scan shows the walk is
     // issue-bound from ~14 wavefronts/CU, so the registers cost nothing and each hop saves 8 LDS reads
-    RowRegs<STEPS> qreg;
+    RowRegs<kQSteps> qreg;
     if constexpr (kEarlyLoad) {
 #pragma unroll
-        for (int t = 0; t < STEPS; ++t) qreg.v[t] = qs[t];
+        for (int t = 0; t < kQSteps; ++t) qreg.v[t] = qs[kQSteps * half + t];
     }
 
     RegList<R> L;  // this lane's R list entries
@@ -808,6 +942,9 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                 }
                 node = readlane_u32(L.lo[0], q1) >> 1;
                 if (lane == q1) L.lo[0] |= 1u;
+#ifdef GBNNS_STAMPS
+                hist[11] += 1;
+#endif
                 goto have_node;
             }
         slow_select:
@@ -889,7 +1026,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), node, p.ell_stride));
         uint32_t nb0;
         if (node == pf_node) nb0 = pf_val;
-        else nb0 = ((uint32_t)lane < p.ell_stride) ? row[lane] : kInvalidId;
+        else nb0 = (slot < p.ell_stride) ? row[slot] : kInvalidId;
         // consume nb0 BEFORE issuing the prefetch: the wait for a (conditionally issued) row load
         // must not also cover the younger prefetch load
         const uint64_t mv0 = __ballot(nb0 != kInvalidId);
@@ -897,41 +1034,47 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         STAMP_ADD(1, t1, t2)
         pf_node = pred;
         if (pred != kInvalidId)
-            pf_val = ((uint32_t)lane < p.ell_stride) ? reinterpret_cast<const uint32_t*>(row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), pred, p.ell_stride))[lane] : kInvalidId;
+            pf_val = (slot < p.ell_stride) ? reinterpret_cast<const uint32_t*>(row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), pred, p.ell_stride))[slot] : kInvalidId;
         STAMP(t3)
         STAMP_ADD(2, t2, t3)
 
         // ---- expand: neighbours in list order, 64 per pass --------------------------------------
         // ONE_CHUNK (rows of at most 64 slots): a single pass, the loop and its bookkeeping fold away
-        for (uint32_t c = 0; c < (ONE_CHUNK ? 64u : p.ell_stride); c += 64) {
+        for (uint32_t c = 0; c < (ONE_CHUNK ? kChunk : p.ell_stride); c += kChunk) {
             uint32_t nb = nb0;
             uint64_t mv = mv0;
             if (c) {
-                nb = (c + lane < p.ell_stride) ? row[c + lane] : kInvalidId;
+                nb = (c + slot < p.ell_stride) ? row[c + slot] : kInvalidId;
                 mv = __ballot(nb != kInvalidId);
             }
             if (!mv) break;
             if ((uint32_t)dist_calc + 64u > p.hash_limit) { status = 2; break; }
             const bool valid = nb != kInvalidId;
-            edges += __popcll(mv);
+            edges += __popcll(mv & kSlotLanes);
             // row loads go out before the visited test: its LDS round trips overlap the memory latency
             // (rows of already-visited neighbours are fetched in vain -- we are not bandwidth bound)
-            RowRegs<STEPS> rr;
+            RowRegs<kQSteps> rr;
             uint32_t roff = 0;  // row byte offset, kept live past the loads (see below)
             if constexpr (kEarlyLoad) {
                 if constexpr (OFF32) {
-                    roff = nb * (p.dstride * 4u);
-                    if (valid) load_row<STEPS>(rr, reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff));
+                    roff = kPair ? (nb << 7) + half * 64u : nb * (p.dstride * 4u);  // kPair: rows are 128 B
+                    if (valid) load_row<kQSteps>(rr, reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff));
                 } else {
-                    if (valid) load_row<STEPS>(rr, row_ptr<OFF32>(p.db, nb, p.dstride));
+                    if (valid) load_row<kQSteps>(rr, row_ptr<OFF32>(p.db, nb, p.dstride) + half * 16u);
                 }
             }
-            const bool fresh = visited_claim(hash, cap >> 2, nb, valid);
+            // pair form: the even lane of a pair tests / claims the id, the odd lane ends up with the distance
+            const uint64_t mclaimed = visited_claim_mask(hash_lds, cap >> 2, nb, mv & kSlotLanes);
+            const uint64_t mfresh = kPair ? (mclaimed << 1) : mclaimed;
+            const bool fresh = __builtin_amdgcn_inverse_ballot_w64(mfresh);
             STAMP(t4)
             STAMP_ADD(3, t3, t4)
             uint32_t dk = 0xFFFFFFFFu;
             if constexpr (kEarlyLoad) {
-                if constexpr (STEPS == 8) {
+                if constexpr (kPair) {
+                    const uint32_t kd = fkey_sumsq(l2_pair_from_regs(rr, qreg.v));  // all lanes; odd lanes hold distances
+                    dk = fresh ? kd : 0xFFFFFFFFu;
+                } else if constexpr (STEPS == 8) {
                     if (fresh) dk = fkey_sumsq(l2_from_regs8(rr, qreg.v));
                 } else {
                     if (fresh) dk = fkey(l2_from_regs<STEPS>(rr, qreg.v));
@@ -943,16 +1086,34 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             } else {
                 if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, nb, p.dstride), p.dim));
             }
-            dist_calc += __popcll(__ballot(fresh));
+            dist_calc += __popcll(mfresh);
             const bool offer_it = fresh && (size < ef || dk < worst);
             uint64_t m = __ballot(offer_it);
             STAMP(t5)
             STAMP_ADD(4, t4, t5)
             // several survivors: merge them in one pass (falls through to the sequential offers on a
             // boundary tie); reference order = one by one in list order (search_function.h:31-37)
-            if constexpr (R == 1) {
-                if ((m & (m - 1)) != 0 && reg_merge(m, offer_it, dk, nb, L, size, worst, tsize, stage, ef, lane)) m = 0;
+#ifdef GBNNS_STAMPS
+            {
+                const int ns_ = __popcll(m);
+                hist[ns_ <= 4 ? ns_ : (ns_ <= 8 ? 5 : (ns_ <= 16 ? 6 : 7))] += 1;
             }
+#endif
+            if constexpr (R == 1) {
+                if ((m & (m - 1)) != 0) {
+                    if (reg_merge(m, offer_it, dk, nb, L, size, worst, tsize, stage, ef, lane)) {
+                        m = 0;
+#ifdef GBNNS_STAMPS
+                        hist[8] += 1;
+                    } else {
+                        hist[9] += 1;
+#endif
+                    }
+                }
+            }
+#ifdef GBNNS_STAMPS
+            hist[10] += __popcll(m);
+#endif
             while (m) {
                 const int l = __ffsll((unsigned long long)m) - 1;
                 m &= m - 1;
@@ -973,7 +1134,11 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         STAMP(t_end)
         seg[6] = t_end - t_begin;
         if (lane == 0 && p.stamps)
+        {
             for (int i = 0; i < 7; ++i) atomicAdd(p.stamps + i, seg[i]);
+            for (int i = 0; i < 12; ++i) atomicAdd(p.stamps + 8 + i, (unsigned long long)hist[i]);
+            atomicAdd(p.stamps + 20, (unsigned long long)probe_iters);
+        }
     }
 #endif
 
@@ -1514,7 +1679,7 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
     const bool off32 = (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32);
     if constexpr (R == 1) {
         // the common shape (ef <= 64, adjacency rows of at most 64 slots) gets a loop-free expansion
-        if (off32 && !retry && p.ell_stride <= 64)
+        if (off32 && !retry && p.ell_stride <= ((METRIC == 0 && STEPS == 8) ? 32u : 64u))
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
     }
     if (off32)

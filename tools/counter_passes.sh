@@ -13,7 +13,8 @@ python3 $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 i=0
 for g in "${CGROUPS[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $g --kernel-trace --output-format csv -d $OUT/pmc_g$i -- python3 $ARGS > /dev/null 2> $OUT/pmc_g$i.err || echo "pass $i ($g) failed: $(tail -2 $OUT/pmc_g$i.err)"
+  echo "pass $i: $g"
+  timeout -k 5 150 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $OUT/pmc_g$i -- python3 $ARGS > /dev/null 2> $OUT/pmc_g$i.err || echo "pass $i ($g) failed: $(grep -v "^\s*@" $OUT/pmc_g$i.err | grep -i "error\|exceeds" | head -2)"
 done
 python3 tools/digest_profile.py $OUT 2>/dev/null | grep -E "^walk_reg|^walk_fast|^rerank|^mlp" 
 python3 -c "
