@@ -669,6 +669,9 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.all_general = walk_fast_lds_bytes(w) > kMaxLds ? 1 : 0;
 
     w.stamps = reinterpret_cast<unsigned long long*>(ctrl + 8);  // ctrl[8..71], diagnostic builds
+#ifdef GBNNS_STAMPS
+    w.stamps_on = 1;
+#endif
     HIP_TRY(hipMemsetAsync(ctrl, 0, 20, s));
     if (!w.all_general) {
         HIP_TRY(launch_walk_fast(w, ix->metric, s));

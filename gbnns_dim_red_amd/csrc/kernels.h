@@ -54,7 +54,8 @@ struct WalkParams {
     uint64_t* g_tie;         // [slots x n]
     uint32_t bitmap_words;
     int32_t all_general;     // 1: the general kernel takes every query (fast kernel skipped)
-    unsigned long long* stamps;  // diagnostic builds only (GBNNS_STAMPS): [8] segment cycle sums
+    unsigned long long* stamps;  // diagnostic builds only (GBNNS_STAMPS): [32] segment cycle sums / histograms
+    int32_t stamps_on;           // 1 in diagnostic builds: use the instrumented generic kernel
 };
 
 size_t walk_fast_lds_bytes(const WalkParams& p);

@@ -853,6 +853,34 @@ __device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk,
     return true;
 }
 
+// Results of a register-list walk in POP order (worst -> best): rank i goes to position kept-1-i.
+template <int R>
+__device__ __forceinline__ void reg_write_results(const WalkParams& p, uint32_t qi, const RegList<R>& L, int size, int hops,
+                                                  int dist_calc, int edges, int lane) {
+    const int kept = size < p.k ? size : p.k;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int rank = r * 64 + lane;
+        if (rank < (int)p.cand_stride) {
+            if (rank < kept) {
+                p.cand[(size_t)qi * p.cand_stride + (kept - 1 - rank)] = L.lo[r] >> 1;
+                if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + (kept - 1 - rank)] = fkey_inv(L.hi[r]);
+            } else {
+                p.cand[(size_t)qi * p.cand_stride + rank] = kInvalidId;
+                if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + rank] = __builtin_inff();
+            }
+        }
+    }
+    if (lane == 0) {
+        p.count[qi] = kept;
+        p.hops[qi] = hops;
+        p.dist_calc[qi] = dist_calc;
+        atomicMax(p.max_dc, (uint32_t)dist_calc);
+        if (p.edges) p.edges[qi] = edges;
+        if (p.best) p.best[qi] = L.lo[0] >> 1;
+    }
+}
+
 template <int METRIC, int STEPS, bool OFF32, int R, bool ONE_CHUNK = false>
 __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                              uint32_t* ovf_count, uint32_t* ovf_list) {
@@ -1149,29 +1177,317 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         }
         return;
     }
-    // results in POP order (worst -> best): rank i goes to position kept-1-i
-    const int kept = size < p.k ? size : p.k;
+    reg_write_results<R>(p, qi, L, size, hops, dist_calc, edges, lane);
+}
+
+// ---- hot instance: L2, 128-byte rows, ef <= 64, adjacency rows of <= 32 slots, 32-bit offsets ---------
+//
+// Same algorithm and data structures as walk_reg_one<0, 8, true, 1> in its pair form; the hop is laid
+// out as one straight common path (hand-written selection, probe and distance blocks, every rare case
+// out of line), because this instance is bound by instruction issue and by the CU's vector-memory path.
+
+// Rare part of the selection (register list, one entry per lane): an equal-distance run among the
+// unexpanded entries, a non-empty tie list, or nothing left.  Returns false at the end of the walk.
+__device__ __forceinline__ bool reg1_select_slow(RegList<1>& L, uint64_t mu, int& tsize, uint64_t* tie, uint32_t worst,
+                                                 uint64_t lmask, int lane, uint32_t& node) {
+    int best = -1;
+    uint32_t hi_p = 0;
+    if (mu) {
+        hi_p = readlane_u32(L.hi[0], __ffsll((unsigned long long)mu) - 1);
+        const uint64_t ms = __ballot(!(L.lo[0] & 1u) && L.hi[0] == hi_p) & lmask;
+        if (ms) best = 63 - __clzll((long long)ms);
+    }
+    if (tsize > 0 && (best < 0 || hi_p == worst)) {
+        // tie entries all sit at the worst distance: the largest id among them competes
+        uint32_t v = (lane < tsize) ? key_id(tie[lane]) + 1u : 0u;
+        int w = lane;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int rank = r * 64 + lane;
-        if (rank < (int)p.cand_stride) {
-            if (rank < kept) {
-                p.cand[(size_t)qi * p.cand_stride + (kept - 1 - rank)] = L.lo[r] >> 1;
-                if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + (kept - 1 - rank)] = fkey_inv(L.hi[r]);
-            } else {
-                p.cand[(size_t)qi * p.cand_stride + rank] = kInvalidId;
-                if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + rank] = __builtin_inff();
-            }
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t ov = (uint32_t)__shfl_xor((int)v, off);
+            const int ow = __shfl_xor(w, off);
+            if (ov > v) { v = ov; w = ow; }
+        }
+        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        w = __builtin_amdgcn_readfirstlane(w);
+        const uint32_t lid = (best >= 0) ? (readlane_u32(L.lo[0], best) >> 1) : 0u;
+        if (best < 0 || v - 1u > lid) {
+            node = v - 1u;
+            if (lane == 0) tie[w] = tie[tsize - 1];
+            tsize -= 1;
+            wave_sync();
+            return true;
         }
     }
-    if (lane == 0) {
-        p.count[qi] = kept;
-        p.hops[qi] = hops;
-        p.dist_calc[qi] = dist_calc;
-        atomicMax(p.max_dc, (uint32_t)dist_calc);
-        if (p.edges) p.edges[qi] = edges;
-        if (p.best) p.best[qi] = L.lo[0] >> 1;
+    if (best < 0) return false;
+    node = readlane_u32(L.lo[0], best) >> 1;
+    if (lane == best) L.lo[0] |= 1u;
+    return true;
+}
+
+// The expansion of one node in the hot instance, as ONE block (so that no compiler-chosen register can
+// sit between the row loads and their use): issue this lane's four 16-B row loads (lanes of `valid`),
+// run the visited-set protocol of visited_claim_mask on the even lanes while they are in flight, then
+// the pair distance of l2_pair_from_regs.  Returns the sort key of the distance (meaningful in the odd
+// lane of a pair whose id was new); `claimed` = even lanes whose id was new.
+template <typename QP>
+__device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t roff, uint32_t nb, uint64_t valid, uint32_t lds_base,
+                                               uint32_t nbuckets, QP qh, uint64_t& claimed) {
+    const uint32_t end = lds_base + (nbuckets << 4);
+    const uint32_t mulc = 0x9E3779B1u;
+    uint32_t basev = lds_base, neg1 = 0xFFFFFFFFu, addr, t0, t1, t2, key;
+    uint64_t fresh, act, sv;
+    f32x2 ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3;  // row halves, then their squared differences
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 r0, r1, r2, r3;
+#define GBNNS_Q(T) [qa##T] "v"(f32x2{qh[T].x, qh[T].y}), [qb##T] "v"(f32x2{qh[T].z, qh[T].w})
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[valid]\n\t"
+        "global_load_dwordx4 v[72:75], %[roff], %[db]\n\t"
+        "global_load_dwordx4 v[76:79], %[roff], %[db] offset:16\n\t"
+        "global_load_dwordx4 v[80:83], %[roff], %[db] offset:32\n\t"
+        "global_load_dwordx4 v[84:87], %[roff], %[db] offset:48\n\t"
+        // ---- visited set: even lanes of `valid` (visited_claim_mask)
+        "v_mul_lo_u32 %[t0], %[id], %[mulc]\n\t"
+        "s_and_b32 exec_lo, exec_lo, 0x55555555\n\t"
+        "s_and_b32 exec_hi, exec_hi, 0x55555555\n\t"
+        "s_mov_b64 %[fresh], 0\n\t"
+        "v_mul_hi_u32 %[t0], %[t0], %[nb]\n\t"
+        "v_lshl_add_u32 %[addr], %[t0], 4, %[basev]\n"
+        "1:\n\t"
+        "ds_read_b128 v[92:95], %[addr]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_xor_b32 %[t0], v92, %[id]\n\t"
+        "v_xor_b32 %[t1], v93, %[id]\n\t"
+        "v_xor_b32 %[t2], v94, %[id]\n\t"
+        "v_min3_u32 %[t0], %[t0], %[t1], %[t2]\n\t"
+        "v_xor_b32 %[t2], v95, %[id]\n\t"
+        "v_ashrrev_i32 v92, 31, v92\n\t"
+        "v_ashrrev_i32 v93, 31, v93\n\t"
+        "v_ashrrev_i32 v94, 31, v94\n\t"
+        "v_min_u32 %[t0], %[t0], %[t2]\n\t"
+        "v_ashrrev_i32 %[t2], 31, v95\n\t"
+        "v_add3_u32 %[t1], v92, v93, v94\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[t0]\n\t"
+        "v_add3_u32 %[t1], %[t1], %[t2], 4\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 9f\n\t"
+        "s_mov_b64 %[act], exec\n\t"
+        "v_lshl_add_u32 %[t2], %[t1], 2, %[addr]\n"
+        "2:\n\t"
+        "v_cmp_gt_u32 vcc, 4, %[t1]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 3f\n\t"
+        "ds_cmpst_rtn_b32 %[t0], %[t2], %[neg1], %[id]\n\t"
+        "v_add_u32 %[t1], 1, %[t1]\n\t"
+        "v_add_u32 %[t2], 4, %[t2]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_eq_u32 vcc, -1, %[t0]\n\t"
+        "s_or_b64 %[fresh], %[fresh], vcc\n\t"
+        "s_andn2_b64 %[act], %[act], vcc\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execnz 2b\n"
+        "3:\n\t"
+        "s_mov_b64 exec, %[act]\n\t"
+        "s_cbranch_execz 9f\n\t"
+        "v_add_u32 %[addr], 16, %[addr]\n\t"
+        "v_cmp_eq_u32 vcc, %[end], %[addr]\n\t"
+        "v_cndmask_b32 %[addr], %[addr], %[basev], vcc\n\t"
+        "s_branch 1b\n"
+        "9:\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        // ---- pair distance (l2_pair_from_regs), all lanes
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_pk_add_f32 v[72:73], v[72:73], %[qa0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[74:75], v[74:75], %[qb0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[76:77], v[76:77], %[qa1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[78:79], v[78:79], %[qb1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 v[72:73], v[72:73], v[72:73]\n\t"
+        "v_pk_mul_f32 v[74:75], v[74:75], v[74:75]\n\t"
+        "v_pk_mul_f32 v[76:77], v[76:77], v[76:77]\n\t"
+        "v_pk_mul_f32 v[78:79], v[78:79], v[78:79]\n\t"
+        "v_pk_add_f32 v[80:81], v[80:81], %[qa2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[82:83], v[82:83], %[qb2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[84:85], v[84:85], %[qa3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[86:87], v[86:87], %[qb3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 v[80:81], v[80:81], v[80:81]\n\t"
+        "v_pk_mul_f32 v[82:83], v[82:83], v[82:83]\n\t"
+        "v_pk_mul_f32 v[84:85], v[84:85], v[84:85]\n\t"
+        "v_pk_mul_f32 v[86:87], v[86:87], v[86:87]\n\t"
+        "v_pk_add_f32 v[92:93], v[72:73], v[76:77]\n\t"      // even lane: steps 0..3
+        "v_pk_add_f32 v[94:95], v[74:75], v[78:79]\n\t"
+        "v_pk_add_f32 v[92:93], v[92:93], v[80:81]\n\t"
+        "v_pk_add_f32 v[94:95], v[94:95], v[82:83]\n\t"
+        "v_pk_add_f32 v[92:93], v[92:93], v[84:85]\n\t"
+        "v_pk_add_f32 v[94:95], v[94:95], v[86:87]\n\t"
+        "s_nop 1\n\t"
+        "v_mov_b32_dpp v88, v92 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v89, v93 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v90, v94 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v91, v95 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_pk_add_f32 v[88:89], v[88:89], v[72:73]\n\t"      // odd lane: steps 4..7 on top
+        "v_pk_add_f32 v[90:91], v[90:91], v[74:75]\n\t"
+        "v_pk_add_f32 v[88:89], v[88:89], v[76:77]\n\t"
+        "v_pk_add_f32 v[90:91], v[90:91], v[78:79]\n\t"
+        "v_pk_add_f32 v[88:89], v[88:89], v[80:81]\n\t"
+        "v_pk_add_f32 v[90:91], v[90:91], v[82:83]\n\t"
+        "v_pk_add_f32 v[88:89], v[88:89], v[84:85]\n\t"
+        "v_pk_add_f32 v[90:91], v[90:91], v[86:87]\n\t"
+        "v_add_f32 %[key], v88, v89\n\t"
+        "v_add_f32 %[key], %[key], v90\n\t"
+        "v_add_f32 %[key], %[key], v91\n\t"
+        "v_or_b32 %[key], 0x80000000, %[key]"                  // fkey of a non-negative float
+        : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+          [addr] "=&v"(addr), [key] "=&v"(key)
+        : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [neg1] "v"(neg1), [mulc] "s"(mulc),
+          [nb] "s"(nbuckets), [roff] "v"(roff), [db] "s"(db_base), GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
+        : "vcc", "scc", "memory", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84",
+          "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+#undef GBNNS_Q
+    claimed = fresh;
+    return key;
+}
+
+__device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, unsigned char* smem) {
+    const int lane = lane_id();
+    const uint32_t slot = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;  // lane = 2 * adjacency slot + row half
+    const int ef = p.ef;
+    uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* stage = tie + kRegTieCap;
+    float* qf = reinterpret_cast<float*>(stage + kRegStageSlots);
+    uint32_t* hash = reinterpret_cast<uint32_t*>(qf + 32);
+    const float4* qs = reinterpret_cast<const float4*>(qf);
+    const uint32_t cap = p.hash_cap;
+    const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
+
+    for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
+    if (lane < 32) qf[lane] = p.q[(size_t)qi * p.qstride + lane];
+    wave_sync();
+    RowRegs<4> qreg;  // this lane's half of the query
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qreg.v[t] = qs[4 * half + t];
+
+    RegList<1> L;
+    L.clear();
+    int size = 1, tsize = 0, hops = 0, dist_calc = 1, edges = 0;
+    uint32_t worst;
+    const uint32_t entry = p.entries ? p.entries[qi] : 0u;
+    {
+        const float d0 = walk_dist<0, 8>(qs, row_ptr<true>(p.db, entry, 32u), 32u);
+        worst = fkey(d0);
+        if (lane == 0) {
+            L.hi[0] = worst;
+            L.lo[0] = entry << 1;
+            hash[4u * __umulhi(entry * 0x9E3779B1u, cap >> 2)] = entry;
+        }
+        wave_sync();
     }
+
+    const uint64_t lmask = RegList<1>::lane_mask(0, ef);
+    const uint32_t ell_row_bytes = p.ell_stride * 4u;
+    const bool slot_ok = slot < p.ell_stride;             // ell_stride is 16 or 32 here
+    const uint32_t slot_off = slot_ok ? slot * 4u : 0u;    // lanes beyond the row read slot 0 and are masked
+    const char* ell_base = reinterpret_cast<const char*>(p.ell);
+    const char* db_base = reinterpret_cast<const char*>(p.db);
+    const uint32_t dc_limit = p.hash_limit >= 64u ? p.hash_limit - 64u : 0u;
+    bool handed_over = false;
+    uint32_t pf_node = kInvalidId, pf_val = kInvalidId;
+
+    while (true) {
+        // ---- next node: closest unexpanded entry (ties -> largest id), and the runner-up as prediction
+        uint32_t node, pred, ok;
+        {
+            uint64_t fm;
+            uint32_t t0, q1, q2, h1, h2;
+            asm volatile(
+                "v_and_b32 %[t0], 1, %[lo]\n\t"
+                "v_cmp_eq_u32 vcc, 0, %[t0]\n\t"
+                "s_and_b64 %[fm], vcc, %[lmask]\n\t"          // unexpanded list entries
+                "s_cmp_eq_u32 %[tsize], 0\n\t"
+                "s_cselect_b64 %[fm], %[fm], 0\n\t"            // a non-empty tie list -> slow path
+                "s_ff1_i32_b64 %[q1], %[fm]\n\t"               // -1 when nothing is left
+                "s_bitset0_b64 %[fm], %[q1]\n\t"
+                "s_ff1_i32_b64 %[q2], %[fm]\n\t"               // runner-up, -1 when there is none
+                "s_nop 1\n\t"                                   // SALU write -> lane select of v_readlane
+                "v_readlane_b32 %[h1], %[hi], %[q1]\n\t"
+                "v_readlane_b32 %[node], %[lo], %[q1]\n\t"
+                "v_readlane_b32 %[h2], %[hi], %[q2]\n\t"
+                "v_readlane_b32 %[pred], %[lo], %[q2]\n\t"
+                "s_lshr_b32 %[node], %[node], 1\n\t"
+                "s_lshr_b32 %[pred], %[pred], 1\n\t"
+                "s_cmp_lg_u32 %[h1], %[h2]\n\t"
+                "s_cselect_b32 %[ok], 1, 0\n\t"                 // distinct distances: plain pick
+                "s_cmp_lt_i32 %[q2], 0\n\t"
+                "s_cselect_b32 %[ok], 1, %[ok]\n\t"             // no runner-up: plain pick, no prediction
+                "s_cselect_b32 %[pred], -1, %[pred]\n\t"
+                "s_cmp_lt_i32 %[q1], 0\n\t"
+                "s_cselect_b32 %[ok], 0, %[ok]\n\t"             // nothing left (or tie list in play)
+                "s_cmp_lg_u32 %[ok], 0\n\t"
+                "s_cselect_b32 %[q1], %[q1], -1\n\t"
+                "v_cmp_eq_u32 vcc, %[q1], %[lane]\n\t"          // mark the picked entry expanded
+                "v_cndmask_b32 %[t0], 0, 1, vcc\n\t"
+                "v_or_b32 %[lo], %[lo], %[t0]"
+                : [lo] "+v"(L.lo[0]), [fm] "=&s"(fm), [t0] "=&v"(t0), [q1] "=&s"(q1), [q2] "=&s"(q2), [h1] "=&s"(h1),
+                  [h2] "=&s"(h2), [node] "=&s"(node), [pred] "=&s"(pred), [ok] "=&s"(ok)
+                : [hi] "v"(L.hi[0]), [lmask] "s"(lmask), [tsize] "s"(tsize), [lane] "v"(lane)
+                : "vcc", "scc");
+        }
+        if (__builtin_expect(ok == 0, 0)) {
+            const uint64_t mu = __ballot(!(L.lo[0] & 1u)) & lmask;
+            if (!reg1_select_slow(L, mu, tsize, tie, worst, lmask, lane, node)) break;
+            pred = kInvalidId;
+        }
+
+        // ---- adjacency row of `node` (prefetched, or loaded now), then the prefetch for the next hop
+        uint32_t nb;
+        if (node == pf_node) nb = pf_val;
+        else nb = *reinterpret_cast<const uint32_t*>(ell_base + node * ell_row_bytes + slot_off);
+        nb = slot_ok ? nb : kInvalidId;
+        const uint64_t mv = __ballot(nb != kInvalidId);
+        pf_node = pred;
+        if (pred != kInvalidId) pf_val = *reinterpret_cast<const uint32_t*>(ell_base + pred * ell_row_bytes + slot_off);
+        if (__builtin_expect(mv != 0, 1)) {
+            if (__builtin_expect((uint32_t)dist_calc > dc_limit, 0)) { handed_over = true; break; }
+            edges += __popcll(mv & 0x5555555555555555ull);
+            // ---- gather (speculative: before the visited test), visited test, distances -----------
+            uint64_t mclaimed;
+            const uint32_t kd = hot_expand(db_base, (nb << 7) + half * 64u, nb, mv, hash_lds, cap >> 2, qreg.v, mclaimed);
+            const uint64_t mfresh = mclaimed << 1;  // odd lanes hold the distances
+            const uint32_t dk = __builtin_amdgcn_inverse_ballot_w64(mfresh) ? kd : 0xFFFFFFFFu;
+            dist_calc += __popcll(mfresh);
+            uint64_t m = size < ef ? mfresh : __ballot(dk < worst);
+            // ---- survivors into the result list: batch merge, or one by one (reference order) --------
+            if (m != 0) {
+                if ((m & (m - 1)) == 0 ||
+                    !reg_merge(m, __builtin_amdgcn_inverse_ballot_w64(m), dk, nb, L, size, worst, tsize, stage, ef, lane)) {
+                    do {
+                        const int l = __ffsll((unsigned long long)m) - 1;
+                        m &= m - 1;
+                        if (!reg_offer<1>(readlane_u32(dk, l), readlane_u32(nb, l) << 1, L, size, worst, tsize, tie, ef, lane)) {
+                            handed_over = true;
+                            break;
+                        }
+                    } while (m);
+                    if (handed_over) break;
+                }
+            }
+        }
+        hops += 1;
+    }
+
+    if (handed_over) {
+        if (lane == 0) {
+            const uint32_t s = atomicAdd(p.ovf_count, 1u);
+            p.ovf_list[s] = qi;
+        }
+        return;
+    }
+    reg_write_results<1>(p, qi, L, size, hops, dist_calc, edges, lane);
+}
+
+__global__ __launch_bounds__(64) void walk_hot_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_hot_one(p, blockIdx.x, smem);
 }
 
 template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R, bool ONE_CHUNK = false>
@@ -1678,7 +1994,12 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
     // 32-bit byte offsets when both tables are < 4 GiB
     const bool off32 = (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32);
     if constexpr (R == 1) {
-        // the common shape (ef <= 64, adjacency rows of at most 64 slots) gets a loop-free expansion
+        // the common shape (ef <= 64, adjacency rows of one pass) gets a loop-free expansion;
+        // 128-byte rows with L2 additionally the hand-laid-out hop of walk_hot_one
+        if constexpr (METRIC == 0 && STEPS == 8) {
+            if (off32 && !retry && p.ell_stride <= 32u && p.dstride == 32u && !p.stamps_on)
+                return launch_walk_k(walk_hot_kernel, p, false, lds, s);
+        }
         if (off32 && !retry && p.ell_stride <= ((METRIC == 0 && STEPS == 8) ? 32u : 64u))
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
     }

@@ -114,6 +114,24 @@ def test_oracle_parity_medium(g, orc, metric):
     ix.close()
 
 
+def test_pair_gather_multi_pass_and_retry(g, orc):
+    """128-byte rows are gathered by lane pairs, 32 adjacency slots per pass: rows of up to 70
+    neighbours need three passes; a tiny visited set sends queries through the retry pass (which uses
+    the multi-pass form too); ef 100 / 200 use the 2- and 4-register lists."""
+    c, off, nbr, db_low, ent = _oracle_case(orc, 551, 12000, 400, 48, 32, 40, deg=(0, 70))
+    ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+    q_low = orc.project(c.net, c.queries)
+    for ef, cap in ((8, 0), (64, 0), (64, 256), (100, 0), (100, 512), (200, 0)):
+        w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, threads=8)
+        r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"),
+                      hash_capacity=cap)
+        assert np.array_equal(r["cand"], w["ids"]), (ef, cap)
+        assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), (ef, cap)
+        assert np.array_equal(r["hops"], w["hops"]), (ef, cap)
+        assert np.array_equal(r["dist_calc"], w["dist_calc"]), (ef, cap)
+    ix.close()
+
+
 def test_general_kernel_paths(g, orc):
     """Force the hand-over paths: (a) a visited set too small for the walk, (b) a tie list that
     overflows (lattice data, exact distance ties everywhere), (c) ef beyond the LDS list."""
