@@ -117,6 +117,9 @@ struct gbnns_index {
     int stats_ef = 0;
     uint32_t stats_cap = 0;
     std::map<int, uint32_t> cap_for_ef;
+    // which of the two control-word blocks the next call uses, and whether each is known to be zero
+    int ctrl_phase = 0;
+    bool ctrl_clean[2] = {true, true};
 };
 
 namespace {
@@ -364,9 +367,8 @@ int run_project(gbnns_index* ix, const float* x, uint32_t xstride, uint32_t nx, 
     p.bias = ix->b2; p.out = ix->h2.as<float>(); p.din = ix->d_hidden;
     HIP_TRY(launch_mlp_layer(p, s));
     p.x = ix->h2.as<float>(); p.w = ix->w3; p.wstride = ix->ws3; p.bias = ix->b3; p.out = out;
-    p.ostride = ix->dl_pad; p.dout = ix->d_low; p.relu = 0;
+    p.ostride = ix->dl_pad; p.dout = ix->d_low; p.relu = 0; p.normalize = 1;
     HIP_TRY(launch_mlp_layer(p, s));
-    HIP_TRY(launch_normalize(out, ix->dl_pad, ix->d_low, nx, s));
     return GBNNS_OK;
 }
 
@@ -619,11 +621,20 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.edges = a->out_edges ? (host ? ix->edges.as<int32_t>() : a->out_edges) : nullptr;
     uint32_t* out_dev = host ? ix->out.as<uint32_t>() : a->out_ids;
     w.best = plain ? out_dev : nullptr;
-    uint32_t* ctrl = ix->ctrl.as<uint32_t>();
-    // ctrl words: [0] list A count, [1] general cursor, [2] max dist_calc, [3] list B count,
-    // [4] retry cursor (all cleared per call), [5] general-kernel query total (persistent)
+    // Control words, two per-call blocks used alternately: [0] list A count, [1] general cursor,
+    // [2] max dist_calc, [3] list B count, [4] retry cursor.  A call works on one block while its
+    // general kernel (the last walk launch) clears the other for the next call -- no per-call memset
+    // launch.  Word 5 of block 0 = general-kernel query total (persistent); words 8..71 = diagnostics.
+    uint32_t* ctrl_base = ix->ctrl.as<uint32_t>();
+    const int cur = ix->ctrl_phase;
+    uint32_t* ctrl = ctrl_base + (cur ? 72 : 0);
+    uint32_t* ctrl_next = ctrl_base + (cur ? 0 : 72);
+    if (!ix->ctrl_clean[cur]) HIP_TRY(hipMemsetAsync(ctrl, 0, 20, s));  // after a failed call only
+    ix->ctrl_clean[cur] = false;
+    ix->ctrl_phase = cur ^ 1;
+    w.next_ctrl = ctrl_next;
     w.ovf_count = ctrl; w.g_cursor = ctrl + 1; w.max_dc = ctrl + 2; w.ovf2_count = ctrl + 3; w.r_cursor = ctrl + 4;
-    w.g_total = ctrl + 5; w.ovf_list = ix->ovf_list.as<uint32_t>(); w.ovf2_list = ix->ovf2_list.as<uint32_t>();
+    w.g_total = ctrl_base + 5; w.ovf_list = ix->ovf_list.as<uint32_t>(); w.ovf2_list = ix->ovf2_list.as<uint32_t>();
     w.g_bitmap = ix->g_bitmap.as<uint32_t>(); w.g_keys = ix->g_keys.as<uint64_t>();
     w.g_tie = ix->g_tie.as<uint64_t>(); w.bitmap_words = bitmap_words;
 
@@ -668,11 +679,10 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.hash_limit = cap - cap / 8;
     w.all_general = walk_fast_lds_bytes(w) > kMaxLds ? 1 : 0;
 
-    w.stamps = reinterpret_cast<unsigned long long*>(ctrl + 8);  // ctrl[8..71], diagnostic builds
+    w.stamps = reinterpret_cast<unsigned long long*>(ctrl_base + 8);  // words 8..71, diagnostic builds
 #ifdef GBNNS_STAMPS
     w.stamps_on = 1;
 #endif
-    HIP_TRY(hipMemsetAsync(ctrl, 0, 20, s));
     if (!w.all_general) {
         HIP_TRY(launch_walk_fast(w, ix->metric, s));
         // retry pass: hand-overs of the first pass, one wavefront per CU with all the LDS
@@ -689,6 +699,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     }
     if (prof) HIP_TRY(hipEventRecord(pc.ev[2], s));
     HIP_TRY(launch_walk_general(w, ix->metric, s));
+    ix->ctrl_clean[cur ^ 1] = true;  // cleared by that launch
     if (prof) HIP_TRY(hipEventRecord(pc.ev[3], s));
     if (auto_cap && !w.all_general && !ix->stats_pending) {
         if (!ix->h_stats) {

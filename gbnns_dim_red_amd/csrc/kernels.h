@@ -49,6 +49,7 @@ struct WalkParams {
     uint32_t* g_cursor;      // [1] work-queue head
     uint32_t* g_total;       // [1] running count of queries the general kernel processed
     uint32_t* max_dc;        // [1] max dist_calc over the batch (feeds the host's visited-set sizing)
+    uint32_t* next_ctrl;     // [5] control words of the NEXT call: the general kernel clears them
     uint32_t* g_bitmap;      // [slots x bitmap_words]
     uint64_t* g_keys;        // [slots x ef]
     uint64_t* g_tie;         // [slots x n]
@@ -92,6 +93,7 @@ struct LayerParams {
     uint32_t nq, din, dout;
     int32_t relu;
     int32_t mfma;            // 1: matrix-core variant (k-ordered fma chain: not bit-exact, opt-in)
+    int32_t normalize;       // 1: follow the layer by normalizeVector over its dout outputs (fused when dout <= 64)
 };
 hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s);
 // y [nq x stride]: y /= sqrt(L2(y, 0)) over dim (4-lane order, d%4 tail ignored in the norm),

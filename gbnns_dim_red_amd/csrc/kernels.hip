@@ -1519,6 +1519,7 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
     const int ef = p.ef;
     const uint32_t total = p.all_general ? p.nq : *p.ovf2_count;
     if (slot == 0 && lane == 0 && total) atomicAdd(p.g_total, total);
+    if (slot == 0 && lane < 5 && p.next_ctrl) p.next_ctrl[lane] = 0u;  // control words of the next call
 
     while (true) {
         uint32_t w = 0;
@@ -1630,7 +1631,30 @@ __global__ __launch_bounds__(64) void rerank_kernel(RerankParams p) {
 
 constexpr int kTQ = 32, kTO = 64, kKC = 32, kLd = kKC + 4;
 
-template <bool RELU>
+// NORM (last layer, dout <= 64, one block column): the block also applies normalizeVector
+// (support_func.h:636-642) to its 32 output rows -- same arithmetic as normalize_kernel, one launch less.
+constexpr int kNormLd = kTO + 1;
+
+__device__ __forceinline__ void mlp_normalize_rows(const LayerParams& p, const float* ys, uint32_t qbase, int t) {
+    if (t >= kTQ) return;
+    const uint32_t qg = qbase + t;
+    if (qg >= p.nq) return;
+    const float* y = ys + t * kNormLd;
+    const uint32_t steps = p.dout >> 2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (uint32_t k = 0; k < steps; ++k) {
+        const float e0 = y[4 * k + 0] - 0.f, e1 = y[4 * k + 1] - 0.f;
+        const float e2 = y[4 * k + 2] - 0.f, e3 = y[4 * k + 3] - 0.f;
+        s0 = s0 + e0 * e0; s1 = s1 + e1 * e1; s2 = s2 + e2 * e2; s3 = s3 + e3 * e3;
+    }
+    float norm = ((s0 + s1) + s2) + s3;
+    norm = __fsqrt_rn(norm);
+    float* r = p.out + (size_t)qg * p.ostride;
+    for (uint32_t i = 0; i < p.dout; ++i) r[i] = __fdiv_rn(y[i], norm);
+    for (uint32_t i = p.dout; i < p.ostride; ++i) r[i] = 0.f;
+}
+
+template <bool RELU, bool NORM = false>
 __global__ __launch_bounds__(256) void mlp_layer_kernel(LayerParams p) {
     __shared__ __attribute__((aligned(16))) float xs[kTQ * kLd];
     __shared__ __attribute__((aligned(16))) float ws[kTO * kLd];
@@ -1727,15 +1751,20 @@ __global__ __launch_bounds__(256) void mlp_layer_kernel(LayerParams p) {
             v = v - dist;               // support_func.h:627
             v = v + p.bias[og];         // :628
             if (RELU && v < 0.f) v = 0.f;  // :629-631
-            p.out[(size_t)qg * p.ostride + og] = v;
+            if constexpr (NORM) ws[(2 * tq + a) * kNormLd + to + 16 * b] = v;  // ws is free after the k loop
+            else p.out[(size_t)qg * p.ostride + og] = v;
         }
+    }
+    if constexpr (NORM) {
+        __syncthreads();
+        mlp_normalize_rows(p, ws, qbase, t);
     }
 }
 
 // Same tile and arithmetic as mlp_layer_kernel, for 16-B aligned operands (xstride % 4 == 0):
 // 16-B global loads, and the next k-chunk is fetched into registers while the current one is
 // being consumed from LDS (the generic kernel exposes one global round trip per chunk).
-template <bool RELU>
+template <bool RELU, bool NORM = false>
 __global__ __launch_bounds__(256) void mlp_layer_vec_kernel(LayerParams p) {
     __shared__ __attribute__((aligned(16))) float xs[kTQ * kLd];
     __shared__ __attribute__((aligned(16))) float ws[kTO * kLd];
@@ -1840,8 +1869,13 @@ __global__ __launch_bounds__(256) void mlp_layer_vec_kernel(LayerParams p) {
             v = v - dist;               // support_func.h:627
             v = v + p.bias[og];         // :628
             if (RELU && v < 0.f) v = 0.f;  // :629-631
-            p.out[(size_t)qg * p.ostride + og] = v;
+            if constexpr (NORM) ws[(2 * tq + a) * kNormLd + to + 16 * b] = v;  // ws is free after the k loop
+            else p.out[(size_t)qg * p.ostride + og] = v;
         }
+    }
+    if constexpr (NORM) {
+        __syncthreads();
+        mlp_normalize_rows(p, ws, qbase, t);
     }
 }
 
@@ -2083,17 +2117,32 @@ hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s) {
             if (p.relu) hipLaunchKernelGGL((mlp_layer_mfma_kernel<true, false>), gm, dim3(256), 0, s, p);
             else hipLaunchKernelGGL((mlp_layer_mfma_kernel<false, false>), gm, dim3(256), 0, s, p);
         }
+        if (p.normalize) {
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            return launch_normalize(p.out, p.ostride, p.dout, p.nq, s);
+        }
         return hipGetLastError();
     }
     const dim3 grid((p.nq + kTQ - 1) / kTQ, (p.dout + kTO - 1) / kTO);
     const bool aligned = p.xstride % 4 == 0 && p.wstride % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
+    if (p.normalize && !p.relu && p.dout <= (uint32_t)kTO) {  // fused normalizeVector (one block column)
+        if (aligned) hipLaunchKernelGGL((mlp_layer_vec_kernel<false, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((mlp_layer_kernel<false, true>), grid, dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
     if (aligned) {
         if (p.relu) hipLaunchKernelGGL((mlp_layer_vec_kernel<true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((mlp_layer_vec_kernel<false>), grid, dim3(256), 0, s, p);
     } else {
         if (p.relu) hipLaunchKernelGGL((mlp_layer_kernel<true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((mlp_layer_kernel<false>), grid, dim3(256), 0, s, p);
+    }
+    if (p.normalize) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        return launch_normalize(p.out, p.ostride, p.dout, p.nq, s);
     }
     return hipGetLastError();
 }
