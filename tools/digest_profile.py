@@ -22,7 +22,7 @@ def short(name):
             retry = len(args) > idx and args[idx] in ("true", "1")
             regs = "/R%s" % args[4] if key == "walk_reg_kernel" and len(args) > 4 and args[4] != "1" else ""
             return key + regs + ("/retry" if retry else "")
-    for key in ("walk_general_kernel", "rerank_kernel", "mlp_layer_mfma_kernel", "mlp_layer_vec_kernel", "mlp_layer_kernel",
+    for key in ("walk_hot_kernel", "walk_general_kernel", "rerank_kernel", "mlp_layer_mfma_kernel", "mlp_layer_vec_kernel", "mlp_layer_kernel",
                 "normalize_kernel", "fill_u32_kernel"):
         if key in name:
             return key
@@ -71,7 +71,7 @@ def main():
                 line.append("%s=%.4g" % (c, m))
                 res.setdefault(k, {})[c] = m
             print("%-24s %s" % (k, "  ".join(line)))
-    dom = "walk_reg_kernel" if "walk_reg_kernel" in res else "walk_fast_kernel"
+    dom = next((k for k in ("walk_hot_kernel", "walk_reg_kernel", "walk_fast_kernel") if k in res), "walk_fast_kernel")
     w = res.get(dom, {})
     if "FETCH_SIZE" in w:
         fetch_kib, write_kib = w["FETCH_SIZE"], w.get("WRITE_SIZE", 0.0)
