@@ -814,23 +814,38 @@ __device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk,
     const uint32_t slo = nb << 1;
     const uint64_t skey = ((uint64_t)dk << 32) | slo;
     const bool is_entry = lane < size;
-    const uint64_t entry_mask = size >= 64 ? ~0ull : ((1ull << size) - 1ull);
-    // a lane plays two roles: it holds list entry `lane` and (maybe) the survivor of neighbour `lane`
-    uint32_t shift = 0;   // entry: survivors with a smaller key
-    uint32_t dst_su = 0;  // survivor: its rank in the merged list, deposited by v_writelane
-    uint64_t mm = m;
-    do {
-        const int sl = __ffsll((unsigned long long)mm) - 1;
-        mm = clear_bit64(mm, sl);
-        const uint64_t ks = ((uint64_t)readlane_u32(dk, sl) << 32) | readlane_u32(slo, sl);
-        // keys are distinct (a survivor was never visited), so "entry < ks" is "!(entry > ks)"
-        const bool gt = key > ks;
-        shift += gt ? 1u : 0u;
-        const uint32_t below = (uint32_t)__popcll(~__ballot(gt) & entry_mask);  // entries before it
-        const uint32_t before = (uint32_t)__popcll(__ballot(skey < ks) & m);     // survivors before it
-        dst_su = writelane_u32(dst_su, below + before, sl);
-    } while (mm);
-    const int dst_e = lane + (int)shift, dst_s = (int)dst_su;
+    // A lane plays two roles: it holds list entry `lane` and (maybe) a survivor.  One pass over the
+    // survivors (hand-scheduled: the compiler's version of this loop is 19 instructions, 13 of them
+    // scalar, and the walk is bound by scalar issue): survivor `sl`'s key is broadcast through
+    // s[98:99]; every entry counts the survivors below it (shift), every survivor the survivors below
+    // it (rank), and the number of entries below survivor `sl` -- the zero bits of the compare mask,
+    // because lanes that hold no entry hold all-ones or evicted keys, both greater than any survivor --
+    // is dropped into lane `sl` (below).  Keys are distinct (a survivor was never visited).
+    uint32_t shift, rank, below, sl_, t_;
+    uint64_t ma, mb, mm = m;
+    asm volatile(
+        "v_mov_b32 %[shift], 0\n\t"
+        "v_mov_b32 %[rank], 0\n\t"
+        "v_mov_b32 %[below], 0\n"
+        "1:\n\t"
+        "s_ff1_i32_b64 %[sl], %[mm]\n\t"
+        "v_readlane_b32 s99, %[dk], %[sl]\n\t"
+        "v_readlane_b32 s98, %[slo], %[sl]\n\t"
+        "s_bitset0_b64 %[mm], %[sl]\n\t"
+        "s_mov_b32 m0, %[sl]\n\t"
+        "v_cmp_gt_u64_e64 %[ma], %[key], s[98:99]\n\t"
+        "v_cmp_gt_u64_e64 %[mb], %[skey], s[98:99]\n\t"
+        "s_bcnt0_i32_b64 %[t], %[ma]\n\t"
+        "v_addc_co_u32_e64 %[shift], vcc, 0, %[shift], %[ma]\n\t"
+        "v_addc_co_u32_e64 %[rank], vcc, 0, %[rank], %[mb]\n\t"
+        "v_writelane_b32 %[below], %[t], m0\n\t"
+        "s_cmp_lg_u64 %[mm], 0\n\t"
+        "s_cbranch_scc1 1b"
+        : [shift] "=&v"(shift), [rank] "=&v"(rank), [below] "=&v"(below), [sl] "=&s"(sl_), [t] "=&s"(t_), [ma] "=&s"(ma),
+          [mb] "=&s"(mb), [mm] "+s"(mm)
+        : [dk] "v"(dk), [slo] "v"(slo), [key] "v"(key), [skey] "v"(skey)
+        : "vcc", "scc", "m0", "s98", "s99");
+    const int dst_e = lane + (int)shift, dst_s = (int)(rank + below);
     const int total = size + ns;
     const int new_size = total < ef ? total : ef;
     // rank ef (the first element that falls off) is staged too: it decides the boundary-tie test
@@ -1391,14 +1406,15 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     const char* db_base = reinterpret_cast<const char*>(p.db);
     const uint32_t dc_limit = p.hash_limit >= 64u ? p.hash_limit - 64u : 0u;
     bool handed_over = false;
-    uint32_t pf_node = kInvalidId, pf_val = kInvalidId;
+    uint32_t pf_node = kInvalidId, pf_val = kInvalidId;    // prefetch 1: the runner-up of the selection
+    uint32_t pf2_node = kInvalidId, pf2_val = kInvalidId;  // prefetch 2: the closest new survivor (see below)
 
     while (true) {
         // ---- next node: closest unexpanded entry (ties -> largest id), and the runner-up as prediction
-        uint32_t node, pred, ok;
+        uint32_t node, pred, ok, h2;
         {
             uint64_t fm;
-            uint32_t t0, q1, q2, h1, h2;
+            uint32_t t0, q1, q2, h1;
             asm volatile(
                 "v_and_b32 %[t0], 1, %[lo]\n\t"
                 "v_cmp_eq_u32 vcc, 0, %[t0]\n\t"
@@ -1408,7 +1424,6 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
                 "s_ff1_i32_b64 %[q1], %[fm]\n\t"               // -1 when nothing is left
                 "s_bitset0_b64 %[fm], %[q1]\n\t"
                 "s_ff1_i32_b64 %[q2], %[fm]\n\t"               // runner-up, -1 when there is none
-                "s_nop 1\n\t"                                   // SALU write -> lane select of v_readlane
                 "v_readlane_b32 %[h1], %[hi], %[q1]\n\t"
                 "v_readlane_b32 %[node], %[lo], %[q1]\n\t"
                 "v_readlane_b32 %[h2], %[hi], %[q2]\n\t"
@@ -1420,6 +1435,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
                 "s_cmp_lt_i32 %[q2], 0\n\t"
                 "s_cselect_b32 %[ok], 1, %[ok]\n\t"             // no runner-up: plain pick, no prediction
                 "s_cselect_b32 %[pred], -1, %[pred]\n\t"
+                "s_cselect_b32 %[h2], -1, %[h2]\n\t"            // runner-up's distance key (all-ones: none)
                 "s_cmp_lt_i32 %[q1], 0\n\t"
                 "s_cselect_b32 %[ok], 0, %[ok]\n\t"             // nothing left (or tie list in play)
                 "s_cmp_lg_u32 %[ok], 0\n\t"
@@ -1436,13 +1452,16 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
             const uint64_t mu = __ballot(!(L.lo[0] & 1u)) & lmask;
             if (!reg1_select_slow(L, mu, tsize, tie, worst, lmask, lane, node)) break;
             pred = kInvalidId;
+            h2 = 0xFFFFFFFFu;
         }
 
         // ---- adjacency row of `node` (prefetched, or loaded now), then the prefetch for the next hop
         uint32_t nb;
         if (node == pf_node) nb = pf_val;
+        else if (node == pf2_node) nb = pf2_val;
         else nb = *reinterpret_cast<const uint32_t*>(ell_base + node * ell_row_bytes + slot_off);
         nb = slot_ok ? nb : kInvalidId;
+        pf2_node = kInvalidId;
         const uint64_t mv = __ballot(nb != kInvalidId);
         pf_node = pred;
         if (pred != kInvalidId) pf_val = *reinterpret_cast<const uint32_t*>(ell_base + pred * ell_row_bytes + slot_off);
@@ -1458,6 +1477,24 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
             uint64_t m = size < ef ? mfresh : __ballot(dk < worst);
             // ---- survivors into the result list: batch merge, or one by one (reference order) --------
             if (m != 0) {
+                // Prefetch 2: a survivor closer than the runner-up will be the next node (it becomes the
+                // closest unexpanded entry); request its adjacency row now, before the merge and the next
+                // selection, instead of after them.  Only when it is unique (ties go the slow way).
+                {
+                    uint32_t x = dk;  // all-ones outside the new ids; survivors are below `worst`
+                    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));   // quad_perm 1,0,3,2
+                    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));   // quad_perm 2,3,0,1
+                    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));  // row_half_mirror
+                    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));  // row_mirror
+                    const uint32_t dmin = min(min(readlane_u32(x, 0), readlane_u32(x, 16)), min(readlane_u32(x, 32), readlane_u32(x, 48)));
+                    if (dmin < h2) {
+                        const uint64_t me = __ballot(dk == dmin) & m;
+                        if (me != 0 && (me & (me - 1)) == 0) {
+                            pf2_node = readlane_u32(nb, __ffsll((unsigned long long)me) - 1);
+                            pf2_val = *reinterpret_cast<const uint32_t*>(ell_base + pf2_node * ell_row_bytes + slot_off);
+                        }
+                    }
+                }
                 if ((m & (m - 1)) == 0 ||
                     !reg_merge(m, __builtin_amdgcn_inverse_ballot_w64(m), dk, nb, L, size, worst, tsize, stage, ef, lane)) {
                     do {
