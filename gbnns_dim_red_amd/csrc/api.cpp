@@ -641,17 +641,24 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     // Visited-set capacity.  The walk kernel's occupancy is LDS-bound, and a 10k-query batch is only
     // a few "rounds" deep (queries / (256 CUs x resident wavefronts)), so the table is sized from
     // the LDS budget: take the number of entries the walks need (first guess 43*ef; afterwards
-    // 9/7 x the largest dist_calc of earlier batches, doubled whenever a batch handed queries
+    // 17/15 x the largest dist_calc of earlier batches, doubled whenever a batch handed queries
     // over), find how many wavefronts per CU that allows, then give each wavefront the whole
     // 160 KB / wavefronts share (capacity need not be a power of two: slot = mulhi(hash, cap)).
     if (ix->stats_pending && hipEventQuery(ix->stats_ev) == hipSuccess) {
         ix->stats_pending = false;
         const uint32_t ovf = ix->h_stats[0], maxdc = ix->h_stats[2];
-        uint32_t need = (maxdc + maxdc / 8 + 64) / 7 * 8 + 8;
+        // entries so that the largest walk seen (+ 1/16 margin + one pass of new ids) stays under the
+        // 15/16 fill limit
+        uint32_t need = (maxdc + maxdc / 16 + 64) / 15 * 16 + 16;
         if (ovf > 0) need = std::max<uint32_t>(need, ix->stats_cap * 2);
         ix->cap_for_ef[ix->stats_ef] = need;  // stats_ef = ef * 4 + mode
     }
-    const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride);
+    w.stamps = reinterpret_cast<unsigned long long*>(ctrl_base + 8);  // words 8..71, diagnostic builds
+#ifdef GBNNS_STAMPS
+    w.stamps_on = 1;
+#endif
+    const bool hot = walk_uses_hot(w, ix->metric);
+    const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride, hot);
     uint32_t cap;
     const bool auto_cap = a->hash_capacity == 0;
     if (!auto_cap) {
@@ -676,20 +683,16 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     }
     cap &= ~3u;  // whole 4-slot buckets
     w.hash_cap = cap;
-    w.hash_limit = cap - cap / 8;
-    w.all_general = walk_fast_lds_bytes(w) > kMaxLds ? 1 : 0;
+    w.hash_limit = cap - cap / 16;
+    w.all_general = walk_fast_lds_bytes(w, hot) > kMaxLds ? 1 : 0;
 
-    w.stamps = reinterpret_cast<unsigned long long*>(ctrl_base + 8);  // words 8..71, diagnostic builds
-#ifdef GBNNS_STAMPS
-    w.stamps_on = 1;
-#endif
     if (!w.all_general) {
         HIP_TRY(launch_walk_fast(w, ix->metric, s));
         // retry pass: hand-overs of the first pass, one wavefront per CU with all the LDS
         WalkParams w2 = w;
         const size_t gran = 512;
-        w2.hash_cap = (uint32_t)((kMaxLds / gran * gran - lds_fixed) / 4) & ~3u;
-        w2.hash_limit = w2.hash_cap - w2.hash_cap / 8;
+        w2.hash_cap = (uint32_t)((kMaxLds / gran * gran - walk_fast_lds_fixed_bytes(ef, w.dstride, false)) / 4) & ~3u;
+        w2.hash_limit = w2.hash_cap - w2.hash_cap / 16;
         if (w2.hash_cap > cap) {
             HIP_TRY(launch_walk_retry(w2, ix->metric, s));
         } else {

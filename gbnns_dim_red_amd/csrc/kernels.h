@@ -59,8 +59,9 @@ struct WalkParams {
     int32_t stamps_on;           // 1 in diagnostic builds: use the instrumented generic kernel
 };
 
-size_t walk_fast_lds_bytes(const WalkParams& p);
-size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride);  // everything but the visited set
+bool walk_uses_hot(const WalkParams& p, int metric);           // first pass runs walk_hot_kernel
+size_t walk_fast_lds_bytes(const WalkParams& p, bool hot);
+size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot);  // everything but the visited set
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s);

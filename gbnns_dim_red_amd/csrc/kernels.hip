@@ -1258,10 +1258,10 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[valid]\n\t"
-        "global_load_dwordx4 v[72:75], %[roff], %[db]\n\t"
-        "global_load_dwordx4 v[76:79], %[roff], %[db] offset:16\n\t"
-        "global_load_dwordx4 v[80:83], %[roff], %[db] offset:32\n\t"
-        "global_load_dwordx4 v[84:87], %[roff], %[db] offset:48\n\t"
+        "global_load_dwordx4 v[48:51], %[roff], %[db]\n\t"
+        "global_load_dwordx4 v[52:55], %[roff], %[db] offset:16\n\t"
+        "global_load_dwordx4 v[56:59], %[roff], %[db] offset:32\n\t"
+        "global_load_dwordx4 v[60:63], %[roff], %[db] offset:48\n\t"
         // ---- visited set: even lanes of `valid` (visited_claim_mask)
         "v_mul_lo_u32 %[t0], %[id], %[mulc]\n\t"
         "s_and_b32 exec_lo, exec_lo, 0x55555555\n\t"
@@ -1270,19 +1270,19 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
         "v_mul_hi_u32 %[t0], %[t0], %[nb]\n\t"
         "v_lshl_add_u32 %[addr], %[t0], 4, %[basev]\n"
         "1:\n\t"
-        "ds_read_b128 v[92:95], %[addr]\n\t"
+        "ds_read_b128 v[68:71], %[addr]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_xor_b32 %[t0], v92, %[id]\n\t"
-        "v_xor_b32 %[t1], v93, %[id]\n\t"
-        "v_xor_b32 %[t2], v94, %[id]\n\t"
+        "v_xor_b32 %[t0], v68, %[id]\n\t"
+        "v_xor_b32 %[t1], v69, %[id]\n\t"
+        "v_xor_b32 %[t2], v70, %[id]\n\t"
         "v_min3_u32 %[t0], %[t0], %[t1], %[t2]\n\t"
-        "v_xor_b32 %[t2], v95, %[id]\n\t"
-        "v_ashrrev_i32 v92, 31, v92\n\t"
-        "v_ashrrev_i32 v93, 31, v93\n\t"
-        "v_ashrrev_i32 v94, 31, v94\n\t"
+        "v_xor_b32 %[t2], v71, %[id]\n\t"
+        "v_ashrrev_i32 v68, 31, v68\n\t"
+        "v_ashrrev_i32 v69, 31, v69\n\t"
+        "v_ashrrev_i32 v70, 31, v70\n\t"
         "v_min_u32 %[t0], %[t0], %[t2]\n\t"
-        "v_ashrrev_i32 %[t2], 31, v95\n\t"
-        "v_add3_u32 %[t1], v92, v93, v94\n\t"
+        "v_ashrrev_i32 %[t2], 31, v71\n\t"
+        "v_add3_u32 %[t1], v68, v69, v70\n\t"
         "v_cmp_ne_u32 vcc, 0, %[t0]\n\t"
         "v_add3_u32 %[t1], %[t1], %[t2], 4\n\t"
         "s_and_b64 exec, exec, vcc\n\t"
@@ -1313,51 +1313,51 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
         "s_mov_b64 exec, %[sv]\n\t"
         // ---- pair distance (l2_pair_from_regs), all lanes
         "s_waitcnt vmcnt(0)\n\t"
-        "v_pk_add_f32 v[72:73], v[72:73], %[qa0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[74:75], v[74:75], %[qb0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[76:77], v[76:77], %[qa1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[78:79], v[78:79], %[qb1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_mul_f32 v[72:73], v[72:73], v[72:73]\n\t"
-        "v_pk_mul_f32 v[74:75], v[74:75], v[74:75]\n\t"
-        "v_pk_mul_f32 v[76:77], v[76:77], v[76:77]\n\t"
-        "v_pk_mul_f32 v[78:79], v[78:79], v[78:79]\n\t"
-        "v_pk_add_f32 v[80:81], v[80:81], %[qa2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[82:83], v[82:83], %[qb2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[84:85], v[84:85], %[qa3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[86:87], v[86:87], %[qb3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_mul_f32 v[80:81], v[80:81], v[80:81]\n\t"
-        "v_pk_mul_f32 v[82:83], v[82:83], v[82:83]\n\t"
-        "v_pk_mul_f32 v[84:85], v[84:85], v[84:85]\n\t"
-        "v_pk_mul_f32 v[86:87], v[86:87], v[86:87]\n\t"
-        "v_pk_add_f32 v[92:93], v[72:73], v[76:77]\n\t"      // even lane: steps 0..3
-        "v_pk_add_f32 v[94:95], v[74:75], v[78:79]\n\t"
-        "v_pk_add_f32 v[92:93], v[92:93], v[80:81]\n\t"
-        "v_pk_add_f32 v[94:95], v[94:95], v[82:83]\n\t"
-        "v_pk_add_f32 v[92:93], v[92:93], v[84:85]\n\t"
-        "v_pk_add_f32 v[94:95], v[94:95], v[86:87]\n\t"
+        "v_pk_add_f32 v[48:49], v[48:49], %[qa0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[50:51], v[50:51], %[qb0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[52:53], v[52:53], %[qa1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[54:55], v[54:55], %[qb1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 v[48:49], v[48:49], v[48:49]\n\t"
+        "v_pk_mul_f32 v[50:51], v[50:51], v[50:51]\n\t"
+        "v_pk_mul_f32 v[52:53], v[52:53], v[52:53]\n\t"
+        "v_pk_mul_f32 v[54:55], v[54:55], v[54:55]\n\t"
+        "v_pk_add_f32 v[56:57], v[56:57], %[qa2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[58:59], v[58:59], %[qb2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[60:61], v[60:61], %[qa3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[62:63], v[62:63], %[qb3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 v[56:57], v[56:57], v[56:57]\n\t"
+        "v_pk_mul_f32 v[58:59], v[58:59], v[58:59]\n\t"
+        "v_pk_mul_f32 v[60:61], v[60:61], v[60:61]\n\t"
+        "v_pk_mul_f32 v[62:63], v[62:63], v[62:63]\n\t"
+        "v_pk_add_f32 v[68:69], v[48:49], v[52:53]\n\t"      // even lane: steps 0..3
+        "v_pk_add_f32 v[70:71], v[50:51], v[54:55]\n\t"
+        "v_pk_add_f32 v[68:69], v[68:69], v[56:57]\n\t"
+        "v_pk_add_f32 v[70:71], v[70:71], v[58:59]\n\t"
+        "v_pk_add_f32 v[68:69], v[68:69], v[60:61]\n\t"
+        "v_pk_add_f32 v[70:71], v[70:71], v[62:63]\n\t"
         "s_nop 1\n\t"
-        "v_mov_b32_dpp v88, v92 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v89, v93 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v90, v94 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v91, v95 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_pk_add_f32 v[88:89], v[88:89], v[72:73]\n\t"      // odd lane: steps 4..7 on top
-        "v_pk_add_f32 v[90:91], v[90:91], v[74:75]\n\t"
-        "v_pk_add_f32 v[88:89], v[88:89], v[76:77]\n\t"
-        "v_pk_add_f32 v[90:91], v[90:91], v[78:79]\n\t"
-        "v_pk_add_f32 v[88:89], v[88:89], v[80:81]\n\t"
-        "v_pk_add_f32 v[90:91], v[90:91], v[82:83]\n\t"
-        "v_pk_add_f32 v[88:89], v[88:89], v[84:85]\n\t"
-        "v_pk_add_f32 v[90:91], v[90:91], v[86:87]\n\t"
-        "v_add_f32 %[key], v88, v89\n\t"
-        "v_add_f32 %[key], %[key], v90\n\t"
-        "v_add_f32 %[key], %[key], v91\n\t"
+        "v_mov_b32_dpp v64, v68 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v65, v69 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v66, v70 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v67, v71 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_pk_add_f32 v[64:65], v[64:65], v[48:49]\n\t"      // odd lane: steps 4..7 on top
+        "v_pk_add_f32 v[66:67], v[66:67], v[50:51]\n\t"
+        "v_pk_add_f32 v[64:65], v[64:65], v[52:53]\n\t"
+        "v_pk_add_f32 v[66:67], v[66:67], v[54:55]\n\t"
+        "v_pk_add_f32 v[64:65], v[64:65], v[56:57]\n\t"
+        "v_pk_add_f32 v[66:67], v[66:67], v[58:59]\n\t"
+        "v_pk_add_f32 v[64:65], v[64:65], v[60:61]\n\t"
+        "v_pk_add_f32 v[66:67], v[66:67], v[62:63]\n\t"
+        "v_add_f32 %[key], v64, v65\n\t"
+        "v_add_f32 %[key], %[key], v66\n\t"
+        "v_add_f32 %[key], %[key], v67\n\t"
         "v_or_b32 %[key], 0x80000000, %[key]"                  // fkey of a non-negative float
         : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
           [addr] "=&v"(addr), [key] "=&v"(key)
         : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [neg1] "v"(neg1), [mulc] "s"(mulc),
           [nb] "s"(nbuckets), [roff] "v"(roff), [db] "s"(db_base), GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
-        : "vcc", "scc", "memory", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84",
-          "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",
+          "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
 #undef GBNNS_Q
     claimed = fresh;
     return key;
@@ -1367,10 +1367,11 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     const int lane = lane_id();
     const uint32_t slot = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;  // lane = 2 * adjacency slot + row half
     const int ef = p.ef;
+    // LDS: [tie list 128 B][merge buffer 528 B; its head stages the query until it is in registers][visited set]
     uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
     uint64_t* stage = tie + kRegTieCap;
-    float* qf = reinterpret_cast<float*>(stage + kRegStageSlots);
-    uint32_t* hash = reinterpret_cast<uint32_t*>(qf + 32);
+    float* qf = reinterpret_cast<float*>(stage);
+    uint32_t* hash = reinterpret_cast<uint32_t*>(stage + kRegStageSlots);
     const float4* qs = reinterpret_cast<const float4*>(qf);
     const uint32_t cap = p.hash_cap;
     const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
@@ -1404,7 +1405,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     const uint32_t slot_off = slot_ok ? slot * 4u : 0u;    // lanes beyond the row read slot 0 and are masked
     const char* ell_base = reinterpret_cast<const char*>(p.ell);
     const char* db_base = reinterpret_cast<const char*>(p.db);
-    const uint32_t dc_limit = p.hash_limit >= 64u ? p.hash_limit - 64u : 0u;
+    const uint32_t dc_limit = p.hash_limit >= 32u ? p.hash_limit - 32u : 0u;  // at most 32 new ids per hop
     bool handed_over = false;
     uint32_t pf_node = kInvalidId, pf_val = kInvalidId;    // prefetch 1: the runner-up of the selection
     uint32_t pf2_node = kInvalidId, pf2_val = kInvalidId;  // prefetch 2: the closest new survivor (see below)
@@ -2030,17 +2031,24 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t count) {
 // launchers
 // ------------------------------------------------------------------------------------------
 
-size_t walk_fast_lds_bytes(const WalkParams& p) {
-    if (p.ef <= kRegListMaxEf)  // register kernels: list in registers
-        return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (size_t)p.dstride * 4 + (size_t)p.hash_cap * 4;
-    const size_t ef_pad = ((size_t)p.ef + 63) & ~(size_t)63;
-    return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)p.dstride * 4 + (size_t)p.hash_cap * 4;
+// Shape served by walk_hot_kernel (first pass only): L2, 128-byte rows, ef <= 64, adjacency rows of one
+// 32-slot pass, 32-bit byte offsets.
+bool walk_uses_hot(const WalkParams& p, int metric) {
+    const bool off32 = (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32);
+    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 64 && p.ell_stride <= 32u && off32 && !p.stamps_on;
 }
 
-size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride) {
-    if (ef <= kRegListMaxEf) return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (size_t)dstride * 4;  // tie list + merge buffer + query
+// LDS of one wavefront without the visited set.  Register kernels: tie list + merge buffer + query; the
+// hot kernel stages the query inside the merge buffer (it lives in registers once the walk starts).
+size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot) {
+    if (hot) return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8;
+    if (ef <= kRegListMaxEf) return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (size_t)dstride * 4;
     const size_t ef_pad = ((size_t)ef + 63) & ~(size_t)63;
     return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)dstride * 4;
+}
+
+size_t walk_fast_lds_bytes(const WalkParams& p, bool hot) {
+    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot) + (size_t)p.hash_cap * 4;
 }
 
 template <typename K>
@@ -2068,8 +2076,8 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
         // the common shape (ef <= 64, adjacency rows of one pass) gets a loop-free expansion;
         // 128-byte rows with L2 additionally the hand-laid-out hop of walk_hot_one
         if constexpr (METRIC == 0 && STEPS == 8) {
-            if (off32 && !retry && p.ell_stride <= 32u && p.dstride == 32u && !p.stamps_on)
-                return launch_walk_k(walk_hot_kernel, p, false, lds, s);
+            if (!retry && walk_uses_hot(p, METRIC))
+                return launch_walk_k(walk_hot_kernel, p, false, walk_fast_lds_bytes(p, true), s);
         }
         if (off32 && !retry && p.ell_stride <= ((METRIC == 0 && STEPS == 8) ? 32u : 64u))
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
@@ -2085,7 +2093,7 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
 // registers (generic or 128-B-row distance); beyond that the list lives in LDS.
 template <int METRIC, int STEPS>
 static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) {
-    const size_t lds = walk_fast_lds_bytes(p);
+    const size_t lds = walk_fast_lds_bytes(p, false);
     constexpr int kWideSteps = (STEPS == 8) ? 8 : 0;
     if (p.ef <= 64) return launch_reg_t<METRIC, STEPS, 1>(p, retry, lds, s);
     if (p.ef <= 128) return launch_reg_t<METRIC, kWideSteps, 2>(p, retry, lds, s);
