@@ -1659,6 +1659,80 @@ __global__ __launch_bounds__(64) void rerank_kernel(RerankParams p) {
     if (lane == 0) p.out[qi] = (cnt > 0) ? cand[(uint32_t)(bestk & 0xFFFFFFFFu)] : kInvalidId;
 }
 
+// Pair form for the L2 metric (dim % 8 == 0): lanes 2i / 2i+1 share candidate i's row and take its even /
+// odd 16-byte steps, so the two lanes of a pair read 32 contiguous bytes per load.  The re-rank was bound
+// by the CU's vector-memory path (one cache-line access per 16-B load when a lane streams a row alone,
+// DESIGN.md section 5.1); pairs cost that path 1.4x less.  The running sums hop between the two lanes
+// once per step (DPP quad_perm 1,0,3,2): step 2k is added in the even lane on top of the odd lane's
+// sums, step 2k+1 in the odd lane on top of the even lane's -- the reference's order 0, 1, 2, ...
+__device__ __forceinline__ float dpp_swap_pair(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));
+}
+
+__global__ __launch_bounds__(64) void rerank_pair_kernel(RerankParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id();
+    const uint32_t half = (uint32_t)lane & 1u, slot = (uint32_t)lane >> 1;
+    const uint32_t qi = blockIdx.x;
+    float* qf = reinterpret_cast<float*>(smem);
+    const float4* qs = reinterpret_cast<const float4*>(qf);
+    for (uint32_t i = lane; i < p.dstride; i += 64)
+        qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
+    wave_sync();
+    const int cnt = p.count[qi];
+    const uint32_t* cand = p.cand + (size_t)qi * p.cand_stride;
+    const uint32_t pairs = p.dim >> 3;  // steps / 2
+    uint64_t bestk = ~0ull;
+    for (int base = 0; base < cnt; base += 32) {
+        const int r = base + (int)slot;
+        const bool valid = r < cnt;
+        const uint32_t id = cand[valid ? r : base];  // lanes beyond the list redo the first row (discarded)
+        const float4* row = reinterpret_cast<const float4*>(p.db + (size_t)id * p.dstride) + half;
+        const float4* qh = qs + half;
+        float u0, u1, u2, u3, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        uint32_t k = 0;
+        for (; k + 4 <= pairs; k += 4) {
+            float4 rv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[j] = row[2 * (k + j)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 qv = qh[2 * (k + j)];
+                float e;
+                e = rv[j].x - qv.x; const float p0 = e * e;
+                e = rv[j].y - qv.y; const float p1 = e * e;
+                e = rv[j].z - qv.z; const float p2 = e * e;
+                e = rv[j].w - qv.w; const float p3 = e * e;
+                u0 = dpp_swap_pair(v0) + p0; u1 = dpp_swap_pair(v1) + p1; u2 = dpp_swap_pair(v2) + p2; u3 = dpp_swap_pair(v3) + p3;
+                v0 = dpp_swap_pair(u0) + p0; v1 = dpp_swap_pair(u1) + p1; v2 = dpp_swap_pair(u2) + p2; v3 = dpp_swap_pair(u3) + p3;
+            }
+        }
+        for (; k < pairs; ++k) {
+            const float4 rv = row[2 * k];
+            const float4 qv = qh[2 * k];
+            float e;
+            e = rv.x - qv.x; const float p0 = e * e;
+            e = rv.y - qv.y; const float p1 = e * e;
+            e = rv.z - qv.z; const float p2 = e * e;
+            e = rv.w - qv.w; const float p3 = e * e;
+            u0 = dpp_swap_pair(v0) + p0; u1 = dpp_swap_pair(v1) + p1; u2 = dpp_swap_pair(v2) + p2; u3 = dpp_swap_pair(v3) + p3;
+            v0 = dpp_swap_pair(u0) + p0; v1 = dpp_swap_pair(u1) + p1; v2 = dpp_swap_pair(u2) + p2; v3 = dpp_swap_pair(u3) + p3;
+        }
+        // the odd lane's v holds all steps: in the even lane `u` is the valid one, in the odd lane `v`
+        const float dv = ((v0 + v1) + v2) + v3;
+        if (valid && half) {
+            const uint64_t kv = ((uint64_t)fkey(dv) << 32) | (uint32_t)r;
+            bestk = kv < bestk ? kv : bestk;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = shfl_u64(bestk, lane ^ off);
+        bestk = o < bestk ? o : bestk;
+    }
+    if (lane == 0) p.out[qi] = (cnt > 0) ? cand[(uint32_t)(bestk & 0xFFFFFFFFu)] : kInvalidId;
+}
+
 // ------------------------------------------------------------------------------------------
 // MLP projection (support_func.h:624-633 computeNetLayer over a batch)
 // ------------------------------------------------------------------------------------------
@@ -2141,6 +2215,10 @@ hipError_t launch_rerank(const RerankParams& p, int metric, hipStream_t s) {
         hipError_t e = set_lds(rerank_kernel<1>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((rerank_kernel<1>), dim3(p.nq), dim3(64), lds, s, p);
+    } else if (p.dim % 8 == 0 && p.dim > 0) {
+        hipError_t e = set_lds(rerank_pair_kernel, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(rerank_pair_kernel, dim3(p.nq), dim3(64), lds, s, p);
     } else {
         hipError_t e = set_lds(rerank_kernel<0>, lds);
         if (e != hipSuccess) return e;
