@@ -22,7 +22,7 @@ def short(name):
             retry = len(args) > idx and args[idx] in ("true", "1")
             regs = "/R%s" % args[4] if key == "walk_reg_kernel" and len(args) > 4 and args[4] != "1" else ""
             return key + regs + ("/retry" if retry else "")
-    for key in ("walk_hot_kernel", "walk_general_kernel", "rerank_kernel", "mlp_layer_mfma_kernel", "mlp_layer_vec_kernel", "mlp_layer_kernel",
+    for key in ("walk_hot_kernel", "walk_general_kernel", "rerank_pair_kernel", "rerank_kernel", "mlp_layer_mfma_kernel", "mlp_layer_vec_kernel", "mlp_layer_kernel",
                 "normalize_kernel", "fill_u32_kernel"):
         if key in name:
             return key
