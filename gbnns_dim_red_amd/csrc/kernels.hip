@@ -1748,22 +1748,28 @@ constexpr int kTQ = 32, kTO = 64, kKC = 32, kLd = kKC + 4;
 constexpr int kNormLd = kTO + 1;
 
 __device__ __forceinline__ void mlp_normalize_rows(const LayerParams& p, const float* ys, uint32_t qbase, int t) {
-    if (t >= kTQ) return;
-    const uint32_t qg = qbase + t;
-    if (qg >= p.nq) return;
-    const float* y = ys + t * kNormLd;
-    const uint32_t steps = p.dout >> 2;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (uint32_t k = 0; k < steps; ++k) {
-        const float e0 = y[4 * k + 0] - 0.f, e1 = y[4 * k + 1] - 0.f;
-        const float e2 = y[4 * k + 2] - 0.f, e3 = y[4 * k + 3] - 0.f;
-        s0 = s0 + e0 * e0; s1 = s1 + e1 * e1; s2 = s2 + e2 * e2; s3 = s3 + e3 * e3;
+    // 8 threads per query: threads 0..3 of a query run the four running sums of L2Metric::Dist(y, 0)
+    // (support_func.h:107-128, d % 4 tail ignored), then every thread divides its share of the outputs.
+    __shared__ float nsum[kTQ][4];
+    const int q = t >> 3, part = t & 7;
+    const uint32_t qg = qbase + q;
+    const float* y = ys + q * kNormLd;
+    if (part < 4) {
+        const uint32_t steps = p.dout >> 2;
+        float sc = 0.f;
+        for (uint32_t k = 0; k < steps; ++k) {
+            const float e = y[4 * k + part] - 0.f;
+            sc = sc + e * e;
+        }
+        nsum[q][part] = sc;
     }
-    float norm = ((s0 + s1) + s2) + s3;
-    norm = __fsqrt_rn(norm);
+    __syncthreads();
+    if (qg >= p.nq) return;
+    float norm = ((nsum[q][0] + nsum[q][1]) + nsum[q][2]) + nsum[q][3];
+    norm = __builtin_sqrtf(norm);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn maps to the native sqrt here
     float* r = p.out + (size_t)qg * p.ostride;
-    for (uint32_t i = 0; i < p.dout; ++i) r[i] = __fdiv_rn(y[i], norm);
-    for (uint32_t i = p.dout; i < p.ostride; ++i) r[i] = 0.f;
+    for (uint32_t i = part; i < p.dout; i += 8) r[i] = __fdiv_rn(y[i], norm);
+    for (uint32_t i = p.dout + part; i < p.ostride; i += 8) r[i] = 0.f;
 }
 
 template <bool RELU, bool NORM = false>
@@ -1991,6 +1997,126 @@ __global__ __launch_bounds__(256) void mlp_layer_vec_kernel(LayerParams p) {
     }
 }
 
+// Narrow layers (dout <= 32, din <= 256: the last projection layer): the chunked kernels above spend
+// their time waiting -- eight dependent chunk round trips for two microseconds of arithmetic.  Here a
+// block stages its whole x tile [32 queries x din] and W tile [32 neurons x din] in one go (all loads in
+// flight together), then computes; thread = 2 queries x 2 neurons x 8 running sums, same order, same
+// tail rules, optional fused normalizeVector.  Dynamic LDS: 64 rows x (din8 + 4) floats (at least 32 x 65 for the normalise step).
+template <bool RELU, bool NORM>
+__global__ __launch_bounds__(256) void mlp_narrow_kernel(LayerParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const uint32_t kpad = (p.din + 7u) & ~7u;
+    const uint32_t ld = kpad + 4;  // row stride: 16-B reads of 16 consecutive rows hit distinct bank groups
+    float* xs = smf;               // [32][ld]
+    float* ws = smf + 32 * ld;     // [32][ld]
+    const int t = threadIdx.x;
+    const int tq = t >> 4;         // queries 2*tq, 2*tq+1
+    const int to = t & 15;         // neurons to, to+16
+    const uint32_t qbase = blockIdx.x * 32;
+    const uint32_t c4n = kpad >> 2;  // float4 per row
+    for (uint32_t e = t; e < 64 * c4n; e += 256) {
+        const uint32_t r = e / c4n, c4 = (e % c4n) * 4;
+        const bool isx = r < 32;
+        const uint32_t row = isx ? qbase + r : r - 32;
+        const bool in = isx ? row < p.nq : row < p.dout;
+        const float* src = isx ? p.x + (size_t)row * p.xstride + c4 : p.w + (size_t)row * p.wstride + c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) {
+            if (c4 + 4 <= p.din) v = *reinterpret_cast<const float4*>(src);
+            else {
+                if (c4 + 0 < p.din) v.x = src[0];
+                if (c4 + 1 < p.din) v.y = src[1];
+                if (c4 + 2 < p.din) v.z = src[2];
+            }
+        }
+        *reinterpret_cast<float4*>(&smf[r * ld + c4]) = v;
+    }
+    __syncthreads();
+    float acc[2][2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[a][b][l] = 0.f;
+    const uint32_t kmain = (p.din >> 3) << 3;
+    for (uint32_t k = 0; k < kmain; k += 8) {
+        float4 xv[2][2], wv[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float4* xp = reinterpret_cast<const float4*>(&xs[(2 * tq + a) * ld + k]);
+            xv[a][0] = xp[0]; xv[a][1] = xp[1];
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float4* wp = reinterpret_cast<const float4*>(&ws[(to + 16 * b) * ld + k]);
+            wv[b][0] = wp[0]; wv[b][1] = wp[1];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc[a][b][0] = acc[a][b][0] + wv[b][0].x * xv[a][0].x;
+                acc[a][b][1] = acc[a][b][1] + wv[b][0].y * xv[a][0].y;
+                acc[a][b][2] = acc[a][b][2] + wv[b][0].z * xv[a][0].z;
+                acc[a][b][3] = acc[a][b][3] + wv[b][0].w * xv[a][0].w;
+                acc[a][b][4] = acc[a][b][4] + wv[b][1].x * xv[a][1].x;
+                acc[a][b][5] = acc[a][b][5] + wv[b][1].y * xv[a][1].y;
+                acc[a][b][6] = acc[a][b][6] + wv[b][1].z * xv[a][1].z;
+                acc[a][b][7] = acc[a][b][7] + wv[b][1].w * xv[a][1].w;
+            }
+    }
+    // fold, tail steps (x and W tiles are zero beyond din, so the masked step is a full one), bias, ReLU
+    const uint32_t rem = p.din & 7u;
+    float outv[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float m[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = acc[a][b][j + 4] + acc[a][b][j];
+            const float* xr = &xs[(2 * tq + a) * ld + kmain];
+            const float* wr = &ws[(to + 16 * b) * ld + kmain];
+            uint32_t kk = 0;
+            if (rem >= 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = m[j] + wr[j] * xr[j];
+                kk = 4;
+            }
+            if (rem > kk) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = m[j] + wr[kk + j] * xr[kk + j];
+            }
+            const uint32_t og = to + 16 * b;
+            const float dist = -((m[0] + m[1]) + (m[2] + m[3]));  // Angular::Dist
+            float v = 0.f;
+            v = v - dist;                                  // support_func.h:627
+            v = v + (og < p.dout ? p.bias[og] : 0.f);      // :628
+            if (RELU && v < 0.f) v = 0.f;                  // :629-631
+            outv[a][b] = v;
+        }
+    if constexpr (NORM) {
+        __syncthreads();  // tiles are dead: reuse xs as [32][kNormLd] output rows
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                if (to + 16 * b < (int)p.dout) smf[(2 * tq + a) * kNormLd + to + 16 * b] = outv[a][b];
+        __syncthreads();
+        mlp_normalize_rows(p, smf, qbase, t);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const uint32_t qg = qbase + 2 * tq + a;
+            if (qg >= p.nq) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                if (to + 16 * b < (int)p.dout) p.out[(size_t)qg * p.ostride + to + 16 * b] = outv[a][b];
+        }
+    }
+}
+
 // Throughput variant of the projection layer on the matrix cores (opt-in, NOT bit-exact):
 // v_mfma_f32_32x32x2_f32 computes each dot product as one k-ordered f32 fma chain, which differs
 // from the reference's 8 separately rounded running sums in the last ulp.  Block = 4 wavefronts =
@@ -2088,7 +2214,7 @@ __global__ __launch_bounds__(256) void normalize_kernel(float* y, uint32_t strid
         s0 = s0 + e0 * e0; s1 = s1 + e1 * e1; s2 = s2 + e2 * e2; s3 = s3 + e3 * e3;
     }
     float norm = ((s0 + s1) + s2) + s3;
-    norm = __fsqrt_rn(norm);
+    norm = __builtin_sqrtf(norm);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn maps to the native sqrt here
     for (uint32_t i = 0; i < dim; ++i) r[i] = __fdiv_rn(r[i], norm);
     for (uint32_t i = dim; i < stride; ++i) r[i] = 0.f;
 }
@@ -2250,6 +2376,24 @@ hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s) {
     const dim3 grid((p.nq + kTQ - 1) / kTQ, (p.dout + kTO - 1) / kTO);
     const bool aligned = p.xstride % 4 == 0 && p.wstride % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
+    if (aligned && p.dout <= 32u && p.din <= 256u && (!p.normalize || !p.relu)) {
+        // narrow layer: whole-K staging, one load phase (the last projection layer)
+        const uint32_t kpad = (p.din + 7u) & ~7u;
+        const size_t lds = std::max<size_t>((size_t)64 * (kpad + 4), (size_t)32 * kNormLd) * sizeof(float);  // tiles, or the rows to normalise
+        const dim3 gn((p.nq + 31) / 32);
+        hipError_t e = hipSuccess;
+        if (p.normalize) {
+            e = set_lds(mlp_narrow_kernel<false, true>, lds);
+            if (e == hipSuccess) hipLaunchKernelGGL((mlp_narrow_kernel<false, true>), gn, dim3(256), lds, s, p);
+        } else if (p.relu) {
+            e = set_lds(mlp_narrow_kernel<true, false>, lds);
+            if (e == hipSuccess) hipLaunchKernelGGL((mlp_narrow_kernel<true, false>), gn, dim3(256), lds, s, p);
+        } else {
+            e = set_lds(mlp_narrow_kernel<false, false>, lds);
+            if (e == hipSuccess) hipLaunchKernelGGL((mlp_narrow_kernel<false, false>), gn, dim3(256), lds, s, p);
+        }
+        return e != hipSuccess ? e : hipGetLastError();
+    }
     if (p.normalize && !p.relu && p.dout <= (uint32_t)kTO) {  // fused normalizeVector (one block column)
         if (aligned) hipLaunchKernelGGL((mlp_layer_vec_kernel<false, true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((mlp_layer_kernel<false, true>), grid, dim3(256), 0, s, p);
