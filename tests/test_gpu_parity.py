@@ -132,6 +132,30 @@ def test_pair_gather_multi_pass_and_retry(g, orc):
     ix.close()
 
 
+def test_hot_kernel_tie_paths(g, orc):
+    """The hand-laid-out instance (L2, 128-byte rows, ef <= 64, rows of <= 32 slots) on data full of exact
+    distance ties: a 32-dimensional lattice with every vector stored three times, walked directly (PLAIN
+    mode, so the walked rows are 128 bytes).  Exercises its out-of-line selection (equal-distance runs,
+    tie list), the boundary-tie fallback of the batch merge, both adjacency prefetches on wrong guesses,
+    and the hand-over to the retry pass / general kernel when the 16-entry tie list overflows."""
+    cl = datagen.Case("lat32", 777, 9000, 300, 32, 4, 8, kind="lattice")
+    rng = np.random.Generator(np.random.PCG64(778))
+    off, nbr = datagen.random_graph(rng, cl.n, 6, 30)
+    ent = rng.integers(0, cl.n, size=cl.nq).astype(np.uint32)
+    ix = g.Index(cl.base, off, nbr)
+    ix.profile_enable(True)
+    for ef in (1, 2, 5, 16, 33, 64):
+        w = orc.walk(cl.queries, cl.base, off, nbr, ef, entries=ent, threads=8)
+        r = ix.search(cl.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent,
+                      want=("hops", "dist_calc", "cand", "cand_dist"))
+        assert np.array_equal(r["cand"], w["ids"]), ef
+        assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), ef
+        assert np.array_equal(r["hops"], w["hops"]), ef
+        assert np.array_equal(r["dist_calc"], w["dist_calc"]), ef
+    ix.profile_read()
+    ix.close()
+
+
 def test_general_kernel_paths(g, orc):
     """Force the hand-over paths: (a) a visited set too small for the walk, (b) a tie list that
     overflows (lattice data, exact distance ties everywhere), (c) ef beyond the LDS list."""
