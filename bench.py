@@ -51,11 +51,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path)"
+    # rehearsal on a one-GPU box (not a measurement): GBNNS_BENCH_REHEARSAL=1 puts every rank on cuda:0 and
+    # runs the collective over gloo, to exercise the N > 1 control flow without an 8-GPU node
+    rehearsal = os.environ.get("GBNNS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import gbnns_dim_red_amd as g
     from gbnns_dim_red_amd import synth
@@ -104,21 +112,39 @@ def main():
     recall = sweep[ef]
 
     # ---- timed region -----------------------------------------------------------------------
-    out = {}
     want = ("hops", "dist_calc", "edges")
-    gathered = None
+    # Two sets of output buffers used alternately: the all-gather of step i (RCCL's own stream) runs
+    # beside the kernels of step i+1; step i+2 reuses step i's buffers and therefore waits for that
+    # gather first (a stream-level wait, the host never blocks).
+    outs = [{}, {}]
+    gathered = [None, None]
+    pending = [None, None]
+    nstep = 0
 
     def step():
-        nonlocal gathered
-        r = ix.search(q, ef, want=want, out=out, hash_capacity=args.hash_capacity)
+        nonlocal nstep
+        b = nstep & 1
+        nstep += 1
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+        r = ix.search(q, ef, want=want, out=outs[b], hash_capacity=args.hash_capacity)
         if world > 1:
             # the path's only exchange step: all-gather of the int32 answer ids over RCCL/xGMI
-            gathered = torch.empty(world * args.nq, dtype=r["ids"].dtype, device=dev)
-            dist.all_gather_into_tensor(gathered, r["ids"])
+            if gathered[b] is None:
+                gathered[b] = torch.empty(world * args.nq, dtype=r["ids"].dtype, device=dev)
+            pending[b] = dist.all_gather_into_tensor(gathered[b], r["ids"], async_op=True)
         return r
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     ix.profile_read(reset=True)
     ix.profile_enable(True)
@@ -128,6 +154,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+    drain()  # every step's gather is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
