@@ -650,8 +650,9 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         // entries so that the largest walk seen (+ 1/16 margin + one pass of new ids) stays under the
         // 15/16 fill limit
         uint32_t need = (maxdc + maxdc / 16 + 64) / 15 * 16 + 16;
-        if (ovf > 0) need = std::max<uint32_t>(need, ix->stats_cap * 2);
-        ix->cap_for_ef[ix->stats_ef] = need;  // stats_ef = ef * 4 + mode
+        (void)ovf;  // max_dc covers the retry / general passes too, so a hand-over needs no extra rule
+        uint32_t& slot = ix->cap_for_ef[ix->stats_ef];  // stats_ef = ef * 4 + mode
+        slot = std::max(slot, need);  // never shrinks: batches with one long walk do not make it oscillate
     }
     w.stamps = reinterpret_cast<unsigned long long*>(ctrl_base + 8);  // words 8..71, diagnostic builds
 #ifdef GBNNS_STAMPS

@@ -1312,21 +1312,24 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
         "9:\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
         // ---- pair distance (l2_pair_from_regs), all lanes
-        "s_waitcnt vmcnt(0)\n\t"
+        "s_waitcnt vmcnt(3)\n\t"                               // loads return in order: square each step as it lands
         "v_pk_add_f32 v[48:49], v[48:49], %[qa0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_add_f32 v[50:51], v[50:51], %[qb0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[52:53], v[52:53], %[qa1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[54:55], v[54:55], %[qb1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_mul_f32 v[48:49], v[48:49], v[48:49]\n\t"
         "v_pk_mul_f32 v[50:51], v[50:51], v[50:51]\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_pk_add_f32 v[52:53], v[52:53], %[qa1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[54:55], v[54:55], %[qb1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_mul_f32 v[52:53], v[52:53], v[52:53]\n\t"
         "v_pk_mul_f32 v[54:55], v[54:55], v[54:55]\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
         "v_pk_add_f32 v[56:57], v[56:57], %[qa2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_add_f32 v[58:59], v[58:59], %[qb2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[60:61], v[60:61], %[qa3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[62:63], v[62:63], %[qb3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_mul_f32 v[56:57], v[56:57], v[56:57]\n\t"
         "v_pk_mul_f32 v[58:59], v[58:59], v[58:59]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_pk_add_f32 v[60:61], v[60:61], %[qa3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[62:63], v[62:63], %[qb3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_mul_f32 v[60:61], v[60:61], v[60:61]\n\t"
         "v_pk_mul_f32 v[62:63], v[62:63], v[62:63]\n\t"
         "v_pk_add_f32 v[68:69], v[48:49], v[52:53]\n\t"      // even lane: steps 0..3
