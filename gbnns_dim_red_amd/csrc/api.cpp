@@ -408,6 +408,30 @@ int gbnns_debug_read_stamps(gbnns_index* ix, unsigned long long* out32) {
     return GBNNS_OK;
 }
 
+// Diagnostic (not in gbnns.h): one batch merge of the register-list walk kernels on host-supplied keys.
+// entries: sorted u64 keys [size]; surv: 64 keys, ~0 = no survivor in that lane; out: 64*regs keys;
+// out_info: {new size, merged (0 = boundary tie, list untouched), new worst}.
+int gbnns_debug_merge(int regs, const unsigned long long* entries, int size, const unsigned long long* surv, int ef,
+                      unsigned long long* out, int* out_info) {
+    if (!(regs == 1 || regs == 2 || regs == 4) || size < 1 || size > ef || ef > 64 * regs)
+        return fail(GBNNS_ERR_INVALID, "bad debug_merge arguments");
+    unsigned long long *d_e = nullptr, *d_s = nullptr, *d_o = nullptr;
+    int* d_i = nullptr;
+    HIP_TRY(hipMalloc(&d_e, 256 * 8));
+    HIP_TRY(hipMalloc(&d_s, 64 * 8));
+    HIP_TRY(hipMalloc(&d_o, 256 * 8));
+    HIP_TRY(hipMalloc(&d_i, 16));
+    HIP_TRY(hipMemcpy(d_e, entries, (size_t)size * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_s, surv, 64 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(launch_debug_merge(regs, reinterpret_cast<const uint64_t*>(d_e), size, reinterpret_cast<const uint64_t*>(d_s), ef,
+                               reinterpret_cast<uint64_t*>(d_o), d_i, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d_o, (size_t)64 * regs * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_info, d_i, 12, hipMemcpyDeviceToHost));
+    (void)hipFree(d_e); (void)hipFree(d_s); (void)hipFree(d_o); (void)hipFree(d_i);
+    return GBNNS_OK;
+}
+
 int gbnns_profile_enable(gbnns_index* ix, int on) {
     if (!ix) return fail(GBNNS_ERR_INVALID, "null index");
     ix->profiling = on != 0;
@@ -480,7 +504,7 @@ int gbnns_rerank(gbnns_index* ix, const float* queries, uint64_t n_q, const uint
     int rc;
     RerankParams r{};
     r.db = ix->db; r.dstride = ix->d_pad; r.dim = ix->d; r.qstride = ix->d; r.cand_stride = cand_stride;
-    r.nq = nq;
+    r.nq = nq; r.n = (uint32_t)ix->n;
     if ((rc = ix->cnt.ensure((size_t)nq * 4))) return rc;
     int32_t* cnt_dev = ix->cnt.as<int32_t>();
     if (host) {
@@ -721,7 +745,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     if (!plain) {
         RerankParams r{};
         r.q = q_dev; r.qstride = ix->d; r.db = ix->db; r.dstride = ix->d_pad; r.dim = ix->d;
-        r.cand = w.cand; r.cand_stride = cstride; r.count = w.count; r.nq = nq; r.out = out_dev;
+        r.cand = w.cand; r.cand_stride = cstride; r.count = w.count; r.nq = nq; r.n = (uint32_t)ix->n; r.out = out_dev;
         HIP_TRY(launch_rerank(r, ix->metric, s));
     }
     if (prof) {

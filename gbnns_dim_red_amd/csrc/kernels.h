@@ -77,9 +77,13 @@ struct RerankParams {
     uint32_t cand_stride;
     const int32_t* count;    // [nq]
     uint32_t nq;
+    uint32_t n;              // rows of db (ids are clamped against it)
     uint32_t* out;           // [nq]
 };
 hipError_t launch_rerank(const RerankParams& p, int metric, hipStream_t s);
+// diagnostic (tests): one batch merge of a sorted list [size] with up to 64 survivor keys (~0 = none)
+hipError_t launch_debug_merge(int regs, const uint64_t* entries, int size, const uint64_t* surv, int ef, uint64_t* out,
+                              int* out_size, hipStream_t s);
 
 // MLP projection (support_func.h:624-658).  W is repacked by the host: [dout x wstride] weights
 // (zero padded, wstride multiple of 8) + separate bias[dout].

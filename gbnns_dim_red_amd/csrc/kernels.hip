@@ -868,6 +868,76 @@ __device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk,
     return true;
 }
 
+// The same batch merge for lists of R = 2 / 4 registers per lane (64 < ef <= 256): entry of rank i lives in
+// register i / 64 of lane i % 64, the scatter buffer holds ranks 0..ef.  Plain C++ (these instances are not
+// the hot one); same rule, same fallback on a boundary tie.
+__device__ __forceinline__ constexpr int reg_stage_slots(int R) { return 64 * R + 2; }
+
+template <int R>
+__device__ __forceinline__ bool reg_merge_multi(uint64_t m, bool is_surv, uint32_t dk, uint32_t nb, RegList<R>& L, int& size,
+                                                uint32_t& worst, int& tsize, uint64_t* stage, int ef, int lane) {
+    const int ns = __popcll(m);
+    uint64_t key[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) key[r] = ((uint64_t)L.hi[r] << 32) | L.lo[r];
+    const uint32_t slo = nb << 1;
+    const uint64_t skey = ((uint64_t)dk << 32) | slo;
+    uint32_t shift[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) shift[r] = 0;
+    uint32_t rank = 0, below = 0;
+    uint64_t mm = m;
+    do {
+        const int sl = __ffsll((unsigned long long)mm) - 1;
+        mm = clear_bit64(mm, sl);
+        const uint64_t ks = ((uint64_t)readlane_u32(dk, sl) << 32) | readlane_u32(slo, sl);
+        uint32_t cnt = 0;  // entries below this survivor: lanes without an entry hold all-ones / evicted keys (greater)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool gt = key[r] > ks;
+            shift[r] += gt ? 1u : 0u;
+            cnt += (uint32_t)__popcll(~__ballot(gt));
+        }
+        rank += skey > ks ? 1u : 0u;
+        below = writelane_u32(below, cnt, sl);
+    } while (mm);
+    const int total = size + ns;
+    const int new_size = total < ef ? total : ef;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int re = r * 64 + lane, dst = re + (int)shift[r];
+        if (re < size && dst <= ef) stage[dst] = key[r];
+    }
+    {
+        const int dst_s = (int)(rank + below);
+        if (is_surv && dst_s <= ef) stage[dst_s] = skey;
+    }
+    wave_sync();
+    // the element of merged rank ef (the first one that falls off) decides the boundary-tie test
+    uint32_t first_dropped = 0;
+    if (total > ef) first_dropped = (uint32_t)__builtin_amdgcn_readfirstlane((int)(stage[ef] >> 32));
+    uint32_t nlo[R], nhi[R], nw = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint64_t v = (r * 64 + lane < new_size) ? stage[r * 64 + lane] : ~0ull;
+        nlo[r] = (uint32_t)v;
+        nhi[r] = (uint32_t)(v >> 32);
+        const uint32_t t = readlane_u32(nhi[r], (new_size - 1) & 63);
+        if (((new_size - 1) >> 6) == r) nw = t;
+    }
+    wave_sync();  // (the buffer is reused by the next merge)
+    if (total > ef && first_dropped == nw) return false;  // order matters: the caller goes sequential, list untouched
+    if (total > ef) tsize = 0;  // something was evicted and (no tie) the worst distance decreased
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        L.lo[r] = nlo[r];
+        L.hi[r] = nhi[r];
+    }
+    size = new_size;
+    worst = nw;
+    return true;
+}
+
 // Results of a register-list walk in POP order (worst -> best): rank i goes to position kept-1-i.
 template <int R>
 __device__ __forceinline__ void reg_write_results(const WalkParams& p, uint32_t qi, const RegList<R>& L, int size, int hops,
@@ -917,7 +987,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     const int ef = p.ef;
     uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
     uint64_t* stage = tie + kRegTieCap;  // scatter buffer of the batch merge
-    float* qf = reinterpret_cast<float*>(stage + kRegStageSlots);
+    float* qf = reinterpret_cast<float*>(stage + reg_stage_slots(R));
     uint32_t* hash = reinterpret_cast<uint32_t*>(qf + p.dstride);
     const float4* qs = reinterpret_cast<const float4*>(qf);
     const uint32_t cap = p.hash_cap;  // any size: slot = mulhi(id * C, cap)
@@ -1142,9 +1212,12 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                 hist[ns_ <= 4 ? ns_ : (ns_ <= 8 ? 5 : (ns_ <= 16 ? 6 : 7))] += 1;
             }
 #endif
-            if constexpr (R == 1) {
+            {
                 if ((m & (m - 1)) != 0) {
-                    if (reg_merge(m, offer_it, dk, nb, L, size, worst, tsize, stage, ef, lane)) {
+                    bool merged;
+                    if constexpr (R == 1) merged = reg_merge(m, offer_it, dk, nb, L, size, worst, tsize, stage, ef, lane);
+                    else merged = reg_merge_multi<R>(m, offer_it, dk, nb, L, size, worst, tsize, stage, ef, lane);
+                    if (merged) {
                         m = 0;
 #ifdef GBNNS_STAMPS
                         hist[8] += 1;
@@ -1541,6 +1614,42 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
     }
 }
 
+// Diagnostic kernel (tests only): runs one batch merge on a list / survivor set supplied by the host.
+template <int R>
+__global__ __launch_bounds__(64) void debug_merge_kernel(const uint64_t* entries, int size, const uint64_t* surv, int ef,
+                                                         uint64_t* out, int* out_size) {
+    __shared__ uint64_t stage[64 * R + 2];
+    const int lane = lane_id();
+    RegList<R> L;
+    L.clear();
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (r * 64 + lane < size) {
+            L.lo[r] = (uint32_t)entries[r * 64 + lane];
+            L.hi[r] = (uint32_t)(entries[r * 64 + lane] >> 32);
+        }
+    const uint64_t sk = surv[lane];
+    const bool is_surv = sk != ~0ull;
+    const uint64_t m = __ballot(is_surv);
+    uint32_t worst = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t t = readlane_u32(L.hi[r], (size - 1) & 63);
+        if (((size - 1) >> 6) == r) worst = t;
+    }
+    int tsize = 0;
+    bool ok;
+    if constexpr (R == 1) ok = reg_merge(m, is_surv, (uint32_t)(sk >> 32), (uint32_t)sk >> 1, L, size, worst, tsize, stage, ef, lane);
+    else ok = reg_merge_multi<R>(m, is_surv, (uint32_t)(sk >> 32), (uint32_t)sk >> 1, L, size, worst, tsize, stage, ef, lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[r * 64 + lane] = ((uint64_t)L.hi[r] << 32) | L.lo[r];
+    if (lane == 0) {
+        out_size[0] = size;
+        out_size[1] = ok ? 1 : 0;
+        out_size[2] = (int)worst;
+    }
+}
+
 // ---- general kernel: exact for every input (any ef, any number of ties, any visited count) ----
 //
 // Persistent wavefronts pull query indices from the hand-over list.  Visited set = one bit per
@@ -1647,7 +1756,8 @@ __global__ __launch_bounds__(64) void rerank_kernel(RerankParams p) {
     for (int base = 0; base < cnt; base += 64) {
         const int r = base + lane;
         if (r < cnt) {
-            const uint32_t id = cand[r];
+            uint32_t id = cand[r];
+            id = id < p.n ? id : 0u;  // (never dereference an id outside the table)
             const float dv = metric_dist<METRIC>(
                 reinterpret_cast<const float4*>(p.db + (size_t)id * p.dstride), qs, p.dim);
             const uint64_t kv = ((uint64_t)fkey(dv) << 32) | (uint32_t)r;
@@ -1689,7 +1799,8 @@ __global__ __launch_bounds__(64) void rerank_pair_kernel(RerankParams p) {
     for (int base = 0; base < cnt; base += 32) {
         const int r = base + (int)slot;
         const bool valid = r < cnt;
-        const uint32_t id = cand[valid ? r : base];  // lanes beyond the list redo the first row (discarded)
+        uint32_t id = cand[valid ? r : base];  // lanes beyond the list redo the first row (discarded)
+        id = id < p.n ? id : 0u;               // (never dereference an id outside the table)
         const float4* row = reinterpret_cast<const float4*>(p.db + (size_t)id * p.dstride) + half;
         const float4* qh = qs + half;
         float u0, u1, u2, u3, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
@@ -2245,7 +2356,10 @@ bool walk_uses_hot(const WalkParams& p, int metric) {
 // hot kernel stages the query inside the merge buffer (it lives in registers once the walk starts).
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot) {
     if (hot) return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8;
-    if (ef <= kRegListMaxEf) return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (size_t)dstride * 4;
+    if (ef <= kRegListMaxEf) {  // tie list + merge buffer (ranks 0..ef of the 1 / 2 / 4-register list) + query
+        const int regs = ef <= 64 ? 1 : (ef <= 128 ? 2 : 4);
+        return (size_t)kRegTieCap * 8 + (size_t)(64 * regs + 2) * 8 + (size_t)dstride * 4;
+    }
     const size_t ef_pad = ((size_t)ef + 63) & ~(size_t)63;
     return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)dstride * 4;
 }
@@ -2428,6 +2542,14 @@ hipError_t launch_fill_u32(uint32_t* p, uint32_t v, size_t count, hipStream_t s)
     size_t blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, v, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_merge(int regs, const uint64_t* entries, int size, const uint64_t* surv, int ef, uint64_t* out,
+                              int* out_size, hipStream_t s) {
+    if (regs == 1) hipLaunchKernelGGL((debug_merge_kernel<1>), dim3(1), dim3(64), 0, s, entries, size, surv, ef, out, out_size);
+    else if (regs == 2) hipLaunchKernelGGL((debug_merge_kernel<2>), dim3(1), dim3(64), 0, s, entries, size, surv, ef, out, out_size);
+    else hipLaunchKernelGGL((debug_merge_kernel<4>), dim3(1), dim3(64), 0, s, entries, size, surv, ef, out, out_size);
     return hipGetLastError();
 }
 

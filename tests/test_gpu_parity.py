@@ -156,6 +156,57 @@ def test_hot_kernel_tie_paths(g, orc):
     ix.close()
 
 
+def test_batch_merge_unit(g):
+    """The batch merge of the register-list walk kernels (1 / 2 / 4 list registers per lane) in isolation,
+    through the library's diagnostic entry point: random sorted lists and survivor sets, result = the ef
+    smallest keys of the union, or "not merged, list untouched" when a dropped key ties the new worst."""
+    import ctypes as C
+    import random
+    lib = g.load_library()
+    U64 = C.c_ulonglong
+    lib.gbnns_debug_merge.argtypes = [C.c_int, C.POINTER(U64), C.c_int, C.POINTER(U64), C.c_int, C.POINTER(U64),
+                                      C.POINTER(C.c_int)]
+    rnd = random.Random(20261003)
+    FULL = (1 << 64) - 1
+    done = ties = 0
+    for _ in range(400):
+        R = rnd.choice([1, 2, 4])
+        ef = rnd.randint(64 * (R // 2) + 1, 64 * R)
+        size = rnd.randint(1, ef)
+        span = rnd.choice([1 << 20, 40])  # a narrow distance range produces boundary ties
+        pool = [rnd.randrange(1, span) for _ in range(size + 64)]
+        mk = lambda dist, ident: (dist << 32) | (ident << 1)
+        entries = sorted(mk(pool[i], i) | rnd.randint(0, 1) for i in range(size))  # random "expanded" flags
+        lanes = rnd.sample(range(64), rnd.randint(2, 40))
+        surv = [FULL] * 64
+        for j, l in enumerate(lanes):
+            surv[l] = mk(pool[size + j], 100000 + j)
+        if size == ef:  # a full list only admits keys below its worst distance
+            wh = entries[-1] >> 32
+            surv = [s if s != FULL and (s >> 32) < wh else FULL for s in surv]
+        sv = [s for s in surv if s != FULL]
+        if len(sv) < 2:
+            continue
+        E = (U64 * 256)(*entries)
+        S = (U64 * 64)(*surv)
+        O = (U64 * 256)()
+        info = (C.c_int * 4)()
+        assert lib.gbnns_debug_merge(R, E, size, S, ef, O, info) == 0
+        merged = sorted(entries + sv)
+        new_size = min(len(merged), ef)
+        tie = len(merged) > ef and (merged[ef] >> 32) == (merged[new_size - 1] >> 32)
+        if tie:
+            ties += 1
+            assert info[1] == 0 and [O[i] for i in range(size)] == entries, (R, ef, size)
+        else:
+            assert info[1] == 1 and info[0] == new_size, (R, ef, size)
+            assert [O[i] for i in range(new_size)] == merged[:new_size], (R, ef, size)
+            assert all(O[i] == FULL for i in range(new_size, 64 * R)), (R, ef, size)
+            assert info[2] == (merged[new_size - 1] >> 32), (R, ef, size)
+        done += 1
+    assert done > 200 and ties > 5
+
+
 def test_general_kernel_paths(g, orc):
     """Force the hand-over paths: (a) a visited set too small for the walk, (b) a tie list that
     overflows (lattice data, exact distance ties everywhere), (c) ef beyond the LDS list."""
