@@ -500,6 +500,34 @@ def test_randomised_small_cases(g, orc):
         ix.close()
 
 
+def test_randomised_rows128(g, orc):
+    """Seeded random configurations with 128-byte walked rows (d_low = 32, L2): the shapes served by the
+    hand-laid-out instance, the pair-gather generic kernels and the 2 / 4-register lists -- ragged degrees up
+    to 32 or up to 70 slots, every ef class, random entry points, tie-heavy lattice data every third case,
+    tiny visited sets (hand-over chain) every fourth."""
+    rng = np.random.Generator(np.random.PCG64(777001))
+    for case in range(36):
+        n = int(rng.integers(300, 6000))
+        nq = int(rng.integers(8, 80))
+        kind = "lattice" if case % 3 == 0 else "clustered"
+        c = datagen.Case("h", 5000 + case, n, nq, 32, 4, 8, kind=kind)
+        deg_hi = int(rng.choice([9, 30, 32, 70]))
+        off, nbr = datagen.random_graph(rng, n, 0, min(deg_hi, n - 1))
+        ent = rng.integers(0, n, size=nq).astype(np.uint32)
+        ef = int(rng.choice([1, 2, 7, 31, 64, 65, 100, 128, 129, 200, 256, 300]))
+        cap = int(rng.choice([128, 256])) if case % 4 == 3 else 0
+        tag = (case, n, nq, kind, deg_hi, ef, cap)
+        ix = g.Index(c.base, off, nbr)
+        w = orc.walk(c.queries, c.base, off, nbr, ef, entries=ent, threads=8)
+        r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"),
+                      hash_capacity=cap)
+        assert np.array_equal(r["cand"], w["ids"]), tag
+        assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), tag
+        assert np.array_equal(r["hops"], w["hops"]), tag
+        assert np.array_equal(r["dist_calc"], w["dist_calc"]), tag
+        ix.close()
+
+
 def test_mfma_projection_option(g, orc):
     """The opt-in matrix-core projection is a throughput variant, not part of the bit-exact
     contract: its projected queries must agree with the exact path to f32 rounding (tolerance
