@@ -2128,22 +2128,38 @@ __global__ __launch_bounds__(256) void mlp_narrow_kernel(LayerParams p) {
     const int to = t & 15;         // neurons to, to+16
     const uint32_t qbase = blockIdx.x * 32;
     const uint32_t c4n = kpad >> 2;  // float4 per row
-    for (uint32_t e = t; e < 64 * c4n; e += 256) {
-        const uint32_t r = e / c4n, c4 = (e % c4n) * 4;
-        const bool isx = r < 32;
-        const uint32_t row = isx ? qbase + r : r - 32;
-        const bool in = isx ? row < p.nq : row < p.dout;
-        const float* src = isx ? p.x + (size_t)row * p.xstride + c4 : p.w + (size_t)row * p.wstride + c4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in) {
-            if (c4 + 4 <= p.din) v = *reinterpret_cast<const float4*>(src);
-            else {
-                if (c4 + 0 < p.din) v.x = src[0];
-                if (c4 + 1 < p.din) v.y = src[1];
-                if (c4 + 2 < p.din) v.z = src[2];
+    // staging: 8 loads in flight per thread, then 8 LDS stores (a load -> store loop would pay one
+    // round trip per 16 bytes)
+    for (uint32_t e0 = t; e0 < 64 * c4n; e0 += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t e = e0 + 256u * u;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < 64 * c4n) {
+                const uint32_t r = e / c4n, c4 = (e % c4n) * 4;
+                const bool isx = r < 32;
+                const uint32_t row = isx ? qbase + r : r - 32;
+                const bool in = isx ? row < p.nq : row < p.dout;
+                const float* src = isx ? p.x + (size_t)row * p.xstride + c4 : p.w + (size_t)row * p.wstride + c4;
+                if (in) {
+                    if (c4 + 4 <= p.din) v[u] = *reinterpret_cast<const float4*>(src);
+                    else {
+                        if (c4 + 0 < p.din) v[u].x = src[0];
+                        if (c4 + 1 < p.din) v[u].y = src[1];
+                        if (c4 + 2 < p.din) v[u].z = src[2];
+                    }
+                }
             }
         }
-        *reinterpret_cast<float4*>(&smf[r * ld + c4]) = v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t e = e0 + 256u * u;
+            if (e < 64 * c4n) {
+                const uint32_t r = e / c4n, c4 = (e % c4n) * 4;
+                *reinterpret_cast<float4*>(&smf[r * ld + c4]) = v[u];
+            }
+        }
     }
     __syncthreads();
     float acc[2][2][8];
