@@ -15,6 +15,7 @@ METRIC_L2, METRIC_NEG_DOT = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 MODE_NET, MODE_LOWQ, MODE_PLAIN = 0, 1, 2
 FLAG_MFMA_PROJECT = 1
+FLAG_NO_FUSED_RERANK = 2
 
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [

@@ -710,6 +710,15 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.hash_cap = cap;
     w.hash_limit = cap - cap / 16;
     w.all_general = walk_fast_lds_bytes(w, hot) > kMaxLds ? 1 : 0;
+    // Fused re-rank: with the hot first pass (and its retry / general successors) every wavefront re-ranks
+    // its own query when its walk ends; no re-rank launch.  Needs the pair form (L2, d % 8 == 0) and room
+    // for the original-space query in the walk kernels' LDS.
+    const bool fuse = hot && !plain && !w.all_general && ix->metric == GBNNS_METRIC_L2 && ix->d % 8 == 0 &&
+                      (size_t)ix->d_pad * 4 <= walk_fast_lds_bytes(w, hot) && !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
+    if (fuse) {
+        w.rr_q = q_dev; w.rr_qstride = ix->d; w.rr_db = ix->db; w.rr_dstride = ix->d_pad; w.rr_dim = ix->d;
+        w.rr_n = (uint32_t)ix->n; w.rr_out = out_dev;
+    }
 
     if (!w.all_general) {
         HIP_TRY(launch_walk_fast(w, ix->metric, s));
@@ -742,7 +751,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     }
 
     // ---- stage 3: re-rank in the original space ------------------------------------------
-    if (!plain) {
+    if (!plain && !fuse) {
         RerankParams r{};
         r.q = q_dev; r.qstride = ix->d; r.db = ix->db; r.dstride = ix->d_pad; r.dim = ix->d;
         r.cand = w.cand; r.cand_stride = cstride; r.count = w.count; r.nq = nq; r.n = (uint32_t)ix->n; r.out = out_dev;

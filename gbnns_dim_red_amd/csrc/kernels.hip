@@ -250,6 +250,106 @@ __device__ __forceinline__ uint64_t visited_claim_mask(uint32_t lds_base, uint32
 }
 
 // ------------------------------------------------------------------------------------------
+// re-rank, pair form (search_function.h:105-125 getRealNearest) -- shared by rerank_pair_kernel and by the
+// walk kernels that re-rank their own query at the end of its walk
+// ------------------------------------------------------------------------------------------
+// L2 metric, dim % 8 == 0: lanes 2i / 2i+1 share candidate i's row and take its even / odd 16-byte steps,
+// so the two lanes of a pair read 32 contiguous bytes per load.  The re-rank was bound by the CU's
+// vector-memory path (one cache-line access per 16-B load when a lane streams a row alone, DESIGN.md
+// section 5.1); pairs cost that path 1.4x less.  The running sums hop between the two lanes once per step
+// (DPP quad_perm 1,0,3,2): step 2k is added in the even lane on top of the odd lane's sums, step 2k+1 in
+// the odd lane on top of the even lane's -- the reference's order 0, 1, 2, ...
+// Winner = strict minimum in pop order  <=>  min over (distance, pop index).  Returns the pop index of the
+// winner (wave-uniform), -1 for an empty list.  `id_at(r)` gives the id of pop index r (called by all lanes).
+struct RerankSrc {
+    const float* q;      // [nq x qstride] original-space queries
+    uint32_t qstride;
+    const float* db;     // [n x dstride]
+    uint32_t dstride, dim, n;
+};
+
+__device__ __forceinline__ float dpp_swap_pair(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));
+}
+
+template <typename IdAt>
+__device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi, int cnt, float* qf, int lane, IdAt id_at) {
+    const uint32_t half = (uint32_t)lane & 1u, slot = (uint32_t)lane >> 1;
+    const float4* qs = reinterpret_cast<const float4*>(qf);
+    for (uint32_t i = lane; i < a.dstride; i += 64)
+        qf[i] = (i < a.dim) ? a.q[(size_t)qi * a.qstride + i] : 0.f;
+    wave_sync();
+    const uint32_t pairs = a.dim >> 3;  // steps / 2
+    uint64_t bestk = ~0ull;
+    for (int base = 0; base < cnt; base += 32) {
+        const int r = base + (int)slot;
+        const bool valid = r < cnt;
+        uint32_t id = id_at(valid ? r : base);  // lanes beyond the list redo the first row (discarded)
+        id = id < a.n ? id : 0u;                // (never dereference an id outside the table)
+        const float4* row = reinterpret_cast<const float4*>(a.db + (size_t)id * a.dstride) + half;
+        const float4* qh = qs + half;
+        float u0, u1, u2, u3, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        uint32_t k = 0;
+        for (; k + 4 <= pairs; k += 4) {
+            float4 rv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[j] = row[2 * (k + j)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 qv = qh[2 * (k + j)];
+                float e;
+                e = rv[j].x - qv.x; const float p0 = e * e;
+                e = rv[j].y - qv.y; const float p1 = e * e;
+                e = rv[j].z - qv.z; const float p2 = e * e;
+                e = rv[j].w - qv.w; const float p3 = e * e;
+                u0 = dpp_swap_pair(v0) + p0; u1 = dpp_swap_pair(v1) + p1; u2 = dpp_swap_pair(v2) + p2; u3 = dpp_swap_pair(v3) + p3;
+                v0 = dpp_swap_pair(u0) + p0; v1 = dpp_swap_pair(u1) + p1; v2 = dpp_swap_pair(u2) + p2; v3 = dpp_swap_pair(u3) + p3;
+            }
+        }
+        for (; k < pairs; ++k) {
+            const float4 rv = row[2 * k];
+            const float4 qv = qh[2 * k];
+            float e;
+            e = rv.x - qv.x; const float p0 = e * e;
+            e = rv.y - qv.y; const float p1 = e * e;
+            e = rv.z - qv.z; const float p2 = e * e;
+            e = rv.w - qv.w; const float p3 = e * e;
+            u0 = dpp_swap_pair(v0) + p0; u1 = dpp_swap_pair(v1) + p1; u2 = dpp_swap_pair(v2) + p2; u3 = dpp_swap_pair(v3) + p3;
+            v0 = dpp_swap_pair(u0) + p0; v1 = dpp_swap_pair(u1) + p1; v2 = dpp_swap_pair(u2) + p2; v3 = dpp_swap_pair(u3) + p3;
+        }
+        // the odd lane's v holds all steps: in the even lane `u` is the valid one, in the odd lane `v`
+        const float dv = ((v0 + v1) + v2) + v3;
+        if (valid && half) {
+            const uint64_t kv = ((uint64_t)fkey(dv) << 32) | (uint32_t)r;
+            bestk = kv < bestk ? kv : bestk;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = shfl_u64(bestk, lane ^ off);
+        bestk = o < bestk ? o : bestk;
+    }
+    bestk = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bestk >> 32)) << 32) |
+            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bestk);
+    return cnt > 0 ? (int)(uint32_t)(bestk & 0xFFFFFFFFu) : -1;
+}
+
+// Fused re-rank at the end of a walk: the wavefront re-ranks its own query's candidates (pop index r =
+// list rank kept-1-r) instead of leaving them to a second kernel -- the re-rank's memory-bound work then
+// runs beside other wavefronts' walks and fills the slots the last "round" of a batch leaves idle.  The
+// walk's LDS is dead by now and stages the original-space query.
+template <typename IdAtRank>
+__device__ __forceinline__ void fused_rerank(const WalkParams& p, uint32_t qi, int kept, unsigned char* smem, int lane,
+                                             IdAtRank id_at_rank) {
+    RerankSrc a{p.rr_q, p.rr_qstride, p.rr_db, p.rr_dstride, p.rr_dim, p.rr_n};
+    wave_sync();  // every lane is done with the walk's LDS
+    const int win = rerank_pairs_core(a, qi, kept, reinterpret_cast<float*>(smem), lane,
+                                      [&](int r) { return id_at_rank(kept - 1 - r); });
+    const uint32_t ans = id_at_rank(win >= 0 ? kept - 1 - win : 0);
+    if (lane == 0) p.rr_out[qi] = win >= 0 ? ans : kInvalidId;
+}
+
+// ------------------------------------------------------------------------------------------
 // sorted result list (search_function.h:50 topResults) -- ascending u64 keys, capacity ef
 // ------------------------------------------------------------------------------------------
 
@@ -966,6 +1066,18 @@ __device__ __forceinline__ void reg_write_results(const WalkParams& p, uint32_t 
     }
 }
 
+// the id of list rank `rank` (per-lane rank; all lanes call)
+template <int R>
+__device__ __forceinline__ uint32_t reg_id_at_rank(const RegList<R>& L, int rank) {
+    uint32_t v = (uint32_t)__shfl((int)(L.lo[0] >> 1), rank & 63);
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+        const uint32_t t = (uint32_t)__shfl((int)(L.lo[r] >> 1), rank & 63);
+        if ((rank >> 6) == r) v = t;
+    }
+    return v;
+}
+
 template <int METRIC, int STEPS, bool OFF32, int R, bool ONE_CHUNK = false>
 __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                              uint32_t* ovf_count, uint32_t* ovf_list) {
@@ -1266,6 +1378,10 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         return;
     }
     reg_write_results<R>(p, qi, L, size, hops, dist_calc, edges, lane);
+    if (p.rr_db) {
+        const int kept = size < p.k ? size : p.k;
+        fused_rerank(p, qi, kept, smem, lane, [&](int rank) { return reg_id_at_rank<R>(L, rank); });
+    }
 }
 
 // ---- hot instance: L2, 128-byte rows, ef <= 64, adjacency rows of <= 32 slots, 32-bit offsets ---------
@@ -1597,6 +1713,10 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
         return;
     }
     reg_write_results<1>(p, qi, L, size, hops, dist_calc, edges, lane);
+    if (p.rr_db) {
+        const int kept = size < p.k ? size : p.k;
+        fused_rerank(p, qi, kept, smem, lane, [&](int rank) { return reg_id_at_rank<1>(L, rank); });
+    }
 }
 
 __global__ __launch_bounds__(64) void walk_hot_kernel(WalkParams p) {
@@ -1730,6 +1850,10 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
             st.hops += 1;
         }
         write_results(p, qi, keys, st, lane);
+        if (p.rr_db) {
+            const int kept = st.size < p.k ? st.size : p.k;
+            fused_rerank(p, qi, kept, smem, lane, [&](int rank) { return key_id(keys[rank]); });
+        }
         wave_sync();
     }
 }
@@ -1772,79 +1896,15 @@ __global__ __launch_bounds__(64) void rerank_kernel(RerankParams p) {
     if (lane == 0) p.out[qi] = (cnt > 0) ? cand[(uint32_t)(bestk & 0xFFFFFFFFu)] : kInvalidId;
 }
 
-// Pair form for the L2 metric (dim % 8 == 0): lanes 2i / 2i+1 share candidate i's row and take its even /
-// odd 16-byte steps, so the two lanes of a pair read 32 contiguous bytes per load.  The re-rank was bound
-// by the CU's vector-memory path (one cache-line access per 16-B load when a lane streams a row alone,
-// DESIGN.md section 5.1); pairs cost that path 1.4x less.  The running sums hop between the two lanes
-// once per step (DPP quad_perm 1,0,3,2): step 2k is added in the even lane on top of the odd lane's
-// sums, step 2k+1 in the odd lane on top of the even lane's -- the reference's order 0, 1, 2, ...
-__device__ __forceinline__ float dpp_swap_pair(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));
-}
-
 __global__ __launch_bounds__(64) void rerank_pair_kernel(RerankParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
-    const uint32_t half = (uint32_t)lane & 1u, slot = (uint32_t)lane >> 1;
     const uint32_t qi = blockIdx.x;
-    float* qf = reinterpret_cast<float*>(smem);
-    const float4* qs = reinterpret_cast<const float4*>(qf);
-    for (uint32_t i = lane; i < p.dstride; i += 64)
-        qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
-    wave_sync();
     const int cnt = p.count[qi];
     const uint32_t* cand = p.cand + (size_t)qi * p.cand_stride;
-    const uint32_t pairs = p.dim >> 3;  // steps / 2
-    uint64_t bestk = ~0ull;
-    for (int base = 0; base < cnt; base += 32) {
-        const int r = base + (int)slot;
-        const bool valid = r < cnt;
-        uint32_t id = cand[valid ? r : base];  // lanes beyond the list redo the first row (discarded)
-        id = id < p.n ? id : 0u;               // (never dereference an id outside the table)
-        const float4* row = reinterpret_cast<const float4*>(p.db + (size_t)id * p.dstride) + half;
-        const float4* qh = qs + half;
-        float u0, u1, u2, u3, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        uint32_t k = 0;
-        for (; k + 4 <= pairs; k += 4) {
-            float4 rv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rv[j] = row[2 * (k + j)];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 qv = qh[2 * (k + j)];
-                float e;
-                e = rv[j].x - qv.x; const float p0 = e * e;
-                e = rv[j].y - qv.y; const float p1 = e * e;
-                e = rv[j].z - qv.z; const float p2 = e * e;
-                e = rv[j].w - qv.w; const float p3 = e * e;
-                u0 = dpp_swap_pair(v0) + p0; u1 = dpp_swap_pair(v1) + p1; u2 = dpp_swap_pair(v2) + p2; u3 = dpp_swap_pair(v3) + p3;
-                v0 = dpp_swap_pair(u0) + p0; v1 = dpp_swap_pair(u1) + p1; v2 = dpp_swap_pair(u2) + p2; v3 = dpp_swap_pair(u3) + p3;
-            }
-        }
-        for (; k < pairs; ++k) {
-            const float4 rv = row[2 * k];
-            const float4 qv = qh[2 * k];
-            float e;
-            e = rv.x - qv.x; const float p0 = e * e;
-            e = rv.y - qv.y; const float p1 = e * e;
-            e = rv.z - qv.z; const float p2 = e * e;
-            e = rv.w - qv.w; const float p3 = e * e;
-            u0 = dpp_swap_pair(v0) + p0; u1 = dpp_swap_pair(v1) + p1; u2 = dpp_swap_pair(v2) + p2; u3 = dpp_swap_pair(v3) + p3;
-            v0 = dpp_swap_pair(u0) + p0; v1 = dpp_swap_pair(u1) + p1; v2 = dpp_swap_pair(u2) + p2; v3 = dpp_swap_pair(u3) + p3;
-        }
-        // the odd lane's v holds all steps: in the even lane `u` is the valid one, in the odd lane `v`
-        const float dv = ((v0 + v1) + v2) + v3;
-        if (valid && half) {
-            const uint64_t kv = ((uint64_t)fkey(dv) << 32) | (uint32_t)r;
-            bestk = kv < bestk ? kv : bestk;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint64_t o = shfl_u64(bestk, lane ^ off);
-        bestk = o < bestk ? o : bestk;
-    }
-    if (lane == 0) p.out[qi] = (cnt > 0) ? cand[(uint32_t)(bestk & 0xFFFFFFFFu)] : kInvalidId;
+    RerankSrc a{p.q, p.qstride, p.db, p.dstride, p.dim, p.n};
+    const int win = rerank_pairs_core(a, qi, cnt, reinterpret_cast<float*>(smem), lane, [&](int r) { return cand[r]; });
+    if (lane == 0) p.out[qi] = (win >= 0) ? cand[win] : kInvalidId;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2454,7 +2514,7 @@ hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s) { r
 
 hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
-    const size_t lds = (size_t)p.dstride * 4;
+    const size_t lds = std::max((size_t)p.dstride * 4, p.rr_db ? (size_t)p.rr_dstride * 4 : (size_t)0);
     if (metric == 1) {
         hipError_t e = set_lds(walk_general_kernel<1>, lds);
         if (e != hipSuccess) return e;

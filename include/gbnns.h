@@ -111,6 +111,11 @@ typedef struct {
  * number of changed answers.  Without this flag results are bit-identical to the reference. */
 #define GBNNS_FLAG_MFMA_PROJECT 1u
 
+/* Diagnostic: keep the re-rank (getRealNearest, search_function.h:105-125) in its own kernel launch even
+ * where the walk kernels could re-rank each query at the end of its walk.  Results are identical either
+ * way; the flag exists for A/B measurements and for timing the two stages separately. */
+#define GBNNS_FLAG_NO_FUSED_RERANK 2u
+
 /* Replaces the timed query loop of performNetTest (search_function.h:346-387) / performTest
  * (:151-188): one call = the whole batch.  With HOST buffers the call copies in, runs and
  * copies out synchronously (what the drop-in harness times).  With DEVICE buffers everything is
