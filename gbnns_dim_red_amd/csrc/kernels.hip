@@ -290,6 +290,22 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
         const float4* qh = qs + half;
         float u0, u1, u2, u3, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
         uint32_t k = 0;
+        for (; k + 8 <= pairs; k += 8) {  // eight 16-B loads in flight per lane
+            float4 rv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rv[j] = row[2 * (k + j)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 qv = qh[2 * (k + j)];
+                float e;
+                e = rv[j].x - qv.x; const float p0 = e * e;
+                e = rv[j].y - qv.y; const float p1 = e * e;
+                e = rv[j].z - qv.z; const float p2 = e * e;
+                e = rv[j].w - qv.w; const float p3 = e * e;
+                u0 = dpp_swap_pair(v0) + p0; u1 = dpp_swap_pair(v1) + p1; u2 = dpp_swap_pair(v2) + p2; u3 = dpp_swap_pair(v3) + p3;
+                v0 = dpp_swap_pair(u0) + p0; v1 = dpp_swap_pair(u1) + p1; v2 = dpp_swap_pair(u2) + p2; v3 = dpp_swap_pair(u3) + p3;
+            }
+        }
         for (; k + 4 <= pairs; k += 4) {
             float4 rv[4];
 #pragma unroll
