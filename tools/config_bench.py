@@ -39,7 +39,7 @@ for name in a.configs:
         k = {x: round(p[x + "_ms"] / p["calls"], 4) for x in ("project", "walk", "walk_general", "rerank")}
         rr_bytes = ds.nq * ef * 4.0 * ds.d
         print(json.dumps(dict(config=name, ef=ef, recall=round(rec, 4), qps=round(ds.nq / dt), ms=round(dt * 1e3, 3),
-                              kernels_ms=k, rerank_GBps=round(rr_bytes / (k["rerank"] * 1e-3) / 1e9, 1),
+                              kernels_ms=k, rerank_GBps=(round(rr_bytes / (k["rerank"] * 1e-3) / 1e9, 1) if k["rerank"] > 0.02 else None),
                               hops=round(r["hops"].float().mean().item(), 1),
                               dist_calc=round(r["dist_calc"].float().mean().item(), 1),
                               general=p["general_queries"])), flush=True)
