@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the diagnostic sections (separate stages, MFMA option, host buffers): profiling runs")
     ap.add_argument("--hash-capacity", type=int, default=0, help="0 = library default (tuning knob)")
     ap.add_argument("--sweep", action="store_true", help="also time every reference ef (stderr)")
     ap.add_argument("--cache-dir", default=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"))
@@ -249,7 +251,7 @@ def main():
     }
 
     # ---- the same step with the re-rank in its own launch (diagnostic flag): per-stage kernel times -------
-    if world == 1 and fused:
+    if world == 1 and fused and not args.no_extras:
         for _ in range(3):
             ix.search(q, ef, want=(), flags=g.FLAG_NO_FUSED_RERANK)
         torch.cuda.synchronize()
@@ -271,7 +273,7 @@ def main():
         }
 
     # ---- opt-in matrix-core projection (not bit-exact): how fast, and how many answers change --------
-    if world == 1:
+    if world == 1 and not args.no_extras:
         for _ in range(3):
             rm = ix.search(q, ef, want=(), flags=g.FLAG_MFMA_PROJECT)
         torch.cuda.synchronize()
@@ -290,7 +292,7 @@ def main():
         }
 
     # ---- PCIe-inclusive rate (host buffers in, ids out: what the C++ drop-in times); never `value`
-    if world == 1:
+    if world == 1 and not args.no_extras:
         qh = q.cpu().numpy()
         ix.search(qh, ef, want=())
         t1 = time.perf_counter()

@@ -9,7 +9,7 @@ TAG=${1:-r00}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export GBNNS_CACHE=/tmp/gbnns_cache
-ARGS="bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+ARGS="bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"
 cd /tmp >/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 python3 $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
