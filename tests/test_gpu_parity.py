@@ -528,6 +528,22 @@ def test_randomised_rows128(g, orc):
         ix.close()
 
 
+def test_fused_and_separate_rerank_agree(g, orc):
+    """Walk kernels that re-rank their own query (the default where the pair form applies) against the
+    re-rank in its own launch (GBNNS_FLAG_NO_FUSED_RERANK) and against the oracle: identical answers, also
+    when a tiny visited set pushes queries through the retry pass / general kernel."""
+    c, off, nbr, db_low, ent = _oracle_case(orc, 881, 15000, 500, 64, 32, 48)
+    ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+    for ef, cap in ((1, 0), (16, 0), (64, 0), (64, 128), (100, 0), (200, 256)):
+        s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net,
+                             entries=ent, threads=8)
+        fused = ix.search(c.queries, ef, entry_ids=ent, want=(), hash_capacity=cap)
+        apart = ix.search(c.queries, ef, entry_ids=ent, want=(), hash_capacity=cap, flags=g.FLAG_NO_FUSED_RERANK)
+        assert np.array_equal(fused["ids"], s["ids"]), (ef, cap)
+        assert np.array_equal(apart["ids"], s["ids"]), (ef, cap)
+    ix.close()
+
+
 def test_mfma_projection_option(g, orc):
     """The opt-in matrix-core projection is a throughput variant, not part of the bit-exact
     contract: its projected queries must agree with the exact path to f32 rounding (tolerance
