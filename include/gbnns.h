@@ -148,7 +148,7 @@ typedef struct {
     double project_ms;            /* MLP layers + normalise */
     double walk_ms;               /* LDS-resident beam-walk kernel */
     double walk_general_ms;       /* exact general-case kernel (queries the LDS kernel handed over) */
-    double rerank_ms;             /* original-space re-rank kernel */
+    double rerank_ms;             /* original-space re-rank kernel (~0 when the walk kernels re-rank: then it is part of walk_ms) */
     double total_ms;              /* first launch .. last launch of each call */
     uint64_t queries;             /* queries processed */
     uint64_t general_queries;     /* of which were (re)run by the general kernel */
