@@ -711,13 +711,13 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.hash_limit = cap - cap / 16;
     w.all_general = walk_fast_lds_bytes(w, hot) > kMaxLds ? 1 : 0;
     // Fused re-rank: with a register-list first pass (ef <= 256; and its retry / general successors) every
-    // wavefront re-ranks its own query when its walk ends; no re-rank launch.  Needs the pair form (L2,
-    // d % 8 == 0) and room for the original-space query in the walk kernels' LDS.
-    const bool fuse = ef <= 256 && !plain && !w.all_general && ix->metric == GBNNS_METRIC_L2 && ix->d % 8 == 0 &&
+    // wavefront re-ranks its own query when its walk ends; no re-rank launch.  Needs the pair form
+    // (d % 8 == 0) and room for the original-space query in the walk kernels' LDS.
+    const bool fuse = ef <= 256 && !plain && !w.all_general && ix->d % 8 == 0 &&
                       (size_t)ix->d_pad * 4 <= walk_fast_lds_bytes(w, hot) && !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
     if (fuse) {
         w.rr_q = q_dev; w.rr_qstride = ix->d; w.rr_db = ix->db; w.rr_dstride = ix->d_pad; w.rr_dim = ix->d;
-        w.rr_n = (uint32_t)ix->n; w.rr_out = out_dev;
+        w.rr_n = (uint32_t)ix->n; w.rr_out = out_dev; w.rr_metric = ix->metric;
     }
 
     if (!w.all_general) {

@@ -56,11 +56,12 @@ struct WalkParams {
     uint32_t bitmap_words;
     int32_t all_general;     // 1: the general kernel takes every query (fast kernel skipped)
     // fused re-rank (rr_db != nullptr): every walk kernel re-ranks its own query at the end of the walk
-    // (L2 metric, rr_dim % 8 == 0, rr_dstride * 4 bytes of LDS available) and writes the answer to rr_out
+    // (pair form: rr_dim % 8 == 0; rr_dstride * 4 bytes of LDS available) and writes the answer to rr_out
     const float* rr_q;       // [nq x rr_qstride] original-space queries
     uint32_t rr_qstride;
     const float* rr_db;      // [n x rr_dstride] original-space vectors
     uint32_t rr_dstride, rr_dim, rr_n;
+    int32_t rr_metric;       // gbnns_metric of the re-rank
     uint32_t* rr_out;        // [nq]
     unsigned long long* stamps;  // diagnostic builds only (GBNNS_STAMPS): [32] segment cycle sums / histograms
     int32_t stamps_on;           // 1 in diagnostic builds: use the instrumented generic kernel

@@ -272,7 +272,15 @@ __device__ __forceinline__ float dpp_swap_pair(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));
 }
 
-template <typename IdAt>
+// Negative-dot form (Angular::Dist, support_func.h:131-163, dim % 8 == 0): the reference keeps 8 running
+// sums (k mod 8); the even lane of a pair owns sums 0..3 (first 16 bytes of every 32-byte step), the odd lane
+// sums 4..7 -- independent chains, folded once at the end: m_j = c_{j+4} + c_j (one DPP add per j, in the
+// even lane), then -((m0 + m1) + (m2 + m3)).
+__device__ __forceinline__ float dpp_from_odd(float x) {  // even lane <- its odd partner (quad_perm 1,1,3,3)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xF5, 0xf, 0xf, false));
+}
+
+template <int METRIC, typename IdAt>
 __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi, int cnt, float* qf, int lane, IdAt id_at) {
     const uint32_t half = (uint32_t)lane & 1u, slot = (uint32_t)lane >> 1;
     const float4* qs = reinterpret_cast<const float4*>(qf);
@@ -288,6 +296,33 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
         id = id < a.n ? id : 0u;                // (never dereference an id outside the table)
         const float4* row = reinterpret_cast<const float4*>(a.db + (size_t)id * a.dstride) + half;
         const float4* qh = qs + half;
+        if constexpr (METRIC == 1) {
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;  // this lane's four of the eight running sums
+            uint32_t k = 0;
+            for (; k + 8 <= pairs; k += 8) {
+                float4 rv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rv[j] = row[2 * (k + j)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 qv = qh[2 * (k + j)];
+                    c0 = c0 + rv[j].x * qv.x; c1 = c1 + rv[j].y * qv.y; c2 = c2 + rv[j].z * qv.z; c3 = c3 + rv[j].w * qv.w;
+                }
+            }
+            for (; k < pairs; ++k) {
+                const float4 rv = row[2 * k];
+                const float4 qv = qh[2 * k];
+                c0 = c0 + rv.x * qv.x; c1 = c1 + rv.y * qv.y; c2 = c2 + rv.z * qv.z; c3 = c3 + rv.w * qv.w;
+            }
+            const float m0 = dpp_from_odd(c0) + c0, m1 = dpp_from_odd(c1) + c1;  // c_{j+4} + c_j, valid in the even lane
+            const float m2 = dpp_from_odd(c2) + c2, m3 = dpp_from_odd(c3) + c3;
+            const float dv = -((m0 + m1) + (m2 + m3));
+            if (valid && !half) {
+                const uint64_t kv = ((uint64_t)fkey(dv) << 32) | (uint32_t)r;
+                bestk = kv < bestk ? kv : bestk;
+            }
+            continue;
+        }
         float u0, u1, u2, u3, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
         uint32_t k = 0;
         for (; k + 8 <= pairs; k += 8) {  // eight 16-B loads in flight per lane
@@ -359,8 +394,11 @@ __device__ __forceinline__ void fused_rerank(const WalkParams& p, uint32_t qi, i
                                              IdAtRank id_at_rank) {
     RerankSrc a{p.rr_q, p.rr_qstride, p.rr_db, p.rr_dstride, p.rr_dim, p.rr_n};
     wave_sync();  // every lane is done with the walk's LDS
-    const int win = rerank_pairs_core(a, qi, kept, reinterpret_cast<float*>(smem), lane,
-                                      [&](int r) { return id_at_rank(kept - 1 - r); });
+    int win;
+    if (p.rr_metric == 1)
+        win = rerank_pairs_core<1>(a, qi, kept, reinterpret_cast<float*>(smem), lane, [&](int r) { return id_at_rank(kept - 1 - r); });
+    else
+        win = rerank_pairs_core<0>(a, qi, kept, reinterpret_cast<float*>(smem), lane, [&](int r) { return id_at_rank(kept - 1 - r); });
     const uint32_t ans = id_at_rank(win >= 0 ? kept - 1 - win : 0);
     if (lane == 0) p.rr_out[qi] = win >= 0 ? ans : kInvalidId;
 }
@@ -1912,6 +1950,7 @@ __global__ __launch_bounds__(64) void rerank_kernel(RerankParams p) {
     if (lane == 0) p.out[qi] = (cnt > 0) ? cand[(uint32_t)(bestk & 0xFFFFFFFFu)] : kInvalidId;
 }
 
+template <int METRIC>
 __global__ __launch_bounds__(64) void rerank_pair_kernel(RerankParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
@@ -1919,7 +1958,7 @@ __global__ __launch_bounds__(64) void rerank_pair_kernel(RerankParams p) {
     const int cnt = p.count[qi];
     const uint32_t* cand = p.cand + (size_t)qi * p.cand_stride;
     RerankSrc a{p.q, p.qstride, p.db, p.dstride, p.dim, p.n};
-    const int win = rerank_pairs_core(a, qi, cnt, reinterpret_cast<float*>(smem), lane, [&](int r) { return cand[r]; });
+    const int win = rerank_pairs_core<METRIC>(a, qi, cnt, reinterpret_cast<float*>(smem), lane, [&](int r) { return cand[r]; });
     if (lane == 0) p.out[qi] = (win >= 0) ? cand[win] : kInvalidId;
 }
 
@@ -2546,16 +2585,24 @@ hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s) {
 hipError_t launch_rerank(const RerankParams& p, int metric, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
     const size_t lds = (size_t)p.dstride * 4;
+    const bool pairs = p.dim % 8 == 0 && p.dim > 0;  // pair form (both metrics)
+    hipError_t e;
     if (metric == 1) {
-        hipError_t e = set_lds(rerank_kernel<1>, lds);
+        if (pairs) {
+            e = set_lds(rerank_pair_kernel<1>, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((rerank_pair_kernel<1>), dim3(p.nq), dim3(64), lds, s, p);
+        } else {
+            e = set_lds(rerank_kernel<1>, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((rerank_kernel<1>), dim3(p.nq), dim3(64), lds, s, p);
+        }
+    } else if (pairs) {
+        e = set_lds(rerank_pair_kernel<0>, lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((rerank_kernel<1>), dim3(p.nq), dim3(64), lds, s, p);
-    } else if (p.dim % 8 == 0 && p.dim > 0) {
-        hipError_t e = set_lds(rerank_pair_kernel, lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(rerank_pair_kernel, dim3(p.nq), dim3(64), lds, s, p);
+        hipLaunchKernelGGL((rerank_pair_kernel<0>), dim3(p.nq), dim3(64), lds, s, p);
     } else {
-        hipError_t e = set_lds(rerank_kernel<0>, lds);
+        e = set_lds(rerank_kernel<0>, lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((rerank_kernel<0>), dim3(p.nq), dim3(64), lds, s, p);
     }

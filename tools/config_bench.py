@@ -15,6 +15,7 @@ CONFIGS = {
 ap = argparse.ArgumentParser()
 ap.add_argument("configs", nargs="*", default=["gist", "glove"])
 ap.add_argument("--scale", type=float, default=1.0, help="scale n (and nq for deep) down for a quick look")
+ap.add_argument("--negdot", action="store_true", help="walk / re-rank with the negative-dot metric (Angular::Dist)")
 a = ap.parse_args()
 for name in a.configs:
     c = dict(CONFIGS[name])
@@ -22,7 +23,11 @@ for name in a.configs:
     c["n"] = int(c["n"] * a.scale)
     t0 = time.time()
     ds = synth.make_dataset(device="cuda:0", cache_dir=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"), **c)
-    ix = ds.index()
+    if a.negdot:
+        from gbnns_dim_red_amd import binding
+        ix = ds.index(metric=binding.METRIC_NEG_DOT)
+    else:
+        ix = ds.index()
     print(f"== {name}: n={ds.n} nq={ds.nq} {ds.d}->{ds.d_low} (h {ds.d_hidden}) built in {time.time()-t0:.1f}s", flush=True)
     for ef in efs:
         for _ in range(3):
