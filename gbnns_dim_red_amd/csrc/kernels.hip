@@ -845,6 +845,33 @@ __device__ __forceinline__ float l2_pair_from_regs(const RowRegs<4>& r, QP qh) {
 #undef GBNNS_P_MUL
 #undef GBNNS_P_ACC
 
+// Pair form of Angular::Dist for 128-byte rows (support_func.h:131-163, dim = 32: four steps of eight): the
+// lanes 2i / 2i+1 hold the EVEN / ODD 16-byte pieces of row i, i.e. the even lane owns the running sums 0..3
+// and the odd lane the sums 4..7 of every step -- independent chains.  The fold m_j = c_{j+4} + c_j happens in
+// the odd lane (its own sums + the even lane's through DPP quad_perm 0,0,2,2), then -((m0 + m1) + (m2 + m3)):
+// the reference's operations in the reference's order; the odd lane holds the distance.
+__device__ __forceinline__ float dpp_from_even(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xA0, 0xf, 0xf, false));
+}
+template <typename QP>
+__device__ __forceinline__ float dot_pair_from_regs(const RowRegs<4>& r, QP qh) {
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        c0 = c0 + r.v[t].x * qh[t].x; c1 = c1 + r.v[t].y * qh[t].y;
+        c2 = c2 + r.v[t].z * qh[t].z; c3 = c3 + r.v[t].w * qh[t].w;
+    }
+    const float m0 = c0 + dpp_from_even(c0), m1 = c1 + dpp_from_even(c1);
+    const float m2 = c2 + dpp_from_even(c2), m3 = c3 + dpp_from_even(c3);
+    return -((m0 + m1) + (m2 + m3));
+}
+// four 16-B loads at a stride of 32 bytes (the even or the odd pieces of a 128-byte row)
+__device__ __forceinline__ void load_row_alt(RowRegs<4>& r, const float* row) {
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) r.v[t] = r4[2 * t];
+}
+
 // Row address.  OFF32: every byte offset into the table fits 32 bits, so the load can use the
 // "scalar base + 32-bit lane offset" form (one address VGPR instead of two, no 64-bit multiply).
 template <bool OFF32>
@@ -1141,9 +1168,10 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     unsigned int hist[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0..7] survivors per hop (0,1,2,3,4,5-8,9-16,17+), [8] merges, [9] merge fallbacks, [10] sequential offers, [11] fast selects
     STAMP(t_begin)
 #endif
-    constexpr bool kEarlyLoad = (METRIC == 0 && STEPS > 0);  // speculative row loads
+    constexpr bool kEarlyLoad = (STEPS > 0);  // speculative row loads (METRIC 1 is instantiated with STEPS 0 or 8 only)
     // 128-byte rows: two lanes per neighbour (lane = 2 * slot + half), 32 adjacency slots per pass
-    constexpr bool kPair = (METRIC == 0 && STEPS == 8);
+    constexpr bool kPair = (STEPS == 8);
+    constexpr bool kAlt = (kPair && METRIC == 1);            // dot metric: even / odd 16-B pieces instead of halves
     constexpr int kQSteps = kPair ? 4 : STEPS;               // 16-B steps of the row one lane holds
     constexpr uint32_t kChunk = kPair ? 32u : 64u;           // adjacency slots per pass
     constexpr uint64_t kSlotLanes = kPair ? 0x5555555555555555ull : ~0ull;  // lanes that own a slot
@@ -1169,7 +1197,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     RowRegs<kQSteps> qreg;
     if constexpr (kEarlyLoad) {
 #pragma unroll
-        for (int t = 0; t < kQSteps; ++t) qreg.v[t] = qs[kQSteps * half + t];
+        for (int t = 0; t < kQSteps; ++t) qreg.v[t] = kAlt ? qs[2 * t + half] : qs[kQSteps * half + t];
     }
 
     RegList<R> L;  // this lane's R list entries
@@ -1336,10 +1364,14 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             uint32_t roff = 0;  // row byte offset, kept live past the loads (see below)
             if constexpr (kEarlyLoad) {
                 if constexpr (OFF32) {
-                    roff = kPair ? (nb << 7) + half * 64u : nb * (p.dstride * 4u);  // kPair: rows are 128 B
-                    if (valid) load_row<kQSteps>(rr, reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff));
+                    roff = kPair ? (nb << 7) + half * (kAlt ? 16u : 64u) : nb * (p.dstride * 4u);  // kPair: rows are 128 B
+                    const float* rp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff);
+                    if constexpr (kAlt) { if (valid) load_row_alt(rr, rp); }
+                    else { if (valid) load_row<kQSteps>(rr, rp); }
                 } else {
-                    if (valid) load_row<kQSteps>(rr, row_ptr<OFF32>(p.db, nb, p.dstride) + half * 16u);
+                    const float* rp = row_ptr<OFF32>(p.db, nb, p.dstride) + half * (kAlt ? 4u : 16u);
+                    if constexpr (kAlt) { if (valid) load_row_alt(rr, rp); }
+                    else { if (valid) load_row<kQSteps>(rr, rp); }
                 }
             }
             // pair form: the even lane of a pair tests / claims the id, the odd lane ends up with the distance
@@ -1350,7 +1382,10 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             STAMP_ADD(3, t3, t4)
             uint32_t dk = 0xFFFFFFFFu;
             if constexpr (kEarlyLoad) {
-                if constexpr (kPair) {
+                if constexpr (kAlt) {
+                    const uint32_t kd = fkey(dot_pair_from_regs(rr, qreg.v));  // all lanes; odd lanes hold distances
+                    dk = fresh ? kd : 0xFFFFFFFFu;
+                } else if constexpr (kPair) {
                     const uint32_t kd = fkey_sumsq(l2_pair_from_regs(rr, qreg.v));  // all lanes; odd lanes hold distances
                     dk = fresh ? kd : 0xFFFFFFFFu;
                 } else if constexpr (STEPS == 8) {
@@ -2527,7 +2562,7 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
             if (!retry && walk_uses_hot(p, METRIC))
                 return launch_walk_k(walk_hot_kernel, p, false, walk_fast_lds_bytes(p, true), s);
         }
-        if (off32 && !retry && p.ell_stride <= ((METRIC == 0 && STEPS == 8) ? 32u : 64u))
+        if (off32 && !retry && p.ell_stride <= (STEPS == 8 ? 32u : 64u))
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
     }
     if (off32)
@@ -2552,7 +2587,10 @@ static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) 
 
 static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
-    if (metric == 1) return launch_fast_t<1, 0>(p, retry, s);
+    if (metric == 1) {
+        if (p.dstride == p.dim && p.dim == 32) return launch_fast_t<1, 8>(p, retry, s);  // 128-byte rows: pair form
+        return launch_fast_t<1, 0>(p, retry, s);
+    }
     if (p.dstride == p.dim) {
         switch (p.dim) {
             case 32: return launch_fast_t<0, 8>(p, retry, s);

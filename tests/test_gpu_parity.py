@@ -501,7 +501,7 @@ def test_randomised_small_cases(g, orc):
 
 
 def test_randomised_rows128(g, orc):
-    """Seeded random configurations with 128-byte walked rows (d_low = 32, L2): the shapes served by the
+    """Seeded random configurations with 128-byte walked rows (d_low = 32; L2 and negative dot): the shapes served by the
     hand-laid-out instance, the pair-gather generic kernels and the 2 / 4-register lists -- ragged degrees up
     to 32 or up to 70 slots, every ef class, random entry points, tie-heavy lattice data every third case,
     tiny visited sets (hand-over chain) every fourth."""
@@ -516,9 +516,10 @@ def test_randomised_rows128(g, orc):
         ent = rng.integers(0, n, size=nq).astype(np.uint32)
         ef = int(rng.choice([1, 2, 7, 31, 64, 65, 100, 128, 129, 200, 256, 300]))
         cap = int(rng.choice([128, 256])) if case % 4 == 3 else 0
-        tag = (case, n, nq, kind, deg_hi, ef, cap)
-        ix = g.Index(c.base, off, nbr)
-        w = orc.walk(c.queries, c.base, off, nbr, ef, entries=ent, threads=8)
+        metric = 1 if case % 5 in (1, 3) else 0  # negative-dot walks use the pair form too (alternating 16-B pieces)
+        tag = (case, n, nq, kind, deg_hi, ef, cap, metric)
+        ix = g.Index(c.base, off, nbr, metric=metric)
+        w = orc.walk(c.queries, c.base, off, nbr, ef, entries=ent, metric=metric, threads=8)
         r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"),
                       hash_capacity=cap)
         assert np.array_equal(r["cand"], w["ids"]), tag
