@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Stress (GPU box, not part of the suite): many seeded random configurations with 128-byte walked rows against
+the oracle -- two-stage NET mode (fused re-rank) and PLAIN walks, both metrics.  usage: stress_rows128.py [seed] [cases]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import gbnns_dim_red_amd as g, oracle, datagen, golden_util as gu
+g.load_library()
+orc = oracle.Oracle()
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+rng = np.random.Generator(np.random.PCG64(seed))
+bad = 0
+for case in range(cases):
+    n = int(rng.integers(200, 8000)); nq = int(rng.integers(4, 100))
+    kind = "lattice" if rng.integers(0, 3) == 0 else "clustered"
+    metric = int(rng.integers(0, 2))
+    net_mode = bool(rng.integers(0, 2))
+    d = int(rng.choice([32, 64, 96, 128])) if net_mode else 32
+    c = datagen.Case("s", 9000 + seed * 1000 + case, n, nq, d, 32 if net_mode else 4, int(rng.choice([16, 40])), kind=kind)
+    deg_hi = int(rng.choice([5, 17, 32, 33, 64, 70]))
+    off, nbr = datagen.random_graph(rng, n, 0, min(deg_hi, n - 1))
+    ent = rng.integers(0, n, size=nq).astype(np.uint32)
+    ef = int(rng.choice([1, 3, 16, 40, 64, 65, 90, 128, 130, 256, 257]))
+    cap = int(rng.choice([0, 0, 0, 128, 512]))
+    tag = (case, n, nq, kind, metric, net_mode, d, deg_hi, ef, cap)
+    try:
+        if net_mode:
+            db_low = orc.project(c.net, c.base)
+            if not np.isfinite(db_low).all():
+                continue
+            ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net, metric=metric)
+            s = orc.search_batch(oracle.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net, entries=ent, metric=metric)
+            if not np.isfinite(orc.project(c.net, c.queries)).all():
+                ix.close(); continue
+            r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc"), hash_capacity=cap)
+            ok = np.array_equal(r["ids"], s["ids"]) and np.array_equal(r["hops"], s["hops"]) and np.array_equal(r["dist_calc"] + ef, s["dist_calc"])
+        else:
+            ix = g.Index(c.base, off, nbr, metric=metric)
+            w = orc.walk(c.queries, c.base, off, nbr, ef, entries=ent, metric=metric)
+            r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), hash_capacity=cap)
+            ok = (np.array_equal(r["cand"], w["ids"]) and np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"]))
+                  and np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]))
+        ix.close()
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        print("EXC", tag, e)
+    if not ok:
+        bad += 1
+        print("MISMATCH", tag, flush=True)
+print("seed", seed, "cases", cases, "bad", bad)
