@@ -117,6 +117,8 @@ struct gbnns_index {
     int stats_ef = 0;
     uint32_t stats_cap = 0;
     std::map<int, uint32_t> cap_for_ef;
+    std::map<int, int> calm_streak;   // per (ef, mode): consecutive observed batches without hand-over / resize
+    uint32_t stats_tick = 0;
     // which of the two control-word blocks the next call uses, and whether each is known to be zero
     int ctrl_phase = 0;
     bool ctrl_clean[2] = {true, true};
@@ -674,10 +676,16 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         // entries so that the largest walk seen (+ 1/16 margin + one pass of new ids) stays under the
         // 15/16 fill limit
         uint32_t need = (maxdc + maxdc / 16 + 64) / 15 * 16 + 16;
-        (void)ovf;  // max_dc covers the retry / general passes too, so a hand-over needs no extra rule
+        // max_dc covers the retry / general passes too, so a hand-over needs no extra sizing rule
         uint32_t& slot = ix->cap_for_ef[ix->stats_ef];  // stats_ef = ef * 4 + mode
+        const bool grew = need > slot;
         slot = std::max(slot, need);  // never shrinks: batches with one long walk do not make it oscillate
+        // calm = the last observed batch of this (ef, mode) handed nothing over and did not move the size
+        const bool quiet = ovf + ix->h_stats[3] == 0 && !grew;
+        int& streak = ix->calm_streak[ix->stats_ef];
+        streak = quiet ? std::min(streak + 1, 1 << 20) : 0;
     }
+    const int calm = ix->calm_streak.count(ef * 4 + a->mode) ? ix->calm_streak[ef * 4 + a->mode] : 0;
     w.stamps = reinterpret_cast<unsigned long long*>(ctrl_base + 8);  // words 8..71, diagnostic builds
 #ifdef GBNNS_STAMPS
     w.stamps_on = 1;
@@ -720,6 +728,14 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         w.rr_n = (uint32_t)ix->n; w.rr_out = out_dev; w.rr_metric = ix->metric;
     }
 
+    // Once batches of this (ef, mode) have been calm (no hand-over, size settled), the retry launch is left
+    // out: the first pass then appends what it cannot finish to list B directly and the general kernel --
+    // always launched -- takes it.  Still exact; a surprise hand-over is just slower once, and un-calms.
+    const bool skip_retry = auto_cap && calm >= 2 && !w.all_general;
+    if (skip_retry) {
+        w.ovf_count = w.ovf2_count;
+        w.ovf_list = w.ovf2_list;
+    }
     if (!w.all_general) {
         HIP_TRY(launch_walk_fast(w, ix->metric, s));
         // retry pass: hand-overs of the first pass, one wavefront per CU with all the LDS
@@ -727,7 +743,9 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         const size_t gran = 512;
         w2.hash_cap = (uint32_t)((kMaxLds / gran * gran - walk_fast_lds_fixed_bytes(ef, w.dstride, false)) / 4) & ~3u;
         w2.hash_limit = w2.hash_cap - w2.hash_cap / 16;
-        if (w2.hash_cap > cap) {
+        if (skip_retry) {
+            // nothing to launch
+        } else if (w2.hash_cap > cap) {
             HIP_TRY(launch_walk_retry(w2, ix->metric, s));
         } else {
             HIP_TRY(hipMemcpyAsync(ctrl + 3, ctrl, 4, hipMemcpyDeviceToDevice, s));  // nothing to gain: A -> B
@@ -738,7 +756,10 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     HIP_TRY(launch_walk_general(w, ix->metric, s));
     ix->ctrl_clean[cur ^ 1] = true;  // cleared by that launch
     if (prof) HIP_TRY(hipEventRecord(pc.ev[3], s));
-    if (auto_cap && !w.all_general && !ix->stats_pending) {
+    // statistics of this call (hand-over counts, largest walk), read back asynchronously: every call until
+    // things are calm, every 16th afterwards (each read is a small copy on the stream)
+    ix->stats_tick += 1;
+    if (auto_cap && !w.all_general && !ix->stats_pending && (calm < 4 || (ix->stats_tick & 15u) == 0)) {
         if (!ix->h_stats) {
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ix->h_stats), 16, hipHostMallocDefault));
             HIP_TRY(hipEventCreateWithFlags(&ix->stats_ev, hipEventDisableTiming));

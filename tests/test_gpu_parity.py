@@ -545,6 +545,41 @@ def test_fused_and_separate_rerank_agree(g, orc):
     ix.close()
 
 
+def test_calm_batches_then_surprise(g, orc):
+    """After a few calm batches (no hand-over, visited-set size settled) the library leaves the retry launch
+    out and reads its statistics only now and then.  A later batch whose walks are several times longer than
+    anything seen (a denser part of the graph) must still come out exact: the first pass hands those queries
+    straight to the general kernel."""
+    rng = np.random.Generator(np.random.PCG64(4242))
+    n_a, n_b, nq = 6000, 6000, 64
+    c = datagen.Case("calm", 4243, n_a + n_b, 2 * nq, 32, 4, 8)
+    off_a, nbr_a = datagen.random_graph(rng, n_a, 2, 4)     # sparse part: short walks
+    off_b, nbr_b = datagen.random_graph(rng, n_b, 26, 32)   # dense part: long walks, no edges between the parts
+    off = np.concatenate([off_a, off_b[1:] + off_a[-1]]).astype(np.uint64)
+    nbr = np.concatenate([nbr_a, nbr_b + np.uint32(n_a)]).astype(np.uint32)
+    ix = g.Index(c.base, off, nbr)
+    q_a, q_b = c.queries[:nq], c.queries[nq:]
+    ent_a = rng.integers(0, n_a, size=nq).astype(np.uint32)
+    ent_b = (n_a + rng.integers(0, n_b, size=nq)).astype(np.uint32)
+    w_a = orc.walk(q_a, c.base, off, nbr, 64, entries=ent_a, threads=8)
+    w_b = orc.walk(q_b, c.base, off, nbr, 64, entries=ent_b, threads=8)
+    assert w_b["dist_calc"].max() > 3 * w_a["dist_calc"].max()
+    import torch
+    for _ in range(8):  # calm phase (device buffers: the statistics arrive asynchronously)
+        r = ix.search(torch.from_numpy(q_a).cuda(), 64, mode=g.MODE_PLAIN, k=64,
+                      entry_ids=torch.from_numpy(ent_a.astype(np.int32)).cuda(), want=("hops", "dist_calc", "cand"))
+        torch.cuda.synchronize()
+    assert np.array_equal(r["cand"].cpu().numpy().astype(np.uint32), w_a["ids"])
+    for rep in range(3):  # the surprise, then the same batch again (sizes have adapted by then)
+        r = ix.search(torch.from_numpy(q_b).cuda(), 64, mode=g.MODE_PLAIN, k=64,
+                      entry_ids=torch.from_numpy(ent_b.astype(np.int32)).cuda(), want=("hops", "dist_calc", "cand"))
+        torch.cuda.synchronize()
+        assert np.array_equal(r["cand"].cpu().numpy().astype(np.uint32), w_b["ids"]), rep
+        assert np.array_equal(r["hops"].cpu().numpy(), w_b["hops"]), rep
+        assert np.array_equal(r["dist_calc"].cpu().numpy(), w_b["dist_calc"]), rep
+    ix.close()
+
+
 def test_mfma_projection_option(g, orc):
     """The opt-in matrix-core projection is a throughput variant, not part of the bit-exact
     contract: its projected queries must agree with the exact path to f32 rounding (tolerance
