@@ -291,6 +291,33 @@ def main():
             "note": "f32 MFMA fma-chain rounding; off by default, default path is bit-exact",
         }
 
+    # ---- two batches in flight: two handles over the same resident index, one HIP stream each, used
+    # alternately, so the tail of batch i (a 10 k batch is < 2 "rounds" of resident wavefronts) runs
+    # beside the projection and the first round of batch i+1.  A serving-throughput figure; never `value`
+    # (which keeps one batch at a time on one stream).
+    if world == 1 and not args.no_extras:
+        ix2 = ds.index(device_index=local)
+        handles = (ix, ix2)
+        streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        outs2 = ({}, {})
+        torch.cuda.synchronize()
+        for i in range(12):  # both handles reach their settled sizing
+            handles[i & 1].search(q, ef, want=(), stream=streams[i & 1], out=outs2[i & 1])
+        torch.cuda.synchronize()
+        nrep = 40
+        t1 = time.perf_counter()
+        for i in range(nrep):
+            handles[i & 1].search(q, ef, want=(), stream=streams[i & 1], out=outs2[i & 1])
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        result["two_batches_in_flight"] = {
+            "queries_per_s": round(nrep * args.nq / dt2, 1),
+            "ms_per_batch": round(dt2 * 1e3 / nrep, 4),
+            "answers_identical": bool(((outs2[0]["ids"] == res["ids"]) & (outs2[1]["ids"] == res["ids"])).all().item()),
+            "note": "two index handles (shared resident tensors) on two HIP streams, batches alternate",
+        }
+        ix2.close()
+
     # ---- PCIe-inclusive rate (host buffers in, ids out: what the C++ drop-in times); never `value`
     if world == 1 and not args.no_extras:
         qh = q.cpu().numpy()
