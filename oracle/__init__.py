@@ -92,6 +92,16 @@ class Oracle(_Base):
             "walk", None,
             [_f32p, C.c_uint64, _f32p, C.c_uint64, C.c_int, _u64p, _u32p, C.c_int, C.c_int, _u32p,
              C.c_int, C.c_int, _u32p, _f32p, _i32p, _i32p, _i32p, C.c_int])
+        self._walk_aux = self._fn(
+            "walk_aux", None,
+            [_f32p, C.c_uint64, _f32p, C.c_uint64, C.c_int, _u64p, _u32p, C.c_int, C.c_int, _u32p,
+             C.c_int, C.c_int, _u32p, _f32p, _i32p, _i32p, _i32p, C.c_int, _u64p, _u32p, C.c_int,
+             C.c_uint32])
+        self._search_aux = self._fn(
+            "search_batch_aux", None,
+            [C.c_int, _f32p, _f32p, C.c_uint64, _f32p, _f32p, C.c_uint64, C.c_int, C.c_int,
+             C.c_int, _f32p, _f32p, _f32p, _u64p, _u32p, C.c_int, C.c_int, _u32p, C.c_int, _u32p,
+             _i32p, _i32p, C.c_int, _u64p, _u32p, C.c_int, C.c_uint32])
         self._rerank = self._fn(
             "rerank", None,
             [_f32p, C.c_uint64, C.c_int, _u32p, C.c_int, _i32p, _f32p, C.c_int, _u32p, C.c_int])
@@ -117,9 +127,12 @@ class Oracle(_Base):
                       nq, d, dh, dlow, threads)
         return out
 
-    def walk(self, q, db, off, nbr, ef, k=None, entries=None, metric=L2, threads=1):
-        """Returns dict(ids [nq x min(k,ef)] pop order, dists, count, hops, dist_calc)."""
+    def walk(self, q, db, off, nbr, ef, k=None, entries=None, metric=L2, threads=1, aux=None,
+             llf=False, hops_bound=50):
+        """Returns dict(ids [nq x min(k,ef)] pop order, dists, count, hops, dist_calc).
+        aux = (off, nbr) of an auxiliary graph: the reference's use_second_graph walk."""
         q, db, off, nbr = _f32(q), _f32(db), _u64(off), _u32(nbr)
+        aoff, anbr = (None, None) if aux is None else (_u64(aux[0]), _u32(aux[1]))
         nq, d = q.shape
         n = db.shape[0]
         k = ef if k is None else k
@@ -133,9 +146,10 @@ class Oracle(_Base):
         count = np.empty(nq, np.int32)
         hops = np.empty(nq, np.int32)
         dc = np.empty(nq, np.int32)
-        self._walk(_p(q, _f32p), nq, _p(db, _f32p), n, d, _p(off, _u64p), _p(nbr, _u32p), ef, k,
-                   _p(entries, _u32p), n_entries, metric, _p(ids, _u32p), _p(dists, _f32p),
-                   _p(count, _i32p), _p(hops, _i32p), _p(dc, _i32p), threads)
+        self._walk_aux(_p(q, _f32p), nq, _p(db, _f32p), n, d, _p(off, _u64p), _p(nbr, _u32p), ef, k,
+                       _p(entries, _u32p), n_entries, metric, _p(ids, _u32p), _p(dists, _f32p),
+                       _p(count, _i32p), _p(hops, _i32p), _p(dc, _i32p), threads, _p(aoff, _u64p),
+                       _p(anbr, _u32p), int(llf), hops_bound)
         return dict(ids=ids, dists=dists, count=count, hops=hops, dist_calc=dc)
 
     def rerank(self, q, cand, count, db, metric=L2, threads=1):
@@ -148,8 +162,10 @@ class Oracle(_Base):
         return out
 
     def search_batch(self, mode, queries, db, off, nbr, ef, k=1, db_low=None, net=None,
-                     q_low=None, entries=None, metric=L2, threads=1):
+                     q_low=None, entries=None, metric=L2, threads=1, aux=None, llf=False,
+                     hops_bound=50):
         queries, db, off, nbr = _f32(queries), _f32(db), _u64(off), _u32(nbr)
+        aoff, anbr = (None, None) if aux is None else (_u64(aux[0]), _u32(aux[1]))
         nq, d = queries.shape
         n = db.shape[0]
         dlow = dh = 0
@@ -166,10 +182,11 @@ class Oracle(_Base):
         ids = np.empty(nq, np.uint32)
         hops = np.empty(nq, np.int32)
         dc = np.empty(nq, np.int32)
-        self._search(mode, _p(queries, _f32p), _p(q_low, _f32p), nq, _p(db, _f32p),
-                     _p(db_low, _f32p), n, d, dlow, dh, _p(l1, _f32p), _p(l2, _f32p),
-                     _p(l3, _f32p), _p(off, _u64p), _p(nbr, _u32p), ef, k, _p(entries, _u32p),
-                     metric, _p(ids, _u32p), _p(hops, _i32p), _p(dc, _i32p), threads)
+        self._search_aux(mode, _p(queries, _f32p), _p(q_low, _f32p), nq, _p(db, _f32p),
+                         _p(db_low, _f32p), n, d, dlow, dh, _p(l1, _f32p), _p(l2, _f32p),
+                         _p(l3, _f32p), _p(off, _u64p), _p(nbr, _u32p), ef, k, _p(entries, _u32p),
+                         metric, _p(ids, _u32p), _p(hops, _i32p), _p(dc, _i32p), threads,
+                         _p(aoff, _u64p), _p(anbr, _u32p), int(llf), hops_bound)
         return dict(ids=ids, hops=hops, dist_calc=dc)
 
     def hnswlike_gd(self, koff, knbr, ds, M, metric=L2, reverse=True, threads=0):
@@ -205,6 +222,16 @@ class Ref(_Base):
             [C.c_int, _f32p, _f32p, C.c_uint64, _f32p, _f32p, C.c_uint64, C.c_int, C.c_int,
              C.c_int, _f32p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, _u32p, C.c_int, _u32p,
              _i32p, _i32p, C.c_int])
+        self._walk_aux = self._fn(
+            "walk_aux", None,
+            [_f32p, C.c_uint64, _f32p, C.c_uint64, C.c_int, C.c_void_p, C.c_int, C.c_int, _u32p,
+             C.c_int, C.c_int, _u32p, _f32p, _i32p, _i32p, _i32p, C.c_int, C.c_void_p, C.c_int,
+             C.c_uint32])
+        self._search_aux = self._fn(
+            "search_batch_aux", None,
+            [C.c_int, _f32p, _f32p, C.c_uint64, _f32p, _f32p, C.c_uint64, C.c_int, C.c_int,
+             C.c_int, _f32p, _f32p, _f32p, C.c_void_p, C.c_int, C.c_int, _u32p, C.c_int, _u32p,
+             _i32p, _i32p, C.c_int, C.c_void_p, C.c_int, C.c_uint32])
         self._prepare = self._fn("prepare_db_cache", None, [_f32p, C.c_uint64, C.c_int])
         self._gd = self._fn("hnswlike_gd", C.c_uint64,
                             [_u64p, _u32p, _f32p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int,
@@ -244,9 +271,11 @@ class Ref(_Base):
                       nq, d, dh, dlow)
         return out
 
-    def walk(self, q, db, off, nbr, ef, k=None, entries=None, metric=L2, threads=1):
+    def walk(self, q, db, off, nbr, ef, k=None, entries=None, metric=L2, threads=1, aux=None,
+             llf=False, hops_bound=50):
         q, db = _f32(q), _f32(db)
         g = self._graph(off, nbr)
+        ga = None if aux is None else self._graph(aux[0], aux[1])
         nq, d = q.shape
         n = db.shape[0]
         k = ef if k is None else k
@@ -260,9 +289,9 @@ class Ref(_Base):
         count = np.empty(nq, np.int32)
         hops = np.empty(nq, np.int32)
         dc = np.empty(nq, np.int32)
-        self._walk(_p(q, _f32p), nq, _p(db, _f32p), n, d, g, ef, k, _p(entries, _u32p), n_entries,
-                   metric, _p(ids, _u32p), _p(dists, _f32p), _p(count, _i32p), _p(hops, _i32p),
-                   _p(dc, _i32p), threads)
+        self._walk_aux(_p(q, _f32p), nq, _p(db, _f32p), n, d, g, ef, k, _p(entries, _u32p), n_entries,
+                       metric, _p(ids, _u32p), _p(dists, _f32p), _p(count, _i32p), _p(hops, _i32p),
+                       _p(dc, _i32p), threads, ga, int(llf), hops_bound)
         return dict(ids=ids, dists=dists, count=count, hops=hops, dist_calc=dc)
 
     def prepare(self, db):
@@ -270,9 +299,11 @@ class Ref(_Base):
         self._prepare(_p(db, _f32p), db.shape[0], db.shape[1])
 
     def search_batch(self, mode, queries, db, off, nbr, ef, k=1, db_low=None, net=None,
-                     q_low=None, entries=None, metric=L2, threads=1):
+                     q_low=None, entries=None, metric=L2, threads=1, aux=None, llf=False,
+                     hops_bound=50):
         queries, db = _f32(queries), _f32(db)
         g = self._graph(off, nbr)
+        ga = None if aux is None else self._graph(aux[0], aux[1])
         nq, d = queries.shape
         n = db.shape[0]
         dlow = dh = 0
@@ -289,10 +320,10 @@ class Ref(_Base):
         ids = np.empty(nq, np.uint32)
         hops = np.empty(nq, np.int32)
         dc = np.empty(nq, np.int32)
-        self._search(mode, _p(queries, _f32p), _p(q_low, _f32p), nq, _p(db, _f32p),
+        self._search_aux(mode, _p(queries, _f32p), _p(q_low, _f32p), nq, _p(db, _f32p),
                      _p(db_low, _f32p), n, d, dlow, dh, _p(l1, _f32p), _p(l2, _f32p),
                      _p(l3, _f32p), g, ef, k, _p(entries, _u32p), metric, _p(ids, _u32p),
-                     _p(hops, _i32p), _p(dc, _i32p), threads)
+                     _p(hops, _i32p), _p(dc, _i32p), threads, ga, int(llf), hops_bound)
         return dict(ids=ids, hops=hops, dist_calc=dc)
 
     def hnswlike_gd(self, koff, knbr, ds, M, metric=L2, reverse=True, threads=0):

@@ -158,9 +158,21 @@ struct WalkOut {
 //    order (:23-39): skip visited, else mark, distance, dist_calc++, insert when
 //    worst.dist > dist || size < ef (strict, distance only), evict the largest pair if size > ef;
 //  - afterwards trim to k (:96-98).
+//
+// Auxiliary graph (use_second_graph = true, :73-80; naive_test.cpp:103-105 passes the KL graph with
+// llf = true): while num_hops < hops_bound the node's auxiliary list is expanded first (same makeStep);
+// `found` (makeStep's flag, :34) says whether that step inserted anything; the main list is expanded
+// unless llf && found (:82).  aux_off == NULL restates use_second_graph = false.
+struct AuxGraph {
+    const uint64_t* off = nullptr;
+    const uint32_t* nbr = nullptr;
+    bool llf = false;
+    uint32_t hops_bound = 50;
+};
+
 void walk_one(const float* q, const float* db, size_t n, int d, const uint64_t* off,
               const uint32_t* nbr, int ef, int k, const uint32_t* entries, int n_entries,
-              int metric, Visited& vis, WalkOut& out) {
+              int metric, Visited& vis, WalkOut& out, const AuxGraph& aux = AuxGraph()) {
     out.top = std::priority_queue<Entry>();
     out.dist_calc = 1;
     out.hops = 0;
@@ -177,17 +189,23 @@ void walk_one(const float* q, const float* db, size_t n, int d, const uint64_t* 
             if (-c.first > out.top.top().first) break;
             cand.pop();
             const uint32_t node = (uint32_t)c.second;
-            for (uint64_t j = off[node]; j < off[node + 1]; ++j) {
-                const uint32_t v = nbr[j];
-                if (vis.test_and_set(v)) continue;
-                const float dv = metric_dist(metric, q, db + (size_t)v * d, (size_t)d);
-                out.dist_calc++;
-                if (out.top.top().first > dv || (int)out.top.size() < ef) {
-                    cand.emplace(-dv, (int)v);
-                    out.top.emplace(dv, (int)v);
-                    if ((int)out.top.size() > ef) out.top.pop();
+            bool found = false;
+            auto make_step = [&](const uint64_t* o, const uint32_t* nb) {  // :15-40
+                for (uint64_t j = o[node]; j < o[node + 1]; ++j) {
+                    const uint32_t v = nb[j];
+                    if (vis.test_and_set(v)) continue;
+                    const float dv = metric_dist(metric, q, db + (size_t)v * d, (size_t)d);
+                    out.dist_calc++;
+                    if (out.top.top().first > dv || (int)out.top.size() < ef) {
+                        cand.emplace(-dv, (int)v);
+                        found = true;
+                        out.top.emplace(dv, (int)v);
+                        if ((int)out.top.size() > ef) out.top.pop();
+                    }
                 }
-            }
+            };
+            if (aux.off && (uint32_t)out.hops < aux.hops_bound) make_step(aux.off, aux.nbr);  // :73-80
+            if (!(found && aux.llf) || !aux.off) make_step(off, nbr);                         // :82-89
             out.hops++;
         }
     }
@@ -238,10 +256,14 @@ void gbo_project(const float* l1, const float* l2, const float* l3, const float*
 // Batched getOneSearchResults.  Per query i: entry points entries[i*n_entries ..] (NULL -> 0).
 // out_ids/out_dists (optional, [nq x k_out], k_out = min(k, ef)) receive the trimmed result heap
 // in POP order (worst -> best), padded with 0xFFFFFFFF / +inf; out_count its size.
-void gbo_walk(const float* q, uint64_t nq, const float* db, uint64_t n, int d,
-              const uint64_t* off, const uint32_t* nbr, int ef, int k, const uint32_t* entries,
-              int n_entries, int metric, uint32_t* out_ids, float* out_dists, int32_t* out_count,
-              int32_t* out_hops, int32_t* out_dist_calc, int threads) {
+// aux_off != NULL: the auxiliary-graph walk (see walk_one).
+void gbo_walk_aux(const float* q, uint64_t nq, const float* db, uint64_t n, int d,
+                  const uint64_t* off, const uint32_t* nbr, int ef, int k, const uint32_t* entries,
+                  int n_entries, int metric, uint32_t* out_ids, float* out_dists, int32_t* out_count,
+                  int32_t* out_hops, int32_t* out_dist_calc, int threads, const uint64_t* aux_off,
+                  const uint32_t* aux_nbr, int llf, uint32_t hops_bound) {
+    AuxGraph aux;
+    aux.off = aux_off; aux.nbr = aux_nbr; aux.llf = llf != 0; aux.hops_bound = hops_bound;
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #endif
@@ -255,7 +277,7 @@ void gbo_walk(const float* q, uint64_t nq, const float* db, uint64_t n, int d,
         for (int64_t i = 0; i < (int64_t)nq; ++i) {
             const uint32_t* ep = entries ? entries + (size_t)i * n_entries : &zero;
             walk_one(q + (size_t)i * d, db, (size_t)n, d, off, nbr, ef, k, ep,
-                     entries ? n_entries : 1, metric, vis, w);
+                     entries ? n_entries : 1, metric, vis, w, aux);
             if (out_hops) out_hops[i] = w.hops;
             if (out_dist_calc) out_dist_calc[i] = w.dist_calc;
             int c = 0;
@@ -272,6 +294,14 @@ void gbo_walk(const float* q, uint64_t nq, const float* db, uint64_t n, int d,
             }
         }
     }
+}
+
+void gbo_walk(const float* q, uint64_t nq, const float* db, uint64_t n, int d,
+              const uint64_t* off, const uint32_t* nbr, int ef, int k, const uint32_t* entries,
+              int n_entries, int metric, uint32_t* out_ids, float* out_dists, int32_t* out_count,
+              int32_t* out_hops, int32_t* out_dist_calc, int threads) {
+    gbo_walk_aux(q, nq, db, n, d, off, nbr, ef, k, entries, n_entries, metric, out_ids, out_dists,
+                 out_count, out_hops, out_dist_calc, threads, nullptr, nullptr, 0, 50);
 }
 
 // Batched getRealNearest over candidate lists in pop order ([nq x stride], count[i] valid).
@@ -294,12 +324,15 @@ void gbo_rerank(const float* q, uint64_t nq, int d, const uint32_t* cand, int st
 //         to k (:174-181; also :165-172).
 // hops / dist_calc are per query; for modes 0/1 dist_calc[i] includes the "+ recheck_size" the
 // harness adds (:362 / :164).  threads = 1 reproduces final_test.cpp:71.
-void gbo_search_batch(int mode, const float* queries, const float* q_low_in, uint64_t nq,
-                      const float* db, const float* db_low, uint64_t n, int d, int dlow, int dh,
-                      const float* l1, const float* l2, const float* l3, const uint64_t* off,
-                      const uint32_t* nbr, int ef, int k, const uint32_t* entries, int metric,
-                      uint32_t* out_ids, int32_t* out_hops, int32_t* out_dist_calc,
-                      int threads) {
+void gbo_search_batch_aux(int mode, const float* queries, const float* q_low_in, uint64_t nq,
+                          const float* db, const float* db_low, uint64_t n, int d, int dlow, int dh,
+                          const float* l1, const float* l2, const float* l3, const uint64_t* off,
+                          const uint32_t* nbr, int ef, int k, const uint32_t* entries, int metric,
+                          uint32_t* out_ids, int32_t* out_hops, int32_t* out_dist_calc,
+                          int threads, const uint64_t* aux_off, const uint32_t* aux_nbr, int llf,
+                          uint32_t hops_bound) {
+    AuxGraph aux;
+    aux.off = aux_off; aux.nbr = aux_nbr; aux.llf = llf != 0; aux.hops_bound = hops_bound;
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(threads);
 #endif
@@ -316,7 +349,7 @@ void gbo_search_batch(int mode, const float* queries, const float* q_low_in, uin
             const uint32_t* ep = entries ? entries + i : &zero;
             const float* qi = queries + (size_t)i * d;
             if (mode == 2) {
-                walk_one(qi, db, (size_t)n, d, off, nbr, ef, k, ep, 1, metric, vis, w);
+                walk_one(qi, db, (size_t)n, d, off, nbr, ef, k, ep, 1, metric, vis, w, aux);
                 out_ids[i] = (uint32_t)w.top.top().second;
                 if (out_hops) out_hops[i] = w.hops;
                 if (out_dist_calc) out_dist_calc[i] = w.dist_calc;
@@ -330,7 +363,7 @@ void gbo_search_batch(int mode, const float* queries, const float* q_low_in, uin
             } else {
                 qlow = q_low_in + (size_t)i * dlow;
             }
-            walk_one(qlow, db_low, (size_t)n, dlow, off, nbr, ef, ef, ep, 1, metric, vis, w);
+            walk_one(qlow, db_low, (size_t)n, dlow, off, nbr, ef, ef, ep, 1, metric, vis, w, aux);
             ids.clear();
             while (!w.top.empty()) {
                 ids.push_back((uint32_t)w.top.top().second);
@@ -341,6 +374,17 @@ void gbo_search_batch(int mode, const float* queries, const float* q_low_in, uin
             if (out_dist_calc) out_dist_calc[i] = w.dist_calc + ef;
         }
     }
+}
+
+void gbo_search_batch(int mode, const float* queries, const float* q_low_in, uint64_t nq,
+                      const float* db, const float* db_low, uint64_t n, int d, int dlow, int dh,
+                      const float* l1, const float* l2, const float* l3, const uint64_t* off,
+                      const uint32_t* nbr, int ef, int k, const uint32_t* entries, int metric,
+                      uint32_t* out_ids, int32_t* out_hops, int32_t* out_dist_calc,
+                      int threads) {
+    gbo_search_batch_aux(mode, queries, q_low_in, nq, db, db_low, n, d, dlow, dh, l1, l2, l3, off, nbr,
+                         ef, k, entries, metric, out_ids, out_hops, out_dist_calc, threads, nullptr,
+                         nullptr, 0, 50);
 }
 
 // support_func.h:521-575 hnswlikeGD (need_const_degree=false) + :402-445 addReverseEdgesForGD.

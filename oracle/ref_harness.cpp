@@ -89,11 +89,14 @@ void ref_project(const float* l1, const float* l2, const float* l3, const float*
 }
 
 // getOneSearchResults (search_function.h:43) per query; result heap dumped in pop order.
-void ref_walk(const float* q, uint64_t nq, const float* db, uint64_t n, int d, void* graph,
-              int ef, int k, const uint32_t* entries, int n_entries, int metric,
-              uint32_t* out_ids, float* out_dists, int32_t* out_count, int32_t* out_hops,
-              int32_t* out_dist_calc, int threads) {
+// aux_graph != NULL: use_second_graph = true with that auxiliary graph, llf and hops_bound as given.
+void ref_walk_aux(const float* q, uint64_t nq, const float* db, uint64_t n, int d, void* graph,
+                  int ef, int k, const uint32_t* entries, int n_entries, int metric,
+                  uint32_t* out_ids, float* out_dists, int32_t* out_count, int32_t* out_hops,
+                  int32_t* out_dist_calc, int threads, void* aux_graph, int llf, uint32_t hops_bound) {
     RefGraph* g = (RefGraph*)graph;
+    RefGraph* ga = aux_graph ? (RefGraph*)aux_graph : g;
+    const bool use2 = aux_graph != nullptr;
     VisitedListPool* pool = new VisitedListPool(1, n);
     Metric* m = pick_metric(metric);
     const int stride = k < ef ? k : ef;
@@ -103,8 +106,8 @@ void ref_walk(const float* q, uint64_t nq, const float* db, uint64_t n, int d, v
         vector<uint32_t> ep;
         if (entries) ep.assign(entries + i * n_entries, entries + (i + 1) * n_entries);
         else ep.push_back(0);
-        TripleResult r = getOneSearchResults(q + i * d, db, n, d, g->lists, g->lists, ef, k, ep, m,
-                                             pool, false, false, 50);
+        TripleResult r = getOneSearchResults(q + i * d, db, n, d, g->lists, ga->lists, ef, k, ep, m,
+                                             pool, use2, llf != 0, hops_bound);
         if (out_hops) out_hops[i] = r.hops;
         if (out_dist_calc) out_dist_calc[i] = r.dist_calc;
         int c = 0;
@@ -123,14 +126,25 @@ void ref_walk(const float* q, uint64_t nq, const float* db, uint64_t n, int d, v
     delete pool;
 }
 
+void ref_walk(const float* q, uint64_t nq, const float* db, uint64_t n, int d, void* graph,
+              int ef, int k, const uint32_t* entries, int n_entries, int metric,
+              uint32_t* out_ids, float* out_dists, int32_t* out_count, int32_t* out_hops,
+              int32_t* out_dist_calc, int threads) {
+    ref_walk_aux(q, nq, db, n, d, graph, ef, k, entries, n_entries, metric, out_ids, out_dists,
+                 out_count, out_hops, out_dist_calc, threads, nullptr, 0, 50);
+}
+
 // The per-query body of performNetTest (search_function.h:348-385) / performTest (:153-186)
 // calling the reference's own functions; same modes as gbo_search_batch in gbnns_oracle.cpp.
-void ref_search_batch(int mode, const float* queries, const float* q_low_in, uint64_t nq,
-                      const float* db_ptr, const float* db_low, uint64_t n, int d, int dlow,
-                      int dh, const float* l1, const float* l2, const float* l3, void* graph,
-                      int ef, int k, const uint32_t* entries, int metric, uint32_t* out_ids,
-                      int32_t* out_hops, int32_t* out_dist_calc, int threads) {
+void ref_search_batch_aux(int mode, const float* queries, const float* q_low_in, uint64_t nq,
+                          const float* db_ptr, const float* db_low, uint64_t n, int d, int dlow,
+                          int dh, const float* l1, const float* l2, const float* l3, void* graph,
+                          int ef, int k, const uint32_t* entries, int metric, uint32_t* out_ids,
+                          int32_t* out_hops, int32_t* out_dist_calc, int threads, void* aux_graph,
+                          int llf, uint32_t hops_bound) {
     RefGraph* g = (RefGraph*)graph;
+    RefGraph* ga = aux_graph ? (RefGraph*)aux_graph : g;
+    const bool use2 = aux_graph != nullptr;
     VisitedListPool* pool = new VisitedListPool(1, n);
     Metric* m = pick_metric(metric);
     Net net;
@@ -150,8 +164,8 @@ void ref_search_batch(int mode, const float* queries, const float* q_low_in, uin
         const float* point_q = queries + i * d;
         TripleResult r;
         if (mode == 2) {
-            r = getOneSearchResults(point_q, db_ptr, n, d, g->lists, g->lists, ef, k, ep, m, pool,
-                                    false, false, 50);
+            r = getOneSearchResults(point_q, db_ptr, n, d, g->lists, ga->lists, ef, k, ep, m, pool,
+                                    use2, llf != 0, hops_bound);
             while ((int)r.topk.size() > k) r.topk.pop();
             out_ids[i] = r.topk.top().second;
             if (out_hops) out_hops[i] = r.hops;
@@ -166,13 +180,23 @@ void ref_search_batch(int mode, const float* queries, const float* q_low_in, uin
         } else {
             ql = q_low_in + i * dlow;
         }
-        r = getOneSearchResults(ql, db_low, n, dlow, g->lists, g->lists, ef, ef, ep, m, pool,
-                                false, false, 50);
+        r = getOneSearchResults(ql, db_low, n, dlow, g->lists, ga->lists, ef, ef, ep, m, pool,
+                                use2, llf != 0, hops_bound);
         out_ids[i] = getRealNearest(point_q, k, d, dlow, r.topk, ds_cache, m);
         if (out_hops) out_hops[i] = r.hops;
         if (out_dist_calc) out_dist_calc[i] = r.dist_calc + ef;
     }
     delete pool;
+}
+
+void ref_search_batch(int mode, const float* queries, const float* q_low_in, uint64_t nq,
+                      const float* db_ptr, const float* db_low, uint64_t n, int d, int dlow,
+                      int dh, const float* l1, const float* l2, const float* l3, void* graph,
+                      int ef, int k, const uint32_t* entries, int metric, uint32_t* out_ids,
+                      int32_t* out_hops, int32_t* out_dist_calc, int threads) {
+    ref_search_batch_aux(mode, queries, q_low_in, nq, db_ptr, db_low, n, d, dlow, dh, l1, l2, l3, graph,
+                         ef, k, entries, metric, out_ids, out_hops, out_dist_calc, threads, nullptr, 0,
+                         50);
 }
 
 void ref_prepare_db_cache(const float* db_ptr, uint64_t n, int d) { ensure_ds_cache(db_ptr, n, d); }

@@ -92,6 +92,47 @@ def test_tie_heavy_lattice_walks(orc):
     assert (np.diff(np.sort(d, axis=1), axis=1) == 0).mean() > 0.5
 
 
+def _aux_fixture():
+    import json
+    z = np.load(gu.GOLDEN_DIR + "/aux_toy.npz")
+    return z, json.loads(bytes(z["meta"]).decode())
+
+
+def test_auxiliary_graph_walks(orc):
+    """use_second_graph walks (search_function.h:73-89) against the compiled reference's outputs."""
+    z, meta = _aux_fixture()
+    for name, info in meta["cases"].items():
+        g = gu.load(name)
+        c = g.case
+        off, nbr = g.graph
+        aux = (z[f"{name}_aux_off"], z[f"{name}_aux_nbr"])
+        if name == "ties_toy":
+            q, db = c.queries, c.base
+        else:
+            db = orc.project(c.net, c.base, threads=4)
+            q = orc.project(c.net, c.queries)
+        for ef in info["efs"]:
+            for llf, hb in meta["variants"]:
+                tag = f"{name}_{ef}_{llf}_{hb}"
+                w = orc.walk(q, db, off, nbr, ef, entries=g["entries"], metric=c.metric, aux=aux,
+                             llf=bool(llf), hops_bound=hb, threads=2)
+                assert np.array_equal(w["ids"], z[f"walk_ids_{tag}"]), tag
+                assert np.array_equal(gu.bits(w["dists"]), z[f"walk_dist_bits_{tag}"]), tag
+                assert np.array_equal(w["hops"], z[f"walk_hops_{tag}"]), tag
+                assert np.array_equal(w["dist_calc"], z[f"walk_dc_{tag}"]), tag
+                if name == "sift_toy":
+                    s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db,
+                                         net=c.net, entries=g["entries"], metric=c.metric, aux=aux,
+                                         llf=bool(llf), hops_bound=hb, threads=2)
+                    assert np.array_equal(s["ids"], z[f"net_ans_{tag}"]), tag
+                p = orc.search_batch(orc_mod.MODE_PLAIN, c.queries, c.base, off, nbr, ef, k=1,
+                                     entries=g["entries"], metric=c.metric, aux=aux, llf=bool(llf),
+                                     hops_bound=hb, threads=2)
+                assert np.array_equal(p["ids"], z[f"plain_ans_{tag}"]), tag
+                assert np.array_equal(p["hops"], z[f"plain_hops_{tag}"]), tag
+                assert np.array_equal(p["dist_calc"], z[f"plain_dc_{tag}"]), tag
+
+
 def test_graph_builder_restatement(orc):
     g = gu.load("tail_toy")
     c = g.case
@@ -130,6 +171,14 @@ def test_oracle_vs_ref_random(orc, ref, seed):
                                   db_low=db_low, net=c.net, metric=metric)
             for k in ("ids", "hops", "dist_calc"):
                 assert np.array_equal(sa[k], sb[k])
+    # auxiliary graph (use_second_graph), both llf settings, several hop bounds
+    aux = datagen.random_graph(rng, n, 0, 5)
+    for metric in (0, 1):
+        for ef, llf, hb in ((1, True, 50), (10, True, 2), (10, False, 50), (120, True, 50)):
+            a = orc.walk(q_low, db_low, off, nbr, ef, metric=metric, aux=aux, llf=llf, hops_bound=hb)
+            b = ref.walk(q_low, db_low, off, nbr, ef, metric=metric, aux=aux, llf=llf, hops_bound=hb)
+            for k in ("ids", "count", "hops", "dist_calc"):
+                assert np.array_equal(a[k], b[k]), (metric, ef, llf, hb, k)
     # multi entry points and k < ef
     ent = rng.integers(0, n, size=(nq, 3)).astype(np.uint32)
     a = orc.walk(q_low, db_low, off, nbr, 20, k=7, entries=ent)
