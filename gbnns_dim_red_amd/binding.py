@@ -16,10 +16,12 @@ MEM_HOST, MEM_DEVICE = 0, 1
 MODE_NET, MODE_LOWQ, MODE_PLAIN = 0, 1, 2
 FLAG_MFMA_PROJECT = 1
 FLAG_NO_FUSED_RERANK = 2
+FLAG_AUX_GRAPH = 4
+FLAG_LLF = 8
 
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "gbnns_index_create", "gbnns_index_destroy", "gbnns_search_ex", "gbnns_search_batch",
+    "gbnns_index_create", "gbnns_index_destroy", "gbnns_index_set_aux_graph", "gbnns_search_ex", "gbnns_search_batch",
     "gbnns_project", "gbnns_rerank", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd",
     "gbnns_free", "gbnns_device_count", "gbnns_version", "gbnns_last_error",
 ]
@@ -49,7 +51,7 @@ class _SearchArgs(C.Structure):
         ("out_ids", C.c_void_p), ("out_hops", C.c_void_p), ("out_dist_calc", C.c_void_p),
         ("out_cand", C.c_void_p), ("out_cand_dist", C.c_void_p), ("out_q_low", C.c_void_p),
         ("out_edges", C.c_void_p), ("stream", C.c_void_p), ("flags", C.c_uint32),
-        ("reserved1", C.c_uint32),
+        ("hops_bound", C.c_uint32),
     ]
 
 
@@ -84,6 +86,7 @@ def load_library():
     lib.gbnns_last_error.restype = C.c_char_p
     lib.gbnns_index_create.argtypes = [C.POINTER(_IndexDesc), C.POINTER(C.c_void_p)]
     lib.gbnns_index_destroy.argtypes = [C.c_void_p]
+    lib.gbnns_index_set_aux_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gbnns_search_ex.argtypes = [C.c_void_p, C.POINTER(_SearchArgs)]
     lib.gbnns_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -206,6 +209,17 @@ class Index:
         self.metric = metric
         self.device = device
 
+    def set_aux_graph(self, offsets, nbrs):
+        """The reference's auxiliary_graph (host CSR); None, None removes it."""
+        if offsets is None:
+            _check(self._lib.gbnns_index_set_aux_graph(self._h, None, None))
+            return
+        off = _host(offsets, np.uint64)
+        nbr = _host(nbrs, np.uint32)
+        if off.shape[0] != self.n + 1:
+            raise ValueError("auxiliary graph offsets must have n+1 entries")
+        _check(self._lib.gbnns_index_set_aux_graph(self._h, _ptr(off), _ptr(nbr)))
+
     def close(self):
         if self._h:
             self._lib.gbnns_index_destroy(self._h)
@@ -219,10 +233,14 @@ class Index:
 
     # -- search ------------------------------------------------------------------------------
     def search(self, queries, ef, mode=MODE_NET, k=1, queries_low=None, entry_ids=None,
-               want=("hops", "dist_calc"), hash_capacity=0, stream=None, out=None, flags=0):
+               want=("hops", "dist_calc"), hash_capacity=0, stream=None, out=None, flags=0,
+               aux=False, llf=False, hops_bound=50):
         """Runs one batch.  numpy queries -> synchronous call, numpy results.  torch CUDA queries
         -> enqueued on `stream` (torch stream or None = current), torch results, no sync.
-        `want` may also name "cand", "cand_dist", "q_low", "edges".  Returns a dict with "ids" + wanted."""
+        `want` may also name "cand", "cand_dist", "q_low", "edges".  Returns a dict with "ids" + wanted.
+        aux / llf / hops_bound: the reference's use_second_graph walk over set_aux_graph()'s graph."""
+        if aux:
+            flags |= FLAG_AUX_GRAPH | (FLAG_LLF if llf else 0)
         dev = _is_dev(queries)
         queries = _prep(queries, np.float32, "float32")
         queries_low = _prep(queries_low, np.float32, "float32")
@@ -258,7 +276,8 @@ class Index:
         a = _SearchArgs(struct_size=C.sizeof(_SearchArgs), mode=mode, ef=ef, k=kk,
                         mem_kind=MEM_DEVICE if dev else MEM_HOST, hash_capacity=hash_capacity,
                         n_q=nq, queries=_ptr(queries), queries_low=_ptr(queries_low),
-                        entry_ids=_ptr(entry_ids), out_ids=_ptr(ids), stream=sptr, flags=flags)
+                        entry_ids=_ptr(entry_ids), out_ids=_ptr(ids), stream=sptr, flags=flags,
+                        hops_bound=hops_bound if aux else 0)
         if "hops" in want:
             a.out_hops = _ptr(alloc("hops", (nq,), i32))
         if "dist_calc" in want:

@@ -96,8 +96,9 @@ struct gbnns_index {
     uint32_t d_pad = 0, dl_pad = 0;
     const float* db = nullptr;      // [n x d_pad]
     const float* db_low = nullptr;  // [n x dl_pad]
-    DevBuf db_own, db_low_own, ell, net;
-    uint32_t ell_stride = 0;
+    DevBuf db_own, db_low_own, ell, net, aux_ell;
+    uint32_t ell_stride = 0, aux_stride = 0;
+    bool has_aux = false;
     bool has_net = false;
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     uint32_t ws1 = 0, ws2 = 0, ws3 = 0;
@@ -334,6 +335,22 @@ int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out) {
     return GBNNS_OK;
 }
 
+int gbnns_index_set_aux_graph(gbnns_index* ix, const uint64_t* offsets, const uint32_t* nbrs) {
+    if (!ix) return fail(GBNNS_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipDeviceSynchronize());  // no search may still be reading the old table
+    ix->has_aux = false;
+    if (!offsets && !nbrs) return GBNNS_OK;
+    if (!offsets || !nbrs) return fail(GBNNS_ERR_INVALID, "auxiliary graph: offsets / nbrs missing");
+    std::vector<uint32_t> ell;
+    int rc = build_ell(offsets, nbrs, ix->n, ell, ix->aux_stride);
+    if (rc) return rc;
+    if ((rc = ix->aux_ell.ensure(ell.size() * 4))) return rc;
+    HIP_TRY(hipMemcpy(ix->aux_ell.p, ell.data(), ell.size() * 4, hipMemcpyHostToDevice));
+    ix->has_aux = true;
+    return GBNNS_OK;
+}
+
 int gbnns_index_destroy(gbnns_index* ix) {
     if (!ix) return GBNNS_OK;
     (void)hipSetDevice(ix->device);
@@ -341,7 +358,7 @@ int gbnns_index_destroy(gbnns_index* ix) {
         for (auto& e : pc.ev) (void)hipEventDestroy(e);
     if (ix->stats_ev) (void)hipEventDestroy(ix->stats_ev);
     if (ix->h_stats) (void)hipHostFree(ix->h_stats);
-    DevBuf* bufs[] = {&ix->db_own, &ix->db_low_own, &ix->ell, &ix->net, &ix->q_in, &ix->q_low,
+    DevBuf* bufs[] = {&ix->db_own, &ix->db_low_own, &ix->ell, &ix->aux_ell, &ix->net, &ix->q_in, &ix->q_low,
                       &ix->h1, &ix->h2, &ix->cand, &ix->cand_dist, &ix->cnt, &ix->hops, &ix->dc, &ix->edges,
                       &ix->out, &ix->entries, &ix->ovf_list, &ix->ovf2_list, &ix->ctrl, &ix->g_bitmap, &ix->g_keys,
                       &ix->g_tie};
@@ -553,6 +570,10 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     if (a->mode == GBNNS_MODE_NET && !ix->has_net) return fail(GBNNS_ERR_INVALID, "NET mode needs a net");
     if (a->mode != GBNNS_MODE_PLAIN && !ix->db_low) return fail(GBNNS_ERR_INVALID, "mode needs db_low");
     if (a->mode == GBNNS_MODE_LOWQ && !a->queries_low) return fail(GBNNS_ERR_INVALID, "queries_low missing");
+    if ((a->flags & GBNNS_FLAG_LLF) && !(a->flags & GBNNS_FLAG_AUX_GRAPH))
+        return fail(GBNNS_ERR_INVALID, "GBNNS_FLAG_LLF needs GBNNS_FLAG_AUX_GRAPH");
+    if ((a->flags & GBNNS_FLAG_AUX_GRAPH) && !ix->has_aux)
+        return fail(GBNNS_ERR_INVALID, "GBNNS_FLAG_AUX_GRAPH without gbnns_index_set_aux_graph");
     if (a->hash_capacity != 0 && a->hash_capacity < 128)
         return fail(GBNNS_ERR_INVALID, "hash_capacity must be 0 (auto) or >= 128");
     HIP_TRY(hipSetDevice(ix->device));
@@ -677,7 +698,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         // 15/16 fill limit
         uint32_t need = (maxdc + maxdc / 16 + 64) / 15 * 16 + 16;
         // max_dc covers the retry / general passes too, so a hand-over needs no extra sizing rule
-        uint32_t& slot = ix->cap_for_ef[ix->stats_ef];  // stats_ef = ef * 4 + mode
+        uint32_t& slot = ix->cap_for_ef[ix->stats_ef];  // stats_ef = skey of that call
         const bool grew = need > slot;
         slot = std::max(slot, need);  // never shrinks: batches with one long walk do not make it oscillate
         // calm = the last observed batch of this (ef, mode) handed nothing over and did not move the size
@@ -685,21 +706,27 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         int& streak = ix->calm_streak[ix->stats_ef];
         streak = quiet ? std::min(streak + 1, 1 << 20) : 0;
     }
-    const int calm = ix->calm_streak.count(ef * 4 + a->mode) ? ix->calm_streak[ef * 4 + a->mode] : 0;
+    const bool aux = (a->flags & GBNNS_FLAG_AUX_GRAPH) != 0;
+    const int skey = ef * 8 + a->mode * 2 + (aux ? 1 : 0);  // sizing statistics are kept per (ef, mode, aux)
+    const int calm = ix->calm_streak.count(skey) ? ix->calm_streak[skey] : 0;
+    if (aux) {
+        w.aux_ell = ix->aux_ell.as<uint32_t>(); w.aux_stride = ix->aux_stride;
+        w.hops_bound = a->hops_bound; w.llf = (a->flags & GBNNS_FLAG_LLF) ? 1 : 0;
+    }
     w.stamps = reinterpret_cast<unsigned long long*>(ctrl_base + 8);  // words 8..71, diagnostic builds
 #ifdef GBNNS_STAMPS
     w.stamps_on = 1;
 #endif
     const bool hot = walk_uses_hot(w, ix->metric);
-    const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride, hot);
+    const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride, hot, aux);
     uint32_t cap;
     const bool auto_cap = a->hash_capacity == 0;
     if (!auto_cap) {
         cap = (uint32_t)a->hash_capacity;
     } else {
         uint32_t need;
-        if (ix->cap_for_ef.count(ef * 4 + a->mode)) {
-            need = ix->cap_for_ef[ef * 4 + a->mode];
+        if (ix->cap_for_ef.count(skey)) {
+            need = ix->cap_for_ef[skey];
         } else {
             const uint32_t target = std::max<uint32_t>(512u, 32u * (uint32_t)ef);
             need = target + target / 3 + 64;
@@ -721,7 +748,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     // Fused re-rank: with a register-list first pass (ef <= 256; and its retry / general successors) every
     // wavefront re-ranks its own query when its walk ends; no re-rank launch.  Needs the pair form
     // (d % 8 == 0) and room for the original-space query in the walk kernels' LDS.
-    const bool fuse = ef <= 256 && !plain && !w.all_general && ix->d % 8 == 0 &&
+    const bool fuse = ef <= 256 && !plain && !aux && !w.all_general && ix->d % 8 == 0 &&
                       (size_t)ix->d_pad * 4 <= walk_fast_lds_bytes(w, hot) && !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
     if (fuse) {
         w.rr_q = q_dev; w.rr_qstride = ix->d; w.rr_db = ix->db; w.rr_dstride = ix->d_pad; w.rr_dim = ix->d;
@@ -741,7 +768,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         // retry pass: hand-overs of the first pass, one wavefront per CU with all the LDS
         WalkParams w2 = w;
         const size_t gran = 512;
-        w2.hash_cap = (uint32_t)((kMaxLds / gran * gran - walk_fast_lds_fixed_bytes(ef, w.dstride, false)) / 4) & ~3u;
+        w2.hash_cap = (uint32_t)((kMaxLds / gran * gran - walk_fast_lds_fixed_bytes(ef, w.dstride, false, aux)) / 4) & ~3u;
         w2.hash_limit = w2.hash_cap - w2.hash_cap / 16;
         if (skip_retry) {
             // nothing to launch
@@ -767,7 +794,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         HIP_TRY(hipMemcpyAsync(ix->h_stats, ctrl, 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(ix->stats_ev, s));
         ix->stats_pending = true;
-        ix->stats_ef = ef * 4 + a->mode;
+        ix->stats_ef = skey;
         ix->stats_cap = cap;
     }
 

@@ -63,13 +63,20 @@ struct WalkParams {
     uint32_t rr_dstride, rr_dim, rr_n;
     int32_t rr_metric;       // gbnns_metric of the re-rank
     uint32_t* rr_out;        // [nq]
+    // auxiliary graph (search_function.h:73-89, use_second_graph): while hops < hops_bound a node's auxiliary
+    // row is expanded before its main row; with llf the main row is skipped when that step inserted anything
+    const uint32_t* aux_ell; // [n x aux_stride] or nullptr (= use_second_graph false)
+    uint32_t aux_stride;
+    uint32_t hops_bound;
+    int32_t llf;
     unsigned long long* stamps;  // diagnostic builds only (GBNNS_STAMPS): [32] segment cycle sums / histograms
     int32_t stamps_on;           // 1 in diagnostic builds: use the instrumented generic kernel
 };
 
 bool walk_uses_hot(const WalkParams& p, int metric);           // first pass runs walk_hot_kernel
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot);
-size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot);  // everything but the visited set
+size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list = false);  // everything but the visited set
+                                                                                             // (lds_list: the LDS-list kernel at any ef -- auxiliary-graph walks)
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s);

@@ -619,10 +619,10 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
 
     bool handed_over = false;
     uint32_t node;
-    while (select_candidate(keys, tie, st, node, lane)) {
-        const uint32_t* row = p.ell + (size_t)node * p.ell_stride;
-        for (uint32_t c = 0; c < p.ell_stride; c += 64) {
-            const uint32_t nb = (c + lane < p.ell_stride) ? row[c + lane] : kInvalidId;
+    // makeStep (search_function.h:15-40) over one adjacency row; `found` = something was inserted (:34)
+    auto make_step = [&](const uint32_t* row, uint32_t stride, bool& found) {
+        for (uint32_t c = 0; c < stride; c += 64) {
+            const uint32_t nb = (c + lane < stride) ? row[c + lane] : kInvalidId;
             const bool valid = nb != kInvalidId;
             const uint64_t mv = __ballot(valid);
             if (!mv) break;
@@ -636,6 +636,7 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
             // reference order: neighbours are offered one by one in list order
             const uint32_t worst0 = key_hi(keys[st.size - 1]);
             uint64_t m = __ballot(fresh && (st.size < ef || dk < worst0));
+            if (m) found = true;  // the first of them is inserted whatever the others do
             while (m) {
                 const int l = __ffsll((unsigned long long)m) - 1;
                 m &= m - 1;
@@ -645,6 +646,13 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
             }
             if (handed_over) break;
         }
+    };
+    while (select_candidate(keys, tie, st, node, lane)) {
+        bool found = false;
+        if (p.aux_ell && (uint32_t)st.hops < p.hops_bound)  // search_function.h:73-80
+            make_step(p.aux_ell + (size_t)node * p.aux_stride, p.aux_stride, found);
+        if (!handed_over && !(found && p.llf))               // :82-89
+            make_step(p.ell + (size_t)node * p.ell_stride, p.ell_stride, found);
         if (handed_over) break;
         st.hops += 1;
     }
@@ -1907,10 +1915,9 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
             wave_sync();
         }
         uint32_t node;
-        while (select_candidate(keys, tie, st, node, lane)) {
-            const uint32_t* row = p.ell + (size_t)node * p.ell_stride;
-            for (uint32_t c = 0; c < p.ell_stride; c += 64) {
-                const uint32_t nb = (c + lane < p.ell_stride) ? row[c + lane] : kInvalidId;
+        auto make_step = [&](const uint32_t* row, uint32_t stride, bool& found) {  // search_function.h:15-40
+            for (uint32_t c = 0; c < stride; c += 64) {
+                const uint32_t nb = (c + lane < stride) ? row[c + lane] : kInvalidId;
                 const bool valid = nb != kInvalidId;
                 const uint64_t mv = __ballot(valid);
                 if (!mv) break;
@@ -1928,6 +1935,7 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
                 st.dist_calc += __popcll(mf);
                 const uint32_t worst0 = key_hi(keys[st.size - 1]);
                 uint64_t m = __ballot(fresh && (st.size < ef || dk < worst0));
+                if (m) found = true;
                 while (m) {
                     const int l = __ffsll((unsigned long long)m) - 1;
                     m &= m - 1;
@@ -1936,6 +1944,13 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
                     offer(keys, tie, (int)p.n, st, ef, dl, il, lane);
                 }
             }
+        };
+        while (select_candidate(keys, tie, st, node, lane)) {
+            bool found = false;
+            if (p.aux_ell && (uint32_t)st.hops < p.hops_bound)  // :73-80
+                make_step(p.aux_ell + (size_t)node * p.aux_stride, p.aux_stride, found);
+            if (!(found && p.llf))                                // :82-89
+                make_step(p.ell + (size_t)node * p.ell_stride, p.ell_stride, found);
             st.hops += 1;
         }
         write_results(p, qi, keys, st, lane);
@@ -2515,14 +2530,15 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t count) {
 // 32-slot pass, 32-bit byte offsets.
 bool walk_uses_hot(const WalkParams& p, int metric) {
     const bool off32 = (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32);
-    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 64 && p.ell_stride <= 32u && off32 && !p.stamps_on;
+    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 64 && p.ell_stride <= 32u && off32 && !p.stamps_on &&
+           !p.aux_ell;
 }
 
 // LDS of one wavefront without the visited set.  Register kernels: tie list + merge buffer + query; the
 // hot kernel stages the query inside the merge buffer (it lives in registers once the walk starts).
-size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot) {
+size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list) {
     if (hot) return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8;
-    if (ef <= kRegListMaxEf) {  // tie list + merge buffer (ranks 0..ef of the 1 / 2 / 4-register list) + query
+    if (ef <= kRegListMaxEf && !lds_list) {  // tie list + merge buffer (ranks 0..ef of the 1 / 2 / 4-register list) + query
         const int regs = ef <= 64 ? 1 : (ef <= 128 ? 2 : 4);
         return (size_t)kRegTieCap * 8 + (size_t)(64 * regs + 2) * 8 + (size_t)dstride * 4;
     }
@@ -2531,7 +2547,7 @@ size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot) {
 }
 
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot) {
-    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot) + (size_t)p.hash_cap * 4;
+    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, p.aux_ell != nullptr) + (size_t)p.hash_cap * 4;
 }
 
 template <typename K>
@@ -2578,6 +2594,10 @@ template <int METRIC, int STEPS>
 static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) {
     const size_t lds = walk_fast_lds_bytes(p, false);
     constexpr int kWideSteps = (STEPS == 8) ? 8 : 0;
+    // auxiliary-graph walks run the LDS-list kernel at every ef (the register kernels expand one row per hop)
+    if (p.aux_ell)
+        return retry ? launch_walk_k(walk_fast_kernel<METRIC, STEPS, true>, p, true, lds, s)
+                     : launch_walk_k(walk_fast_kernel<METRIC, STEPS, false>, p, false, lds, s);
     if (p.ef <= 64) return launch_reg_t<METRIC, STEPS, 1>(p, retry, lds, s);
     if (p.ef <= 128) return launch_reg_t<METRIC, kWideSteps, 2>(p, retry, lds, s);
     if (p.ef <= kRegListMaxEf) return launch_reg_t<METRIC, kWideSteps, 4>(p, retry, lds, s);

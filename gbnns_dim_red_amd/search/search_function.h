@@ -10,9 +10,12 @@
 // batch (host buffers in, answers out, inside the same timed region); scoring and the result
 // line are produced exactly as the reference does (:389-407).
 //
+// use_second_graph = true / llf / hops_bound (auxiliary "long link" graph, :73-89; naive_test.cpp:103-105)
+// are served by the device too: the auxiliary graph is attached to the index
+// (gbnns_index_set_aux_graph) and the call sets GBNNS_FLAG_AUX_GRAPH / GBNNS_FLAG_LLF.
 // Not available on the device path (the process exits with a message instead of silently doing
-// something else): use_second_graph = true / llf (auxiliary "long link" graph, :73-80) and more
-// than one entry point per query -- final_test.cpp uses neither.
+// something else): more than one entry point per query -- neither final_test.cpp nor naive_test.cpp
+// uses that.
 // makeStep (:15-40) is an internal step of the walk and has no host-visible counterpart.
 #pragma once
 
@@ -76,11 +79,26 @@ inline gbnns_index* gbnnsIndexFor(vector<vector<uint32_t>>& graph, const float* 
     return ix;
 }
 
-inline void gbnnsRequireDevicePath(bool use_second_graph, bool llf) {
-    if (use_second_graph || llf) {
-        std::cerr << "gbnns: use_second_graph / llf are not implemented on the MI355X path" << std::endl;
-        exit(2);
+// The reference's (auxiliary_graph, use_second_graph, llf, hops_bound) quadruple of one call.  llf has no
+// effect without use_second_graph (:82), exactly as in the reference.
+struct GbnnsAux {
+    vector<vector<uint32_t>>* graph;
+    bool use;
+    bool llf;
+    uint32_t hops_bound;
+};
+
+// Attaches `aux.graph` to the index unless it already is (keyed on the vector's address, like the index
+// cache) and returns the flags of the search call.
+inline uint32_t gbnnsAttachAux(gbnns_index* ix, const GbnnsAux& aux) {
+    if (!aux.use) return 0;
+    static std::map<gbnns_index*, const void*> attached;
+    if (attached[ix] != (const void*)aux.graph) {
+        const GbnnsCsr csr = gbnnsToCsr(*aux.graph);
+        if (gbnns_index_set_aux_graph(ix, csr.offsets.data(), csr.nbrs.data())) gbnnsDie("gbnns_index_set_aux_graph");
+        attached[ix] = (const void*)aux.graph;
     }
+    return GBNNS_FLAG_AUX_GRAPH | (aux.llf ? GBNNS_FLAG_LLF : 0u);
 }
 
 inline vector<uint32_t> gbnnsEntries(const vector<vector<uint32_t>>& inter_points, size_t n_q) {
@@ -99,8 +117,10 @@ inline vector<uint32_t> gbnnsEntries(const vector<vector<uint32_t>>& inter_point
 // mode PLAIN: walk in the space of the index's `db` with (ef, k), answer = best.
 inline void gbnnsBatch(gbnns_index* ix, int mode, const float* queries, const float* queries_low,
                        size_t n_q, int ef, int k, const vector<uint32_t>& entries, vector<uint32_t>& ans,
-                       vector<int32_t>& hops, vector<int32_t>& dist_calc) {
+                       vector<int32_t>& hops, vector<int32_t>& dist_calc, const GbnnsAux& aux) {
     gbnns_search_args a = {};
+    a.flags = gbnnsAttachAux(ix, aux);
+    a.hops_bound = aux.hops_bound;
     a.struct_size = sizeof a;
     a.mode = mode;
     a.ef = ef;
@@ -124,8 +144,8 @@ TripleResult getOneSearchResults(const float* query, const float* db, uint32_t N
                                  int ef, int k, vector<uint32_t>& inter_points, Metric* metric,
                                  VisitedListPool* visitedlistpool, bool use_second_graph, bool llf,
                                  uint32_t hops_bound) {
-    (void)auxiliary_graph; (void)visitedlistpool; (void)hops_bound;
-    gbnnsRequireDevicePath(use_second_graph, llf);
+    (void)visitedlistpool;
+    const GbnnsAux aux = {&auxiliary_graph, use_second_graph, llf, hops_bound};
     if (inter_points.size() != 1) {
         std::cerr << "gbnns: exactly one entry point per query is supported" << std::endl;
         exit(2);
@@ -150,6 +170,8 @@ TripleResult getOneSearchResults(const float* query, const float* db, uint32_t N
     a.out_dist_calc = &dc;
     a.out_cand = cand.data();
     a.out_cand_dist = cdist.data();
+    a.flags = gbnnsAttachAux(ix, aux);
+    a.hops_bound = hops_bound;
     if (gbnns_search_ex(ix, &a)) gbnnsDie("gbnns_search_ex");
     TripleResult r;
     for (int i = 0; i < kept; ++i)
@@ -210,8 +232,8 @@ void performTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>>& 
                  string graph_name, Metric* metric, const char* output_txt,
                  vector<vector<uint32_t>> inter_points, bool use_second_graph, bool llf, uint32_t hops_bound,
                  int dist_calc_boost, int recheck_size, int number_exper, int number_of_threads) {
-    (void)kl_graph; (void)hops_bound; (void)number_of_threads;
-    gbnnsRequireDevicePath(use_second_graph, llf);
+    (void)number_of_threads;
+    const GbnnsAux aux = {&kl_graph, use_second_graph, llf, hops_bound};
     std::ofstream outfile;
     outfile.open(output_txt, std::ios_base::app);
 
@@ -244,7 +266,7 @@ void performTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>>& 
         num_exp += 1;
         vector<uint32_t> ans(n_q);
         StopW stopw = StopW();
-        gbnnsBatch(ix, mode, q_main, q_low, n_q, run_ef, run_k, entries, ans, q_hops, q_dc);
+        gbnnsBatch(ix, mode, q_main, q_low, n_q, run_ef, run_k, entries, ans, q_hops, q_dc, aux);
         work_time += stopw.getElapsedTimeMicro();
         for (int i = 0; i < n_q; ++i) {
             hops += q_hops[i];
@@ -283,8 +305,8 @@ void performNetTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>
                     string graph_name, Metric* metric, const char* output_txt,
                     vector<vector<uint32_t>> inter_points, bool use_second_graph, bool llf, uint32_t hops_bound,
                     int dist_calc_boost, int recheck_size, int number_exper, int number_of_threads) {
-    (void)kl_graph; (void)hops_bound; (void)number_of_threads;
-    gbnnsRequireDevicePath(use_second_graph, llf);
+    (void)number_of_threads;
+    const GbnnsAux aux = {&kl_graph, use_second_graph, llf, hops_bound};
     std::ofstream outfile;
     outfile.open(output_txt, std::ios_base::app);
 
@@ -311,13 +333,13 @@ void performNetTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>
         StopW stopw = StopW();
         if (two_stage) {
             gbnnsBatch(ix, GBNNS_MODE_NET, queries.data(), nullptr, n_q, recheck_size, recheck_size, entries, ans,
-                       q_hops, q_dc);
+                       q_hops, q_dc, aux);
         } else if (low_only) {
             q_low.resize((size_t)n_q * d_low);
             if (gbnns_project(ix, queries.data(), n_q, q_low.data(), GBNNS_MEM_HOST, nullptr)) gbnnsDie("gbnns_project");
-            gbnnsBatch(ix_low, GBNNS_MODE_PLAIN, q_low.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc);
+            gbnnsBatch(ix_low, GBNNS_MODE_PLAIN, q_low.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux);
         } else {
-            gbnnsBatch(ix, GBNNS_MODE_PLAIN, queries.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc);
+            gbnnsBatch(ix, GBNNS_MODE_PLAIN, queries.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux);
         }
         work_time += stopw.getElapsedTimeMicro();
         for (int i = 0; i < n_q; ++i) {

@@ -77,6 +77,12 @@ typedef struct {
 int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out);
 int gbnns_index_destroy(gbnns_index* index);
 
+/* The `auxiliary_graph` argument of getOneSearchResults (search_function.h:44; naive_test.cpp:103-105
+ * passes the KL graph): host CSR over the same n nodes, neighbour order preserved, copied to the device
+ * layout.  NULL, NULL removes it.  Used by searches that set GBNNS_FLAG_AUX_GRAPH.  Synchronises the
+ * device. */
+int gbnns_index_set_aux_graph(gbnns_index* index, const uint64_t* offsets, const uint32_t* nbrs);
+
 typedef struct {
     uint32_t struct_size;      /* = sizeof(gbnns_search_args) */
     int32_t mode;              /* gbnns_mode */
@@ -101,7 +107,8 @@ typedef struct {
                                   the expanded nodes) -- feeds the algorithmic-bytes figure */
     void* stream;              /* hipStream_t to enqueue on (NULL = default stream) */
     uint32_t flags;            /* GBNNS_FLAG_* */
-    uint32_t reserved1;
+    uint32_t hops_bound;       /* with GBNNS_FLAG_AUX_GRAPH: auxiliary rows are expanded while hops < hops_bound
+                                  (search_function.h:73; the harness passes 50, :273/:338) */
 } gbnns_search_args;
 
 /* Throughput option, off by default: run the MLP projection on the matrix cores (f32 MFMA).  The
@@ -115,6 +122,14 @@ typedef struct {
  * where the walk kernels could re-rank each query at the end of its walk.  Results are identical either
  * way; the flag exists for A/B measurements and for timing the two stages separately. */
 #define GBNNS_FLAG_NO_FUSED_RERANK 2u
+
+/* use_second_graph = true (search_function.h:73-89): while a query has made fewer than `hops_bound` hops,
+ * the auxiliary row of the expanded node (gbnns_index_set_aux_graph) is offered before its main row.  With
+ * GBNNS_FLAG_LLF (the reference's `llf`) the main row is skipped on a hop whose auxiliary step inserted
+ * something (:82).  Bit-identical to the reference; these walks run the LDS-list kernel at every ef (no
+ * register-list / fused re-rank fast path yet). */
+#define GBNNS_FLAG_AUX_GRAPH 4u
+#define GBNNS_FLAG_LLF 8u
 
 /* Replaces the timed query loop of performNetTest (search_function.h:346-387) / performTest
  * (:151-188): one call = the whole batch.  With HOST buffers the call copies in, runs and

@@ -245,6 +245,10 @@ class Ref(_Base):
             "perform_real_tests", None,
             [C.c_int] * 5 + [_i32p, C.c_int, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _u32p,
                              C.c_char_p, C.c_char_p, C.c_int, C.c_int])
+        self._real_tests_aux = self._fn(
+            "perform_real_tests_aux", None,
+            [C.c_int] * 5 + [_i32p, C.c_int, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _u32p,
+                             C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_uint32])
         self._max_threads = self._fn("max_threads", C.c_int, [])
         self._graphs = {}
 
@@ -351,13 +355,14 @@ class Ref(_Base):
                         threads)
 
     def perform_real_tests(self, db, queries, db_low, queries_low, off, nbr, truth, efs, out_path,
-                           graph_name="hnsw", number_exper=1, threads=1):
+                           graph_name="hnsw", number_exper=1, threads=1, aux=None, llf=False, seed=1):
         db, queries, db_low, queries_low = _f32(db), _f32(queries), _f32(db_low), _f32(queries_low)
         truth = _u32(truth)
         efs = np.ascontiguousarray(efs, np.int32)
         g = self._graph(off, nbr)
         n, d = db.shape
-        self._real_tests(n, d, db_low.shape[1], queries.shape[0], truth.shape[1], _p(efs, _i32p),
-                         efs.size, g, _p(db, _f32p), _p(queries, _f32p), _p(db_low, _f32p),
-                         _p(queries_low, _f32p), _p(truth, _u32p), out_path.encode(),
-                         graph_name.encode(), number_exper, threads)
+        ga = None if aux is None else self._graph(aux[0], aux[1])
+        self._real_tests_aux(n, d, db_low.shape[1], queries.shape[0], truth.shape[1], _p(efs, _i32p),
+                             efs.size, g, _p(db, _f32p), _p(queries, _f32p), _p(db_low, _f32p),
+                             _p(queries_low, _f32p), _p(truth, _u32p), out_path.encode(),
+                             graph_name.encode(), number_exper, threads, ga, int(llf), seed)

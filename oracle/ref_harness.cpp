@@ -248,21 +248,34 @@ void ref_perform_real_net_tests(int n, int d, int d_low, int n_q, int n_tr, cons
                         number_of_threads);
 }
 
-void ref_perform_real_tests(int n, int d, int d_low, int n_q, int n_tr, const int* efs, int n_efs,
-                            void* graph, const float* db, const float* queries,
-                            const float* db_low, const float* queries_low, const uint32_t* truth,
-                            const char* output_txt, const char* graph_name, int number_exper,
-                            int number_of_threads) {
+// aux_graph != NULL: the reference's `kl` argument with use_second_graph = true and the given llf
+// (naive_test.cpp:102-105); seed = state of the mt19937 the harness receives by value.
+void ref_perform_real_tests_aux(int n, int d, int d_low, int n_q, int n_tr, const int* efs, int n_efs,
+                                void* graph, const float* db, const float* queries,
+                                const float* db_low, const float* queries_low, const uint32_t* truth,
+                                const char* output_txt, const char* graph_name, int number_exper,
+                                int number_of_threads, void* aux_graph, int llf, uint32_t seed) {
     RefGraph* g = (RefGraph*)graph;
+    RefGraph* ga = aux_graph ? (RefGraph*)aux_graph : g;
     vector<int> efv(efs, efs + n_efs);
     vector<float> dbv(db, db + (size_t)n * d), qv(queries, queries + (size_t)n_q * d),
         dblv(db_low, db_low + (size_t)n * d_low),
         qlv(queries_low, queries_low + (size_t)n_q * d_low);
     vector<uint32_t> tv(truth, truth + (size_t)n_q * n_tr);
     L2Metric l2m;
-    std::mt19937 rng(1);
-    performRealTests(n, d, d_low, n_q, n_tr, efv, rng, g->lists, g->lists, dbv, qv, dblv, qlv, tv,
-                     output_txt, &l2m, graph_name, false, false, number_exper, number_of_threads);
+    std::mt19937 rng(seed);
+    performRealTests(n, d, d_low, n_q, n_tr, efv, rng, g->lists, ga->lists, dbv, qv, dblv, qlv, tv,
+                     output_txt, &l2m, graph_name, aux_graph != nullptr, llf != 0, number_exper,
+                     number_of_threads);
+}
+
+void ref_perform_real_tests(int n, int d, int d_low, int n_q, int n_tr, const int* efs, int n_efs,
+                            void* graph, const float* db, const float* queries,
+                            const float* db_low, const float* queries_low, const uint32_t* truth,
+                            const char* output_txt, const char* graph_name, int number_exper,
+                            int number_of_threads) {
+    ref_perform_real_tests_aux(n, d, d_low, n_q, n_tr, efs, n_efs, graph, db, queries, db_low, queries_low,
+                               truth, output_txt, graph_name, number_exper, number_of_threads, nullptr, 0, 1);
 }
 
 int ref_max_threads() { return omp_get_max_threads(); }

@@ -65,6 +65,22 @@ def main():
                 out[f"plain_ans_{tag}"] = p["ids"]
                 out[f"plain_hops_{tag}"] = p["hops"]
                 out[f"plain_dc_{tag}"] = p["dist_calc"]
+        if name == "sift_toy":
+            # the reference's harness end to end, as naive_test.cpp:98-105 calls it (entry points from
+            # mt19937(7) because the graph names do not start with "hnsw")
+            import tempfile
+            truth = g["truth"]
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "res.txt")
+                for gname, a, l in (("hnsw", None, False), ("knn", None, False), ("knn_lk", (aoff, anbr), True)):
+                    ref.perform_real_tests(c.base, c.queries, c.base, c.queries, goff, gnbr, truth, efs, path,
+                                           graph_name=gname, number_exper=2, threads=1, aux=a, llf=l, seed=7)
+                ref.perform_real_tests(c.base, c.queries, db, q, goff, gnbr, truth, efs, path,
+                                       graph_name="knn_lk_low", number_exper=2, threads=1, aux=(aoff, anbr),
+                                       llf=True, seed=7)
+                lines = open(path).read().splitlines()
+            meta["naive_result_lines"] = [ln.split(" work_time ")[0] for ln in lines]
+            meta["naive_seed"] = 7
         # hops_bound = 0 must equal the walk without an auxiliary graph
         w0 = ref.walk(q, db, goff, gnbr, efs[-1], entries=entries, metric=c.metric)
         assert np.array_equal(w0["ids"], out[f"walk_ids_{name}_{efs[-1]}_0_0"])

@@ -81,3 +81,51 @@ def test_final_test_rejects_bad_files(tmp_path):
     assert p.returncode == 1 and "file error" in p.stdout
     p = subprocess.run([BIN], capture_output=True, text=True, timeout=60)
     assert p.returncode == 1 and "Need to specify parameters" in p.stdout
+
+
+def test_naive_test_result_lines(tmp_path, orc):
+    """The second driver (naive_test.cpp:98-105): plain, knn, knn + auxiliary KL graph with llf, and the same in
+    the low-dim space with re-rank -- result lines equal to the reference harness's (tests/golden/aux_toy.npz)."""
+    import json
+    nbin = os.path.join(ROOT, "gbnns_dim_red_amd", "search", "naive_test")
+    assert os.path.exists(nbin), "build() must produce the naive_test driver"
+    z = np.load(gu.GOLDEN_DIR + "/aux_toy.npz")
+    meta = json.loads(bytes(z["meta"]).decode())
+    gd = gu.load("sift_toy")
+    c = gd.case
+    ds = "toy"
+    data = tmp_path / "data"
+    models = tmp_path / "models"
+    data.mkdir()
+    models.mkdir()
+    db_low = orc.project(c.net, c.base, threads=4)
+    q_low = orc.project(c.net, c.queries)
+    write_xvecs(data / f"{ds}_base.fvecs", c.base)
+    write_xvecs(data / f"{ds}_query.fvecs", c.queries)
+    write_xvecs(data / f"{ds}_groundtruth.ivecs", gd["truth"])
+    write_xvecs(data / f"{ds}_base_naive.fvecs", db_low)
+    write_xvecs(data / f"{ds}_querynaive.fvecs", q_low)
+    off, nbr = gd.graph
+    aoff, anbr = z["sift_toy_aux_off"], z["sift_toy_aux_nbr"]
+    for fn in ("hnsw_toygraph.ivecs", f"{ds}knn.ivecs", f"{ds}knn_low.ivecs"):
+        write_edges(models / fn, off, nbr)
+    for fn in (f"{ds}_kl_sqrt_style.ivecs", f"{ds}_kl_llow_sqrt_style.ivecs"):
+        write_edges(models / fn, aoff, anbr)
+    efs = ",".join(str(e) for e in meta["cases"]["sift_toy"]["efs"])
+    params = tmp_path / "params.txt"
+    params.write_text("\n".join([
+        f"{ds} n {c.n}", f"{ds} n_q {c.nq}", f"{ds} n_tr {gd['truth'].shape[1]}", f"{ds} d {c.d}",
+        f"{ds} d_low {c.dlow}", f"{ds} kl_size 5", f"{ds} efs {efs}", f"{ds} efs_hnsw {efs}",
+        f"{ds} hnsw_name toygraph"]) + "\n")
+    env = dict(os.environ, GBNNS_NUM_EXPER="2", GBNNS_SEED=str(meta["naive_seed"]))
+    p = subprocess.run([nbin, ds, str(data), str(models), str(tmp_path), str(params)], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = open(tmp_path / f"naive_results_{ds}.txt").read().splitlines()
+    got = [ln.split(" work_time ")[0] for ln in lines]
+    assert got == meta["naive_result_lines"]
+    # missing KL files: a message and exit(1), nothing silently different
+    os.remove(models / f"{ds}_kl_sqrt_style.ivecs")
+    p = subprocess.run([nbin, ds, str(data), str(models), str(tmp_path), str(params)], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 1 and "KL graph files missing" in p.stdout

@@ -600,3 +600,86 @@ def test_mfma_projection_option(g, orc):
     assert np.abs(f2["q_low"] - orc.project(c2.net, c2.queries)).max() < 2e-6
     ix.close()
     ix2.close()
+
+
+def test_golden_auxiliary_graph(g, orc):
+    """use_second_graph / llf / hops_bound (search_function.h:73-89) against the compiled reference's outputs
+    (tests/golden/aux_toy.npz): walks, two-stage answers, plain answers, on clustered and tie-heavy data."""
+    import json
+    z = np.load(gu.GOLDEN_DIR + "/aux_toy.npz")
+    meta = json.loads(bytes(z["meta"]).decode())
+    for name, info in meta["cases"].items():
+        gd = gu.load(name)
+        c = gd.case
+        off, nbr = gd.graph
+        lattice = name == "ties_toy"
+        if lattice:
+            ix = g.Index(c.base, off, nbr)
+        else:
+            ix, db_low = _index(g, gd, orc)
+        with pytest.raises(g.GbnnsError):  # flag without a graph
+            ix.search(c.queries, 8, mode=g.MODE_PLAIN, aux=True)
+        ix.set_aux_graph(z[f"{name}_aux_off"], z[f"{name}_aux_nbr"])
+        for ef in info["efs"]:
+            for llf, hb in meta["variants"]:
+                tag = f"{name}_{ef}_{llf}_{hb}"
+                kw = dict(entry_ids=gd["entries"], aux=True, llf=bool(llf), hops_bound=hb)
+                if lattice:
+                    r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef,
+                                  want=("hops", "dist_calc", "cand", "cand_dist"), **kw)
+                else:
+                    r = ix.search(c.queries, ef, mode=g.MODE_NET,
+                                  want=("hops", "dist_calc", "cand", "cand_dist"), **kw)
+                    assert np.array_equal(r["ids"], z[f"net_ans_{tag}"]), tag
+                assert np.array_equal(r["cand"], z[f"walk_ids_{tag}"]), tag
+                assert np.array_equal(gu.bits(r["cand_dist"]), z[f"walk_dist_bits_{tag}"]), tag
+                assert np.array_equal(r["hops"], z[f"walk_hops_{tag}"]), tag
+                assert np.array_equal(r["dist_calc"], z[f"walk_dc_{tag}"]), tag
+                p = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=1, **kw)
+                assert np.array_equal(p["ids"], z[f"plain_ans_{tag}"]), tag
+                assert np.array_equal(p["hops"], z[f"plain_hops_{tag}"]), tag
+                assert np.array_equal(p["dist_calc"], z[f"plain_dc_{tag}"]), tag
+        # the index still serves ordinary searches, and the auxiliary graph can be removed again
+        ef = info["efs"][-1]
+        if not lattice:
+            r = ix.search(c.queries, ef, want=("hops",))
+            assert np.array_equal(r["ids"], gd[f"net_ans_{ef}"])
+        ix.set_aux_graph(None, None)
+        with pytest.raises(g.GbnnsError):
+            ix.search(c.queries, 8, mode=g.MODE_PLAIN, aux=True)
+        ix.close()
+
+
+def test_auxiliary_graph_vs_oracle_all_kernels(g, orc):
+    """The auxiliary-graph walk through every kernel of the hand-over chain, both metrics, against the oracle:
+    LDS-list first pass, retry pass (tiny visited set), general kernel (ef beyond LDS)."""
+    for metric in (0, 1):
+        c, off, nbr, db_low, ent = _oracle_case(orc, 910 + metric, 9000, 250, 40, 32, 64, deg=(3, 24))
+        rng = np.random.Generator(np.random.PCG64(77 + metric))
+        aux = datagen.random_graph(rng, c.n, 0, 70)  # rows longer than one 64-lane pass
+        q_low = orc.project(c.net, c.queries)
+        ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net, metric=metric)
+        ix.set_aux_graph(*aux)
+        ix.profile_enable(True)
+        for ef, llf, hb, hcap in ((1, True, 50, 0), (24, True, 50, 0), (24, False, 5, 0), (64, True, 50, 128),
+                                  (300, True, 1000, 0), (300, False, 50, 128)):
+            w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, metric=metric, aux=aux, llf=llf,
+                         hops_bound=hb, threads=8)
+            s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net,
+                                 entries=ent, metric=metric, aux=aux, llf=llf, hops_bound=hb, threads=8)
+            r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand"), aux=True, llf=llf,
+                          hops_bound=hb, hash_capacity=hcap)
+            key = (metric, ef, llf, hb, hcap)
+            assert np.array_equal(r["cand"], w["ids"]), key
+            assert np.array_equal(r["hops"], w["hops"]), key
+            assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
+            assert np.array_equal(r["ids"], s["ids"]), key
+        ix.profile_read()
+        # ef beyond anything LDS holds: the general kernel takes the batch
+        ef = 20000
+        w = orc.walk(q_low[:24], db_low, off, nbr, ef, metric=metric, aux=aux, llf=True, hops_bound=50, threads=8)
+        r = ix.search(c.queries[:24], ef, want=("hops", "dist_calc", "cand"), aux=True, llf=True, hops_bound=50)
+        assert np.array_equal(r["cand"], w["ids"])
+        assert np.array_equal(r["hops"], w["hops"])
+        assert ix.profile_read()["general_queries"] == 24
+        ix.close()
