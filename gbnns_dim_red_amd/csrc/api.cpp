@@ -718,7 +718,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.stamps_on = 1;
 #endif
     const bool hot = walk_uses_hot(w, ix->metric);
-    const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride, hot, aux);
+    const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride, hot, walk_uses_lds_list(w));
     uint32_t cap;
     const bool auto_cap = a->hash_capacity == 0;
     if (!auto_cap) {
@@ -748,7 +748,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     // Fused re-rank: with a register-list first pass (ef <= 256; and its retry / general successors) every
     // wavefront re-ranks its own query when its walk ends; no re-rank launch.  Needs the pair form
     // (d % 8 == 0) and room for the original-space query in the walk kernels' LDS.
-    const bool fuse = ef <= 256 && !plain && !aux && !w.all_general && ix->d % 8 == 0 &&
+    const bool fuse = !walk_uses_lds_list(w) && !plain && !w.all_general && ix->d % 8 == 0 &&
                       (size_t)ix->d_pad * 4 <= walk_fast_lds_bytes(w, hot) && !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
     if (fuse) {
         w.rr_q = q_dev; w.rr_qstride = ix->d; w.rr_db = ix->db; w.rr_dstride = ix->d_pad; w.rr_dim = ix->d;
@@ -768,7 +768,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         // retry pass: hand-overs of the first pass, one wavefront per CU with all the LDS
         WalkParams w2 = w;
         const size_t gran = 512;
-        w2.hash_cap = (uint32_t)((kMaxLds / gran * gran - walk_fast_lds_fixed_bytes(ef, w.dstride, false, aux)) / 4) & ~3u;
+        w2.hash_cap = (uint32_t)((kMaxLds / gran * gran - walk_fast_lds_fixed_bytes(ef, w.dstride, false, walk_uses_lds_list(w))) / 4) & ~3u;
         w2.hash_limit = w2.hash_cap - w2.hash_cap / 16;
         if (skip_retry) {
             // nothing to launch

@@ -74,9 +74,10 @@ struct WalkParams {
 };
 
 bool walk_uses_hot(const WalkParams& p, int metric);           // first pass runs walk_hot_kernel
+bool walk_uses_lds_list(const WalkParams& p);                   // result list in LDS (walk_fast_kernel) instead of registers
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot);
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list = false);  // everything but the visited set
-                                                                                             // (lds_list: the LDS-list kernel at any ef -- auxiliary-graph walks)
+                                                                                             // (lds_list: walk_uses_lds_list)
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s);

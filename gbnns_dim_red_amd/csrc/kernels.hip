@@ -1167,9 +1167,12 @@ __device__ __forceinline__ uint32_t reg_id_at_rank(const RegList<R>& L, int rank
     return v;
 }
 
-template <int METRIC, int STEPS, bool OFF32, int R, bool ONE_CHUNK = false>
+// AUX: the auxiliary-graph walk (search_function.h:73-89): a hop expands the node's auxiliary row first (while
+// hops < hops_bound), then -- unless llf and that step inserted something -- its main row.
+template <int METRIC, int STEPS, bool OFF32, int R, bool ONE_CHUNK = false, bool AUX = false>
 __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                              uint32_t* ovf_count, uint32_t* ovf_list) {
+    static_assert(!(AUX && ONE_CHUNK), "auxiliary rows have their own length");
 #ifdef GBNNS_STAMPS
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned int probe_iters = 0;  // (the hand-scheduled probe does not count its iterations)
@@ -1355,11 +1358,22 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
 
         // ---- expand: neighbours in list order, 64 per pass --------------------------------------
         // ONE_CHUNK (rows of at most 64 slots): a single pass, the loop and its bookkeeping fold away
-        for (uint32_t c = 0; c < (ONE_CHUNK ? kChunk : p.ell_stride); c += kChunk) {
+        // AUX: two rows per hop -- g = 0 the auxiliary row (makeStep :73-80), g = 1 the main row (:82-89)
+        bool found = false;  // makeStep's flag (:34); only read when AUX
+        for (int g = AUX ? ((uint32_t)hops < p.hops_bound ? 0 : 1) : 1; g < 2; ++g) {
+        const bool is_aux = AUX && g == 0;
+        if (AUX && g == 1 && found && p.llf) break;
+        const uint32_t* grow = row;
+        uint32_t gstride = p.ell_stride;
+        if (is_aux) {
+            grow = reinterpret_cast<const uint32_t*>(row_ptr<OFF32>(reinterpret_cast<const float*>(p.aux_ell), node, p.aux_stride));
+            gstride = p.aux_stride;
+        }
+        for (uint32_t c = 0; c < (ONE_CHUNK ? kChunk : gstride); c += kChunk) {
             uint32_t nb = nb0;
             uint64_t mv = mv0;
-            if (c) {
-                nb = (c + slot < p.ell_stride) ? row[c + slot] : kInvalidId;
+            if (c || is_aux) {
+                nb = (c + slot < gstride) ? grow[c + slot] : kInvalidId;
                 mv = __ballot(nb != kInvalidId);
             }
             if (!mv) break;
@@ -1411,6 +1425,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             dist_calc += __popcll(mfresh);
             const bool offer_it = fresh && (size < ef || dk < worst);
             uint64_t m = __ballot(offer_it);
+            if (AUX && m) found = true;  // the first of them is inserted whatever happens to the others
             STAMP(t5)
             STAMP_ADD(4, t4, t5)
             // several survivors: merge them in one pass (falls through to the sequential offers on a
@@ -1450,6 +1465,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             STAMP(t6)
             STAMP_ADD(5, t5, t6)
             if (status) break;
+        }
+        if (status) break;
         }
         if (status) break;
         hops += 1;
@@ -1821,13 +1838,13 @@ __global__ __launch_bounds__(64) void walk_hot_kernel(WalkParams p) {
     walk_hot_one(p, blockIdx.x, smem);
 }
 
-template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R, bool ONE_CHUNK = false>
+template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R, bool ONE_CHUNK = false, bool AUX = false>
 __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if constexpr (RETRY) {
-        retry_loop(p, [&](uint32_t qi) { walk_reg_one<METRIC, STEPS, OFF32, R>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
+        retry_loop(p, [&](uint32_t qi) { walk_reg_one<METRIC, STEPS, OFF32, R, false, AUX>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
     } else {
-        walk_reg_one<METRIC, STEPS, OFF32, R, ONE_CHUNK>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
+        walk_reg_one<METRIC, STEPS, OFF32, R, ONE_CHUNK, AUX>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
     }
 }
 
@@ -2528,8 +2545,16 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t count) {
 
 // Shape served by walk_hot_kernel (first pass only): L2, 128-byte rows, ef <= 64, adjacency rows of one
 // 32-slot pass, 32-bit byte offsets.
+static bool walk_off32(const WalkParams& p) {  // every table the walk indexes is < 4 GiB
+    return (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32) &&
+           (!p.aux_ell || (uint64_t)p.n * p.aux_stride * 4 < (1ull << 32));
+}
+
+// The LDS-list kernel serves ef beyond the register lists, and auxiliary-graph walks over tables >= 4 GiB.
+bool walk_uses_lds_list(const WalkParams& p) { return p.ef > kRegListMaxEf || (p.aux_ell && !walk_off32(p)); }
+
 bool walk_uses_hot(const WalkParams& p, int metric) {
-    const bool off32 = (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32);
+    const bool off32 = walk_off32(p);
     return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 64 && p.ell_stride <= 32u && off32 && !p.stamps_on &&
            !p.aux_ell;
 }
@@ -2547,7 +2572,7 @@ size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_li
 }
 
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot) {
-    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, p.aux_ell != nullptr) + (size_t)p.hash_cap * 4;
+    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p)) + (size_t)p.hash_cap * 4;
 }
 
 template <typename K>
@@ -2570,7 +2595,10 @@ static hipError_t launch_walk_k(K kernel, const WalkParams& p, bool retry, size_
 template <int METRIC, int STEPS, int R>
 static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipStream_t s) {
     // 32-bit byte offsets when both tables are < 4 GiB
-    const bool off32 = (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32);
+    const bool off32 = walk_off32(p);
+    if (p.aux_ell)  // auxiliary-graph walk (32-bit offsets only; otherwise launch_fast_t took the LDS-list kernel)
+        return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, true, R, false, true>, p, true, lds, s)
+                     : launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, R, false, true>, p, false, lds, s);
     if constexpr (R == 1) {
         // the common shape (ef <= 64, adjacency rows of one pass) gets a loop-free expansion;
         // 128-byte rows with L2 additionally the hand-laid-out hop of walk_hot_one
@@ -2594,15 +2622,12 @@ template <int METRIC, int STEPS>
 static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) {
     const size_t lds = walk_fast_lds_bytes(p, false);
     constexpr int kWideSteps = (STEPS == 8) ? 8 : 0;
-    // auxiliary-graph walks run the LDS-list kernel at every ef (the register kernels expand one row per hop)
-    if (p.aux_ell)
+    if (walk_uses_lds_list(p))
         return retry ? launch_walk_k(walk_fast_kernel<METRIC, STEPS, true>, p, true, lds, s)
                      : launch_walk_k(walk_fast_kernel<METRIC, STEPS, false>, p, false, lds, s);
     if (p.ef <= 64) return launch_reg_t<METRIC, STEPS, 1>(p, retry, lds, s);
     if (p.ef <= 128) return launch_reg_t<METRIC, kWideSteps, 2>(p, retry, lds, s);
-    if (p.ef <= kRegListMaxEf) return launch_reg_t<METRIC, kWideSteps, 4>(p, retry, lds, s);
-    return retry ? launch_walk_k(walk_fast_kernel<METRIC, STEPS, true>, p, true, lds, s)
-                 : launch_walk_k(walk_fast_kernel<METRIC, STEPS, false>, p, false, lds, s);
+    return launch_reg_t<METRIC, kWideSteps, 4>(p, retry, lds, s);
 }
 
 static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, hipStream_t s) {

@@ -126,8 +126,7 @@ typedef struct {
 /* use_second_graph = true (search_function.h:73-89): while a query has made fewer than `hops_bound` hops,
  * the auxiliary row of the expanded node (gbnns_index_set_aux_graph) is offered before its main row.  With
  * GBNNS_FLAG_LLF (the reference's `llf`) the main row is skipped on a hop whose auxiliary step inserted
- * something (:82).  Bit-identical to the reference; these walks run the LDS-list kernel at every ef (no
- * register-list / fused re-rank fast path yet). */
+ * something (:82).  Bit-identical to the reference. */
 #define GBNNS_FLAG_AUX_GRAPH 4u
 #define GBNNS_FLAG_LLF 8u
 

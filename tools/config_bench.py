@@ -16,6 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("configs", nargs="*", default=["gist", "glove"])
 ap.add_argument("--scale", type=float, default=1.0, help="scale n (and nq for deep) down for a quick look")
 ap.add_argument("--negdot", action="store_true", help="walk / re-rank with the negative-dot metric (Angular::Dist)")
+ap.add_argument("--aux", type=int, default=0, help="attach a random long-link auxiliary graph of this degree and "
+                "run the reference's use_second_graph walk (llf, hops_bound 50) beside the plain one")
 a = ap.parse_args()
 for name in a.configs:
     c = dict(CONFIGS[name])
@@ -29,21 +31,28 @@ for name in a.configs:
     else:
         ix = ds.index()
     print(f"== {name}: n={ds.n} nq={ds.nq} {ds.d}->{ds.d_low} (h {ds.d_hidden}) built in {time.time()-t0:.1f}s", flush=True)
-    for ef in efs:
+    variants = [dict()]
+    if a.aux:
+        import numpy as np
+        rng = np.random.Generator(np.random.PCG64(5))
+        anbr = rng.integers(0, ds.n, size=(ds.n, a.aux), dtype=np.int64).astype(np.uint32)
+        ix.set_aux_graph(np.arange(ds.n + 1, dtype=np.uint64) * a.aux, anbr.reshape(-1))
+        variants.append(dict(aux=True, llf=True, hops_bound=50))
+    for ef, kw in [(e, v) for e in efs for v in variants]:
         for _ in range(3):
-            r = ix.search(ds.queries, ef, want=("hops", "dist_calc"))
+            r = ix.search(ds.queries, ef, want=("hops", "dist_calc"), **kw)
         torch.cuda.synchronize()
         ix.profile_read(reset=True); ix.profile_enable(True)
         t1 = time.perf_counter()
         for _ in range(5):
-            r = ix.search(ds.queries, ef, want=("hops", "dist_calc"))
+            r = ix.search(ds.queries, ef, want=("hops", "dist_calc"), **kw)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / 5
         p = ix.profile_read(reset=True); ix.profile_enable(False)
         rec = (r["ids"].long() == ds.gt).float().mean().item()
         k = {x: round(p[x + "_ms"] / p["calls"], 4) for x in ("project", "walk", "walk_general", "rerank")}
         rr_bytes = ds.nq * ef * 4.0 * ds.d
-        print(json.dumps(dict(config=name, ef=ef, recall=round(rec, 4), qps=round(ds.nq / dt), ms=round(dt * 1e3, 3),
+        print(json.dumps(dict(config=name, ef=ef, aux=bool(kw), recall=round(rec, 4), qps=round(ds.nq / dt), ms=round(dt * 1e3, 3),
                               kernels_ms=k, rerank_GBps=(round(rr_bytes / (k["rerank"] * 1e-3) / 1e9, 1) if k["rerank"] > 0.02 else None),
                               hops=round(r["hops"].float().mean().item(), 1),
                               dist_calc=round(r["dist_calc"].float().mean().item(), 1),
