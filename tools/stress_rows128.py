@@ -24,22 +24,33 @@ for case in range(cases):
     ent = rng.integers(0, n, size=nq).astype(np.uint32)
     ef = int(rng.choice([1, 3, 16, 40, 64, 65, 90, 128, 130, 256, 257]))
     cap = int(rng.choice([0, 0, 0, 128, 512]))
-    tag = (case, n, nq, kind, metric, net_mode, d, deg_hi, ef, cap)
+    # a third of the cases walk with an auxiliary graph (use_second_graph), random llf / hops_bound
+    use_aux = rng.integers(0, 3) == 0
+    aux = datagen.random_graph(rng, n, 0, min(int(rng.choice([3, 40, 70])), n - 1)) if use_aux else None
+    llf = bool(rng.integers(0, 2))
+    hb = int(rng.choice([0, 2, 50, 100000]))
+    okw = dict(aux=aux, llf=llf, hops_bound=hb) if use_aux else {}
+    gkw = dict(aux=True, llf=llf, hops_bound=hb) if use_aux else {}
+    tag = (case, n, nq, kind, metric, net_mode, d, deg_hi, ef, cap, use_aux, llf, hb)
     try:
         if net_mode:
             db_low = orc.project(c.net, c.base)
             if not np.isfinite(db_low).all():
                 continue
             ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net, metric=metric)
-            s = orc.search_batch(oracle.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net, entries=ent, metric=metric)
+            if use_aux:
+                ix.set_aux_graph(*aux)
+            s = orc.search_batch(oracle.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net, entries=ent, metric=metric, **okw)
             if not np.isfinite(orc.project(c.net, c.queries)).all():
                 ix.close(); continue
-            r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc"), hash_capacity=cap)
+            r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc"), hash_capacity=cap, **gkw)
             ok = np.array_equal(r["ids"], s["ids"]) and np.array_equal(r["hops"], s["hops"]) and np.array_equal(r["dist_calc"] + ef, s["dist_calc"])
         else:
             ix = g.Index(c.base, off, nbr, metric=metric)
-            w = orc.walk(c.queries, c.base, off, nbr, ef, entries=ent, metric=metric)
-            r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), hash_capacity=cap)
+            if use_aux:
+                ix.set_aux_graph(*aux)
+            w = orc.walk(c.queries, c.base, off, nbr, ef, entries=ent, metric=metric, **okw)
+            r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), hash_capacity=cap, **gkw)
             ok = (np.array_equal(r["cand"], w["ids"]) and np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"]))
                   and np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]))
         ix.close()
