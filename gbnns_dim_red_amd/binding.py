@@ -23,7 +23,7 @@ FLAG_LLF = 8
 SYMBOLS = [
     "gbnns_index_create", "gbnns_index_destroy", "gbnns_index_set_aux_graph", "gbnns_search_ex", "gbnns_search_batch",
     "gbnns_project", "gbnns_rerank", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd",
-    "gbnns_free", "gbnns_device_count", "gbnns_version", "gbnns_last_error",
+    "gbnns_free", "gbnns_exact_knn", "gbnns_device_count", "gbnns_version", "gbnns_last_error",
 ]
 
 
@@ -100,6 +100,8 @@ def load_library():
                                          C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     lib.gbnns_free.argtypes = [C.c_void_p]
+    lib.gbnns_exact_knn.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
+                                    C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     _lib = lib
     return lib
 
@@ -165,6 +167,37 @@ def build_graph_gd(knn_offsets, knn_nbrs, ds, M, metric=METRIC_L2, reverse=True,
         lib.gbnns_free(po)
         lib.gbnns_free(pn)
     return off, nbr
+
+
+def exact_knn(base, queries, k, metric=METRIC_L2, self_offset=-1, want_dist=False, device=0, stream=None):
+    """gbnns_exact_knn: ids [n_q x k] (and distances) of the k nearest base rows of every query, in the
+    reference's distance arithmetic, ascending (distance, id).  numpy in -> numpy out; torch CUDA in -> torch
+    out.  self_offset >= 0: query i is base row i + self_offset (excluded from its own list)."""
+    lib = load_library()
+    dev = _is_dev(base)
+    if _is_dev(queries) != dev:
+        raise TypeError("base and queries must live in the same memory kind")
+    base = _prep(base, np.float32, "float32")
+    queries = _prep(queries, np.float32, "float32")
+    n, d = int(base.shape[0]), int(base.shape[1])
+    nq = int(queries.shape[0])
+    if int(queries.shape[1]) != d:
+        raise ValueError("dimension mismatch")
+    if dev:
+        import torch
+        ids = torch.empty((nq, k), dtype=torch.int32, device=base.device)
+        dist = torch.empty((nq, k), dtype=torch.float32, device=base.device) if want_dist else None
+        if stream is None:
+            stream = torch.cuda.current_stream(base.device)
+        sptr = stream.cuda_stream
+        device = base.device.index or 0
+    else:
+        ids = np.empty((nq, k), np.uint32)
+        dist = np.empty((nq, k), np.float32) if want_dist else None
+        sptr = None
+    _check(lib.gbnns_exact_knn(device, _ptr(base), n, _ptr(queries), nq, d, k, metric, self_offset, _ptr(ids),
+                               _ptr(dist), MEM_DEVICE if dev else MEM_HOST, sptr))
+    return (ids, dist) if want_dist else ids
 
 
 class Index:

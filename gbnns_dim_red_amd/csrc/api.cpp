@@ -213,6 +213,62 @@ int gbnns_version(void) { return GBNNS_VERSION; }
 
 const char* gbnns_last_error(void) { return g_err.c_str(); }
 
+int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* queries, uint64_t n_q,
+                    uint32_t d, int k, int metric, int64_t self_offset, uint32_t* out_ids, float* out_dist,
+                    int mem_kind, void* stream) {
+    if (!base || !queries || !out_ids) return fail(GBNNS_ERR_INVALID, "null argument");
+    if (n == 0 || n >= (1ull << 32) - 1) return fail(GBNNS_ERR_INVALID, "n must be in [1, 2^32 - 1)");
+    if (n_q >= (1ull << 31)) return fail(GBNNS_ERR_INVALID, "n_q too large");
+    if (k < 1 || k > (1 << 20)) return fail(GBNNS_ERR_INVALID, "k must be in [1, 2^20]");
+    if (d == 0) return fail(GBNNS_ERR_INVALID, "d must be >= 1");
+    if (metric != GBNNS_METRIC_L2 && metric != GBNNS_METRIC_NEG_DOT) return fail(GBNNS_ERR_INVALID, "unknown metric %d", metric);
+    if (mem_kind != GBNNS_MEM_HOST && mem_kind != GBNNS_MEM_DEVICE) return fail(GBNNS_ERR_INVALID, "unknown mem_kind %d", mem_kind);
+    if (d > 128) return fail(GBNNS_ERR_UNSUPPORTED, "gbnns_exact_knn holds a query in registers: d <= 128 (got %u)", d);
+    if (metric == GBNNS_METRIC_NEG_DOT && d % 8 != 0)
+        return fail(GBNNS_ERR_UNSUPPORTED, "gbnns_exact_knn: the negative-dot form needs d %% 8 == 0 (got %u)", d);
+    if (self_offset < -1) return fail(GBNNS_ERR_INVALID, "self_offset must be >= -1");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(GBNNS_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= count) return fail(GBNNS_ERR_NO_DEVICE, "device %d out of range (%d devices)", device, count);
+    if (n_q == 0) return GBNNS_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool host = mem_kind == GBNNS_MEM_HOST;
+    const uint32_t nq = (uint32_t)n_q;
+    DevBuf b_dev, q_dev, ids_dev, dist_dev, heap;
+    struct Release {  // DevBuf has no destructor (index members are released by gbnns_index_destroy)
+        DevBuf* b[5];
+        ~Release() { for (DevBuf* x : b) x->release(); }
+    } release{{&b_dev, &q_dev, &ids_dev, &dist_dev, &heap}};
+    int rc;
+    KnnParams p{};
+    p.base = base; p.q = queries; p.out_ids = out_ids; p.out_dist = out_dist;
+    if (host) {
+        if ((rc = b_dev.ensure((size_t)n * d * 4))) return rc;
+        if ((rc = q_dev.ensure((size_t)nq * d * 4))) return rc;
+        if ((rc = ids_dev.ensure((size_t)nq * k * 4))) return rc;
+        if (out_dist && (rc = dist_dev.ensure((size_t)nq * k * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(b_dev.p, base, (size_t)n * d * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(q_dev.p, queries, (size_t)nq * d * 4, hipMemcpyHostToDevice, s));
+        p.base = b_dev.as<float>(); p.q = q_dev.as<float>(); p.out_ids = ids_dev.as<uint32_t>();
+        p.out_dist = out_dist ? dist_dev.as<float>() : nullptr;
+    }
+    p.bstride = d; p.qstride = d; p.n = n; p.nq = nq; p.dim = d; p.k = k; p.self_offset = self_offset;
+    p.heap_stride = ((size_t)nq + 63) & ~(size_t)63;
+    if ((rc = heap.ensure(p.heap_stride * (size_t)k * 8))) return rc;
+    p.heap = heap.as<uint64_t>();
+    HIP_TRY(hipMemsetAsync(p.heap, 0xFF, p.heap_stride * (size_t)k * 8, s));
+    HIP_TRY(launch_knn_scan(p, metric, s));
+    if (host) {
+        HIP_TRY(hipMemcpyAsync(out_ids, p.out_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+        if (out_dist) HIP_TRY(hipMemcpyAsync(out_dist, p.out_dist, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+    }
+    // the temporaries are released below: wait for the work that uses them
+    HIP_TRY(hipStreamSynchronize(s));
+    return GBNNS_OK;
+}
+
 int gbnns_device_count(void) {
     int c = 0;
     if (hipGetDeviceCount(&c) != hipSuccess) return 0;

@@ -121,6 +121,24 @@ hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s);
 // pad columns [dim, stride) are written as zero.
 hipError_t launch_normalize(float* y, uint32_t stride, uint32_t dim, uint32_t nq, hipStream_t s);
 
+// Exact brute-force kNN scan (knn.hip): getTruth (support_func.h:270-290) generalised to k results per query.
+struct KnnParams {
+    const float* base;       // [n x bstride]
+    uint32_t bstride;        // floats
+    uint64_t n;
+    const float* q;          // [nq x qstride]
+    uint32_t qstride;
+    uint32_t nq;
+    uint32_t dim;            // <= 128
+    int32_t k;
+    int64_t self_offset;     // >= 0: query i is base row i + self_offset and is not its own neighbour; -1: off
+    uint64_t* heap;          // workspace [k x heap_stride], pre-filled with all-ones
+    size_t heap_stride;      // >= nq
+    uint32_t* out_ids;       // [nq x k] ascending (distance, id); 0xFFFFFFFF where fewer than k rows exist
+    float* out_dist;         // optional [nq x k]
+};
+hipError_t launch_knn_scan(const KnnParams& p, int metric, hipStream_t s);
+
 // helpers
 hipError_t launch_fill_u32(uint32_t* p, uint32_t v, size_t count, hipStream_t s);
 

@@ -1,0 +1,208 @@
+// knn.hip -- exact brute-force k-nearest-neighbour scan for gfx950 (MI355X).
+//
+// What it replaces in the reference: the brute-force ground truth getTruth (search/support_func.h:270-290,
+// k = 1, strict `<` over ascending ids) and the exact kNN lists that feed the graph builder
+// (dim_red/support_func.py:374-384 get_nearestneighbors_partly -> `<name>_knn_1k_<style>.ivecs`, read by
+// search/prepare_graph.cpp:66).  Result of query i: the k smallest (Dist(base_j, q_i), j) pairs in ascending
+// pair order -- distances in the reference's own arithmetic (L2Metric::Dist / Angular::Dist, support_func.h:
+// 107-163: same running sums, same order, one rounding per operation), ties broken towards the lower id,
+// which is what getTruth's strict `<` over ascending j does.
+//
+// Shape of the work: n_q x n distances of d dims, every one in a fixed summation order, so this is VALU work
+// (sub / mul / add, packed two wide), not an MFMA GEMM: a matrix-core product would round differently.
+// One thread owns QPT queries held in registers (d <= 128); a workgroup of 128 threads streams the base set
+// through LDS in tiles of 64 rows, every thread reading the same row (LDS broadcast reads, one row serves
+// QPT x 128 queries).  Selection: a max-heap of k (distance key, id) pairs per query in global memory
+// ([k][n_q] so that lanes touching the same heap level coalesce); a row is offered only when it beats the
+// heap's root (kept in a register), which after the first few thousand rows is rare
+// (about k * ln(n / k) times per query), then the heap is sorted in place.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace gbnns {
+
+namespace {
+
+__device__ __forceinline__ uint32_t knn_fkey(float x) {  // order-preserving map float -> u32 (-0 == +0)
+    x = x + 0.0f;
+    const uint32_t b = __float_as_uint(x);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float knn_fkey_inv(uint32_t k) {
+    const uint32_t b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+    return __uint_as_float(b);
+}
+
+constexpr int kKnnThreads = 128;
+constexpr int kKnnTile = 64;  // base rows per LDS tile
+
+// Replaces the root of the max-heap h[0..k) (stride `st` elements between levels) by `key` and restores the
+// heap; returns the new root.
+__device__ __forceinline__ uint64_t heap_replace_root(uint64_t* h, size_t st, int k, uint64_t key) {
+    int i = 0;
+    while (true) {
+        const int l = 2 * i + 1;
+        if (l >= k) break;
+        uint64_t cv = h[(size_t)l * st];
+        int c = l;
+        if (l + 1 < k) {
+            const uint64_t cr = h[(size_t)(l + 1) * st];
+            if (cr > cv) { cv = cr; c = l + 1; }
+        }
+        if (cv <= key) break;
+        h[(size_t)i * st] = cv;
+        i = c;
+    }
+    h[(size_t)i * st] = key;
+    return h[0];
+}
+
+// S = 16-byte steps of a query held in registers (d <= 4 * S), QPT = queries per thread.
+template <int METRIC, int S, int QPT>
+__global__ __launch_bounds__(kKnnThreads) void knn_scan_kernel(KnnParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4* tile = reinterpret_cast<float4*>(smem);  // [kKnnTile][S]
+    const int t = threadIdx.x;
+    // L2Metric::Dist uses the first 4 * floor(d / 4) dims only; the dot form is offered for d % 8 == 0
+    const uint32_t steps = p.dim >> 2;
+    const bool vec_ok = (p.bstride & 3u) == 0;   // rows 16-B aligned -> float4 loads
+    const bool qvec_ok = (p.qstride & 3u) == 0;
+
+    float4 q[QPT][S];
+    uint32_t qi[QPT];
+    bool live[QPT];
+    uint64_t root[QPT];
+#pragma unroll
+    for (int a = 0; a < QPT; ++a) {
+        qi[a] = (blockIdx.x * QPT + a) * kKnnThreads + t;
+        live[a] = qi[a] < p.nq;
+        root[a] = ~0ull;  // the heap starts filled with all-ones keys
+        const float* qp = p.q + (size_t)(live[a] ? qi[a] : 0u) * p.qstride;
+#pragma unroll
+        for (int c = 0; c < S; ++c) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((uint32_t)c < steps) {
+                if (qvec_ok) v = reinterpret_cast<const float4*>(qp)[c];
+                else v = make_float4(qp[4 * c], qp[4 * c + 1], qp[4 * c + 2], qp[4 * c + 3]);
+            }
+            q[a][c] = v;
+        }
+    }
+
+    for (uint64_t base0 = 0; base0 < p.n; base0 += kKnnTile) {
+        __syncthreads();  // everyone is done with the previous tile
+        for (int e = t; e < kKnnTile * S; e += kKnnThreads) {
+            const int r = e / S, c = e % S;
+            const uint64_t row = base0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.n && (uint32_t)c < steps) {
+                const float* bp = p.base + (size_t)row * p.bstride;
+                if (vec_ok) v = reinterpret_cast<const float4*>(bp)[c];
+                else v = make_float4(bp[4 * c], bp[4 * c + 1], bp[4 * c + 2], bp[4 * c + 3]);
+            }
+            tile[e] = v;
+        }
+        __syncthreads();
+        const int rows = (p.n - base0 < (uint64_t)kKnnTile) ? (int)(p.n - base0) : kKnnTile;
+        for (int r = 0; r < rows; ++r) {
+            float dist[QPT];
+            if constexpr (METRIC == 0) {
+                float s[QPT][4];
+#pragma unroll
+                for (int a = 0; a < QPT; ++a) s[a][0] = s[a][1] = s[a][2] = s[a][3] = 0.f;
+#pragma unroll
+                for (int c = 0; c < S; ++c) {
+                    const float4 b = tile[r * S + c];  // same address in every lane: LDS broadcast
+#pragma unroll
+                    for (int a = 0; a < QPT; ++a) {  // support_func.h:113-124: e = a - b; sum += e * e, four lanes
+                        float e;
+                        e = b.x - q[a][c].x; s[a][0] = s[a][0] + e * e;
+                        e = b.y - q[a][c].y; s[a][1] = s[a][1] + e * e;
+                        e = b.z - q[a][c].z; s[a][2] = s[a][2] + e * e;
+                        e = b.w - q[a][c].w; s[a][3] = s[a][3] + e * e;
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < QPT; ++a) dist[a] = ((s[a][0] + s[a][1]) + s[a][2]) + s[a][3];  // :125-126
+            } else {
+                float cs[QPT][8];
+#pragma unroll
+                for (int a = 0; a < QPT; ++a)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) cs[a][j] = 0.f;
+#pragma unroll
+                for (int c = 0; c < S; ++c) {
+                    const float4 b = tile[r * S + c];
+                    const int o = (c & 1) * 4;  // support_func.h:140-147: eight running sums, k mod 8
+#pragma unroll
+                    for (int a = 0; a < QPT; ++a) {
+                        cs[a][o + 0] = cs[a][o + 0] + b.x * q[a][c].x;
+                        cs[a][o + 1] = cs[a][o + 1] + b.y * q[a][c].y;
+                        cs[a][o + 2] = cs[a][o + 2] + b.z * q[a][c].z;
+                        cs[a][o + 3] = cs[a][o + 3] + b.w * q[a][c].w;
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < QPT; ++a) {
+                    const float m0 = cs[a][4] + cs[a][0], m1 = cs[a][5] + cs[a][1], m2 = cs[a][6] + cs[a][2],
+                                m3 = cs[a][7] + cs[a][3];       // :148 hi half onto lo half
+                    dist[a] = -((m0 + m1) + (m2 + m3));          // :160-162
+                }
+            }
+            const uint64_t row = base0 + r;
+#pragma unroll
+            for (int a = 0; a < QPT; ++a) {
+                const uint64_t key = ((uint64_t)knn_fkey(dist[a]) << 32) | (uint32_t)row;
+                const bool self = p.self_offset >= 0 && row == (uint64_t)qi[a] + (uint64_t)p.self_offset;
+                if (live[a] && !self && key < root[a])
+                    root[a] = heap_replace_root(p.heap + qi[a], p.heap_stride, p.k, key);
+            }
+        }
+    }
+
+    // heap sort in place (ascending), then the outputs; every lane runs the same trip counts
+#pragma unroll
+    for (int a = 0; a < QPT; ++a) {
+        if (!live[a]) continue;
+        uint64_t* h = p.heap + qi[a];
+        const size_t st = p.heap_stride;
+        for (int m = p.k - 1; m > 0; --m) {
+            const uint64_t last = h[(size_t)m * st];
+            h[(size_t)m * st] = h[0];
+            heap_replace_root(h, st, m, last);
+        }
+        for (int e = 0; e < p.k; ++e) {
+            const uint64_t kv = h[(size_t)e * st];
+            const uint32_t id = (uint32_t)kv;
+            p.out_ids[(size_t)qi[a] * p.k + e] = id;  // all-ones (never offered) -> 0xFFFFFFFF: fewer than k rows
+            if (p.out_dist)
+                p.out_dist[(size_t)qi[a] * p.k + e] = (kv == ~0ull) ? __builtin_inff() : knn_fkey_inv((uint32_t)(kv >> 32));
+        }
+    }
+}
+
+template <int METRIC, int S, int QPT>
+hipError_t launch_knn_t(const KnnParams& p, hipStream_t s) {
+    const size_t lds = (size_t)kKnnTile * S * 16;
+    const unsigned grid = (unsigned)((p.nq + (uint64_t)kKnnThreads * QPT - 1) / ((uint64_t)kKnnThreads * QPT));
+    hipLaunchKernelGGL((knn_scan_kernel<METRIC, S, QPT>), dim3(grid), dim3(kKnnThreads), lds, s, p);
+    return hipGetLastError();
+}
+
+template <int METRIC>
+hipError_t launch_knn_m(const KnnParams& p, hipStream_t s) {
+    if (p.dim <= 32) return launch_knn_t<METRIC, 8, 2>(p, s);
+    if (p.dim <= 64) return launch_knn_t<METRIC, 16, 2>(p, s);
+    return launch_knn_t<METRIC, 32, 1>(p, s);
+}
+
+}  // namespace
+
+hipError_t launch_knn_scan(const KnnParams& p, int metric, hipStream_t s) {
+    if (p.nq == 0) return hipSuccess;
+    return metric == 1 ? launch_knn_m<1>(p, s) : launch_knn_m<0>(p, s);
+}
+
+}  // namespace gbnns

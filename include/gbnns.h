@@ -180,6 +180,21 @@ int gbnns_build_graph_gd(const uint64_t* knn_offsets, const uint32_t* knn_nbrs, 
                          uint64_t** out_offsets, uint32_t** out_nbrs);
 void gbnns_free(void* p);
 
+/* Exact brute-force nearest neighbours on the device, in the reference's distance arithmetic.
+ *   k = 1: getTruth (support_func.h:270-290) -- the strict minimum of Dist(base_j, q_i) over ascending j;
+ *   k > 1: the exact kNN lists that feed the graph builder (dim_red/support_func.py:374-384 writes
+ *          `<name>_knn_1k_<style>.ivecs`, prepare_graph.cpp:66 reads it).
+ * out_ids [n_q x k] (and optional out_dist): the k smallest (distance, id) pairs of each query in ascending
+ * pair order, ties towards the lower id; 0xFFFFFFFF / +inf where fewer than k rows qualify.
+ * self_offset >= 0 says query i IS base row i + self_offset and must not be reported as its own neighbour
+ * (kNN graph of a set over itself, possibly computed in slices of queries); -1 turns that off.
+ * d <= 128; GBNNS_METRIC_NEG_DOT needs d % 8 == 0 (else GBNNS_ERR_UNSUPPORTED).  Buffers are all host or all
+ * device (mem_kind); the work runs on `stream` and the call returns when it has finished (a k x n_q x 8-byte
+ * workspace lives for the duration of the call). */
+int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* queries, uint64_t n_q,
+                    uint32_t d, int k, int metric, int64_t self_offset, uint32_t* out_ids, float* out_dist,
+                    int mem_kind, void* stream);
+
 int gbnns_device_count(void);
 int gbnns_version(void);
 const char* gbnns_last_error(void);

@@ -115,6 +115,20 @@ class Oracle(_Base):
                              C.c_int])
         self._gd_fetch = self._fn("hnswlike_gd_fetch", None, [_u64p, _u32p])
         self._max_threads = self._fn("max_threads", C.c_int, [])
+        self._knn = self._fn("exact_knn", None,
+                             [_f32p, C.c_uint64, _f32p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int64,
+                              _u32p, _f32p, C.c_int])
+
+    def exact_knn(self, base, queries, k, metric=L2, self_offset=-1, threads=0):
+        """(ids, dists) [nq x k]: the k smallest (Dist(base_j, q_i), j) pairs, ascending."""
+        base, queries = _f32(base), _f32(queries)
+        n, d = base.shape
+        nq = queries.shape[0]
+        ids = np.empty((nq, k), np.uint32)
+        dist = np.empty((nq, k), np.float32)
+        self._knn(_p(base, _f32p), n, _p(queries, _f32p), nq, d, k, metric, self_offset, _p(ids, _u32p),
+                  _p(dist, _f32p), threads)
+        return ids, dist
 
     def project(self, net, q, threads=1):
         l1, l2, l3 = (_f32(x) for x in net)
@@ -250,7 +264,17 @@ class Ref(_Base):
             [C.c_int] * 5 + [_i32p, C.c_int, C.c_void_p, _f32p, _f32p, _f32p, _f32p, _u32p,
                              C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_uint32])
         self._max_threads = self._fn("max_threads", C.c_int, [])
+        self._truth = self._fn("get_truth", None, [_f32p, C.c_uint64, _f32p, C.c_uint64, C.c_int, C.c_int,
+                                                   _u32p, C.c_int])
         self._graphs = {}
+
+    def get_truth(self, base, queries, metric=L2, threads=4):
+        """The reference's getTruth: id of the nearest base row of every query."""
+        base, queries = _f32(base), _f32(queries)
+        out = np.empty(queries.shape[0], np.uint32)
+        self._truth(_p(base, _f32p), base.shape[0], _p(queries, _f32p), queries.shape[0], base.shape[1],
+                    metric, _p(out, _u32p), threads)
+        return out
 
     def _graph(self, off, nbr):
         off, nbr = _u64(off), _u32(nbr)

@@ -477,6 +477,38 @@ void gbo_hnswlike_gd_fetch(uint64_t* out_off, uint32_t* out_nbr) {
     g_gd.shrink_to_fit();
 }
 
+// Exact brute-force nearest neighbours: getTruth (support_func.h:270-290) generalised to k results.
+// getTruth keeps the strict minimum of Dist(base_j, query) over ascending j, i.e. the smallest
+// (distance, id) pair; here the k smallest pairs in ascending pair order.  self_offset >= 0: query i is
+// base row i + self_offset and is skipped.  Missing results (k > rows) are 0xFFFFFFFF / +inf.
+void gbo_exact_knn(const float* base, uint64_t n, const float* queries, uint64_t nq, int d, int k,
+                   int metric, int64_t self_offset, uint32_t* out_ids, float* out_dist, int threads) {
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel
+    {
+        std::vector<std::pair<float, uint32_t>> all;
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t i = 0; i < (int64_t)nq; ++i) {
+            all.clear();
+            for (uint64_t j = 0; j < n; ++j) {
+                if (self_offset >= 0 && j == (uint64_t)i + (uint64_t)self_offset) continue;
+                float dv = metric_dist(metric, base + (size_t)j * d, queries + (size_t)i * d, (size_t)d);
+                dv = dv + 0.0f;  // -0 and +0 compare equal in getTruth's `<`; canonical form for the pair order
+                all.emplace_back(dv, (uint32_t)j);
+            }
+            const size_t kk = std::min<size_t>((size_t)k, all.size());
+            std::partial_sort(all.begin(), all.begin() + kk, all.end());
+            for (int e = 0; e < k; ++e) {
+                const bool have = (size_t)e < kk;
+                out_ids[(size_t)i * k + e] = have ? all[e].second : 0xFFFFFFFFu;
+                if (out_dist) out_dist[(size_t)i * k + e] = have ? all[e].first : INFINITY;
+            }
+        }
+    }
+}
+
 int gbo_max_threads() {
 #ifdef _OPENMP
     return omp_get_max_threads();

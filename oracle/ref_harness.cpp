@@ -278,6 +278,15 @@ void ref_perform_real_tests(int n, int d, int d_low, int n_q, int n_tr, const in
                                truth, output_txt, graph_name, number_exper, number_of_threads, nullptr, 0, 1);
 }
 
+// getTruth (support_func.h:270): brute-force nearest base row of every query, the reference's own code.
+void ref_get_truth(const float* base, uint64_t n, const float* queries, uint64_t nq, int d, int metric,
+                   uint32_t* out, int threads) {
+    vector<float> ds(base, base + (size_t)n * d), qv(queries, queries + (size_t)nq * d);
+    omp_set_num_threads(threads > 0 ? threads : 1);
+    vector<uint32_t> t = getTruth(ds, qv, (int)n, d, (int)nq, pick_metric(metric));
+    for (uint64_t i = 0; i < nq; ++i) out[i] = t[i];
+}
+
 int ref_max_threads() { return omp_get_max_threads(); }
 
 }  // extern "C"

@@ -683,3 +683,50 @@ def test_auxiliary_graph_vs_oracle_all_kernels(g, orc):
         assert np.array_equal(r["hops"], w["hops"])
         assert ix.profile_read()["general_queries"] == 24
         ix.close()
+
+
+def test_exact_knn_vs_get_truth_and_oracle(g, orc):
+    """gbnns_exact_knn: k = 1 equals the compiled reference's getTruth (tests/golden/knn_toy.npz), k > 1 equals the
+    brute-force restatement -- ids and distance bit patterns; d % 4 != 0, tie-heavy data, both metrics, a set
+    against itself in slices, k larger than the set, device buffers."""
+    import json
+    import torch
+    z = np.load(gu.GOLDEN_DIR + "/knn_toy.npz")
+    for name, metric, space in json.loads(bytes(z["meta"]).decode())["cases"]:
+        c = gu.load(name).case
+        if space == "low":
+            base, q = orc.project(c.net, c.base, threads=8), orc.project(c.net, c.queries)
+        else:
+            base, q = c.base, c.queries
+        d = base.shape[1]
+        if d > 128 or (metric == 1 and d % 8):
+            with pytest.raises(g.GbnnsError):
+                g.exact_knn(base, q, 1, metric=metric)
+            continue
+        truth = z[f"truth_{name}_{metric}_{space}"]
+        ids1 = g.exact_knn(base, q, 1, metric=metric)
+        assert np.array_equal(ids1[:, 0], truth), (name, metric, space)
+        for k in (5, 33):
+            ids, dist = g.exact_knn(base, q, k, metric=metric, want_dist=True)
+            oi, od = orc.exact_knn(base, q, k, metric, threads=8)
+            assert np.array_equal(ids, oi), (name, metric, space, k)
+            assert np.array_equal(gu.bits(dist), gu.bits(od)), (name, metric, space, k)
+    # kNN graph of a set over itself, computed in two slices of queries; every register-tile width
+    for d, n in ((32, 3000), (24, 1111), (64, 2000), (100, 1500), (128, 1300)):
+        c = datagen.Case("k", 4000 + d, n, 8, d, 4, 8)
+        k = 20
+        want, _ = orc.exact_knn(c.base, c.base, k, 0, self_offset=0, threads=8)
+        half = n // 2 + 7
+        a = g.exact_knn(c.base, c.base[:half], k, self_offset=0)
+        b = g.exact_knn(c.base, c.base[half:], k, self_offset=half)
+        assert np.array_equal(np.concatenate([a, b]), want), d
+    # more neighbours asked for than rows exist; device buffers give the same answer as host buffers
+    c = datagen.Case("k", 4999, 40, 70, 16, 4, 8, kind="lattice")
+    ids, dist = g.exact_knn(c.base, c.queries, 64, want_dist=True)
+    oi, od = orc.exact_knn(c.base, c.queries, 64, 0)
+    assert np.array_equal(ids, oi) and np.array_equal(gu.bits(dist), gu.bits(od))
+    assert (ids[:, 40:] == 0xFFFFFFFF).all() and np.isinf(dist[:, 40:]).all()
+    tb, tq = torch.from_numpy(c.base).cuda(), torch.from_numpy(c.queries).cuda()
+    tids, tdist = g.exact_knn(tb, tq, 64, want_dist=True)
+    assert np.array_equal(tids.cpu().numpy().view(np.uint32), oi)
+    assert np.array_equal(gu.bits(tdist.cpu().numpy()), gu.bits(od))

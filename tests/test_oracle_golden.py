@@ -133,6 +133,36 @@ def test_auxiliary_graph_walks(orc):
                 assert np.array_equal(p["dist_calc"], z[f"plain_dc_{tag}"]), tag
 
 
+def _knn_cases():
+    import json
+    z = np.load(gu.GOLDEN_DIR + "/knn_toy.npz")
+    for name, metric, space in json.loads(bytes(z["meta"]).decode())["cases"]:
+        yield name, metric, space, z[f"truth_{name}_{metric}_{space}"]
+
+
+def test_exact_knn_restatement_vs_get_truth(orc):
+    """k = 1 of the brute-force restatement is the reference's getTruth (support_func.h:270-290); k > 1 extends
+    it by the same (distance, id) order."""
+    for name, metric, space, truth in _knn_cases():
+        c = gu.load(name).case
+        base, q = (orc.project(c.net, c.base, threads=4), orc.project(c.net, c.queries)) if space == "low" \
+            else (c.base, c.queries)
+        ids1, _ = orc.exact_knn(base, q, 1, metric)
+        assert np.array_equal(ids1[:, 0], truth), (name, metric, space)
+        ids, dist = orc.exact_knn(base, q, 7, metric)
+        assert np.array_equal(ids[:, 0], truth)
+        # ascending (distance, id) pairs
+        assert (np.diff(dist, axis=1) >= 0).all()
+        tie = np.diff(dist, axis=1) == 0
+        assert (np.diff(ids.astype(np.int64), axis=1)[tie] > 0).all()
+    # a set against itself: the row itself is left out
+    c = gu.load("tail_toy").case
+    ids, _ = orc.exact_knn(c.base, c.base[100:164], 5, 0, self_offset=100)
+    assert not (ids == (np.arange(64) + 100)[:, None]).any()
+    ids0, _ = orc.exact_knn(c.base, c.base[100:164], 1, 0)
+    assert np.array_equal(ids0[:, 0], np.arange(64) + 100)  # distinct points: nearest is itself
+
+
 def test_graph_builder_restatement(orc):
     g = gu.load("tail_toy")
     c = g.case
