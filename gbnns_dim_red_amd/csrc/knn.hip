@@ -35,6 +35,8 @@ __device__ __forceinline__ float knn_fkey_inv(uint32_t k) {
     return __uint_as_float(b);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int kKnnThreads = 128;
 constexpr int kKnnTile = 64;  // base rows per LDS tile
 
@@ -109,46 +111,46 @@ __global__ __launch_bounds__(kKnnThreads) void knn_scan_kernel(KnnParams p) {
         for (int r = 0; r < rows; ++r) {
             float dist[QPT];
             if constexpr (METRIC == 0) {
-                float s[QPT][4];
+                // two-wide vectors so that the compiler emits v_pk_add_f32 / v_pk_mul_f32 (each lane of a packed
+                // instruction is an ordinary IEEE operation: same results as the scalar form)
+                f32x2 s01[QPT], s23[QPT];
 #pragma unroll
-                for (int a = 0; a < QPT; ++a) s[a][0] = s[a][1] = s[a][2] = s[a][3] = 0.f;
+                for (int a = 0; a < QPT; ++a) s01[a] = s23[a] = f32x2{0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < S; ++c) {
                     const float4 b = tile[r * S + c];  // same address in every lane: LDS broadcast
+                    const f32x2 b01{b.x, b.y}, b23{b.z, b.w};
 #pragma unroll
                     for (int a = 0; a < QPT; ++a) {  // support_func.h:113-124: e = a - b; sum += e * e, four lanes
-                        float e;
-                        e = b.x - q[a][c].x; s[a][0] = s[a][0] + e * e;
-                        e = b.y - q[a][c].y; s[a][1] = s[a][1] + e * e;
-                        e = b.z - q[a][c].z; s[a][2] = s[a][2] + e * e;
-                        e = b.w - q[a][c].w; s[a][3] = s[a][3] + e * e;
+                        const f32x2 e01 = b01 - f32x2{q[a][c].x, q[a][c].y};
+                        const f32x2 e23 = b23 - f32x2{q[a][c].z, q[a][c].w};
+                        s01[a] = s01[a] + e01 * e01;
+                        s23[a] = s23[a] + e23 * e23;
                     }
                 }
 #pragma unroll
-                for (int a = 0; a < QPT; ++a) dist[a] = ((s[a][0] + s[a][1]) + s[a][2]) + s[a][3];  // :125-126
+                for (int a = 0; a < QPT; ++a) dist[a] = ((s01[a].x + s01[a].y) + s23[a].x) + s23[a].y;  // :125-126
             } else {
-                float cs[QPT][8];
+                f32x2 cs[QPT][4];  // eight running sums (k mod 8) as four pairs: {0,1} {2,3} {4,5} {6,7}
 #pragma unroll
                 for (int a = 0; a < QPT; ++a)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) cs[a][j] = 0.f;
+                    for (int j = 0; j < 4; ++j) cs[a][j] = f32x2{0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < S; ++c) {
                     const float4 b = tile[r * S + c];
-                    const int o = (c & 1) * 4;  // support_func.h:140-147: eight running sums, k mod 8
+                    const f32x2 b01{b.x, b.y}, b23{b.z, b.w};
+                    const int o = (c & 1) * 2;  // support_func.h:140-147
 #pragma unroll
                     for (int a = 0; a < QPT; ++a) {
-                        cs[a][o + 0] = cs[a][o + 0] + b.x * q[a][c].x;
-                        cs[a][o + 1] = cs[a][o + 1] + b.y * q[a][c].y;
-                        cs[a][o + 2] = cs[a][o + 2] + b.z * q[a][c].z;
-                        cs[a][o + 3] = cs[a][o + 3] + b.w * q[a][c].w;
+                        cs[a][o + 0] = cs[a][o + 0] + b01 * f32x2{q[a][c].x, q[a][c].y};
+                        cs[a][o + 1] = cs[a][o + 1] + b23 * f32x2{q[a][c].z, q[a][c].w};
                     }
                 }
 #pragma unroll
                 for (int a = 0; a < QPT; ++a) {
-                    const float m0 = cs[a][4] + cs[a][0], m1 = cs[a][5] + cs[a][1], m2 = cs[a][6] + cs[a][2],
-                                m3 = cs[a][7] + cs[a][3];       // :148 hi half onto lo half
-                    dist[a] = -((m0 + m1) + (m2 + m3));          // :160-162
+                    const f32x2 m01 = cs[a][2] + cs[a][0], m23 = cs[a][3] + cs[a][1];  // :148 hi half onto lo half
+                    dist[a] = -((m01.x + m01.y) + (m23.x + m23.y));                     // :160-162
                 }
             }
             const uint64_t row = base0 + r;

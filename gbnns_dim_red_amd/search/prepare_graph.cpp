@@ -6,7 +6,10 @@
 //
 // Files (reference naming): <data_dir>/<dataset>_base_<lat_name>.fvecs,
 // <models_dir>/<dataset>_knn_1k_<lat_name>.ivecs  ->  <models_dir>/<dataset>_gd_knn_<lat_name>.ivecs
-// GBNNS_GD_M overrides M.  Host-only program (the builder is host code, as in the reference).
+// GBNNS_GD_M overrides M.  The builder is host code, as in the reference.  When the kNN file does not exist it
+// is produced first, on the device: exact K-NN lists of the low-dim base set over itself (gbnns_exact_knn, the
+// reference's distance arithmetic; K = 1000 as the file name says, GBNNS_KNN_K overrides) -- the step the
+// reference leaves to dim_red/support_func.py:374-384 (faiss).
 #include "search_function.h"
 
 static string pickPath(int argc, char** argv, int pos, const char* env, const string& fallback) {
@@ -38,6 +41,30 @@ int main(int argc, char** argv) {
 
     L2Metric l2 = L2Metric();
     std::vector<float> db_low = loadXvecs<float>(dataDir + "/" + datasetName + "_base_" + fileLatName + ".fvecs", d_low, n);
+    const string knnPath = modelsDir + "/" + datasetName + "_knn_1k_" + fileLatName + ".ivecs";
+    if (!std::ifstream(knnPath).good()) {
+        int K = 1000;
+        if (const char* e = getenv("GBNNS_KNN_K")) K = atoi(e);
+        if ((size_t)K > n - 1) K = (int)n - 1;
+        if (K < 1) {
+            cout << "kNN lists need at least two base vectors" << endl;
+            return 1;
+        }
+        cout << "kNN file missing: building exact " << K << "-NN lists on the device" << endl;
+        const char* dev = getenv("GBNNS_DEVICE");
+        vector<vector<uint32_t>> knn(n);
+        const size_t slice = 32768;  // queries per call: bounds the k x slice workspace and the id buffer
+        vector<uint32_t> ids;
+        for (size_t s0 = 0; s0 < n; s0 += slice) {
+            const size_t cnt = std::min(slice, n - s0);
+            ids.resize(cnt * K);
+            if (gbnns_exact_knn(dev ? atoi(dev) : 0, db_low.data(), n, db_low.data() + s0 * d_low, cnt, (uint32_t)d_low, K,
+                                GBNNS_METRIC_L2, (int64_t)s0, ids.data(), nullptr, GBNNS_MEM_HOST, nullptr))
+                gbnnsDie("gbnns_exact_knn");
+            for (size_t i = 0; i < cnt; ++i) knn[s0 + i].assign(ids.begin() + i * K, ids.begin() + (i + 1) * K);
+        }
+        writeEdges(knnPath, knn);
+    }
     vector<vector<uint32_t>> knn_low =
         loadEdges(modelsDir + "/" + datasetName + "_knn_1k_" + fileLatName + ".ivecs", n, "knn_low");
 

@@ -129,3 +129,29 @@ def test_naive_test_result_lines(tmp_path, orc):
     p = subprocess.run([nbin, ds, str(data), str(models), str(tmp_path), str(params)], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 1 and "KL graph files missing" in p.stdout
+
+
+def test_prepare_graph_builds_missing_knn_on_device(tmp_path, orc):
+    """prepare_graph without a kNN file: exact K-NN lists are built on the device first (gbnns_exact_knn), written
+    in the reference's edge format, then pruned -- both files equal what the CPU restatements give."""
+    pbin = os.path.join(ROOT, "gbnns_dim_red_amd", "search", "prepare_graph")
+    gd = gu.load("tail_toy")
+    c = gd.case
+    db_low = orc.project(c.net, c.base)
+    write_xvecs(tmp_path / "toy_base_lat.fvecs", db_low)
+    (tmp_path / "params.txt").write_text(f"toy n {c.n}\ntoy d_low {c.dlow}\n")
+    K, M = 24, 12
+    env = dict(os.environ, GBNNS_GD_M=str(M), GBNNS_KNN_K=str(K))
+    p = subprocess.run([pbin, "toy", "lat", str(tmp_path), str(tmp_path), str(tmp_path / "params.txt")],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "building exact 24-NN lists on the device" in p.stdout
+    want_knn, _ = orc.exact_knn(db_low, db_low, K, 0, self_offset=0, threads=8)
+    raw = np.fromfile(tmp_path / "toy_knn_1k_lat.ivecs", np.uint32).reshape(c.n, K + 1)
+    assert (raw[:, 0] == K).all() and np.array_equal(raw[:, 1:], want_knn)
+    koff = np.arange(c.n + 1, dtype=np.uint64) * np.uint64(K)
+    off, nbr = orc.hnswlike_gd(koff, want_knn.reshape(-1), db_low, M, reverse=True, threads=4)
+    got = np.fromfile(tmp_path / "toy_gd_knn_lat.ivecs", np.uint32)
+    want = np.concatenate([np.concatenate([[int(off[i + 1] - off[i])], nbr[int(off[i]):int(off[i + 1])]])
+                           for i in range(c.n)]).astype(np.uint32)
+    assert np.array_equal(got, want)
