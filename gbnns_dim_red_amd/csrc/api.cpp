@@ -788,16 +788,16 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
             need = target + target / 3 + 64;
         }
         const size_t gran = 512;  // LDS allocation granularity
-        const size_t want = (lds_fixed + (size_t)need * 4 + gran - 1) / gran * gran;
+        const size_t want = (lds_fixed + walk_hash_bytes(need + 4, hot) + gran - 1) / gran * gran;
         size_t slots = std::min<size_t>(32, kMaxLds / want);
         if (slots == 0) {
             cap = need;  // does not fit LDS at all: the general kernel takes the batch
         } else {
             const size_t share = kMaxLds / slots / gran * gran;
-            cap = (uint32_t)((share - lds_fixed) / 4);
+            cap = walk_hash_entries(share - lds_fixed, hot);
         }
     }
-    cap &= ~3u;  // whole 4-slot buckets
+    cap = walk_hash_entries(walk_hash_bytes(cap, hot), hot);  // whole buckets
     w.hash_cap = cap;
     w.hash_limit = cap - cap / 16;
     w.all_general = walk_fast_lds_bytes(w, hot) > kMaxLds ? 1 : 0;

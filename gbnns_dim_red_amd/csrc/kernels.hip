@@ -1552,7 +1552,7 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
                                                uint32_t nbuckets, QP qh, uint64_t& claimed) {
     const uint32_t end = lds_base + (nbuckets << 4);
     const uint32_t mulc = 0x9E3779B1u;
-    uint32_t basev = lds_base, neg1 = 0xFFFFFFFFu, addr, t0, t1, t2, key;
+    uint32_t basev = lds_base, inc = 1u << 24, addr, t0, t1, t2, key;
     uint64_t fresh, act, sv;
     f32x2 ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3;  // row halves, then their squared differences
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1565,7 +1565,11 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
         "global_load_dwordx4 v[52:55], %[roff], %[db] offset:16\n\t"
         "global_load_dwordx4 v[56:59], %[roff], %[db] offset:32\n\t"
         "global_load_dwordx4 v[60:63], %[roff], %[db] offset:48\n\t"
-        // ---- visited set: even lanes of `valid` (visited_claim_mask)
+        // ---- visited set: even lanes of `valid`.  Packed table: a 16-byte bucket holds five 24-bit ids (bits
+        // 24k .. 24k+23, all-ones = empty) and, in its top byte, the number of slots handed out.  An id is in the
+        // set iff it is found in a bucket of its probe sequence before a bucket with a free slot; a new id takes
+        // the slot index an atomic add on that counter returns (unique per lane, so no compare-and-swap and no
+        // retry inside a bucket) and writes its three bytes.
         "v_mul_lo_u32 %[t0], %[id], %[mulc]\n\t"
         "s_and_b32 exec_lo, exec_lo, 0x55555555\n\t"
         "s_and_b32 exec_hi, exec_hi, 0x55555555\n\t"
@@ -1575,38 +1579,43 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
         "1:\n\t"
         "ds_read_b128 v[68:71], %[addr]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_xor_b32 %[t0], v68, %[id]\n\t"
-        "v_xor_b32 %[t1], v69, %[id]\n\t"
-        "v_xor_b32 %[t2], v70, %[id]\n\t"
-        "v_min3_u32 %[t0], %[t0], %[t1], %[t2]\n\t"
-        "v_xor_b32 %[t2], v71, %[id]\n\t"
-        "v_ashrrev_i32 v68, 31, v68\n\t"
-        "v_ashrrev_i32 v69, 31, v69\n\t"
-        "v_ashrrev_i32 v70, 31, v70\n\t"
-        "v_min_u32 %[t0], %[t0], %[t2]\n\t"
-        "v_ashrrev_i32 %[t2], 31, v71\n\t"
-        "v_add3_u32 %[t1], v68, v69, v70\n\t"
-        "v_cmp_ne_u32 vcc, 0, %[t0]\n\t"
-        "v_add3_u32 %[t1], %[t1], %[t2], 4\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
+        "v_bfe_u32 v64, v68, 0, 24\n\t"                        // slot 0
+        "v_alignbit_b32 v65, v69, v68, 24\n\t"                 // slot 1 (bits 24..47) in the low 24 bits
+        "v_alignbit_b32 v66, v70, v69, 16\n\t"                 // slot 2 (bits 48..71)
+        "v_lshrrev_b32 v67, 8, v70\n\t"                        // slot 3 (bits 72..95)
+        "v_bfe_u32 %[t1], v71, 0, 24\n\t"                      // slot 4 (bits 96..119)
+        "v_bfe_u32 v65, v65, 0, 24\n\t"
+        "v_bfe_u32 v66, v66, 0, 24\n\t"
+        "v_xor_b32 v64, v64, %[id]\n\t"
+        "v_xor_b32 v65, v65, %[id]\n\t"
+        "v_xor_b32 v66, v66, %[id]\n\t"
+        "v_xor_b32 v67, v67, %[id]\n\t"
+        "v_xor_b32 %[t1], %[t1], %[id]\n\t"
+        "v_min3_u32 v64, v64, v65, v66\n\t"
+        "v_min3_u32 v64, v64, v67, %[t1]\n\t"                  // 0 <=> id is in the bucket
+        "v_lshrrev_b32 %[t1], 24, v71\n\t"                     // slots handed out
+        "v_cmp_ne_u32 vcc, 0, v64\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"                        // lanes that found their id are done
         "s_cbranch_execz 9f\n\t"
         "s_mov_b64 %[act], exec\n\t"
-        "v_lshl_add_u32 %[t2], %[t1], 2, %[addr]\n"
-        "2:\n\t"
-        "v_cmp_gt_u32 vcc, 4, %[t1]\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"
+        "v_cmp_gt_u32 vcc, 5, %[t1]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"                        // the bucket had room when it was read
         "s_cbranch_execz 3f\n\t"
-        "ds_cmpst_rtn_b32 %[t0], %[t2], %[neg1], %[id]\n\t"
-        "v_add_u32 %[t1], 1, %[t1]\n\t"
-        "v_add_u32 %[t2], 4, %[t2]\n\t"
+        "ds_add_rtn_u32 %[t0], %[addr], %[inc] offset:12\n\t"  // take a slot number
+        "v_lshrrev_b32 %[t2], 8, %[id]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_eq_u32 vcc, -1, %[t0]\n\t"
-        "s_or_b64 %[fresh], %[fresh], vcc\n\t"
-        "s_andn2_b64 %[act], %[act], vcc\n\t"
-        "s_andn2_b64 exec, exec, vcc\n\t"
-        "s_cbranch_execnz 2b\n"
+        "v_lshrrev_b32 %[t0], 24, %[t0]\n\t"
+        "v_cmp_gt_u32 vcc, 5, %[t0]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"                        // lanes whose number is a real slot
+        "s_cbranch_execz 3f\n\t"
+        "v_mad_u32_u24 %[t0], %[t0], 3, %[addr]\n\t"           // byte address of the slot
+        "ds_write_b8 %[t0], %[id]\n\t"
+        "ds_write_b8 %[t0], %[t2] offset:1\n\t"
+        "ds_write_b8_d16_hi %[t0], %[id] offset:2\n\t"
+        "s_or_b64 %[fresh], %[fresh], exec\n\t"
+        "s_andn2_b64 %[act], %[act], exec\n"
         "3:\n\t"
-        "s_mov_b64 exec, %[act]\n\t"
+        "s_mov_b64 exec, %[act]\n\t"                           // absent and unplaced: their bucket is full
         "s_cbranch_execz 9f\n\t"
         "v_add_u32 %[addr], 16, %[addr]\n\t"
         "v_cmp_eq_u32 vcc, %[end], %[addr]\n\t"
@@ -1660,7 +1669,7 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
         "v_or_b32 %[key], 0x80000000, %[key]"                  // fkey of a non-negative float
         : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
           [addr] "=&v"(addr), [key] "=&v"(key)
-        : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [neg1] "v"(neg1), [mulc] "s"(mulc),
+        : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [inc] "v"(inc), [mulc] "s"(mulc),
           [nb] "s"(nbuckets), [roff] "v"(roff), [db] "s"(db_base), GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
         : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",
           "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
@@ -1682,7 +1691,9 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     const uint32_t cap = p.hash_cap;
     const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
 
-    for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
+    // packed visited set (hot_expand): cap / 5 buckets of 16 bytes, five 24-bit ids + a counter byte each
+    const uint32_t nbuckets = cap / 5u;
+    for (uint32_t i = lane; i < nbuckets * 4u; i += 64) hash[i] = (i & 3u) == 3u ? 0x00FFFFFFu : 0xFFFFFFFFu;
     if (lane < 32) qf[lane] = p.q[(size_t)qi * p.qstride + lane];
     wave_sync();
     RowRegs<4> qreg;  // this lane's half of the query
@@ -1700,7 +1711,9 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
         if (lane == 0) {
             L.hi[0] = worst;
             L.lo[0] = entry << 1;
-            hash[4u * __umulhi(entry * 0x9E3779B1u, cap >> 2)] = entry;
+            const uint32_t b = __umulhi(entry * 0x9E3779B1u, nbuckets);
+            hash[4u * b] = 0xFF000000u | entry;   // slot 0 (slot 1's low byte stays empty)
+            hash[4u * b + 3u] = 0x01FFFFFFu;      // one slot handed out
         }
         wave_sync();
     }
@@ -1777,7 +1790,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
             edges += __popcll(mv & 0x5555555555555555ull);
             // ---- gather (speculative: before the visited test), visited test, distances -----------
             uint64_t mclaimed;
-            const uint32_t kd = hot_expand(db_base, (nb << 7) + half * 64u, nb, mv, hash_lds, cap >> 2, qreg.v, mclaimed);
+            const uint32_t kd = hot_expand(db_base, (nb << 7) + half * 64u, nb, mv, hash_lds, nbuckets, qreg.v, mclaimed);
             const uint64_t mfresh = mclaimed << 1;  // odd lanes hold the distances
             const uint32_t dk = __builtin_amdgcn_inverse_ballot_w64(mfresh) ? kd : 0xFFFFFFFFu;
             dist_calc += __popcll(mfresh);
@@ -2556,7 +2569,7 @@ bool walk_uses_lds_list(const WalkParams& p) { return p.ef > kRegListMaxEf || (p
 bool walk_uses_hot(const WalkParams& p, int metric) {
     const bool off32 = walk_off32(p);
     return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 64 && p.ell_stride <= 32u && off32 && !p.stamps_on &&
-           !p.aux_ell;
+           !p.aux_ell && p.n <= 0xFFFFFFu;  // its visited set stores 24-bit ids
 }
 
 // LDS of one wavefront without the visited set.  Register kernels: tie list + merge buffer + query; the
@@ -2571,8 +2584,13 @@ size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_li
     return ef_pad * 8 + (size_t)kTieCap * 8 + (size_t)dstride * 4;
 }
 
+// Visited set of `entries` ids: 4-byte slots in 4-slot buckets; the hot kernel packs five 24-bit ids and a
+// counter byte into each 16-byte bucket (3.2 bytes per id).
+size_t walk_hash_bytes(uint32_t entries, bool hot) { return hot ? (size_t)(entries / 5u) * 16 : (size_t)entries * 4; }
+uint32_t walk_hash_entries(size_t bytes, bool hot) { return hot ? (uint32_t)(bytes / 16) * 5u : ((uint32_t)(bytes / 4) & ~3u); }
+
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot) {
-    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p)) + (size_t)p.hash_cap * 4;
+    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p)) + walk_hash_bytes(p.hash_cap, hot);
 }
 
 template <typename K>
