@@ -774,6 +774,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.stamps_on = 1;
 #endif
     const bool hot = walk_uses_hot(w, ix->metric);
+    const bool packed = walk_uses_packed(w);
     const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride, hot, walk_uses_lds_list(w));
     uint32_t cap;
     const bool auto_cap = a->hash_capacity == 0;
@@ -788,16 +789,16 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
             need = target + target / 3 + 64;
         }
         const size_t gran = 512;  // LDS allocation granularity
-        const size_t want = (lds_fixed + walk_hash_bytes(need + 4, hot) + gran - 1) / gran * gran;
+        const size_t want = (lds_fixed + walk_hash_bytes(need + 4, packed) + gran - 1) / gran * gran;
         size_t slots = std::min<size_t>(32, kMaxLds / want);
         if (slots == 0) {
             cap = need;  // does not fit LDS at all: the general kernel takes the batch
         } else {
             const size_t share = kMaxLds / slots / gran * gran;
-            cap = walk_hash_entries(share - lds_fixed, hot);
+            cap = walk_hash_entries(share - lds_fixed, packed);
         }
     }
-    cap = walk_hash_entries(walk_hash_bytes(cap, hot), hot);  // whole buckets
+    cap = walk_hash_entries(walk_hash_bytes(cap, packed), packed);  // whole buckets
     w.hash_cap = cap;
     w.hash_limit = cap - cap / 16;
     w.all_general = walk_fast_lds_bytes(w, hot) > kMaxLds ? 1 : 0;
@@ -824,7 +825,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         // retry pass: hand-overs of the first pass, one wavefront per CU with all the LDS
         WalkParams w2 = w;
         const size_t gran = 512;
-        w2.hash_cap = (uint32_t)((kMaxLds / gran * gran - walk_fast_lds_fixed_bytes(ef, w.dstride, false, walk_uses_lds_list(w))) / 4) & ~3u;
+        w2.hash_cap = walk_hash_entries(kMaxLds / gran * gran - walk_fast_lds_fixed_bytes(ef, w.dstride, false, walk_uses_lds_list(w)), packed);
         w2.hash_limit = w2.hash_cap - w2.hash_cap / 16;
         if (skip_retry) {
             // nothing to launch

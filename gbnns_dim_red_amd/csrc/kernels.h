@@ -76,8 +76,9 @@ struct WalkParams {
 bool walk_uses_hot(const WalkParams& p, int metric);           // first pass runs walk_hot_kernel
 bool walk_uses_lds_list(const WalkParams& p);                   // result list in LDS (walk_fast_kernel) instead of registers
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot);
-size_t walk_hash_bytes(uint32_t entries, bool hot);             // LDS bytes of a visited set of `entries` ids
-uint32_t walk_hash_entries(size_t bytes, bool hot);             // ids that fit into `bytes` (whole buckets)
+bool walk_uses_packed(const WalkParams& p);                     // visited set of 24-bit ids, five per 16-byte bucket
+size_t walk_hash_bytes(uint32_t entries, bool packed);          // LDS bytes of a visited set of `entries` ids
+uint32_t walk_hash_entries(size_t bytes, bool packed);          // ids that fit into `bytes` (whole buckets)
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list = false);  // everything but the visited set
                                                                                              // (lds_list: walk_uses_lds_list)
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s);

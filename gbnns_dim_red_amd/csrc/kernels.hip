@@ -249,6 +249,90 @@ __device__ __forceinline__ uint64_t visited_claim_mask(uint32_t lds_base, uint32
     return fresh;
 }
 
+// Packed form of the table (n < 2^24, register-list kernels): a 16-byte bucket holds five 24-bit ids (bits
+// 24k .. 24k+23, all-ones = empty) and, in its top byte, the number of slots handed out -- 3.2 bytes per id, so
+// more wavefronts fit a CU.  Present iff found in a bucket of the probe sequence before a bucket with a free
+// slot; a new id takes the slot number an atomic add on the counter returns (unique per lane: no
+// compare-and-swap, no retry inside a bucket; a number >= 5 means the bucket filled up meanwhile -> next
+// bucket; at most 4 + 64 additions per bucket ever, the byte cannot wrap) and writes its three bytes.
+__device__ __forceinline__ uint64_t visited_claim_mask_packed(uint32_t lds_base, uint32_t nbuckets, uint32_t id, uint64_t valid) {
+    const uint32_t end = lds_base + (nbuckets << 4);
+    const uint32_t mulc = 0x9E3779B1u;
+    uint32_t basev = lds_base, inc = 1u << 24, addr;
+    uint64_t fresh, act, sv;
+    uint32_t t0, t1, t2;
+    asm volatile(
+        "v_mul_lo_u32 %[t0], %[id], %[mulc]\n\t"
+        "s_mov_b64 %[fresh], 0\n\t"
+        "v_mul_hi_u32 %[t0], %[t0], %[nb]\n\t"
+        "v_lshl_add_u32 %[addr], %[t0], 4, %[basev]\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[valid]\n"
+        "1:\n\t"
+        "ds_read_b128 v[92:95], %[addr]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bfe_u32 v88, v92, 0, 24\n\t"
+        "v_alignbit_b32 v89, v93, v92, 24\n\t"
+        "v_alignbit_b32 v90, v94, v93, 16\n\t"
+        "v_lshrrev_b32 v91, 8, v94\n\t"
+        "v_bfe_u32 %[t1], v95, 0, 24\n\t"
+        "v_bfe_u32 v89, v89, 0, 24\n\t"
+        "v_bfe_u32 v90, v90, 0, 24\n\t"
+        "v_xor_b32 v88, v88, %[id]\n\t"
+        "v_xor_b32 v89, v89, %[id]\n\t"
+        "v_xor_b32 v90, v90, %[id]\n\t"
+        "v_xor_b32 v91, v91, %[id]\n\t"
+        "v_xor_b32 %[t1], %[t1], %[id]\n\t"
+        "v_min3_u32 v88, v88, v89, v90\n\t"
+        "v_min3_u32 v88, v88, v91, %[t1]\n\t"               // 0 <=> id is in the bucket
+        "v_lshrrev_b32 %[t1], 24, v95\n\t"                  // slots handed out
+        "v_cmp_ne_u32 vcc, 0, v88\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 9f\n\t"
+        "s_mov_b64 %[act], exec\n\t"
+        "v_cmp_gt_u32 vcc, 5, %[t1]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 3f\n\t"
+        "ds_add_rtn_u32 %[t0], %[addr], %[inc] offset:12\n\t"
+        "v_lshrrev_b32 %[t2], 8, %[id]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_lshrrev_b32 %[t0], 24, %[t0]\n\t"
+        "v_cmp_gt_u32 vcc, 5, %[t0]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 3f\n\t"
+        "v_mad_u32_u24 %[t0], %[t0], 3, %[addr]\n\t"
+        "ds_write_b8 %[t0], %[id]\n\t"
+        "ds_write_b8 %[t0], %[t2] offset:1\n\t"
+        "ds_write_b8_d16_hi %[t0], %[id] offset:2\n\t"
+        "s_or_b64 %[fresh], %[fresh], exec\n\t"
+        "s_andn2_b64 %[act], %[act], exec\n"
+        "3:\n\t"
+        "s_mov_b64 exec, %[act]\n\t"
+        "s_cbranch_execz 9f\n\t"
+        "v_add_u32 %[addr], 16, %[addr]\n\t"
+        "v_cmp_eq_u32 vcc, %[end], %[addr]\n\t"
+        "v_cndmask_b32 %[addr], %[addr], %[basev], vcc\n\t"
+        "s_branch 1b\n"
+        "9:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [t2] "=&v"(t2), [addr] "=&v"(addr)
+        : [id] "v"(id), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [inc] "v"(inc), [mulc] "s"(mulc),
+          [nb] "s"(nbuckets)
+        : "vcc", "memory", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+    return fresh;
+}
+
+// Initial state of a packed table of `nbuckets` buckets holding `entry` (every lane calls; no sync inside).
+__device__ __forceinline__ void packed_table_init(uint32_t* hash, uint32_t nbuckets, uint32_t entry, int lane) {
+    for (uint32_t i = lane; i < nbuckets * 4u; i += 64) hash[i] = (i & 3u) == 3u ? 0x00FFFFFFu : 0xFFFFFFFFu;
+}
+__device__ __forceinline__ void packed_table_put_first(uint32_t* hash, uint32_t nbuckets, uint32_t entry) {
+    const uint32_t b = __umulhi(entry * 0x9E3779B1u, nbuckets);
+    hash[4u * b] = 0xFF000000u | entry;   // slot 0 (slot 1's low byte stays empty)
+    hash[4u * b + 3u] = 0x01FFFFFFu;      // one slot handed out
+}
+
 // ------------------------------------------------------------------------------------------
 // re-rank, pair form (search_function.h:105-125 getRealNearest) -- shared by rerank_pair_kernel and by the
 // walk kernels that re-rank their own query at the end of its walk
@@ -1198,7 +1282,12 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     const uint32_t cap = p.hash_cap;  // any size: slot = mulhi(id * C, cap)
     const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
 
-    for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
+    // OFF32 instantiations serve "compact" indexes (tables < 4 GiB and n < 2^24, walk_off32): 32-bit byte
+    // offsets and the packed visited set (24-bit ids, five per 16-byte bucket)
+    constexpr bool packed = OFF32;
+    const uint32_t nbuckets = packed ? cap / 5u : cap >> 2;
+    if constexpr (packed) packed_table_init(hash, nbuckets, 0u, lane);
+    else for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
     for (uint32_t i = lane; i < p.dstride; i += 64)
         qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
     wave_sync();
@@ -1222,7 +1311,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         if (lane == 0) {
             L.hi[0] = worst;
             L.lo[0] = entry << 1;
-            hash[4u * __umulhi(entry * 0x9E3779B1u, cap >> 2)] = entry;  // first slot of its bucket
+            if constexpr (packed) packed_table_put_first(hash, nbuckets, entry);
+            else hash[4u * __umulhi(entry * 0x9E3779B1u, nbuckets)] = entry;  // first slot of its bucket
         }
         wave_sync();
     }
@@ -1397,7 +1487,9 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                 }
             }
             // pair form: the even lane of a pair tests / claims the id, the odd lane ends up with the distance
-            const uint64_t mclaimed = visited_claim_mask(hash_lds, cap >> 2, nb, mv & kSlotLanes);
+            uint64_t mclaimed;
+            if constexpr (packed) mclaimed = visited_claim_mask_packed(hash_lds, nbuckets, nb, mv & kSlotLanes);
+            else mclaimed = visited_claim_mask(hash_lds, nbuckets, nb, mv & kSlotLanes);
             const uint64_t mfresh = kPair ? (mclaimed << 1) : mclaimed;
             const bool fresh = __builtin_amdgcn_inverse_ballot_w64(mfresh);
             STAMP(t4)
@@ -1693,7 +1785,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
 
     // packed visited set (hot_expand): cap / 5 buckets of 16 bytes, five 24-bit ids + a counter byte each
     const uint32_t nbuckets = cap / 5u;
-    for (uint32_t i = lane; i < nbuckets * 4u; i += 64) hash[i] = (i & 3u) == 3u ? 0x00FFFFFFu : 0xFFFFFFFFu;
+    packed_table_init(hash, nbuckets, 0u, lane);
     if (lane < 32) qf[lane] = p.q[(size_t)qi * p.qstride + lane];
     wave_sync();
     RowRegs<4> qreg;  // this lane's half of the query
@@ -1711,9 +1803,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
         if (lane == 0) {
             L.hi[0] = worst;
             L.lo[0] = entry << 1;
-            const uint32_t b = __umulhi(entry * 0x9E3779B1u, nbuckets);
-            hash[4u * b] = 0xFF000000u | entry;   // slot 0 (slot 1's low byte stays empty)
-            hash[4u * b + 3u] = 0x01FFFFFFu;      // one slot handed out
+            packed_table_put_first(hash, nbuckets, entry);
         }
         wave_sync();
     }
@@ -2558,9 +2648,9 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t count) {
 
 // Shape served by walk_hot_kernel (first pass only): L2, 128-byte rows, ef <= 64, adjacency rows of one
 // 32-slot pass, 32-bit byte offsets.
-static bool walk_off32(const WalkParams& p) {  // every table the walk indexes is < 4 GiB
+static bool walk_off32(const WalkParams& p) {  // "compact" index: every table the walk indexes is < 4 GiB, ids fit 24 bits
     return (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32) &&
-           (!p.aux_ell || (uint64_t)p.n * p.aux_stride * 4 < (1ull << 32));
+           (!p.aux_ell || (uint64_t)p.n * p.aux_stride * 4 < (1ull << 32)) && p.n <= 0xFFFFFFu;
 }
 
 // The LDS-list kernel serves ef beyond the register lists, and auxiliary-graph walks over tables >= 4 GiB.
@@ -2569,7 +2659,7 @@ bool walk_uses_lds_list(const WalkParams& p) { return p.ef > kRegListMaxEf || (p
 bool walk_uses_hot(const WalkParams& p, int metric) {
     const bool off32 = walk_off32(p);
     return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 64 && p.ell_stride <= 32u && off32 && !p.stamps_on &&
-           !p.aux_ell && p.n <= 0xFFFFFFu;  // its visited set stores 24-bit ids
+           !p.aux_ell;  // (off32 includes n < 2^24: its visited set stores 24-bit ids)
 }
 
 // LDS of one wavefront without the visited set.  Register kernels: tie list + merge buffer + query; the
@@ -2586,11 +2676,14 @@ size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_li
 
 // Visited set of `entries` ids: 4-byte slots in 4-slot buckets; the hot kernel packs five 24-bit ids and a
 // counter byte into each 16-byte bucket (3.2 bytes per id).
-size_t walk_hash_bytes(uint32_t entries, bool hot) { return hot ? (size_t)(entries / 5u) * 16 : (size_t)entries * 4; }
-uint32_t walk_hash_entries(size_t bytes, bool hot) { return hot ? (uint32_t)(bytes / 16) * 5u : ((uint32_t)(bytes / 4) & ~3u); }
+size_t walk_hash_bytes(uint32_t entries, bool packed) { return packed ? (size_t)(entries / 5u) * 16 : (size_t)entries * 4; }
+uint32_t walk_hash_entries(size_t bytes, bool packed) { return packed ? (uint32_t)(bytes / 16) * 5u : ((uint32_t)(bytes / 4) & ~3u); }
+
+// The register-list kernels (hot instance included) pack their visited set when ids fit 24 bits.
+bool walk_uses_packed(const WalkParams& p) { return !walk_uses_lds_list(p) && walk_off32(p); }
 
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot) {
-    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p)) + walk_hash_bytes(p.hash_cap, hot);
+    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p)) + walk_hash_bytes(p.hash_cap, walk_uses_packed(p));
 }
 
 template <typename K>
