@@ -718,6 +718,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.cand = (!host && a->out_cand) ? a->out_cand : ix->cand.as<uint32_t>();
     w.cand_dist = a->out_cand_dist ? (host ? ix->cand_dist.as<float>() : a->out_cand_dist) : nullptr;
     w.cand_stride = cstride;
+    w.zero_dist_bits = ix->metric == GBNNS_METRIC_NEG_DOT ? 0x80000000u : 0u;
     w.count = ix->cnt.as<int32_t>();
     w.hops = (!host && a->out_hops) ? a->out_hops : ix->hops.as<int32_t>();
     w.dist_calc = (!host && a->out_dist_calc) ? a->out_dist_calc : ix->dc.as<int32_t>();

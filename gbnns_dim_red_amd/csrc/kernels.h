@@ -33,6 +33,7 @@ struct WalkParams {
     // outputs
     uint32_t* cand;          // [nq x cand_stride] pop order (worst -> best), kInvalidId pad
     float* cand_dist;        // optional, same shape
+    uint32_t zero_dist_bits; // bit pattern of a zero distance on output: 0 (L2), 0x80000000 (negative dot: -0)
     uint32_t cand_stride;
     int32_t* count;          // [nq] valid entries in cand
     int32_t* hops;           // [nq]

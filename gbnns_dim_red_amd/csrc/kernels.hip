@@ -42,6 +42,12 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
     const uint32_t b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
     return __uint_as_float(b);
 }
+// The key merges -0 and +0 (they compare equal in the reference's heaps).  A zero distance the reference
+// reports is +0 for L2 (a sum of squares from +0) and -0 for the negative dot product (-(+0): the running sums
+// start at +0 and +0 + -0 = +0, so the sum itself is never -0): `zero_bits` restores that sign on output.
+__device__ __forceinline__ float fkey_inv_out(uint32_t k, uint32_t zero_bits) {
+    return k == 0x80000000u ? __uint_as_float(zero_bits) : fkey_inv(k);
+}
 
 // Result-list entry: [63:32] fkey(dist) | [31:1] id | [0] expanded.  Ascending u64 order ==
 // ascending (dist, id) pair order of the reference's result heap (search_function.h:50).
@@ -640,7 +646,7 @@ __device__ __forceinline__ void write_results(const WalkParams& p, uint32_t qi, 
         if (r < kept) {
             const uint64_t kv = keys[kept - 1 - r];
             id = key_id(kv);
-            dv = fkey_inv(key_hi(kv));
+            dv = fkey_inv_out(key_hi(kv), p.zero_dist_bits);
         }
         p.cand[(size_t)qi * p.cand_stride + r] = id;
         if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + r] = dv;
@@ -669,7 +675,7 @@ __device__ __forceinline__ float walk_dist(QP qs, const float* row, uint32_t dim
 // was inserted).  A query that would exceed hash_limit entries, or whose tie list overflows, is
 // appended to the hand-over list and re-run from scratch by the general kernel.
 
-template <int METRIC, int STEPS>
+template <int METRIC, int STEPS, bool PACKED>
 __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                               uint32_t* ovf_count, uint32_t* ovf_list) {
     const int lane = lane_id();
@@ -681,8 +687,12 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
     uint32_t* hash = reinterpret_cast<uint32_t*>(qf + p.dstride);
     const float4* qs = reinterpret_cast<const float4*>(qf);
     const uint32_t cap = p.hash_cap;  // any size: slot = mulhi(id * C, cap)
+    // PACKED (n < 2^24): five 24-bit ids per 16-byte bucket (visited_claim_mask_packed), else 4-byte slots
+    const uint32_t nbuckets = PACKED ? cap / 5u : cap >> 2;
+    const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
 
-    for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
+    if constexpr (PACKED) packed_table_init(hash, nbuckets, 0u, lane);
+    else for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
     for (uint32_t i = lane; i < p.dstride; i += 64)
         qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
     wave_sync();
@@ -695,7 +705,8 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
         const float d0 = walk_dist<METRIC, STEPS>(qs, p.db + (size_t)entry * p.dstride, p.dim);
         if (lane == 0) {
             keys[0] = make_key(fkey(d0), entry);
-            hash[4u * __umulhi(entry * 0x9E3779B1u, cap >> 2)] = entry;  // first slot of its bucket
+            if constexpr (PACKED) packed_table_put_first(hash, nbuckets, entry);
+            else hash[4u * __umulhi(entry * 0x9E3779B1u, nbuckets)] = entry;  // first slot of its bucket
         }
         st.size = 1;
         wave_sync();
@@ -712,7 +723,9 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
             if (!mv) break;
             if ((uint32_t)st.dist_calc + 64u > p.hash_limit) { handed_over = true; break; }
             st.edges += __popcll(mv);
-            const bool fresh = visited_claim(hash, cap >> 2, nb, valid);
+            bool fresh;
+            if constexpr (PACKED) fresh = __builtin_amdgcn_inverse_ballot_w64(visited_claim_mask_packed(hash_lds, nbuckets, nb, mv));
+            else fresh = visited_claim(hash, nbuckets, nb, valid);
             uint32_t dk = 0xFFFFFFFFu;
             if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, p.db + (size_t)nb * p.dstride, p.dim));
             const uint64_t mf = __ballot(fresh);
@@ -767,13 +780,13 @@ __device__ __forceinline__ void retry_loop(const WalkParams& p, F&& run) {
     }
 }
 
-template <int METRIC, int STEPS, bool RETRY>
+template <int METRIC, int STEPS, bool RETRY, bool PACKED>
 __global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if constexpr (RETRY) {
-        retry_loop(p, [&](uint32_t qi) { walk_fast_one<METRIC, STEPS>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
+        retry_loop(p, [&](uint32_t qi) { walk_fast_one<METRIC, STEPS, PACKED>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
     } else {
-        walk_fast_one<METRIC, STEPS>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
+        walk_fast_one<METRIC, STEPS, PACKED>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
     }
 }
 
@@ -1222,7 +1235,7 @@ __device__ __forceinline__ void reg_write_results(const WalkParams& p, uint32_t 
         if (rank < (int)p.cand_stride) {
             if (rank < kept) {
                 p.cand[(size_t)qi * p.cand_stride + (kept - 1 - rank)] = L.lo[r] >> 1;
-                if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + (kept - 1 - rank)] = fkey_inv(L.hi[r]);
+                if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + (kept - 1 - rank)] = fkey_inv_out(L.hi[r], p.zero_dist_bits);
             } else {
                 p.cand[(size_t)qi * p.cand_stride + rank] = kInvalidId;
                 if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + rank] = __builtin_inff();
@@ -2679,8 +2692,9 @@ size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_li
 size_t walk_hash_bytes(uint32_t entries, bool packed) { return packed ? (size_t)(entries / 5u) * 16 : (size_t)entries * 4; }
 uint32_t walk_hash_entries(size_t bytes, bool packed) { return packed ? (uint32_t)(bytes / 16) * 5u : ((uint32_t)(bytes / 4) & ~3u); }
 
-// The register-list kernels (hot instance included) pack their visited set when ids fit 24 bits.
-bool walk_uses_packed(const WalkParams& p) { return !walk_uses_lds_list(p) && walk_off32(p); }
+// Every LDS kernel packs its visited set when ids fit 24 bits (the register-list kernels: in their compact,
+// 32-bit-offset instantiations).
+bool walk_uses_packed(const WalkParams& p) { return walk_uses_lds_list(p) ? p.n <= 0xFFFFFFu : walk_off32(p); }
 
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot) {
     return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p)) + walk_hash_bytes(p.hash_cap, walk_uses_packed(p));
@@ -2733,9 +2747,13 @@ template <int METRIC, int STEPS>
 static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) {
     const size_t lds = walk_fast_lds_bytes(p, false);
     constexpr int kWideSteps = (STEPS == 8) ? 8 : 0;
-    if (walk_uses_lds_list(p))
-        return retry ? launch_walk_k(walk_fast_kernel<METRIC, STEPS, true>, p, true, lds, s)
-                     : launch_walk_k(walk_fast_kernel<METRIC, STEPS, false>, p, false, lds, s);
+    if (walk_uses_lds_list(p)) {
+        if (walk_uses_packed(p))
+            return retry ? launch_walk_k(walk_fast_kernel<METRIC, STEPS, true, true>, p, true, lds, s)
+                         : launch_walk_k(walk_fast_kernel<METRIC, STEPS, false, true>, p, false, lds, s);
+        return retry ? launch_walk_k(walk_fast_kernel<METRIC, STEPS, true, false>, p, true, lds, s)
+                     : launch_walk_k(walk_fast_kernel<METRIC, STEPS, false, false>, p, false, lds, s);
+    }
     if (p.ef <= 64) return launch_reg_t<METRIC, STEPS, 1>(p, retry, lds, s);
     if (p.ef <= 128) return launch_reg_t<METRIC, kWideSteps, 2>(p, retry, lds, s);
     return launch_reg_t<METRIC, kWideSteps, 4>(p, retry, lds, s);

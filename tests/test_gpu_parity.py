@@ -730,3 +730,29 @@ def test_exact_knn_vs_get_truth_and_oracle(g, orc):
     tids, tdist = g.exact_knn(tb, tq, 64, want_dist=True)
     assert np.array_equal(tids.cpu().numpy().view(np.uint32), oi)
     assert np.array_equal(gu.bits(tdist.cpu().numpy()), gu.bits(od))
+
+
+def test_zero_distance_sign(g, orc):
+    """A zero distance is +0 under L2 and -0 under the negative dot product (-(+0)) in the reference; the device
+    keys merge the two zeros for ordering and must hand the right one back (every list kernel)."""
+    rng = np.random.Generator(np.random.PCG64(123))
+    n, nq, d = 1500, 40, 32
+    base = (rng.integers(-8, 9, size=(n, d)) / 4.0).astype(np.float32)
+    base[::7] = 0.0                      # zero rows: dot product exactly 0 with every query
+    queries = (rng.integers(-8, 9, size=(nq, d)) / 4.0).astype(np.float32)
+    queries[:5] = base[1:6]              # and exact L2 hits
+    off, nbr = datagen.random_graph(rng, n, 6, 24)
+    for metric in (0, 1):
+        # negative dot: non-negative base, non-positive queries -> every distance is >= 0 and the zero rows
+        # (distance -0) are the nearest ones
+        b, q = (base, queries) if metric == 0 else (np.abs(base), -np.abs(queries))
+        ix = g.Index(b, off, nbr, metric=metric)
+        seen = False
+        for ef in (8, 64, 128, 300):
+            w = orc.walk(q, b, off, nbr, ef, metric=metric, threads=4)
+            r = ix.search(q, ef, mode=g.MODE_PLAIN, k=ef, want=("hops", "dist_calc", "cand", "cand_dist"))
+            assert np.array_equal(r["cand"], w["ids"]), (metric, ef)
+            assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), (metric, ef)
+            seen |= bool((gu.bits(w["dists"]) == (0x80000000 if metric == 1 else 0)).any())
+        assert seen, metric   # the case really occurs
+        ix.close()

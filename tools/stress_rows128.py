@@ -10,6 +10,7 @@ g.load_library()
 orc = oracle.Oracle()
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+only = int(sys.argv[3]) if len(sys.argv) > 3 else -1  # replay the generator, run just this case, print details
 rng = np.random.Generator(np.random.PCG64(seed))
 bad = 0
 for case in range(cases):
@@ -32,6 +33,8 @@ for case in range(cases):
     okw = dict(aux=aux, llf=llf, hops_bound=hb) if use_aux else {}
     gkw = dict(aux=True, llf=llf, hops_bound=hb) if use_aux else {}
     tag = (case, n, nq, kind, metric, net_mode, d, deg_hi, ef, cap, use_aux, llf, hb)
+    if only >= 0 and case != only:
+        continue
     try:
         if net_mode:
             db_low = orc.project(c.net, c.base)
@@ -53,6 +56,16 @@ for case in range(cases):
             r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), hash_capacity=cap, **gkw)
             ok = (np.array_equal(r["cand"], w["ids"]) and np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"]))
                   and np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]))
+            if only >= 0:
+                bq = np.nonzero((r["cand"] != w["ids"]).any(1) | (r["hops"] != w["hops"]) | (r["dist_calc"] != w["dist_calc"]))[0]
+                print("bad queries", bq[:10], "of", nq)
+                for q in bq[:2]:
+                    print(" q", q, "hops", r["hops"][q], w["hops"][q], "dc", r["dist_calc"][q], w["dist_calc"][q])
+                    dif = np.nonzero(r["cand"][q] != w["ids"][q])[0]
+                    print("  first diff positions", dif[:8], "gpu", r["cand"][q][dif[:8]], "ref", w["ids"][q][dif[:8]])
+                    print("  gpu dist", r["cand_dist"][q][dif[:4]], "ref dist", w["dists"][q][dif[:4]])
+                dd = np.nonzero(gu.bits(r["cand_dist"]) != gu.bits(w["dists"]))
+                print("dist-bit diffs", len(dd[0]), [(hex(a), hex(b)) for a, b in zip(gu.bits(r["cand_dist"])[dd][:4], gu.bits(w["dists"])[dd][:4])])
         ix.close()
     except Exception as e:  # noqa: BLE001
         ok = False
