@@ -112,11 +112,15 @@ def ground_truth(base, queries, k=2, chunk=2048):
 
 def make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=1234,
                  device="cuda:0", intrinsic=16, n_clusters=1000, cluster_scale=0.5, sigma=0.03,
-                 knn_k=48, M=16, threads=0, cache_dir=None, projector=None, verbose=False):
+                 knn_k=48, M=16, threads=0, cache_dir=None, projector=None, verbose=False, native_knn=False):
     """Builds (or loads from `cache_dir`) the synthetic workload.  Returns a Dataset whose tensors
     live on `device`; graph arrays are numpy (host), as gbnns_index_create wants them."""
     recipe = dict(n=n, nq=nq, d=d, d_low=d_low, d_hidden=d_hidden, seed=seed, intrinsic=intrinsic,
                   n_clusters=n_clusters, cluster_scale=cluster_scale, sigma=sigma, knn_k=knn_k, M=M)
+    if native_knn:
+        # kNN lists and ground truth from gbnns_exact_knn (the reference's distance arithmetic) instead of torch's
+        # formula-based top-k: what large n needs (torch's n x chunk distance matrices do not scale to 10^7)
+        recipe["knn"] = "gbnns_exact_knn"
     key = hashlib.sha1(repr(sorted(recipe.items())).encode()).hexdigest()[:16]
     dev = torch.device(device)
     path = os.path.join(cache_dir, f"gbnns_synth_{key}.pt") if cache_dir else None
@@ -154,7 +158,17 @@ def make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=123
     timings["project_base_s"] = time.time() - t1
 
     t1 = time.time()
-    knn = knn_exact(db_low, knn_k)
+    if native_knn:
+        parts = []
+        step = 1 << 20
+        for s0 in range(0, n, step):
+            parts.append(binding.exact_knn(db_low, db_low[s0:s0 + step], knn_k, self_offset=s0))
+            if verbose:
+                print("synth: kNN rows", min(n, s0 + step), "of", n, "at %.1fs" % (time.time() - t1), flush=True)
+        knn = torch.cat(parts)
+        del parts
+    else:
+        knn = knn_exact(db_low, knn_k)
     timings["knn_s"] = time.time() - t1
 
     t1 = time.time()
@@ -166,7 +180,10 @@ def make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=123
     timings["gd_s"] = time.time() - t1
 
     t1 = time.time()
-    gt2 = ground_truth(base, queries, 2)
+    if native_knn and d <= 128:
+        gt2 = binding.exact_knn(base, queries, 2).to(torch.int64)
+    else:
+        gt2 = ground_truth(base, queries, 2)
     timings["gt_s"] = time.time() - t1
     timings["total_s"] = time.time() - t0
     if verbose:

@@ -18,13 +18,15 @@ ap.add_argument("--scale", type=float, default=1.0, help="scale n (and nq for de
 ap.add_argument("--negdot", action="store_true", help="walk / re-rank with the negative-dot metric (Angular::Dist)")
 ap.add_argument("--aux", type=int, default=0, help="attach a random long-link auxiliary graph of this degree and "
                 "run the reference's use_second_graph walk (llf, hops_bound 50) beside the plain one")
+ap.add_argument("--native-knn", action="store_true", help="build the dataset's kNN lists / ground truth with gbnns_exact_knn (needed for n = 10^7)")
 a = ap.parse_args()
 for name in a.configs:
     c = dict(CONFIGS[name])
     efs = c.pop("efs")
     c["n"] = int(c["n"] * a.scale)
     t0 = time.time()
-    ds = synth.make_dataset(device="cuda:0", cache_dir=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"), **c)
+    ds = synth.make_dataset(device="cuda:0", cache_dir=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"),
+                            native_knn=a.native_knn, verbose=a.native_knn, **c)
     if a.negdot:
         from gbnns_dim_red_amd import binding
         ix = ds.index(metric=binding.METRIC_NEG_DOT)
