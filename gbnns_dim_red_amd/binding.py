@@ -18,6 +18,7 @@ FLAG_MFMA_PROJECT = 1
 FLAG_NO_FUSED_RERANK = 2
 FLAG_AUX_GRAPH = 4
 FLAG_LLF = 8
+FLAG_WIDE_INDEX = 16
 
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [

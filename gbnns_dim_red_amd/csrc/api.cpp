@@ -763,8 +763,9 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         int& streak = ix->calm_streak[ix->stats_ef];
         streak = quiet ? std::min(streak + 1, 1 << 20) : 0;
     }
+    w.force_wide = (a->flags & GBNNS_FLAG_WIDE_INDEX) ? 1 : 0;
     const bool aux = (a->flags & GBNNS_FLAG_AUX_GRAPH) != 0;
-    const int skey = ef * 8 + a->mode * 2 + (aux ? 1 : 0);  // sizing statistics are kept per (ef, mode, aux)
+    const int skey = (ef * 8 + a->mode * 2 + (aux ? 1 : 0)) * 2 + w.force_wide;  // sizing statistics are kept per (ef, mode, aux, wide)
     const int calm = ix->calm_streak.count(skey) ? ix->calm_streak[skey] : 0;
     if (aux) {
         w.aux_ell = ix->aux_ell.as<uint32_t>(); w.aux_stride = ix->aux_stride;

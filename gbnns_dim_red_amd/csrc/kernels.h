@@ -70,6 +70,7 @@ struct WalkParams {
     uint32_t aux_stride;
     uint32_t hops_bound;
     int32_t llf;
+    int32_t force_wide;      // diagnostic: treat the index as a large one (64-bit offsets, 4-byte visited-set slots)
     unsigned long long* stamps;  // diagnostic builds only (GBNNS_STAMPS): [32] segment cycle sums / histograms
     int32_t stamps_on;           // 1 in diagnostic builds: use the instrumented generic kernel
 };

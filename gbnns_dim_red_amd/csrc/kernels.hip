@@ -2662,7 +2662,7 @@ __global__ void fill_u32_kernel(uint32_t* p, uint32_t v, size_t count) {
 // Shape served by walk_hot_kernel (first pass only): L2, 128-byte rows, ef <= 64, adjacency rows of one
 // 32-slot pass, 32-bit byte offsets.
 static bool walk_off32(const WalkParams& p) {  // "compact" index: every table the walk indexes is < 4 GiB, ids fit 24 bits
-    return (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32) &&
+    return !p.force_wide && (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32) &&
            (!p.aux_ell || (uint64_t)p.n * p.aux_stride * 4 < (1ull << 32)) && p.n <= 0xFFFFFFu;
 }
 
@@ -2694,7 +2694,7 @@ uint32_t walk_hash_entries(size_t bytes, bool packed) { return packed ? (uint32_
 
 // Every LDS kernel packs its visited set when ids fit 24 bits (the register-list kernels: in their compact,
 // 32-bit-offset instantiations).
-bool walk_uses_packed(const WalkParams& p) { return walk_uses_lds_list(p) ? p.n <= 0xFFFFFFu : walk_off32(p); }
+bool walk_uses_packed(const WalkParams& p) { return walk_uses_lds_list(p) ? (p.n <= 0xFFFFFFu && !p.force_wide) : walk_off32(p); }
 
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot) {
     return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p)) + walk_hash_bytes(p.hash_cap, walk_uses_packed(p));

@@ -130,6 +130,10 @@ typedef struct {
 #define GBNNS_FLAG_AUX_GRAPH 4u
 #define GBNNS_FLAG_LLF 8u
 
+/* Diagnostic: run the kernels an index of n >= 2^24 nodes or tables >= 4 GiB would get (64-bit offsets, 4-byte
+ * visited-set slots) on a small index, so that the tests can reach them.  Same results. */
+#define GBNNS_FLAG_WIDE_INDEX 16u
+
 /* Replaces the timed query loop of performNetTest (search_function.h:346-387) / performTest
  * (:151-188): one call = the whole batch.  With HOST buffers the call copies in, runs and
  * copies out synchronously (what the drop-in harness times).  With DEVICE buffers everything is

@@ -756,3 +756,33 @@ def test_zero_distance_sign(g, orc):
             seen |= bool((gu.bits(w["dists"]) == (0x80000000 if metric == 1 else 0)).any())
         assert seen, metric   # the case really occurs
         ix.close()
+
+
+def test_wide_index_kernels(g, orc):
+    """The instantiations a large index gets (n >= 2^24 or a table >= 4 GiB: 64-bit offsets, 4-byte visited-set
+    slots), forced on small inputs with the diagnostic flag: every list kernel, both metrics, hand-over chain,
+    auxiliary graph (which then runs on the LDS-list kernel)."""
+    for metric in (0, 1):
+        for d, dlow, dh in ((64, 32, 64), (40, 24, 32), (128, 64, 128)):
+            c, off, nbr, db_low, ent = _oracle_case(orc, 1300 + d + metric, 6000, 120, d, dlow, dh, deg=(2, 40))
+            rng = np.random.Generator(np.random.PCG64(d))
+            aux = datagen.random_graph(rng, c.n, 0, 6)
+            q_low = orc.project(c.net, c.queries)
+            ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net, metric=metric)
+            ix.set_aux_graph(*aux)
+            for ef, hcap, use_aux in ((1, 0, False), (40, 0, False), (64, 128, False), (100, 0, False), (200, 0, True),
+                                      (300, 0, False), (50, 0, True)):
+                okw = dict(aux=aux, llf=True, hops_bound=50) if use_aux else {}
+                gkw = dict(aux=True, llf=True, hops_bound=50) if use_aux else {}
+                w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, metric=metric, threads=8, **okw)
+                s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net,
+                                     entries=ent, metric=metric, threads=8, **okw)
+                r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"),
+                              hash_capacity=hcap, flags=g.FLAG_WIDE_INDEX, **gkw)
+                key = (metric, d, ef, hcap, use_aux)
+                assert np.array_equal(r["cand"], w["ids"]), key
+                assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
+                assert np.array_equal(r["hops"], w["hops"]), key
+                assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
+                assert np.array_equal(r["ids"], s["ids"]), key
+            ix.close()
