@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Stress (GPU box, not part of the suite): many seeded random configurations with 128-byte walked rows against
-the oracle -- two-stage NET mode (fused re-rank) and PLAIN walks, both metrics.  usage: stress_rows128.py [seed] [cases]"""
+"""Stress (GPU box; lives under tests/ because it uses the oracle as the checker, but it is not collected by
+pytest): many seeded random configurations with 128-byte walked rows against the oracle -- two-stage NET mode
+(fused re-rank) and PLAIN walks, both metrics, auxiliary graphs.
+usage: python tests/stress_rows128.py [seed] [cases] [only_case]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gbnns_dim_red_amd as g, oracle, datagen, golden_util as gu
 g.load_library()
 orc = oracle.Oracle()
