@@ -52,7 +52,7 @@ class _SearchArgs(C.Structure):
         ("out_ids", C.c_void_p), ("out_hops", C.c_void_p), ("out_dist_calc", C.c_void_p),
         ("out_cand", C.c_void_p), ("out_cand_dist", C.c_void_p), ("out_q_low", C.c_void_p),
         ("out_edges", C.c_void_p), ("stream", C.c_void_p), ("flags", C.c_uint32),
-        ("hops_bound", C.c_uint32),
+        ("hops_bound", C.c_uint32), ("n_entries", C.c_uint32), ("reserved2", C.c_uint32),
     ]
 
 
@@ -306,12 +306,15 @@ class Index:
                 return res[name]
             i32, f32 = np.int32, np.float32
             sptr = None
+        n_entries = 0
+        if entry_ids is not None and len(entry_ids.shape) == 2:
+            n_entries = int(entry_ids.shape[1])   # several entry points per query (row-major)
         ids = alloc("ids", (nq,), i32 if dev else np.uint32)
         a = _SearchArgs(struct_size=C.sizeof(_SearchArgs), mode=mode, ef=ef, k=kk,
                         mem_kind=MEM_DEVICE if dev else MEM_HOST, hash_capacity=hash_capacity,
                         n_q=nq, queries=_ptr(queries), queries_low=_ptr(queries_low),
                         entry_ids=_ptr(entry_ids), out_ids=_ptr(ids), stream=sptr, flags=flags,
-                        hops_bound=hops_bound if aux else 0)
+                        hops_bound=hops_bound if aux else 0, n_entries=n_entries)
         if "hops" in want:
             a.out_hops = _ptr(alloc("hops", (nq,), i32))
         if "dist_calc" in want:

@@ -658,7 +658,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         if ((rc = ix->edges.ensure((size_t)nq * 4))) return rc;
     const uint32_t bitmap_words = (uint32_t)((ix->n + 31) / 32);
     if ((rc = ix->g_bitmap.ensure((size_t)kGeneralSlots * bitmap_words * 4))) return rc;
-    if ((rc = ix->g_keys.ensure((size_t)kGeneralSlots * ef * 8))) return rc;
+    if ((rc = ix->g_keys.ensure((size_t)kGeneralSlots * ((size_t)ef + (a->n_entries ? a->n_entries : 1u) - 1) * 8))) return rc;
     if ((rc = ix->g_tie.ensure((size_t)kGeneralSlots * ix->n * 8))) return rc;
 
     // ---- inputs -------------------------------------------------------------------------
@@ -668,14 +668,17 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         HIP_TRY(hipMemcpyAsync(ix->q_in.p, a->queries, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice, s));
         q_dev = ix->q_in.as<float>();
     }
+    const uint32_t n_ent = a->n_entries ? a->n_entries : 1u;
+    if (n_ent > 1 && !a->entry_ids) return fail(GBNNS_ERR_INVALID, "n_entries > 1 needs entry_ids");
+    if (n_ent > 4096) return fail(GBNNS_ERR_INVALID, "n_entries too large");
     const uint32_t* entries_dev = a->entry_ids;
     if (a->entry_ids && host) {
-        if ((rc = ix->entries.ensure((size_t)nq * 4))) return rc;
-        HIP_TRY(hipMemcpyAsync(ix->entries.p, a->entry_ids, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+        if ((rc = ix->entries.ensure((size_t)nq * n_ent * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->entries.p, a->entry_ids, (size_t)nq * n_ent * 4, hipMemcpyHostToDevice, s));
         entries_dev = ix->entries.as<uint32_t>();
     }
     if (a->entry_ids && host) {
-        for (uint32_t i = 0; i < nq; ++i)
+        for (size_t i = 0; i < (size_t)nq * n_ent; ++i)
             if (a->entry_ids[i] >= ix->n) return fail(GBNNS_ERR_INVALID, "entry id %u >= n", a->entry_ids[i]);
     }
 
@@ -714,7 +717,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
 
     // ---- stage 2: beam walk -----------------------------------------------------------
     w.ell = ix->ell.as<uint32_t>(); w.ell_stride = ix->ell_stride; w.n = (uint32_t)ix->n; w.nq = nq;
-    w.ef = ef; w.k = k; w.entries = entries_dev;
+    w.ef = ef; w.k = k; w.entries = entries_dev; w.n_entries = n_ent;
     w.cand = (!host && a->out_cand) ? a->out_cand : ix->cand.as<uint32_t>();
     w.cand_dist = a->out_cand_dist ? (host ? ix->cand_dist.as<float>() : a->out_cand_dist) : nullptr;
     w.cand_stride = cstride;
@@ -803,7 +806,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     cap = walk_hash_entries(walk_hash_bytes(cap, packed), packed);  // whole buckets
     w.hash_cap = cap;
     w.hash_limit = cap - cap / 16;
-    w.all_general = walk_fast_lds_bytes(w, hot) > kMaxLds ? 1 : 0;
+    w.all_general = (walk_fast_lds_bytes(w, hot) > kMaxLds || n_ent > 1) ? 1 : 0;  // several entry points: general kernel only
     // Fused re-rank: with a register-list first pass (ef <= 256; and its retry / general successors) every
     // wavefront re-ranks its own query when its walk ends; no re-rank launch.  Needs the pair form
     // (d % 8 == 0) and room for the original-space query in the walk kernels' LDS.

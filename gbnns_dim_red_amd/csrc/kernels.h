@@ -26,7 +26,8 @@ struct WalkParams {
     uint32_t nq;
     int32_t ef;
     int32_t k;               // results kept (<= ef); cand_stride = min(k, ef)
-    const uint32_t* entries; // [nq] or nullptr (= node 0)
+    const uint32_t* entries; // [nq x n_entries] or nullptr (= node 0)
+    uint32_t n_entries;      // entry points per query (0 / 1: one); more than one runs on the general kernel only
     // LDS visited set of the fast kernel
     uint32_t hash_cap;       // entries of the LDS visited set (any size >= 128)
     uint32_t hash_limit;     // max entries before a query is handed to the general kernel

@@ -502,7 +502,7 @@ __device__ __forceinline__ void fused_rerank(const WalkParams& p, uint32_t qi, i
 template <typename KP>
 __device__ __forceinline__ int list_insert(KP keys, int& size, int ef, uint64_t nk,
                                            uint64_t& evicted, bool& did_evict, int lane) {
-    did_evict = (size == ef);
+    did_evict = (size >= ef);  // (> ef only with several entry points: the list then stays one longer per extra entry)
     evicted = did_evict ? keys[size - 1] : 0ull;
     const int top = did_evict ? size - 1 : size;  // keys [0, top) may have to move
     int pos = 0;
@@ -2014,7 +2014,8 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
     float* qf = reinterpret_cast<float*>(smem);
     const float4* qs = reinterpret_cast<const float4*>(qf);
     uint32_t* bitmap = p.g_bitmap + (size_t)slot * p.bitmap_words;
-    uint64_t* keys = p.g_keys + (size_t)slot * (size_t)p.ef;
+    const uint32_t n_ent = p.n_entries ? p.n_entries : 1u;
+    uint64_t* keys = p.g_keys + (size_t)slot * ((size_t)p.ef + n_ent - 1u);  // one extra slot per extra entry point
     uint64_t* tie = p.g_tie + (size_t)slot * (size_t)p.n;
     const int ef = p.ef;
     const uint32_t total = p.all_general ? p.nq : *p.ovf2_count;
@@ -2028,23 +2029,38 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
         if (w >= total) break;
         const uint32_t qi = p.all_general ? w : p.ovf2_list[w];
 
-        for (uint32_t i = lane; i < p.bitmap_words; i += 64) bitmap[i] = 0u;
         for (uint32_t i = lane; i < p.dstride; i += 64)
             qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
         wave_sync();
 
         WalkState st;
         st.size = 0; st.tsize = 0; st.first_un = 0; st.hops = 0; st.dist_calc = 1; st.edges = 0;
-        const uint32_t entry = p.entries ? p.entries[qi] : 0u;
+        // search_function.h:54-64: one walk per entry point -- fresh candidate set (every result so far counts as
+        // expanded, the tie list is dropped) and fresh visited set; the result heap, hops and dist_calc carry
+        // over; the entry's own distance is not counted and it is pushed without the size test (so the heap
+        // stays one longer per extra entry point: makeStep pops once per push, :36-37)
+        for (uint32_t e = 0; e < n_ent; ++e) {
+        for (uint32_t i = lane; i < p.bitmap_words; i += 64) bitmap[i] = 0u;
+        if (e > 0) {
+            for (int i = lane; i < st.size; i += 64) keys[i] = keys[i] | 1ull;
+            st.tsize = 0;
+        }
+        wave_sync();
+        const uint32_t entry = p.entries ? p.entries[(size_t)qi * n_ent + e] : 0u;
         {
             const float d0 =
                 metric_dist<METRIC>(qs, reinterpret_cast<const float4*>(p.db + (size_t)entry * p.dstride),
                                     p.dim);
-            if (lane == 0) {
-                keys[0] = make_key(fkey(d0), entry);
-                bitmap[entry >> 5] = 1u << (entry & 31u);
+            if (e == 0) {
+                if (lane == 0) keys[0] = make_key(fkey(d0), entry);
+                st.size = 1;
+            } else {
+                uint64_t ev;
+                bool did;
+                const int pos = list_insert(keys, st.size, 0x7FFFFFFF, make_key(fkey(d0), entry), ev, did, lane);
+                st.first_un = pos;
             }
-            st.size = 1;
+            if (lane == 0) bitmap[entry >> 5] = 1u << (entry & 31u);
             wave_sync();
         }
         uint32_t node;
@@ -2086,6 +2102,7 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
                 make_step(p.ell + (size_t)node * p.ell_stride, p.ell_stride, found);
             st.hops += 1;
         }
+        }  // entry points
         write_results(p, qi, keys, st, lane);
         if (p.rr_db) {
             const int kept = st.size < p.k ? st.size : p.k;

@@ -13,9 +13,8 @@
 // use_second_graph = true / llf / hops_bound (auxiliary "long link" graph, :73-89; naive_test.cpp:103-105)
 // are served by the device too: the auxiliary graph is attached to the index
 // (gbnns_index_set_aux_graph) and the call sets GBNNS_FLAG_AUX_GRAPH / GBNNS_FLAG_LLF.
-// Not available on the device path (the process exits with a message instead of silently doing
-// something else): more than one entry point per query -- neither final_test.cpp nor naive_test.cpp
-// uses that.
+// Several entry points per query (:54) are served too (same count for every query of a batch; exact, on the
+// general kernel -- no driver of the reference uses them).
 // makeStep (:15-40) is an internal step of the walk and has no host-visible counterpart.
 #pragma once
 
@@ -101,14 +100,22 @@ inline uint32_t gbnnsAttachAux(gbnns_index* ix, const GbnnsAux& aux) {
     return GBNNS_FLAG_AUX_GRAPH | (aux.llf ? GBNNS_FLAG_LLF : 0u);
 }
 
-inline vector<uint32_t> gbnnsEntries(const vector<vector<uint32_t>>& inter_points, size_t n_q) {
-    vector<uint32_t> e(n_q, 0);
+// Entry points as the flat [n_q x m] array of the C ABI.  The reference takes a ragged vector per query
+// (search_function.h:54); every driver passes exactly one, the device path takes any m as long as it is the same
+// for all queries of a batch (it exits with a message otherwise -- never a silent difference).
+inline vector<uint32_t> gbnnsEntries(const vector<vector<uint32_t>>& inter_points, size_t n_q, uint32_t& m) {
+    m = inter_points.empty() ? 1u : (uint32_t)inter_points[0].size();
+    if (m == 0) {
+        std::cerr << "gbnns: a query without an entry point" << std::endl;
+        exit(2);
+    }
+    vector<uint32_t> e(n_q * m, 0);
     for (size_t i = 0; i < n_q && i < inter_points.size(); ++i) {
-        if (inter_points[i].size() != 1) {
-            std::cerr << "gbnns: exactly one entry point per query is supported" << std::endl;
+        if (inter_points[i].size() != m) {
+            std::cerr << "gbnns: the device path needs the same number of entry points for every query" << std::endl;
             exit(2);
         }
-        e[i] = inter_points[i][0];
+        for (uint32_t j = 0; j < m; ++j) e[i * m + j] = inter_points[i][j];
     }
     return e;
 }
@@ -117,8 +124,9 @@ inline vector<uint32_t> gbnnsEntries(const vector<vector<uint32_t>>& inter_point
 // mode PLAIN: walk in the space of the index's `db` with (ef, k), answer = best.
 inline void gbnnsBatch(gbnns_index* ix, int mode, const float* queries, const float* queries_low,
                        size_t n_q, int ef, int k, const vector<uint32_t>& entries, vector<uint32_t>& ans,
-                       vector<int32_t>& hops, vector<int32_t>& dist_calc, const GbnnsAux& aux) {
+                       vector<int32_t>& hops, vector<int32_t>& dist_calc, const GbnnsAux& aux, uint32_t n_entries = 1) {
     gbnns_search_args a = {};
+    a.n_entries = n_entries;
     a.flags = gbnnsAttachAux(ix, aux);
     a.hops_bound = aux.hops_bound;
     a.struct_size = sizeof a;
@@ -146,8 +154,8 @@ TripleResult getOneSearchResults(const float* query, const float* db, uint32_t N
                                  uint32_t hops_bound) {
     (void)visitedlistpool;
     const GbnnsAux aux = {&auxiliary_graph, use_second_graph, llf, hops_bound};
-    if (inter_points.size() != 1) {
-        std::cerr << "gbnns: exactly one entry point per query is supported" << std::endl;
+    if (inter_points.empty()) {
+        std::cerr << "gbnns: a query without an entry point" << std::endl;
         exit(2);
     }
     gbnns_index* ix = gbnnsIndexFor(main_graph, db, N, d, nullptr, 0, nullptr, 0, metric);
@@ -165,6 +173,7 @@ TripleResult getOneSearchResults(const float* query, const float* db, uint32_t N
     a.n_q = 1;
     a.queries = query;
     a.entry_ids = inter_points.data();
+    a.n_entries = (uint32_t)inter_points.size();
     a.out_ids = &best;
     a.out_hops = &hops;
     a.out_dist_calc = &dc;
@@ -254,7 +263,8 @@ void performTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>>& 
         ix = gbnnsIndexFor(knn_graph, ds.data(), n, d, nullptr, 0, nullptr, 0, metric);
         mode = GBNNS_MODE_PLAIN; run_ef = ef; run_k = k;
     }
-    const vector<uint32_t> entries = gbnnsEntries(inter_points, n_q);
+    uint32_t n_entries = 1;
+    const vector<uint32_t> entries = gbnnsEntries(inter_points, n_q, n_entries);
 
     long long hops = 0;
     long long dist_calc = 0 + (long long)dist_calc_boost * n_q;
@@ -266,7 +276,7 @@ void performTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>>& 
         num_exp += 1;
         vector<uint32_t> ans(n_q);
         StopW stopw = StopW();
-        gbnnsBatch(ix, mode, q_main, q_low, n_q, run_ef, run_k, entries, ans, q_hops, q_dc, aux);
+        gbnnsBatch(ix, mode, q_main, q_low, n_q, run_ef, run_k, entries, ans, q_hops, q_dc, aux, n_entries);
         work_time += stopw.getElapsedTimeMicro();
         for (int i = 0; i < n_q; ++i) {
             hops += q_hops[i];
@@ -318,7 +328,8 @@ void performNetTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>
                           : gbnnsIndexFor(knn_graph, ds.data(), n, d, nullptr, 0, nullptr, 0, metric);
     gbnns_index* ix_low = low_only ? gbnnsIndexFor(knn_graph, ds_low.data(), n, d_low, nullptr, 0, nullptr, 0, metric)
                                    : nullptr;
-    const vector<uint32_t> entries = gbnnsEntries(inter_points, n_q);
+    uint32_t n_entries = 1;
+    const vector<uint32_t> entries = gbnnsEntries(inter_points, n_q, n_entries);
 
     long long hops = 0;
     long long dist_calc = 0 + (long long)dist_calc_boost * n_q;
@@ -333,13 +344,13 @@ void performNetTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>
         StopW stopw = StopW();
         if (two_stage) {
             gbnnsBatch(ix, GBNNS_MODE_NET, queries.data(), nullptr, n_q, recheck_size, recheck_size, entries, ans,
-                       q_hops, q_dc, aux);
+                       q_hops, q_dc, aux, n_entries);
         } else if (low_only) {
             q_low.resize((size_t)n_q * d_low);
             if (gbnns_project(ix, queries.data(), n_q, q_low.data(), GBNNS_MEM_HOST, nullptr)) gbnnsDie("gbnns_project");
-            gbnnsBatch(ix_low, GBNNS_MODE_PLAIN, q_low.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux);
+            gbnnsBatch(ix_low, GBNNS_MODE_PLAIN, q_low.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux, n_entries);
         } else {
-            gbnnsBatch(ix, GBNNS_MODE_PLAIN, queries.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux);
+            gbnnsBatch(ix, GBNNS_MODE_PLAIN, queries.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux, n_entries);
         }
         work_time += stopw.getElapsedTimeMicro();
         for (int i = 0; i < n_q; ++i) {

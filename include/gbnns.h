@@ -94,7 +94,8 @@ typedef struct {
     uint64_t n_q;
     const float* queries;      /* [n_q x d] */
     const float* queries_low;  /* LOWQ: [n_q x d_low], else NULL */
-    const uint32_t* entry_ids; /* [n_q] entry node per query, NULL = node 0 (search_function.h:417-427) */
+    const uint32_t* entry_ids; /* [n_q x max(n_entries, 1)] entry node(s) per query, NULL = node 0
+                                  (search_function.h:417-427) */
     uint32_t* out_ids;         /* [n_q] answers (ans[i], search_function.h:361) */
     int32_t* out_hops;         /* optional [n_q]  TripleResult.hops */
     int32_t* out_dist_calc;    /* optional [n_q]  TripleResult.dist_calc (walk only, without the
@@ -109,6 +110,11 @@ typedef struct {
     uint32_t flags;            /* GBNNS_FLAG_* */
     uint32_t hops_bound;       /* with GBNNS_FLAG_AUX_GRAPH: auxiliary rows are expanded while hops < hops_bound
                                   (search_function.h:73; the harness passes 50, :273/:338) */
+    uint32_t n_entries;        /* entry points per query (inter_points[i].size(), search_function.h:54); 0 or 1 =
+                                  one.  More than one: one walk per entry point over a shared result heap, exactly
+                                  as :54-93 -- served by the general kernel (exact, not tuned: no driver of the
+                                  reference uses it) */
+    uint32_t reserved2;
 } gbnns_search_args;
 
 /* Throughput option, off by default: run the MLP projection on the matrix cores (f32 MFMA).  The

@@ -786,3 +786,39 @@ def test_wide_index_kernels(g, orc):
                 assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
                 assert np.array_equal(r["ids"], s["ids"]), key
             ix.close()
+
+
+def test_several_entry_points(g, orc):
+    """inter_points with more than one entry per query (search_function.h:54-93): one walk per entry point over a
+    shared result heap -- fresh candidates and visited set per entry, the heap one longer per extra entry,
+    duplicates allowed.  Against the oracle (itself checked against the compiled reference for this case in
+    tests/test_oracle_golden.py::test_oracle_vs_ref_random)."""
+    for metric in (0, 1):
+        c, off, nbr, db_low, _ = _oracle_case(orc, 1500 + metric, 5000, 60, 48, 16, 32, deg=(2, 20))
+        rng = np.random.Generator(np.random.PCG64(5 + metric))
+        aux = datagen.random_graph(rng, c.n, 0, 5)
+        q_low = orc.project(c.net, c.queries)
+        ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net, metric=metric)
+        ix.set_aux_graph(*aux)
+        for m in (2, 3, 7):
+            ent = rng.integers(0, c.n, size=(c.nq, m)).astype(np.uint32)
+            ent[0, :] = ent[0, 0]          # the same entry point several times
+            for ef, use_aux in ((1, False), (5, False), (40, False), (40, True), (300, False)):
+                okw = dict(aux=aux, llf=True, hops_bound=50) if use_aux else {}
+                gkw = dict(aux=True, llf=True, hops_bound=50) if use_aux else {}
+                w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, metric=metric, threads=8, **okw)
+                r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), **gkw)
+                key = (metric, m, ef, use_aux)
+                assert np.array_equal(r["cand"], w["ids"]), key
+                assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
+                assert np.array_equal(r["hops"], w["hops"]), key
+                assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
+                want = orc.rerank(c.queries, w["ids"], w["count"], c.base, metric=metric)
+                assert np.array_equal(r["ids"], want), key
+                # plain walk in the original space, k < ef
+                wp = orc.walk(c.queries, c.base, off, nbr, ef, k=max(1, ef // 2), entries=ent, metric=metric, threads=8)
+                rp = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=max(1, ef // 2), entry_ids=ent,
+                               want=("hops", "dist_calc", "cand"))
+                assert np.array_equal(rp["cand"], wp["ids"]), key
+                assert np.array_equal(rp["hops"], wp["hops"]), key
+        ix.close()
