@@ -60,6 +60,27 @@ def test_argument_validation(lib):
     assert b"struct_size" in lib.gbnns_last_error()
 
 
+def test_exact_knn_argument_validation(lib):
+    base = np.zeros((8, 200), np.float32)
+    ids = np.zeros((8, 3), np.uint32)
+
+    def call(n, nq, d, k, metric, self_offset=-1, mem=0, b=base, out=ids):
+        return lib.gbnns_exact_knn(0, b.ctypes.data if b is not None else None, n, base.ctypes.data, nq, d, k,
+                                   metric, self_offset, out.ctypes.data if out is not None else None, None, mem, None)
+    assert call(8, 8, 16, 3, 0, b=None) == 1          # null pointer
+    assert call(0, 8, 16, 3, 0) == 1                  # empty base
+    assert call(8, 8, 16, 0, 0) == 1                  # k < 1
+    assert call(8, 8, 16, 3, 7) == 1                  # unknown metric
+    assert call(8, 8, 16, 3, 0, mem=5) == 1           # unknown memory kind
+    assert call(8, 8, 16, 3, 0, self_offset=-2) == 1
+    assert call(8, 8, 200, 3, 0) == 5                 # d > 128: GBNNS_ERR_UNSUPPORTED
+    assert b"d <= 128" in lib.gbnns_last_error()
+    assert call(8, 8, 12, 3, 1) == 5                  # dot form needs d % 8 == 0
+    if _no_gpu():
+        assert call(8, 8, 16, 3, 0) == 2              # valid request, no device: no CPU path
+    assert lib.gbnns_index_set_aux_graph(None, None, None) == 1
+
+
 def test_graph_builder_matches_reference_golden(lib):
     gd = gu.load("tail_toy")
     # db_low bytes are pinned by sha in the golden; regenerate through the fixture's q_low path is
