@@ -34,7 +34,11 @@ for case in range(cases):
     hb = int(rng.choice([0, 2, 50, 100000]))
     okw = dict(aux=aux, llf=llf, hops_bound=hb) if use_aux else {}
     gkw = dict(aux=True, llf=llf, hops_bound=hb) if use_aux else {}
-    tag = (case, n, nq, kind, metric, net_mode, d, deg_hi, ef, cap, use_aux, llf, hb)
+    # a sixth of the plain walks start from several entry points (general kernel)
+    m_ent = int(rng.choice([1, 1, 1, 1, 1, 2, 3]))
+    if m_ent > 1 and not net_mode:
+        ent = rng.integers(0, n, size=(nq, m_ent)).astype(np.uint32)
+    tag = (case, n, nq, kind, metric, net_mode, d, deg_hi, ef, cap, use_aux, llf, hb, m_ent)
     if only >= 0 and case != only:
         continue
     try:
