@@ -23,7 +23,7 @@ FLAG_WIDE_INDEX = 16
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "gbnns_index_create", "gbnns_index_destroy", "gbnns_index_set_aux_graph", "gbnns_search_ex", "gbnns_search_batch",
-    "gbnns_project", "gbnns_rerank", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd",
+    "gbnns_project", "gbnns_rerank", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd", "gbnns_build_graph_gd_device",
     "gbnns_free", "gbnns_exact_knn", "gbnns_device_count", "gbnns_version", "gbnns_last_error",
 ]
 
@@ -101,6 +101,10 @@ def load_library():
                                          C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     lib.gbnns_free.argtypes = [C.c_void_p]
+    lib.gbnns_build_graph_gd_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                                C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                C.POINTER(C.c_uint64)]
     lib.gbnns_exact_knn.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
                                     C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     _lib = lib
@@ -168,6 +172,26 @@ def build_graph_gd(knn_offsets, knn_nbrs, ds, M, metric=METRIC_L2, reverse=True,
         lib.gbnns_free(po)
         lib.gbnns_free(pn)
     return off, nbr
+
+
+def build_graph_gd_device(knn_offsets, knn_nbrs, ds, M, metric=METRIC_L2, reverse=True, threads=0, device=0):
+    """gbnns_build_graph_gd_device: per-node pruning on the device (ties finished on the host), same result as
+    build_graph_gd.  Returns (offsets, nbrs, nodes_finished_on_host)."""
+    lib = load_library()
+    koff, knbr, ds = _host(knn_offsets, np.uint64), _host(knn_nbrs, np.uint32), _host(ds, np.float32)
+    n, d = ds.shape
+    po, pn, hn = C.c_void_p(), C.c_void_p(), C.c_uint64(0)
+    _check(lib.gbnns_build_graph_gd_device(device, koff.ctypes.data, knbr.ctypes.data, ds.ctypes.data, n, d, M,
+                                           metric, int(reverse), threads, C.byref(po), C.byref(pn), C.byref(hn)))
+    try:
+        off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+        total = int(off[n])
+        nbr = (np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_uint32)), shape=(max(total, 1),))
+               [:total].copy())
+    finally:
+        lib.gbnns_free(po)
+        lib.gbnns_free(pn)
+    return off, nbr, int(hn.value)
 
 
 def exact_knn(base, queries, k, metric=METRIC_L2, self_offset=-1, want_dist=False, device=0, stream=None):

@@ -269,6 +269,68 @@ int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* quer
     return GBNNS_OK;
 }
 
+// graph_build.cpp
+extern "C" int gbnns_internal_gd_finish(const uint64_t* knn_offsets, const uint32_t* knn_nbrs, const float* ds,
+                                        uint64_t n, uint32_t d, int M, int metric, int reverse, int threads,
+                                        uint32_t* adj, uint32_t* deg, uint64_t* host_nodes, uint64_t** out_offsets,
+                                        uint32_t** out_nbrs);
+
+int gbnns_build_graph_gd_device(int device, const uint64_t* knn_offsets, const uint32_t* knn_nbrs, const float* ds,
+                                uint64_t n, uint32_t d, int M, int metric, int reverse, int threads,
+                                uint64_t** out_offsets, uint32_t** out_nbrs, uint64_t* out_host_nodes) {
+    if (!knn_offsets || !knn_nbrs || !ds || !out_offsets || !out_nbrs || M < 2 || n == 0)
+        return fail(GBNNS_ERR_INVALID, "gbnns_build_graph_gd_device: bad argument");
+    if (n >= (1ull << 31)) return fail(GBNNS_ERR_INVALID, "n must be < 2^31");
+    if (metric != GBNNS_METRIC_L2 && metric != GBNNS_METRIC_NEG_DOT) return fail(GBNNS_ERR_INVALID, "unknown metric %d", metric);
+    *out_offsets = nullptr;
+    *out_nbrs = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(GBNNS_ERR_NO_DEVICE, "no HIP device available (use gbnns_build_graph_gd for the host builder)");
+    if (device < 0 || device >= count) return fail(GBNNS_ERR_NO_DEVICE, "device %d out of range (%d devices)", device, count);
+    const uint32_t cap = 2u * (uint32_t)M;
+    std::vector<uint32_t> adj, deg;
+    try {
+        adj.resize((size_t)n * cap);
+        deg.assign(n, 0xFFFFFFFFu);
+    } catch (...) {
+        return fail(GBNNS_ERR_OOM, "host allocation failed");
+    }
+    // shapes the kernel does not take (kept neighbours sit one per lane; the node's vector is staged in LDS) stay
+    // on the host entirely -- same result, the host path is the reference's own algorithm
+    const bool on_device = M <= 64 && d <= 128;
+    if (on_device) {
+        HIP_TRY(hipSetDevice(device));
+        DevBuf ds_dev, off_dev, nbr_dev, adj_dev, deg_dev;
+        struct Release {
+            DevBuf* b[5];
+            ~Release() { for (DevBuf* x : b) x->release(); }
+        } release{{&ds_dev, &off_dev, &nbr_dev, &adj_dev, &deg_dev}};
+        const uint64_t total = knn_offsets[n];
+        const uint32_t dpad = round_up(d, 4);
+        int rc;
+        if ((rc = upload(ds_dev, ds, n, d, dpad, GBNNS_MEM_HOST))) return rc;
+        if ((rc = off_dev.ensure((n + 1) * 8))) return rc;
+        if ((rc = nbr_dev.ensure(std::max<uint64_t>(total, 1) * 4))) return rc;
+        if ((rc = adj_dev.ensure((size_t)n * cap * 4))) return rc;
+        if ((rc = deg_dev.ensure((size_t)n * 4))) return rc;
+        HIP_TRY(hipMemcpy(off_dev.p, knn_offsets, (n + 1) * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(nbr_dev.p, knn_nbrs, total * 4, hipMemcpyHostToDevice));
+        GdParams p{};
+        p.ds = ds_dev.as<float>(); p.dstride = dpad; p.dim = d; p.n = (uint32_t)n; p.M = M;
+        p.knn_off = off_dev.as<uint64_t>(); p.knn_nbr = nbr_dev.as<uint32_t>();
+        p.adj = adj_dev.as<uint32_t>(); p.deg = deg_dev.as<uint32_t>();
+        HIP_TRY(launch_gd_prune(p, metric, nullptr));
+        HIP_TRY(hipMemcpy(adj.data(), adj_dev.p, (size_t)n * cap * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(deg.data(), deg_dev.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    const int rc = gbnns_internal_gd_finish(knn_offsets, knn_nbrs, ds, n, d, M, metric, reverse, threads, adj.data(),
+                                            deg.data(), out_host_nodes, out_offsets, out_nbrs);
+    if (rc == GBNNS_ERR_INVALID) return fail(rc, "gbnns_build_graph_gd_device: neighbour id out of range");
+    if (rc) return fail(rc, "gbnns_build_graph_gd_device: host allocation failed");
+    return GBNNS_OK;
+}
+
 int gbnns_device_count(void) {
     int c = 0;
     if (hipGetDeviceCount(&c) != hipSuccess) return 0;

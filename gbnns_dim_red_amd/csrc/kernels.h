@@ -145,6 +145,20 @@ struct KnnParams {
 };
 hipError_t launch_knn_scan(const KnnParams& p, int metric, hipStream_t s);
 
+// GD pruning of a kNN graph, one node per wavefront (support_func.h:521-563).  deg[i] = 0xFFFFFFFF marks a node
+// left to the host (equal distances in its list, list longer than 1024, id out of range).
+struct GdParams {
+    const float* ds;         // [n x dstride], rows zero-padded to a multiple of 4 floats
+    uint32_t dstride, dim;
+    uint32_t n;
+    int32_t M;               // 2 .. 64
+    const uint64_t* knn_off; // [n + 1]
+    const uint32_t* knn_nbr;
+    uint32_t* adj;           // [n x 2M]
+    uint32_t* deg;           // [n]
+};
+hipError_t launch_gd_prune(const GdParams& p, int metric, hipStream_t s);
+
 // helpers
 hipError_t launch_fill_u32(uint32_t* p, uint32_t v, size_t count, hipStream_t s);
 

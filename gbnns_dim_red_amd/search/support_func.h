@@ -200,8 +200,10 @@ inline void gbnnsDie(const char* what) {
 }
 
 // hnswlikeGD (reference support_func.h:521-575): prunes a kNN graph into the search graph (the
-// "GD" rule + the M/2 nearest + optional reverse edges).  Same signature; the work is done by the
-// library's host builder gbnns_build_graph_gd (OpenMP, reference operation order).
+// "GD" rule + the M/2 nearest + optional reverse edges).  Same signature; the per-node pruning runs on the
+// device when there is one (gbnns_build_graph_gd_device: nodes with equal candidate distances and the reverse
+// pass are finished on the host, so the graph is the host builder's bit for bit), else -- or with
+// GBNNS_GD_HOST=1 -- on the host (gbnns_build_graph_gd, OpenMP, reference operation order).
 // need_const_degree = true (getConstantDegreeForGD, :466-485) is not implemented.
 vector<vector<uint32_t>> hnswlikeGD(vector<vector<uint32_t>>& graph, const float* ds, int M, size_t N, size_t d,
                                     Metric* metric, bool reverse, bool need_const_degree) {
@@ -212,9 +214,19 @@ vector<vector<uint32_t>> hnswlikeGD(vector<vector<uint32_t>>& graph, const float
     const GbnnsCsr knn = gbnnsToCsr(graph);
     uint64_t* off = nullptr;
     uint32_t* nbr = nullptr;
-    if (gbnns_build_graph_gd(knn.offsets.data(), knn.nbrs.data(), ds, N, (uint32_t)d, M, metric->gbnnsMetric(),
-                             reverse ? 1 : 0, 0, &off, &nbr)) {
-        std::cerr << "gbnns: gbnns_build_graph_gd failed (bad ids, M < 2 or out of memory)" << std::endl;
+    const char* force_host = getenv("GBNNS_GD_HOST");
+    const char* dev = getenv("GBNNS_DEVICE");
+    int rc;
+    if (gbnns_device_count() > 0 && !(force_host && atoi(force_host))) {
+        uint64_t on_host = 0;
+        rc = gbnns_build_graph_gd_device(dev ? atoi(dev) : 0, knn.offsets.data(), knn.nbrs.data(), ds, N, (uint32_t)d, M,
+                                         metric->gbnnsMetric(), reverse ? 1 : 0, 0, &off, &nbr, &on_host);
+    } else {
+        rc = gbnns_build_graph_gd(knn.offsets.data(), knn.nbrs.data(), ds, N, (uint32_t)d, M, metric->gbnnsMetric(),
+                                  reverse ? 1 : 0, 0, &off, &nbr);
+    }
+    if (rc) {
+        std::cerr << "gbnns: graph builder failed (bad ids, M < 2 or out of memory): " << gbnns_last_error() << std::endl;
         exit(2);
     }
     vector<vector<uint32_t>> out(N);

@@ -190,6 +190,16 @@ int gbnns_build_graph_gd(const uint64_t* knn_offsets, const uint32_t* knn_nbrs, 
                          uint64_t** out_offsets, uint32_t** out_nbrs);
 void gbnns_free(void* p);
 
+/* The same builder with the per-node pruning (support_func.h:528-563) on the device, one node per wavefront.
+ * The reference sorts a node's candidates with std::sort on the distance alone, which leaves the order of EQUAL
+ * distances to the library's algorithm; nodes whose list contains equal distances (and lists longer than 1024)
+ * are therefore finished on the host by that very call, so the result is always the host builder's, bit for bit.
+ * The reverse-edge pass (:402-445) is serial and order dependent and stays on the host.  *out_host_nodes
+ * (optional) = nodes that went to the host.  M > 64 or d > 128: everything runs on the host. */
+int gbnns_build_graph_gd_device(int device, const uint64_t* knn_offsets, const uint32_t* knn_nbrs, const float* ds,
+                                uint64_t n, uint32_t d, int M, int metric, int reverse, int threads,
+                                uint64_t** out_offsets, uint32_t** out_nbrs, uint64_t* out_host_nodes);
+
 /* Exact brute-force nearest neighbours on the device, in the reference's distance arithmetic.
  *   k = 1: getTruth (support_func.h:270-290) -- the strict minimum of Dist(base_j, q_i) over ascending j;
  *   k > 1: the exact kNN lists that feed the graph builder (dim_red/support_func.py:374-384 writes

@@ -822,3 +822,47 @@ def test_several_entry_points(g, orc):
                 assert np.array_equal(rp["cand"], wp["ids"]), key
                 assert np.array_equal(rp["hops"], wp["hops"]), key
         ix.close()
+
+
+def test_gd_pruning_on_device(g, orc):
+    """gbnns_build_graph_gd_device (per-node pruning on the device, ties and the reverse pass on the host) gives the
+    host builder's graph bit for bit: the compiled reference's golden graph, random data for several (K, M, d),
+    unsorted and ragged candidate lists, and tie-heavy lattice data (where most nodes are finished on the host)."""
+    gd = gu.load("tail_toy")
+    c = gd.case
+    db_low = orc.project(c.net, c.base)
+    koff, knbr = datagen.dense_to_csr(gd["knn"])
+    off, nbr, on_host = g.build_graph_gd_device(koff, knbr, db_low, gd.meta["gd_M"])
+    assert np.array_equal(off, gd["graph_off"]) and np.array_equal(nbr, gd["graph_nbr"])
+    rng = np.random.Generator(np.random.PCG64(321))
+    for n, d, K, M, metric in ((3000, 32, 40, 12, 0), (2500, 14, 100, 30, 0), (1500, 64, 300, 16, 0),
+                               (1200, 100, 33, 5, 0), (1300, 128, 1100, 8, 0), (2000, 16, 50, 10, 1)):
+        cc = datagen.Case("gd", 7000 + n, n, 4, d, 4, 8)
+        x = cc.base if metric == 0 else np.abs(cc.base) * -1.0   # negative dot: keep some distances positive
+        if metric == 1:
+            x = x.copy(); x[::2] *= -1.0
+        knn, _ = orc.exact_knn(x, x, K, 0, self_offset=0, threads=8)
+        # ragged, shuffled lists: the builder sorts them itself
+        lists = []
+        for i in range(n):
+            row = knn[i][:int(rng.integers(1, K + 1))].copy()
+            rng.shuffle(row)
+            lists.append(row)
+        ko, kn = datagen.lists_to_csr(lists)
+        want_off, want_nbr = g.build_graph_gd(ko, kn, x, M, metric=metric, threads=8)
+        for rev in (True, False):
+            w_off, w_nbr = (want_off, want_nbr) if rev else g.build_graph_gd(ko, kn, x, M, metric=metric, reverse=False, threads=8)
+            off, nbr, on_host = g.build_graph_gd_device(ko, kn, x, M, metric=metric, reverse=rev, threads=8)
+            assert np.array_equal(off, w_off) and np.array_equal(nbr, w_nbr), (n, d, K, M, metric, rev)
+        if K <= 1024 and metric == 0:
+            assert on_host < n // 2, (on_host, n)       # most nodes are decided on the device (the generator's
+                                                        # quantised coordinates produce some equal distances)
+        if K > 1024:
+            assert on_host > 0                            # lists beyond the kernel's capacity go to the host
+    lat = datagen.Case("lat", 7777, 2000, 4, 12, 4, 8, kind="lattice")
+    knn, _ = orc.exact_knn(lat.base, lat.base, 30, 0, self_offset=0, threads=8)
+    ko, kn = datagen.dense_to_csr(knn)
+    want_off, want_nbr = g.build_graph_gd(ko, kn, lat.base, 8, threads=8)
+    off, nbr, on_host = g.build_graph_gd_device(ko, kn, lat.base, 8, threads=8)
+    assert np.array_equal(off, want_off) and np.array_equal(nbr, want_nbr)
+    assert on_host > 1000   # equal distances everywhere
