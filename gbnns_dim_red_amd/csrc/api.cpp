@@ -869,7 +869,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.hash_cap = cap;
     w.hash_limit = cap - cap / 16;
     w.all_general = (walk_fast_lds_bytes(w, hot) > kMaxLds || n_ent > 1) ? 1 : 0;  // several entry points: general kernel only
-    // Fused re-rank: with a register-list first pass (ef <= 256; and its retry / general successors) every
+    // Fused re-rank: with a register-list first pass (ef <= 512; and its retry / general successors) every
     // wavefront re-ranks its own query when its walk ends; no re-rank launch.  Needs the pair form
     // (d % 8 == 0) and room for the original-space query in the walk kernels' LDS.
     const bool fuse = !walk_uses_lds_list(w) && !plain && !w.all_general && ix->d % 8 == 0 &&

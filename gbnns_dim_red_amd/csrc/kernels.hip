@@ -812,7 +812,7 @@ __device__ __forceinline__ uint64_t clear_bit64(uint64_t m, int bit) {  // wave-
 }
 
 constexpr int kRegTieCap = 16;       // tie list of the register kernel (LDS, 128 B)
-constexpr int kRegListMaxEf = 256;   // largest ef served by the register-list kernels (4 registers per lane)
+constexpr int kRegListMaxEf = 512;   // largest ef served by the register-list kernels (8 registers per lane)
 
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
@@ -2824,7 +2824,7 @@ bool walk_uses_hot(const WalkParams& p, int metric) {
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list) {
     if (hot) return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8;
     if (ef <= kRegListMaxEf && !lds_list) {  // tie list + merge buffer (ranks 0..ef of the 1 / 2 / 4-register list) + query
-        const int regs = ef <= 64 ? 1 : (ef <= 128 ? 2 : 4);
+        const int regs = ef <= 64 ? 1 : (ef <= 128 ? 2 : (ef <= 256 ? 4 : 8));
         return (size_t)kRegTieCap * 8 + (size_t)(64 * regs + 2) * 8 + (size_t)dstride * 4;
     }
     const size_t ef_pad = ((size_t)ef + 63) & ~(size_t)63;
@@ -2900,7 +2900,8 @@ static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) 
     }
     if (p.ef <= 64) return launch_reg_t<METRIC, STEPS, 1>(p, retry, lds, s);
     if (p.ef <= 128) return launch_reg_t<METRIC, kWideSteps, 2>(p, retry, lds, s);
-    return launch_reg_t<METRIC, kWideSteps, 4>(p, retry, lds, s);
+    if (p.ef <= 256) return launch_reg_t<METRIC, kWideSteps, 4>(p, retry, lds, s);
+    return launch_reg_t<METRIC, kWideSteps, 8>(p, retry, lds, s);
 }
 
 static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, hipStream_t s) {
