@@ -2891,6 +2891,9 @@ template <int METRIC, int STEPS>
 static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) {
     const size_t lds = walk_fast_lds_bytes(p, false);
     constexpr int kWideSteps = (STEPS == 8) ? 8 : 0;
+    // 256-byte rows (d_low = 64, the GIST shape, whose efs start at 200): the 4- and 8-register lists keep the
+    // unrolled distance with early row loads as well
+    constexpr int kWideSteps48 = (STEPS == 8 || STEPS == 16) ? STEPS : 0;
     if (walk_uses_lds_list(p)) {
         if (walk_uses_packed(p))
             return retry ? launch_walk_k(walk_fast_kernel<METRIC, STEPS, true, true>, p, true, lds, s)
@@ -2900,8 +2903,8 @@ static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) 
     }
     if (p.ef <= 64) return launch_reg_t<METRIC, STEPS, 1>(p, retry, lds, s);
     if (p.ef <= 128) return launch_reg_t<METRIC, kWideSteps, 2>(p, retry, lds, s);
-    if (p.ef <= 256) return launch_reg_t<METRIC, kWideSteps, 4>(p, retry, lds, s);
-    return launch_reg_t<METRIC, kWideSteps, 8>(p, retry, lds, s);
+    if (p.ef <= 256) return launch_reg_t<METRIC, kWideSteps48, 4>(p, retry, lds, s);
+    return launch_reg_t<METRIC, kWideSteps48, 8>(p, retry, lds, s);
 }
 
 static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, hipStream_t s) {

@@ -777,14 +777,15 @@ def test_wide_index_kernels(g, orc):
                 w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, metric=metric, threads=8, **okw)
                 s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net,
                                      entries=ent, metric=metric, threads=8, **okw)
-                r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"),
-                              hash_capacity=hcap, flags=g.FLAG_WIDE_INDEX, **gkw)
-                key = (metric, d, ef, hcap, use_aux)
-                assert np.array_equal(r["cand"], w["ids"]), key
-                assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
-                assert np.array_equal(r["hops"], w["hops"]), key
-                assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
-                assert np.array_equal(r["ids"], s["ids"]), key
+                for flags in (g.FLAG_WIDE_INDEX, 0):   # 0: the same shapes on the compact instantiations
+                    r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"),
+                                  hash_capacity=hcap, flags=flags, **gkw)
+                    key = (metric, d, ef, hcap, use_aux, flags)
+                    assert np.array_equal(r["cand"], w["ids"]), key
+                    assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
+                    assert np.array_equal(r["hops"], w["hops"]), key
+                    assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
+                    assert np.array_equal(r["ids"], s["ids"]), key
             ix.close()
 
 

@@ -18,6 +18,7 @@ ap.add_argument("--scale", type=float, default=1.0, help="scale n (and nq for de
 ap.add_argument("--negdot", action="store_true", help="walk / re-rank with the negative-dot metric (Angular::Dist)")
 ap.add_argument("--aux", type=int, default=0, help="attach a random long-link auxiliary graph of this degree and "
                 "run the reference's use_second_graph walk (llf, hops_bound 50) beside the plain one")
+ap.add_argument("--inflight", type=int, default=0, help="also measure with this many batches in flight (one index handle and HIP stream each)")
 ap.add_argument("--native-knn", action="store_true", help="build the dataset's kNN lists / ground truth with gbnns_exact_knn (needed for n = 10^7)")
 a = ap.parse_args()
 for name in a.configs:
@@ -59,6 +60,23 @@ for name in a.configs:
                               hops=round(r["hops"].float().mean().item(), 1),
                               dist_calc=round(r["dist_calc"].float().mean().item(), 1),
                               general=p["general_queries"])), flush=True)
+    if a.inflight > 1:
+        hs = [ix] + [ds.index() for _ in range(a.inflight - 1)]
+        ss = [torch.cuda.Stream() for _ in hs]
+        outs = [{} for _ in hs]
+        for ef in efs:
+            for i in range(4 * len(hs)):
+                hs[i % len(hs)].search(ds.queries, ef, want=(), stream=ss[i % len(hs)], out=outs[i % len(hs)])
+            torch.cuda.synchronize()
+            reps = 8 * len(hs)
+            t1 = time.perf_counter()
+            for i in range(reps):
+                hs[i % len(hs)].search(ds.queries, ef, want=(), stream=ss[i % len(hs)], out=outs[i % len(hs)])
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / reps
+            print(json.dumps(dict(config=name, ef=ef, batches_in_flight=len(hs), qps=round(ds.nq / dt), ms_per_batch=round(dt * 1e3, 3))), flush=True)
+        for h in hs[1:]:
+            h.close()
     ix.close()
     del ds
     torch.cuda.empty_cache()
