@@ -35,8 +35,8 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--ef", type=int, default=64, help="beam width of the timed steps (config: 64)")
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--nq", type=int, default=10_000)
