@@ -144,6 +144,11 @@ def main():
                 pending[b].wait()
                 pending[b] = None
 
+    # The library sizes its visited sets from the walks it has seen and drops the retry launch once a few batches
+    # of a configuration were quiet: let that settle before the W warm-up steps, whatever W is.
+    for _ in range(8):
+        ix.search(q, ef, want=(), hash_capacity=args.hash_capacity)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     drain()
