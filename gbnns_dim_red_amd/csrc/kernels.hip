@@ -1652,6 +1652,47 @@ __device__ __forceinline__ bool reg1_select_slow(RegList<1>& L, uint64_t mu, int
 // run the visited-set protocol of visited_claim_mask on the even lanes while they are in flight, then
 // the pair distance of l2_pair_from_regs.  Returns the sort key of the distance (meaningful in the odd
 // lane of a pair whose id was new); `claimed` = even lanes whose id was new.
+// The same for lists of R registers per lane (`p1` = rank of the closest unexpanded entry, -1 if none).
+template <int R>
+__device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsize, uint64_t* tie, uint32_t worst, int ef,
+                                                 int lane, uint32_t& node) {
+    int best = -1;
+    uint32_t hi_p = 0;
+    if (p1 >= 0) {
+        hi_p = L.hi_at(p1);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t ms = __ballot(!(L.lo[r] & 1u) && L.hi[r] == hi_p) & RegList<R>::lane_mask(r, ef);
+            if (ms) best = r * 64 + 63 - __clzll((long long)ms);
+        }
+    }
+    if (tsize > 0 && (best < 0 || hi_p == worst)) {
+        // tie entries all sit at the worst distance: the largest id among them competes
+        uint32_t v = (lane < tsize) ? key_id(tie[lane]) + 1u : 0u;
+        int w = lane;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t ov = (uint32_t)__shfl_xor((int)v, off);
+            const int ow = __shfl_xor(w, off);
+            if (ov > v) { v = ov; w = ow; }
+        }
+        v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        w = __builtin_amdgcn_readfirstlane(w);
+        const uint32_t lid = (best >= 0) ? (L.lo_at(best) >> 1) : 0u;
+        if (best < 0 || v - 1u > lid) {
+            node = v - 1u;
+            if (lane == 0) tie[w] = tie[tsize - 1];
+            tsize -= 1;
+            wave_sync();
+            return true;
+        }
+    }
+    if (best < 0) return false;
+    node = L.lo_at(best) >> 1;
+    L.mark_expanded(best, lane);
+    return true;
+}
+
 template <typename QP>
 __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t roff, uint32_t nb, uint64_t valid, uint32_t lds_base,
                                                uint32_t nbuckets, QP qh, uint64_t& claimed) {
@@ -1783,6 +1824,9 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
     return key;
 }
 
+// R = list registers per lane: 1 (ef <= 64, every block hand-laid-out) or 2 (ef <= 128: the same hop -- one-block
+// expansion, packed visited set, both prefetches -- around the generic selection and merge of 2-register lists).
+template <int R>
 __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, unsigned char* smem) {
     const int lane = lane_id();
     const uint32_t slot = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;  // lane = 2 * adjacency slot + row half
@@ -1791,7 +1835,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
     uint64_t* stage = tie + kRegTieCap;
     float* qf = reinterpret_cast<float*>(stage);
-    uint32_t* hash = reinterpret_cast<uint32_t*>(stage + kRegStageSlots);
+    uint32_t* hash = reinterpret_cast<uint32_t*>(stage + reg_stage_slots(R));
     const float4* qs = reinterpret_cast<const float4*>(qf);
     const uint32_t cap = p.hash_cap;
     const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
@@ -1805,7 +1849,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
 #pragma unroll
     for (int t = 0; t < 4; ++t) qreg.v[t] = qs[4 * half + t];
 
-    RegList<1> L;
+    RegList<R> L;
     L.clear();
     int size = 1, tsize = 0, hops = 0, dist_calc = 1, edges = 0;
     uint32_t worst;
@@ -1821,7 +1865,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
         wave_sync();
     }
 
-    const uint64_t lmask = RegList<1>::lane_mask(0, ef);
+    const uint64_t lmask = RegList<R>::lane_mask(0, ef);
     const uint32_t ell_row_bytes = p.ell_stride * 4u;
     const bool slot_ok = slot < p.ell_stride;             // ell_stride is 16 or 32 here
     const uint32_t slot_off = slot_ok ? slot * 4u : 0u;    // lanes beyond the row read slot 0 and are masked
@@ -1835,7 +1879,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     while (true) {
         // ---- next node: closest unexpanded entry (ties -> largest id), and the runner-up as prediction
         uint32_t node, pred, ok, h2;
-        {
+        if constexpr (R == 1) {
             uint64_t fm;
             uint32_t t0, q1, q2, h1;
             asm volatile(
@@ -1870,12 +1914,44 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
                   [h2] "=&s"(h2), [node] "=&s"(node), [pred] "=&s"(pred), [ok] "=&s"(ok)
                 : [hi] "v"(L.hi[0]), [lmask] "s"(lmask), [tsize] "s"(tsize), [lane] "v"(lane)
                 : "vcc", "scc");
-        }
-        if (__builtin_expect(ok == 0, 0)) {
-            const uint64_t mu = __ballot(!(L.lo[0] & 1u)) & lmask;
-            if (!reg1_select_slow(L, mu, tsize, tie, worst, lmask, lane, node)) break;
-            pred = kInvalidId;
-            h2 = 0xFFFFFFFFu;
+            if (__builtin_expect(ok == 0, 0)) {
+                const uint64_t mu = __ballot(!(L.lo[0] & 1u)) & lmask;
+                if (!reg1_select_slow(L, mu, tsize, tie, worst, lmask, lane, node)) break;
+                pred = kInvalidId;
+                h2 = 0xFFFFFFFFu;
+            }
+        } else {
+            // the two closest unexpanded entries across the R registers (ranks p1 < p2)
+            int p1 = -1, p2 = -1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                uint64_t mm = __ballot(!(L.lo[r] & 1u)) & RegList<R>::lane_mask(r, ef);
+                if (p1 < 0 && mm) {
+                    p1 = r * 64 + __ffsll((unsigned long long)mm) - 1;
+                    mm &= mm - 1;
+                }
+                if (p1 >= 0 && p2 < 0 && mm) p2 = r * 64 + __ffsll((unsigned long long)mm) - 1;
+            }
+            ok = 0; node = 0; pred = kInvalidId; h2 = 0xFFFFFFFFu;
+            if (p1 >= 0 && tsize == 0) {
+                if (p2 >= 0) {
+                    const uint32_t hp2 = L.hi_at(p2);
+                    if (L.hi_at(p1) != hp2) {  // distinct distances: plain pick, the runner-up is the prediction
+                        ok = 1;
+                        node = L.lo_at(p1) >> 1;
+                        pred = L.lo_at(p2) >> 1;
+                        h2 = hp2;
+                        L.mark_expanded(p1, lane);
+                    }
+                } else {
+                    ok = 1;
+                    node = L.lo_at(p1) >> 1;
+                    L.mark_expanded(p1, lane);
+                }
+            }
+            if (__builtin_expect(ok == 0, 0)) {
+                if (!regN_select_slow<R>(L, p1, tsize, tie, worst, ef, lane, node)) break;
+            }
         }
 
         // ---- adjacency row of `node` (prefetched, or loaded now), then the prefetch for the next hop
@@ -1918,12 +1994,16 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
                         }
                     }
                 }
-                if ((m & (m - 1)) == 0 ||
-                    !reg_merge(m, __builtin_amdgcn_inverse_ballot_w64(m), dk, nb, L, size, worst, tsize, stage, ef, lane)) {
+                bool merged = false;
+                if ((m & (m - 1)) != 0) {
+                    if constexpr (R == 1) merged = reg_merge(m, __builtin_amdgcn_inverse_ballot_w64(m), dk, nb, L, size, worst, tsize, stage, ef, lane);
+                    else merged = reg_merge_multi<R>(m, __builtin_amdgcn_inverse_ballot_w64(m), dk, nb, L, size, worst, tsize, stage, ef, lane);
+                }
+                if (!merged) {
                     do {
                         const int l = __ffsll((unsigned long long)m) - 1;
                         m &= m - 1;
-                        if (!reg_offer<1>(readlane_u32(dk, l), readlane_u32(nb, l) << 1, L, size, worst, tsize, tie, ef, lane)) {
+                        if (!reg_offer<R>(readlane_u32(dk, l), readlane_u32(nb, l) << 1, L, size, worst, tsize, tie, ef, lane)) {
                             handed_over = true;
                             break;
                         }
@@ -1942,16 +2022,21 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
         }
         return;
     }
-    reg_write_results<1>(p, qi, L, size, hops, dist_calc, edges, lane);
+    reg_write_results<R>(p, qi, L, size, hops, dist_calc, edges, lane);
     if (p.rr_db) {
         const int kept = size < p.k ? size : p.k;
-        fused_rerank(p, qi, kept, smem, lane, [&](int rank) { return reg_id_at_rank<1>(L, rank); });
+        fused_rerank(p, qi, kept, smem, lane, [&](int rank) { return reg_id_at_rank<R>(L, rank); });
     }
 }
 
 __global__ __launch_bounds__(64) void walk_hot_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    walk_hot_one(p, blockIdx.x, smem);
+    walk_hot_one<1>(p, blockIdx.x, smem);
+}
+
+__global__ __launch_bounds__(64) void walk_hot2_kernel(WalkParams p) {  // 64 < ef <= 128
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_hot_one<2>(p, blockIdx.x, smem);
 }
 
 template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R, bool ONE_CHUNK = false, bool AUX = false>
@@ -2815,14 +2900,14 @@ bool walk_uses_lds_list(const WalkParams& p) { return p.ef > kRegListMaxEf || (p
 
 bool walk_uses_hot(const WalkParams& p, int metric) {
     const bool off32 = walk_off32(p);
-    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 64 && p.ell_stride <= 32u && off32 && !p.stamps_on &&
+    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 128 && p.ell_stride <= 32u && off32 && !p.stamps_on &&
            !p.aux_ell;  // (off32 includes n < 2^24: its visited set stores 24-bit ids)
 }
 
 // LDS of one wavefront without the visited set.  Register kernels: tie list + merge buffer + query; the
 // hot kernel stages the query inside the merge buffer (it lives in registers once the walk starts).
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list) {
-    if (hot) return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8;
+    if (hot) return (size_t)kRegTieCap * 8 + (size_t)(64 * (ef <= 64 ? 1 : 2) + 2) * 8;  // tie list + merge buffer of 1 or 2 registers
     if (ef <= kRegListMaxEf && !lds_list) {  // tie list + merge buffer (ranks 0..ef of the 1 / 2 / 4-register list) + query
         const int regs = ef <= 64 ? 1 : (ef <= 128 ? 2 : (ef <= 256 ? 4 : 8));
         return (size_t)kRegTieCap * 8 + (size_t)(64 * regs + 2) * 8 + (size_t)dstride * 4;
@@ -2877,6 +2962,10 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
         }
         if (off32 && !retry && p.ell_stride <= (STEPS == 8 ? 32u : 64u))
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
+    }
+    if constexpr (R == 2 && METRIC == 0 && STEPS == 8) {
+        if (!retry && walk_uses_hot(p, METRIC))
+            return launch_walk_k(walk_hot2_kernel, p, false, walk_fast_lds_bytes(p, true), s);
     }
     if (off32)
         return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, true, R>, p, true, lds, s)

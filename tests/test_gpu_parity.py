@@ -133,7 +133,7 @@ def test_pair_gather_multi_pass_and_retry(g, orc):
 
 
 def test_hot_kernel_tie_paths(g, orc):
-    """The hand-laid-out instance (L2, 128-byte rows, ef <= 64, rows of <= 32 slots) on data full of exact
+    """The hand-laid-out instances (L2, 128-byte rows, ef <= 128, rows of <= 32 slots) on data full of exact
     distance ties: a 32-dimensional lattice with every vector stored three times, walked directly (PLAIN
     mode, so the walked rows are 128 bytes).  Exercises its out-of-line selection (equal-distance runs,
     tie list), the boundary-tie fallback of the batch merge, both adjacency prefetches on wrong guesses,
@@ -144,7 +144,7 @@ def test_hot_kernel_tie_paths(g, orc):
     ent = rng.integers(0, cl.n, size=cl.nq).astype(np.uint32)
     ix = g.Index(cl.base, off, nbr)
     ix.profile_enable(True)
-    for ef in (1, 2, 5, 16, 33, 64):
+    for ef in (1, 2, 5, 16, 33, 64, 65, 100, 128):   # 65 .. 128: the 2-register instance (walk_hot2_kernel)
         w = orc.walk(cl.queries, cl.base, off, nbr, ef, entries=ent, threads=8)
         r = ix.search(cl.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent,
                       want=("hops", "dist_calc", "cand", "cand_dist"))
