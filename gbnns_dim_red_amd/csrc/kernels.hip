@@ -1824,8 +1824,9 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
     return key;
 }
 
-// R = list registers per lane: 1 (ef <= 64, every block hand-laid-out) or 2 (ef <= 128: the same hop -- one-block
-// expansion, packed visited set, both prefetches -- around the generic selection and merge of 2-register lists).
+// R = list registers per lane: 1 (ef <= 64, every block hand-laid-out), 2 (ef <= 128), 3 (ef <= 192) or 4 (ef <= 256): the same hop
+// -- one-block expansion, packed visited set, both prefetches -- around the generic selection and merge of
+// multi-register lists.
 template <int R>
 __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, unsigned char* smem) {
     const int lane = lane_id();
@@ -2037,6 +2038,16 @@ __global__ __launch_bounds__(64) void walk_hot_kernel(WalkParams p) {
 __global__ __launch_bounds__(64) void walk_hot2_kernel(WalkParams p) {  // 64 < ef <= 128
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<2>(p, blockIdx.x, smem);
+}
+
+__global__ __launch_bounds__(64) void walk_hot3_kernel(WalkParams p) {  // 128 < ef <= 192 (the reference's 140, 160, 180)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_hot_one<3>(p, blockIdx.x, smem);
+}
+
+__global__ __launch_bounds__(64) void walk_hot4_kernel(WalkParams p) {  // 192 < ef <= 256
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_hot_one<4>(p, blockIdx.x, smem);
 }
 
 template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R, bool ONE_CHUNK = false, bool AUX = false>
@@ -2900,14 +2911,14 @@ bool walk_uses_lds_list(const WalkParams& p) { return p.ef > kRegListMaxEf || (p
 
 bool walk_uses_hot(const WalkParams& p, int metric) {
     const bool off32 = walk_off32(p);
-    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 128 && p.ell_stride <= 32u && off32 && !p.stamps_on &&
+    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 256 && p.ell_stride <= 32u && off32 && !p.stamps_on &&
            !p.aux_ell;  // (off32 includes n < 2^24: its visited set stores 24-bit ids)
 }
 
 // LDS of one wavefront without the visited set.  Register kernels: tie list + merge buffer + query; the
 // hot kernel stages the query inside the merge buffer (it lives in registers once the walk starts).
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list) {
-    if (hot) return (size_t)kRegTieCap * 8 + (size_t)(64 * (ef <= 64 ? 1 : 2) + 2) * 8;  // tie list + merge buffer of 1 or 2 registers
+    if (hot) return (size_t)kRegTieCap * 8 + (size_t)(64 * (ef <= 64 ? 1 : (ef <= 128 ? 2 : (ef <= 192 ? 3 : 4))) + 2) * 8;  // tie list + merge buffer of 1 .. 4 registers
     if (ef <= kRegListMaxEf && !lds_list) {  // tie list + merge buffer (ranks 0..ef of the 1 / 2 / 4-register list) + query
         const int regs = ef <= 64 ? 1 : (ef <= 128 ? 2 : (ef <= 256 ? 4 : 8));
         return (size_t)kRegTieCap * 8 + (size_t)(64 * regs + 2) * 8 + (size_t)dstride * 4;
@@ -2963,9 +2974,10 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
         if (off32 && !retry && p.ell_stride <= (STEPS == 8 ? 32u : 64u))
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
     }
-    if constexpr (R == 2 && METRIC == 0 && STEPS == 8) {
+    if constexpr ((R == 2 || R == 4) && METRIC == 0 && STEPS == 8) {
         if (!retry && walk_uses_hot(p, METRIC))
-            return launch_walk_k(walk_hot2_kernel, p, false, walk_fast_lds_bytes(p, true), s);
+            return launch_walk_k(R == 2 ? walk_hot2_kernel : (p.ef <= 192 ? walk_hot3_kernel : walk_hot4_kernel), p, false,
+                                 walk_fast_lds_bytes(p, true), s);
     }
     if (off32)
         return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, true, R>, p, true, lds, s)
