@@ -1824,7 +1824,7 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
     return key;
 }
 
-// R = list registers per lane: 1 (ef <= 64, every block hand-laid-out), 2 (ef <= 128), 3 (ef <= 192) or 4 (ef <= 256): the same hop
+// R = list registers per lane = ceil(ef / 64): 1 (every block hand-laid-out) .. 8 (ef <= 512): the same hop
 // -- one-block expansion, packed visited set, both prefetches -- around the generic selection and merge of
 // multi-register lists.
 template <int R>
@@ -2048,6 +2048,12 @@ __global__ __launch_bounds__(64) void walk_hot3_kernel(WalkParams p) {  // 128 <
 __global__ __launch_bounds__(64) void walk_hot4_kernel(WalkParams p) {  // 192 < ef <= 256
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<4>(p, blockIdx.x, smem);
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void walk_hotN_kernel(WalkParams p) {  // 256 < ef <= 512: R = ceil(ef / 64) registers
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_hot_one<R>(p, blockIdx.x, smem);
 }
 
 template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R, bool ONE_CHUNK = false, bool AUX = false>
@@ -2911,14 +2917,14 @@ bool walk_uses_lds_list(const WalkParams& p) { return p.ef > kRegListMaxEf || (p
 
 bool walk_uses_hot(const WalkParams& p, int metric) {
     const bool off32 = walk_off32(p);
-    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 256 && p.ell_stride <= 32u && off32 && !p.stamps_on &&
+    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 512 && p.ell_stride <= 32u && off32 && !p.stamps_on &&
            !p.aux_ell;  // (off32 includes n < 2^24: its visited set stores 24-bit ids)
 }
 
 // LDS of one wavefront without the visited set.  Register kernels: tie list + merge buffer + query; the
 // hot kernel stages the query inside the merge buffer (it lives in registers once the walk starts).
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list) {
-    if (hot) return (size_t)kRegTieCap * 8 + (size_t)(64 * (ef <= 64 ? 1 : (ef <= 128 ? 2 : (ef <= 192 ? 3 : 4))) + 2) * 8;  // tie list + merge buffer of 1 .. 4 registers
+    if (hot) return (size_t)kRegTieCap * 8 + (size_t)(64 * ((ef + 63) / 64) + 2) * 8;  // tie list + merge buffer of ceil(ef / 64) registers
     if (ef <= kRegListMaxEf && !lds_list) {  // tie list + merge buffer (ranks 0..ef of the 1 / 2 / 4-register list) + query
         const int regs = ef <= 64 ? 1 : (ef <= 128 ? 2 : (ef <= 256 ? 4 : 8));
         return (size_t)kRegTieCap * 8 + (size_t)(64 * regs + 2) * 8 + (size_t)dstride * 4;
@@ -2978,6 +2984,17 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
         if (!retry && walk_uses_hot(p, METRIC))
             return launch_walk_k(R == 2 ? walk_hot2_kernel : (p.ef <= 192 ? walk_hot3_kernel : walk_hot4_kernel), p, false,
                                  walk_fast_lds_bytes(p, true), s);
+    }
+    if constexpr (R == 8 && METRIC == 0 && STEPS == 8) {
+        if (!retry && walk_uses_hot(p, METRIC)) {  // the fewest registers that hold ef entries: a merge costs per register
+            const size_t hl = walk_fast_lds_bytes(p, true);
+            switch ((p.ef + 63) / 64) {
+                case 5: return launch_walk_k(walk_hotN_kernel<5>, p, false, hl, s);
+                case 6: return launch_walk_k(walk_hotN_kernel<6>, p, false, hl, s);
+                case 7: return launch_walk_k(walk_hotN_kernel<7>, p, false, hl, s);
+                default: return launch_walk_k(walk_hotN_kernel<8>, p, false, hl, s);
+            }
+        }
     }
     if (off32)
         return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, true, R>, p, true, lds, s)
