@@ -194,8 +194,9 @@ def main():
     max_degree = int(np.diff(np.asarray(ds.graph_off).astype(np.int64)).max())
     # ef <= 64, 128-B rows, adjacency rows of <= 32 slots: the hand-laid-out instance, which also re-ranks
     # each query at the end of its walk (no re-rank launch) -- its algorithmic bytes are SURVEY 8d's full B(q)
-    hot = ef <= 64 and ds.d_low == 32 and max_degree <= 32
-    fused = hot and ds.d % 8 == 0
+    hot_shape = ds.d_low == 32 and max_degree <= 32
+    hot = ef <= 64 and hot_shape
+    fused = ef <= 512 and ds.d % 8 == 0   # every register-list first pass re-ranks at the end of the walk
     kernel_bytes = walk_bytes + (rerank_bytes if fused else 0.0)
     achieved = kernel_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
     traffic = None
@@ -235,8 +236,10 @@ def main():
         "roofline": {
             "bound": "hbm",
             # ef <= 64, 128-B rows, adjacency rows of <= 32 slots: the hand-laid-out instance
-            "kernel": (("walk_hot_kernel (walk + fused re-rank)" if fused else "walk_hot_kernel") if hot else
-                       "walk_reg_kernel" if ef <= 256 else "walk_fast_kernel"),
+            "kernel": (("walk_hot_kernel" if hot else
+                        ("walk_hot%d_kernel" % ((ef + 63) // 64) if ef <= 256 else "walk_hotN_kernel<%d>" % ((ef + 63) // 64))
+                        if hot_shape and ef <= 512 else "walk_reg_kernel" if ef <= 512 else "walk_fast_kernel")
+                       + (" (walk + fused re-rank)" if fused else "")),
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
