@@ -2985,6 +2985,19 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
             return launch_walk_k(R == 2 ? walk_hot2_kernel : (p.ef <= 192 ? walk_hot3_kernel : walk_hot4_kernel), p, false,
                                  walk_fast_lds_bytes(p, true), s);
     }
+    if constexpr ((R == 4 || R == 8) && STEPS == 8) {
+        // 128-byte rows that the hot instances do not take (dot metric, adjacency rows of more than 32 slots): the
+        // first pass still gets the fewest registers that hold ef entries -- a merge costs per register
+        if (!retry && off32 && !walk_uses_hot(p, METRIC)) {
+            switch ((p.ef + 63) / 64) {
+                case 3: return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 3>, p, false, lds, s);
+                case 5: return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 5>, p, false, lds, s);
+                case 6: return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 6>, p, false, lds, s);
+                case 7: return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 7>, p, false, lds, s);
+                default: break;
+            }
+        }
+    }
     if constexpr (R == 8 && METRIC == 0 && STEPS == 8) {
         if (!retry && walk_uses_hot(p, METRIC)) {  // the fewest registers that hold ef entries: a merge costs per register
             const size_t hl = walk_fast_lds_bytes(p, true);
