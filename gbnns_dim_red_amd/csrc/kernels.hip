@@ -12,6 +12,13 @@
 
 #include "kernels.h"
 
+// This file is compiled three times (csrc/Makefile, -DGBNNS_TU=0/1/2) so that the many walk-kernel instantiations
+// build in parallel: unit 0 holds every launcher and the L2 walks over generic / 128-byte rows, unit 1 the
+// dot-metric walks, unit 2 the L2 walks over 192- and 256-byte rows.  Templates are instantiated where they are used.
+#ifndef GBNNS_TU
+#define GBNNS_TU 0
+#endif
+
 namespace gbnns {
 
 namespace {
@@ -2912,6 +2919,7 @@ static bool walk_off32(const WalkParams& p) {  // "compact" index: every table t
            (!p.aux_ell || (uint64_t)p.n * p.aux_stride * 4 < (1ull << 32)) && p.n <= 0xFFFFFFu;
 }
 
+#if GBNNS_TU == 0
 // The LDS-list kernel serves ef beyond the register lists, and auxiliary-graph walks over tables >= 4 GiB.
 bool walk_uses_lds_list(const WalkParams& p) { return p.ef > kRegListMaxEf || (p.aux_ell && !walk_off32(p)); }
 
@@ -2945,6 +2953,8 @@ bool walk_uses_packed(const WalkParams& p) { return walk_uses_lds_list(p) ? (p.n
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot) {
     return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p)) + walk_hash_bytes(p.hash_cap, walk_uses_packed(p));
 }
+
+#endif  // GBNNS_TU == 0
 
 template <typename K>
 static hipError_t set_lds(K kernel, size_t bytes) {
@@ -3038,17 +3048,32 @@ static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) 
     return launch_reg_t<METRIC, kWideSteps48, 8>(p, retry, lds, s);
 }
 
+// the walk launchers of the other two compilation units of this file
+hipError_t launch_walk_tu1(const WalkParams& p, bool retry, hipStream_t s);              // dot metric
+hipError_t launch_walk_tu2(const WalkParams& p, int steps, bool retry, hipStream_t s);   // L2, 12 / 16 steps per row
+
+#if GBNNS_TU == 1
+hipError_t launch_walk_tu1(const WalkParams& p, bool retry, hipStream_t s) {
+    if (p.dstride == p.dim && p.dim == 32) return launch_fast_t<1, 8>(p, retry, s);  // 128-byte rows: pair form
+    return launch_fast_t<1, 0>(p, retry, s);
+}
+#endif
+
+#if GBNNS_TU == 2
+hipError_t launch_walk_tu2(const WalkParams& p, int steps, bool retry, hipStream_t s) {
+    return steps == 12 ? launch_fast_t<0, 12>(p, retry, s) : launch_fast_t<0, 16>(p, retry, s);
+}
+#endif
+
+#if GBNNS_TU == 0
 static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
-    if (metric == 1) {
-        if (p.dstride == p.dim && p.dim == 32) return launch_fast_t<1, 8>(p, retry, s);  // 128-byte rows: pair form
-        return launch_fast_t<1, 0>(p, retry, s);
-    }
+    if (metric == 1) return launch_walk_tu1(p, retry, s);
     if (p.dstride == p.dim) {
         switch (p.dim) {
             case 32: return launch_fast_t<0, 8>(p, retry, s);
-            case 48: return launch_fast_t<0, 12>(p, retry, s);
-            case 64: return launch_fast_t<0, 16>(p, retry, s);
+            case 48: return launch_walk_tu2(p, 12, retry, s);
+            case 64: return launch_walk_tu2(p, 16, retry, s);
             default: break;
         }
     }
@@ -3189,5 +3214,7 @@ hipError_t launch_debug_merge(int regs, const uint64_t* entries, int size, const
     else hipLaunchKernelGGL((debug_merge_kernel<4>), dim3(1), dim3(64), 0, s, entries, size, surv, ef, out, out_size);
     return hipGetLastError();
 }
+
+#endif  // GBNNS_TU == 0
 
 }  // namespace gbnns
