@@ -144,7 +144,7 @@ def test_hot_kernel_tie_paths(g, orc):
     ent = rng.integers(0, cl.n, size=cl.nq).astype(np.uint32)
     ix = g.Index(cl.base, off, nbr)
     ix.profile_enable(True)
-    for ef in (1, 2, 5, 16, 33, 64, 65, 100, 128, 129, 160, 192, 193, 256, 257, 330, 400, 512):   # > 64: the multi-register instances
+    for ef in (1, 2, 5, 16, 33, 64, 65, 100, 128, 129, 160, 192, 193, 256, 257, 330, 400, 512, 513, 700, 1024):   # > 64: the multi-register instances
         w = orc.walk(cl.queries, cl.base, off, nbr, ef, entries=ent, threads=8)
         r = ix.search(cl.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent,
                       want=("hops", "dist_calc", "cand", "cand_dist"))
