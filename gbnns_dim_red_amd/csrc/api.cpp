@@ -104,7 +104,7 @@ struct gbnns_index {
     uint32_t ws1 = 0, ws2 = 0, ws3 = 0;
     // workspace
     DevBuf q_in, q_low, h1, h2, cand, cand_dist, cnt, hops, dc, edges, out, entries, ovf_list, ovf2_list, ctrl;
-    DevBuf g_bitmap, g_keys, g_tie;
+    DevBuf g_bitmap, g_keys, g_tie, fp_bitmap;
     // profiling
     bool profiling = false;
     std::vector<ProfCall> pending;
@@ -478,7 +478,7 @@ int gbnns_index_destroy(gbnns_index* ix) {
     if (ix->h_stats) (void)hipHostFree(ix->h_stats);
     DevBuf* bufs[] = {&ix->db_own, &ix->db_low_own, &ix->ell, &ix->aux_ell, &ix->net, &ix->q_in, &ix->q_low,
                       &ix->h1, &ix->h2, &ix->cand, &ix->cand_dist, &ix->cnt, &ix->hops, &ix->dc, &ix->edges,
-                      &ix->out, &ix->entries, &ix->ovf_list, &ix->ovf2_list, &ix->ctrl, &ix->g_bitmap, &ix->g_keys,
+                      &ix->out, &ix->entries, &ix->ovf_list, &ix->ovf2_list, &ix->ctrl, &ix->g_bitmap, &ix->fp_bitmap, &ix->g_keys,
                       &ix->g_tie};
     for (DevBuf* b : bufs) b->release();
     delete ix;
@@ -791,14 +791,17 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     uint32_t* out_dev = host ? ix->out.as<uint32_t>() : a->out_ids;
     w.best = plain ? out_dev : nullptr;
     // Control words, two per-call blocks used alternately: [0] list A count, [1] general cursor,
-    // [2] max dist_calc, [3] list B count, [4] retry cursor.  A call works on one block while its
+    // [2] max dist_calc, [3] list B count, [4] retry cursor, [6] bitmap-pass cursor.  A call works on one block while its
     // general kernel (the last walk launch) clears the other for the next call -- no per-call memset
     // launch.  Word 5 of block 0 = general-kernel query total (persistent); words 8..71 = diagnostics.
     uint32_t* ctrl_base = ix->ctrl.as<uint32_t>();
     const int cur = ix->ctrl_phase;
     uint32_t* ctrl = ctrl_base + (cur ? 72 : 0);
     uint32_t* ctrl_next = ctrl_base + (cur ? 0 : 72);
-    if (!ix->ctrl_clean[cur]) HIP_TRY(hipMemsetAsync(ctrl, 0, 20, s));  // after a failed call only
+    if (!ix->ctrl_clean[cur]) {  // after a failed call only (word 5 of block 0 is the persistent general-kernel total)
+        HIP_TRY(hipMemsetAsync(ctrl, 0, 20, s));
+        HIP_TRY(hipMemsetAsync(ctrl + 6, 0, 4, s));
+    }
     ix->ctrl_clean[cur] = false;
     ix->ctrl_phase = cur ^ 1;
     w.next_ctrl = ctrl_next;
@@ -887,8 +890,26 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         w.ovf_count = w.ovf2_count;
         w.ovf_list = w.ovf2_list;
     }
+    // Large ef (LDS-list territory): the visited table of such a walk would leave a handful of wavefronts per CU,
+    // so the first pass keeps its visited sets as bitmaps in HBM and runs as many persistent wavefronts as the
+    // LDS holds result lists; hand-overs (tie-list overflow) take the usual route.
+    bool bitmap_pass = false;
+    if (!w.all_general && walk_uses_lds_list(w) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && a->hash_capacity == 0) {
+        const size_t gran = 512;
+        const size_t per_wave = (walk_bitmap_lds_bytes(w) + gran - 1) / gran * gran;
+        const size_t per_cu = std::min<size_t>(32, kMaxLds / per_wave);
+        const size_t table_waves = std::min<size_t>(32, kMaxLds / ((walk_fast_lds_bytes(w, false) + gran - 1) / gran * gran));
+        const size_t bytes = per_cu * 256 * (size_t)bitmap_words * 4;
+        if (per_cu >= 2 * std::max<size_t>(table_waves, 1) && bytes <= (8ull << 30)) {
+            if ((rc = ix->fp_bitmap.ensure(bytes))) return rc;
+            w.fp_bitmap = ix->fp_bitmap.as<uint32_t>();
+            w.fp_cursor = ctrl + 6;
+            HIP_TRY(launch_walk_bitmap(w, ix->metric, (unsigned)(per_cu * 256), s));
+            bitmap_pass = true;
+        }
+    }
     if (!w.all_general) {
-        HIP_TRY(launch_walk_fast(w, ix->metric, s));
+        if (!bitmap_pass) HIP_TRY(launch_walk_fast(w, ix->metric, s));
         // retry pass: hand-overs of the first pass, one wavefront per CU with all the LDS
         WalkParams w2 = w;
         const size_t gran = 512;

@@ -48,6 +48,9 @@ struct WalkParams {
     uint32_t* ovf2_list;     // [nq]
     uint32_t* r_cursor;      // [1]   work-queue head of the retry pass
     // general kernel workspace: per slot [bitmap words][keys ef][tie n]
+    // first pass with the visited set in HBM (large ef): per-slot bitmaps and the work-queue head
+    uint32_t* fp_bitmap;     // [slots x bitmap_words]
+    uint32_t* fp_cursor;     // [1]
     uint32_t* g_cursor;      // [1] work-queue head
     uint32_t* g_total;       // [1] running count of queries the general kernel processed
     uint32_t* max_dc;        // [1] max dist_calc over the batch (feeds the host's visited-set sizing)
@@ -87,6 +90,8 @@ size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_li
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s);
+size_t walk_bitmap_lds_bytes(const WalkParams& p);
+hipError_t launch_walk_bitmap(const WalkParams& p, int metric, unsigned slots, hipStream_t s);  // persistent first pass, HBM bitmaps
 
 // Re-rank (search_function.h:105-125).  One query per wavefront, one candidate per lane.
 struct RerankParams {

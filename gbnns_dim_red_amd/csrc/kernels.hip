@@ -682,9 +682,12 @@ __device__ __forceinline__ float walk_dist(QP qs, const float* row, uint32_t dim
 // was inserted).  A query that would exceed hash_limit entries, or whose tie list overflows, is
 // appended to the hand-over list and re-run from scratch by the general kernel.
 
-template <int METRIC, int STEPS, bool PACKED>
+// BITMAP: the visited set is one bit per node in HBM (`bitmap`, private to this wavefront's slot, cleared here per
+// query) instead of the LDS table -- for large ef, where the table of a 10 000-distance walk would leave four
+// wavefronts per CU: the LDS then holds the result list, the tie list and the query only.
+template <int METRIC, int STEPS, bool PACKED, bool BITMAP = false>
 __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
-                                              uint32_t* ovf_count, uint32_t* ovf_list) {
+                                              uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
     const int lane = lane_id();
     const int ef = p.ef;
     const int ef_pad = (ef + 63) & ~63;
@@ -698,7 +701,9 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
     const uint32_t nbuckets = PACKED ? cap / 5u : cap >> 2;
     const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
 
-    if constexpr (PACKED) packed_table_init(hash, nbuckets, 0u, lane);
+    if constexpr (BITMAP) {
+        for (uint32_t i = lane; i < p.bitmap_words; i += 64) bitmap[i] = 0u;
+    } else if constexpr (PACKED) packed_table_init(hash, nbuckets, 0u, lane);
     else for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
     for (uint32_t i = lane; i < p.dstride; i += 64)
         qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
@@ -712,7 +717,8 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
         const float d0 = walk_dist<METRIC, STEPS>(qs, p.db + (size_t)entry * p.dstride, p.dim);
         if (lane == 0) {
             keys[0] = make_key(fkey(d0), entry);
-            if constexpr (PACKED) packed_table_put_first(hash, nbuckets, entry);
+            if constexpr (BITMAP) bitmap[entry >> 5] = 1u << (entry & 31u);
+            else if constexpr (PACKED) packed_table_put_first(hash, nbuckets, entry);
             else hash[4u * __umulhi(entry * 0x9E3779B1u, nbuckets)] = entry;  // first slot of its bucket
         }
         st.size = 1;
@@ -728,10 +734,17 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
             const bool valid = nb != kInvalidId;
             const uint64_t mv = __ballot(valid);
             if (!mv) break;
-            if ((uint32_t)st.dist_calc + 64u > p.hash_limit) { handed_over = true; break; }
+            if constexpr (!BITMAP)
+                if ((uint32_t)st.dist_calc + 64u > p.hash_limit) { handed_over = true; break; }
             st.edges += __popcll(mv);
             bool fresh;
-            if constexpr (PACKED) fresh = __builtin_amdgcn_inverse_ballot_w64(visited_claim_mask_packed(hash_lds, nbuckets, nb, mv));
+            if constexpr (BITMAP) {
+                fresh = false;
+                if (valid) {
+                    const uint32_t bit = 1u << (nb & 31u);
+                    fresh = !(atomicOr(&bitmap[nb >> 5], bit) & bit);
+                }
+            } else if constexpr (PACKED) fresh = __builtin_amdgcn_inverse_ballot_w64(visited_claim_mask_packed(hash_lds, nbuckets, nb, mv));
             else fresh = visited_claim(hash, nbuckets, nb, valid);
             uint32_t dk = 0xFFFFFFFFu;
             if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, p.db + (size_t)nb * p.dstride, p.dim));
@@ -794,6 +807,22 @@ __global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
         retry_loop(p, [&](uint32_t qi) { walk_fast_one<METRIC, STEPS, PACKED>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
     } else {
         walk_fast_one<METRIC, STEPS, PACKED>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
+    }
+}
+
+// First pass for large ef: persistent wavefronts (as many as the LDS holds result lists), each with its own
+// visited bitmap in HBM, pulling query indices from a counter.
+template <int METRIC, int STEPS>
+__global__ __launch_bounds__(64) void walk_bitmap_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* bitmap = p.fp_bitmap + (size_t)blockIdx.x * p.bitmap_words;
+    while (true) {
+        uint32_t w = 0;
+        if (lane_id() == 0) w = atomicAdd(p.fp_cursor, 1u);
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+        if (w >= p.nq) break;
+        walk_fast_one<METRIC, STEPS, false, true>(p, w, smem, p.ovf_count, p.ovf_list, bitmap);
+        wave_sync();
     }
 }
 
@@ -2129,7 +2158,7 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
     const int ef = p.ef;
     const uint32_t total = p.all_general ? p.nq : *p.ovf2_count;
     if (slot == 0 && lane == 0 && total) atomicAdd(p.g_total, total);
-    if (slot == 0 && lane < 5 && p.next_ctrl) p.next_ctrl[lane] = 0u;  // control words of the next call
+    if (slot == 0 && lane < 7 && lane != 5 && p.next_ctrl) p.next_ctrl[lane] = 0u;  // control words of the next call (word 5 of block 0 is the persistent general-kernel total)
 
     while (true) {
         uint32_t w = 0;
@@ -3082,6 +3111,28 @@ static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, h
 
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s) { return launch_walk_any(p, metric, false, s); }
 hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s) { return launch_walk_any(p, metric, true, s); }
+
+// LDS of the bitmap first pass: result list + tie list + query (no visited table)
+size_t walk_bitmap_lds_bytes(const WalkParams& p) { return walk_fast_lds_fixed_bytes(p.ef, p.dstride, false, true); }
+
+hipError_t launch_walk_bitmap(const WalkParams& p, int metric, unsigned slots, hipStream_t s) {
+    if (p.nq == 0) return hipSuccess;
+    const size_t lds = walk_bitmap_lds_bytes(p);
+    if (metric == 1) {
+        hipError_t e = set_lds(walk_bitmap_kernel<1, 0>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((walk_bitmap_kernel<1, 0>), dim3(slots), dim3(64), lds, s, p);
+    } else if (p.dstride == p.dim && p.dim == 32) {
+        hipError_t e = set_lds(walk_bitmap_kernel<0, 8>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((walk_bitmap_kernel<0, 8>), dim3(slots), dim3(64), lds, s, p);
+    } else {
+        hipError_t e = set_lds(walk_bitmap_kernel<0, 0>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((walk_bitmap_kernel<0, 0>), dim3(slots), dim3(64), lds, s, p);
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
