@@ -19,6 +19,7 @@ FLAG_NO_FUSED_RERANK = 2
 FLAG_AUX_GRAPH = 4
 FLAG_LLF = 8
 FLAG_WIDE_INDEX = 16
+FLAG_BITMAP_PASS = 32
 
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [

@@ -875,7 +875,28 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     // Fused re-rank: with a register-list first pass (ef <= 512; and its retry / general successors) every
     // wavefront re-ranks its own query when its walk ends; no re-rank launch.  Needs the pair form
     // (d % 8 == 0) and room for the original-space query in the walk kernels' LDS.
-    const bool fuse = !walk_uses_lds_list(w) && !plain && !w.all_general && ix->d % 8 == 0 &&
+    // Large ef: the visited table of such a walk would leave a handful of wavefronts per CU, so the first pass
+    // keeps its visited sets as bitmaps in HBM and runs as many persistent wavefronts as the LDS holds result
+    // lists (LDS-list kernel); taken when that at least doubles the resident wavefronts.
+    size_t bitmap_per_cu = 0;
+    {
+        // measured crossover on the GloVe-like shape: ef = 300 is faster with the register list + LDS table
+        // (4.3 vs 5.5 ms), ef = 400 with the bitmap pass (7.1 vs 9.4 ms); SIFT-like ef <= 180 clearly the former
+        const int min_ef = 385;
+        const bool forced = (a->flags & GBNNS_FLAG_BITMAP_PASS) != 0;  // diagnostic: whatever ef and batch size
+        if (!w.all_general && (ef >= min_ef || forced) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && (a->hash_capacity == 0 || forced)) {
+            const size_t gran = 512;
+            const size_t per_wave = (walk_bitmap_lds_bytes(w) + gran - 1) / gran * gran;
+            const size_t per_cu = std::min<size_t>(32, kMaxLds / per_wave);
+            const size_t table_waves = std::min<size_t>(32, kMaxLds / ((walk_fast_lds_bytes(w, hot) + gran - 1) / gran * gran));
+            // ... and only when the batch is deeper than 1.5 rounds of the wavefronts the table would allow (a
+            // 1 000-query batch is resident at once either way, and the register list is faster per hop)
+            if (((per_cu >= 2 * std::max<size_t>(table_waves, 1) && 2 * (size_t)nq > 3 * table_waves * 256) || forced) &&
+                per_cu >= 1 && per_cu * 256 * (size_t)bitmap_words * 4 <= (8ull << 30))
+                bitmap_per_cu = per_cu;
+        }
+    }
+    const bool fuse = !walk_uses_lds_list(w) && !bitmap_per_cu && !plain && !w.all_general && ix->d % 8 == 0 &&
                       (size_t)ix->d_pad * 4 <= walk_fast_lds_bytes(w, hot) && !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
     if (fuse) {
         w.rr_q = q_dev; w.rr_qstride = ix->d; w.rr_db = ix->db; w.rr_dstride = ix->d_pad; w.rr_dim = ix->d;
@@ -890,23 +911,13 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         w.ovf_count = w.ovf2_count;
         w.ovf_list = w.ovf2_list;
     }
-    // Large ef (LDS-list territory): the visited table of such a walk would leave a handful of wavefronts per CU,
-    // so the first pass keeps its visited sets as bitmaps in HBM and runs as many persistent wavefronts as the
-    // LDS holds result lists; hand-overs (tie-list overflow) take the usual route.
     bool bitmap_pass = false;
-    if (!w.all_general && walk_uses_lds_list(w) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && a->hash_capacity == 0) {
-        const size_t gran = 512;
-        const size_t per_wave = (walk_bitmap_lds_bytes(w) + gran - 1) / gran * gran;
-        const size_t per_cu = std::min<size_t>(32, kMaxLds / per_wave);
-        const size_t table_waves = std::min<size_t>(32, kMaxLds / ((walk_fast_lds_bytes(w, false) + gran - 1) / gran * gran));
-        const size_t bytes = per_cu * 256 * (size_t)bitmap_words * 4;
-        if (per_cu >= 2 * std::max<size_t>(table_waves, 1) && bytes <= (8ull << 30)) {
-            if ((rc = ix->fp_bitmap.ensure(bytes))) return rc;
-            w.fp_bitmap = ix->fp_bitmap.as<uint32_t>();
-            w.fp_cursor = ctrl + 6;
-            HIP_TRY(launch_walk_bitmap(w, ix->metric, (unsigned)(per_cu * 256), s));
-            bitmap_pass = true;
-        }
+    if (bitmap_per_cu) {
+        if ((rc = ix->fp_bitmap.ensure(bitmap_per_cu * 256 * (size_t)bitmap_words * 4))) return rc;
+        w.fp_bitmap = ix->fp_bitmap.as<uint32_t>();
+        w.fp_cursor = ctrl + 6;
+        HIP_TRY(launch_walk_bitmap(w, ix->metric, (unsigned)(bitmap_per_cu * 256), s));
+        bitmap_pass = true;
     }
     if (!w.all_general) {
         if (!bitmap_pass) HIP_TRY(launch_walk_fast(w, ix->metric, s));

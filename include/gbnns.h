@@ -140,6 +140,11 @@ typedef struct {
  * visited-set slots) on a small index, so that the tests can reach them.  Same results. */
 #define GBNNS_FLAG_WIDE_INDEX 16u
 
+/* Diagnostic: take the first pass with HBM visited bitmaps (persistent wavefronts, LDS-list kernel) whatever ef and
+ * batch size -- by default it serves ef >= 385 on batches deeper than 1.5 rounds of the wavefronts an LDS visited
+ * table would allow.  Same results. */
+#define GBNNS_FLAG_BITMAP_PASS 32u
+
 /* Replaces the timed query loop of performNetTest (search_function.h:346-387) / performTest
  * (:151-188): one call = the whole batch.  With HOST buffers the call copies in, runs and
  * copies out synchronously (what the drop-in harness times).  With DEVICE buffers everything is

@@ -867,3 +867,45 @@ def test_gd_pruning_on_device(g, orc):
     off, nbr, on_host = g.build_graph_gd_device(ko, kn, lat.base, 8, threads=8)
     assert np.array_equal(off, want_off) and np.array_equal(nbr, want_nbr)
     assert on_host > 1000   # equal distances everywhere
+
+
+def test_bitmap_first_pass(g, orc):
+    """The first pass with HBM visited bitmaps (default for large ef on deep batches; forced here with the diagnostic
+    flag so that small inputs reach it): every ef class, both metrics, several row lengths, the auxiliary graph,
+    tie-heavy data whose tie lists overflow (hand-over to the retry pass and the general kernel)."""
+    for metric in (0, 1):
+        for d, dlow, dh in ((64, 32, 64), (40, 24, 32)):
+            c, off, nbr, db_low, ent = _oracle_case(orc, 1700 + d + metric, 7000, 150, d, dlow, dh, deg=(2, 70))
+            rng = np.random.Generator(np.random.PCG64(d + 3))
+            aux = datagen.random_graph(rng, c.n, 0, 6)
+            q_low = orc.project(c.net, c.queries)
+            ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net, metric=metric)
+            ix.set_aux_graph(*aux)
+            for ef, use_aux in ((1, False), (40, False), (100, True), (300, False), (700, False), (1024, True)):
+                okw = dict(aux=aux, llf=True, hops_bound=50) if use_aux else {}
+                gkw = dict(aux=True, llf=True, hops_bound=50) if use_aux else {}
+                w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, metric=metric, threads=8, **okw)
+                s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net,
+                                     entries=ent, metric=metric, threads=8, **okw)
+                r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"),
+                              flags=g.FLAG_BITMAP_PASS, **gkw)
+                key = (metric, d, ef, use_aux)
+                assert np.array_equal(r["cand"], w["ids"]), key
+                assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
+                assert np.array_equal(r["hops"], w["hops"]), key
+                assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
+                assert np.array_equal(r["ids"], s["ids"]), key
+            ix.close()
+    cl = datagen.Case("lat32", 779, 6000, 200, 32, 4, 8, kind="lattice")
+    rng = np.random.Generator(np.random.PCG64(780))
+    off, nbr = datagen.random_graph(rng, cl.n, 6, 30)
+    ix = g.Index(cl.base, off, nbr)
+    ix.profile_enable(True)
+    for ef in (3, 64, 200, 600):
+        w = orc.walk(cl.queries, cl.base, off, nbr, ef, threads=8)
+        r = ix.search(cl.queries, ef, mode=g.MODE_PLAIN, k=ef, want=("hops", "dist_calc", "cand"), flags=g.FLAG_BITMAP_PASS)
+        assert np.array_equal(r["cand"], w["ids"]), ef
+        assert np.array_equal(r["hops"], w["hops"]), ef
+        assert np.array_equal(r["dist_calc"], w["dist_calc"]), ef
+    ix.profile_read()
+    ix.close()
