@@ -34,6 +34,8 @@ for case in range(cases):
     hb = int(rng.choice([0, 2, 50, 100000]))
     okw = dict(aux=aux, llf=llf, hops_bound=hb) if use_aux else {}
     gkw = dict(aux=True, llf=llf, hops_bound=hb) if use_aux else {}
+    if rng.integers(0, 8) == 0:   # an eighth of the cases take the HBM-bitmap first pass
+        gkw["flags"] = g.FLAG_BITMAP_PASS
     # a sixth of the plain walks start from several entry points (general kernel)
     m_ent = int(rng.choice([1, 1, 1, 1, 1, 2, 3]))
     if m_ent > 1 and not net_mode:
