@@ -882,11 +882,13 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     {
         // measured crossover on the GloVe-like shape: ef = 300 is faster with the register list + LDS table
         // (4.3 vs 5.5 ms), ef = 400 with the bitmap pass (7.1 vs 9.4 ms); SIFT-like ef <= 180 clearly the former
+        // (with the register-list variant of the pass: ef = 300 4.2 vs 4.3 ms, a tie; SIFT-like ef 140 .. 180 5.2 .. 4.3
+        // against 8.5 .. 6.0 M queries/s on the hot instances -- clearing n/8 bytes per query is not free there)
         const int min_ef = 385;
         const bool forced = (a->flags & GBNNS_FLAG_BITMAP_PASS) != 0;  // diagnostic: whatever ef and batch size
         if (!w.all_general && (ef >= min_ef || forced) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && (a->hash_capacity == 0 || forced)) {
             const size_t gran = 512;
-            const size_t per_wave = (walk_bitmap_lds_bytes(w) + gran - 1) / gran * gran;
+            const size_t per_wave = (walk_bitmap_lds_bytes(w, ix->metric) + gran - 1) / gran * gran;
             const size_t per_cu = std::min<size_t>(32, kMaxLds / per_wave);
             const size_t table_waves = std::min<size_t>(32, kMaxLds / ((walk_fast_lds_bytes(w, hot) + gran - 1) / gran * gran));
             // ... and only when the batch is deeper than 1.5 rounds of the wavefronts the table would allow (a
@@ -896,8 +898,9 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
                 bitmap_per_cu = per_cu;
         }
     }
-    const bool fuse = !walk_uses_lds_list(w) && !bitmap_per_cu && !plain && !w.all_general && ix->d % 8 == 0 &&
-                      (size_t)ix->d_pad * 4 <= walk_fast_lds_bytes(w, hot) && !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
+    const bool fuse = !walk_uses_lds_list(w) && (!bitmap_per_cu || walk_bitmap_uses_reg(w, ix->metric)) && !plain && !w.all_general && ix->d % 8 == 0 &&
+                      (size_t)ix->d_pad * 4 <= (bitmap_per_cu ? walk_bitmap_lds_bytes(w, ix->metric) : walk_fast_lds_bytes(w, hot)) &&
+                      !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
     if (fuse) {
         w.rr_q = q_dev; w.rr_qstride = ix->d; w.rr_db = ix->db; w.rr_dstride = ix->d_pad; w.rr_dim = ix->d;
         w.rr_n = (uint32_t)ix->n; w.rr_out = out_dev; w.rr_metric = ix->metric;

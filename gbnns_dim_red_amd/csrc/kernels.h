@@ -90,7 +90,8 @@ size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_li
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s);
-size_t walk_bitmap_lds_bytes(const WalkParams& p);
+bool walk_bitmap_uses_reg(const WalkParams& p, int metric);
+size_t walk_bitmap_lds_bytes(const WalkParams& p, int metric);
 hipError_t launch_walk_bitmap(const WalkParams& p, int metric, unsigned slots, hipStream_t s);  // persistent first pass, HBM bitmaps
 
 // Re-rank (search_function.h:105-125).  One query per wavefront, one candidate per lane.

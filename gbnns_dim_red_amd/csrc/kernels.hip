@@ -1302,9 +1302,10 @@ __device__ __forceinline__ uint32_t reg_id_at_rank(const RegList<R>& L, int rank
 
 // AUX: the auxiliary-graph walk (search_function.h:73-89): a hop expands the node's auxiliary row first (while
 // hops < hops_bound), then -- unless llf and that step inserted something -- its main row.
-template <int METRIC, int STEPS, bool OFF32, int R, bool ONE_CHUNK = false, bool AUX = false>
+// BITMAP: visited set = one bit per node in HBM (`bitmap`, this wavefront's slot), see walk_bitmap_kernel.
+template <int METRIC, int STEPS, bool OFF32, int R, bool ONE_CHUNK = false, bool AUX = false, bool BITMAP = false>
 __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
-                                             uint32_t* ovf_count, uint32_t* ovf_list) {
+                                             uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
     static_assert(!(AUX && ONE_CHUNK), "auxiliary rows have their own length");
 #ifdef GBNNS_STAMPS
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1335,7 +1336,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     // offsets and the packed visited set (24-bit ids, five per 16-byte bucket)
     constexpr bool packed = OFF32;
     const uint32_t nbuckets = packed ? cap / 5u : cap >> 2;
-    if constexpr (packed) packed_table_init(hash, nbuckets, 0u, lane);
+    if constexpr (BITMAP) { for (uint32_t i = lane; i < p.bitmap_words; i += 64) bitmap[i] = 0u; }
+    else if constexpr (packed) packed_table_init(hash, nbuckets, 0u, lane);
     else for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
     for (uint32_t i = lane; i < p.dstride; i += 64)
         qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
@@ -1360,7 +1362,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
         if (lane == 0) {
             L.hi[0] = worst;
             L.lo[0] = entry << 1;
-            if constexpr (packed) packed_table_put_first(hash, nbuckets, entry);
+            if constexpr (BITMAP) bitmap[entry >> 5] = 1u << (entry & 31u);
+            else if constexpr (packed) packed_table_put_first(hash, nbuckets, entry);
             else hash[4u * __umulhi(entry * 0x9E3779B1u, nbuckets)] = entry;  // first slot of its bucket
         }
         wave_sync();
@@ -1516,7 +1519,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                 mv = __ballot(nb != kInvalidId);
             }
             if (!mv) break;
-            if ((uint32_t)dist_calc + 64u > p.hash_limit) { status = 2; break; }
+            if constexpr (!BITMAP)
+                if ((uint32_t)dist_calc + 64u > p.hash_limit) { status = 2; break; }
             const bool valid = nb != kInvalidId;
             edges += __popcll(mv & kSlotLanes);
             // row loads go out before the visited test: its LDS round trips overlap the memory latency
@@ -1537,7 +1541,14 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             }
             // pair form: the even lane of a pair tests / claims the id, the odd lane ends up with the distance
             uint64_t mclaimed;
-            if constexpr (packed) mclaimed = visited_claim_mask_packed(hash_lds, nbuckets, nb, mv & kSlotLanes);
+            if constexpr (BITMAP) {
+                bool fr = false;
+                if (valid && (!kPair || half == 0u)) {  // the lane that owns the slot tests and sets the bit
+                    const uint32_t bit = 1u << (nb & 31u);
+                    fr = !(atomicOr(&bitmap[nb >> 5], bit) & bit);
+                }
+                mclaimed = __ballot(fr);
+            } else if constexpr (packed) mclaimed = visited_claim_mask_packed(hash_lds, nbuckets, nb, mv & kSlotLanes);
             else mclaimed = visited_claim_mask(hash_lds, nbuckets, nb, mv & kSlotLanes);
             const uint64_t mfresh = kPair ? (mclaimed << 1) : mclaimed;
             const bool fresh = __builtin_amdgcn_inverse_ballot_w64(mfresh);
@@ -2099,6 +2110,21 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
         retry_loop(p, [&](uint32_t qi) { walk_reg_one<METRIC, STEPS, OFF32, R, false, AUX>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
     } else {
         walk_reg_one<METRIC, STEPS, OFF32, R, ONE_CHUNK, AUX>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
+    }
+}
+
+// First pass with HBM visited bitmaps on register lists (128-byte rows, L2 or dot): persistent wavefronts.
+template <int METRIC, int R>
+__global__ __launch_bounds__(64) void walk_bitmap_reg_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* bitmap = p.fp_bitmap + (size_t)blockIdx.x * p.bitmap_words;
+    while (true) {
+        uint32_t w = 0;
+        if (lane_id() == 0) w = atomicAdd(p.fp_cursor, 1u);
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+        if (w >= p.nq) break;
+        walk_reg_one<METRIC, 8, true, R, false, false, true>(p, w, smem, p.ovf_count, p.ovf_list, bitmap);
+        wave_sync();
     }
 }
 
@@ -3112,12 +3138,40 @@ static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, h
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s) { return launch_walk_any(p, metric, false, s); }
 hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s) { return launch_walk_any(p, metric, true, s); }
 
-// LDS of the bitmap first pass: result list + tie list + query (no visited table)
-size_t walk_bitmap_lds_bytes(const WalkParams& p) { return walk_fast_lds_fixed_bytes(p.ef, p.dstride, false, true); }
+// The bitmap first pass keeps the result list in registers for 128-byte rows of a compact index up to 512 entries
+// (L2 only for now), else in LDS.
+bool walk_bitmap_uses_reg(const WalkParams& p, int metric) {
+    return metric == 0 && p.ef <= kRegListMaxEf && p.dim == 32u && p.dstride == 32u && walk_off32(p) && !p.aux_ell;
+}
+
+// LDS of the bitmap first pass: result list (or merge buffer) + tie list + query (no visited table)
+size_t walk_bitmap_lds_bytes(const WalkParams& p, int metric) {
+    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, false, !walk_bitmap_uses_reg(p, metric));
+}
+
+template <int R>
+static hipError_t launch_bitmap_reg(const WalkParams& p, unsigned slots, size_t lds, hipStream_t s) {
+    hipError_t e = set_lds(walk_bitmap_reg_kernel<0, R>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((walk_bitmap_reg_kernel<0, R>), dim3(slots), dim3(64), lds, s, p);
+    return hipGetLastError();
+}
 
 hipError_t launch_walk_bitmap(const WalkParams& p, int metric, unsigned slots, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
-    const size_t lds = walk_bitmap_lds_bytes(p);
+    const size_t lds = walk_bitmap_lds_bytes(p, metric);
+    if (walk_bitmap_uses_reg(p, metric)) {
+        switch ((p.ef + 63) / 64) {
+            case 1: return launch_bitmap_reg<1>(p, slots, lds, s);
+            case 2: return launch_bitmap_reg<2>(p, slots, lds, s);
+            case 3: return launch_bitmap_reg<3>(p, slots, lds, s);
+            case 4: return launch_bitmap_reg<4>(p, slots, lds, s);
+            case 5: return launch_bitmap_reg<5>(p, slots, lds, s);
+            case 6: return launch_bitmap_reg<6>(p, slots, lds, s);
+            case 7: return launch_bitmap_reg<7>(p, slots, lds, s);
+            default: return launch_bitmap_reg<8>(p, slots, lds, s);
+        }
+    }
     if (metric == 1) {
         hipError_t e = set_lds(walk_bitmap_kernel<1, 0>, lds);
         if (e != hipSuccess) return e;
