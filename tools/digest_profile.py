@@ -22,6 +22,12 @@ def short(name):
             retry = len(args) > idx and args[idx] in ("true", "1")
             regs = "/R%s" % args[4] if key == "walk_reg_kernel" and len(args) > 4 and args[4] != "1" else ""
             return key + regs + ("/retry" if retry else "")
+    for key in ("walk_hot2_kernel", "walk_hot3_kernel", "walk_hot4_kernel", "walk_bitmap_reg_kernel", "walk_bitmap_kernel",
+                "mlp_narrow_kernel", "gd_prune_kernel", "knn_scan_kernel"):
+        if key in name:
+            return key
+    if "walk_hotN_kernel" in name:
+        return "walk_hotN_kernel<" + name[name.find("<") + 1:name.find(">")] + ">"
     for key in ("walk_hot_kernel", "walk_general_kernel", "rerank_pair_kernel", "rerank_kernel", "mlp_layer_mfma_kernel", "mlp_layer_vec_kernel", "mlp_layer_kernel",
                 "normalize_kernel", "fill_u32_kernel"):
         if key in name:
