@@ -2,12 +2,22 @@
 """bench.py -- queries/sec of the two-stage graph search on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path (MLP projection -> low-dim beam walk -> original-space
-re-rank) over one 10k-query batch, inputs and index resident in HBM, through the C ABI
-(gbnns_search_ex with device buffers).  At N > 1 every rank holds a replica of the index and
-searches its own 10k batch (weak scaling); the answer ids are all-gathered over RCCL each step.
+re-rank) over one query batch, inputs and index resident in HBM, through the C ABI
+(gbnns_search_ex with device buffers).  The index is replicated per GPU; ranks search disjoint
+query blocks and all-gather the answer ids over RCCL each step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--ef EF]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--ef EF]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+--config picks one of BASELINE.json's shapes (default `sift` = configs[1], the one `metric` is
+quoted on; the others are the survey's configurations 3-5 as bench lines of their own):
+
+    sift       SIFT1M-shaped 128->32 (h 256), 10 000-query batch per GPU, ef 64        weak scaling
+    gist       GIST1M-shaped 960->64 (h 1024), 1 000-query batch per GPU, ef 200       weak scaling
+    glove      GloVe-1.2M-shaped 200->32 (h 256), L2 on normalised data, ef 64         weak scaling
+    glove-dot  the same index walked / re-ranked with the negative-dot metric          weak scaling
+    deep       DEEP10M-shaped 96->32 (h 128), ONE 1 000 000-query batch block-sharded
+               over the ranks (125 000 per GPU at N = 8), ef 40                        strong scaling
 
 Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement" for how every field is derived.
 """
@@ -27,6 +37,20 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 measured)
 REF_EFS = [1, 3, 8, 15, 20, 25, 40, 60, 80, 100, 120, 140, 160, 180]  # parameters_of_databases.txt:7
 
+CONFIGS = {
+    # name: dataset shape, timed ef, further efs reported in `ef_sweep`, metric, batch policy
+    "sift": dict(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, ef=64, efs=[40, 128, 140, 160, 180],
+                 label="SIFT1M 128->32", shape="SIFT1M-shaped"),
+    "gist": dict(n=1_000_000, nq=1_000, d=960, d_low=64, d_hidden=1024, ef=200, efs=[400],
+                 label="GIST1M 960->64", shape="GIST1M-shaped"),
+    "glove": dict(n=1_200_000, nq=10_000, d=200, d_low=32, d_hidden=256, ef=64, efs=[300],
+                  label="GloVe-1.2M 200->32 (L2 on normalised data)", shape="GloVe-1.2M-shaped"),
+    "glove-dot": dict(n=1_200_000, nq=10_000, d=200, d_low=32, d_hidden=256, ef=64, efs=[300], negdot=True,
+                      label="GloVe-1.2M 200->32 (negative-dot metric)", shape="GloVe-1.2M-shaped"),
+    "deep": dict(n=10_000_000, nq=1_000_000, d=96, d_low=32, d_hidden=128, ef=40, efs=[60, 120], strong=True,
+                 native_knn=True, label="DEEP10M 96->32, 1M-query batch", shape="DEEP10M-shaped"),
+}
+
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
@@ -35,18 +59,29 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--ef", type=int, default=64, help="beam width of the timed steps (config: 64)")
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 20 for gist / glove*, 3 for deep)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="sift")
+    ap.add_argument("--ef", type=int, default=None, help="beam width of the timed steps (default: the configuration's)")
+    ap.add_argument("--n", type=int, default=None, help="override the base-set size (quick looks)")
+    ap.add_argument("--nq", type=int, default=None, help="override the batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the diagnostic sections (separate stages, MFMA option, host buffers): profiling runs")
+                    help="skip the diagnostic sections (separate stages, MFMA option, host buffers, ef sweep): profiling runs")
     ap.add_argument("--hash-capacity", type=int, default=0, help="0 = library default (tuning knob)")
     ap.add_argument("--sweep", action="store_true", help="also time every reference ef (stderr)")
     ap.add_argument("--cache-dir", default=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"))
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    cfg["name"] = args.config
+    if args.steps is None:
+        args.steps = {"sift": 200, "deep": 3}.get(args.config, 20)
+    if args.warmup is None:
+        args.warmup = {"sift": 10, "deep": 1}.get(args.config, 3)
+    if args.n:
+        cfg["n"] = args.n
+    if args.nq:
+        cfg["nq"] = args.nq
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -68,49 +103,71 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     import gbnns_dim_red_amd as g
-    from gbnns_dim_red_amd import synth
+    from gbnns_dim_red_amd import sharding, synth
     g.load_library()
 
-    # ---- synthetic SIFT1M-shaped workload (rank 0 builds, the others load the cached copy) ----
+    # ---- synthetic workload (rank 0 builds, the others load the cached copy) ------------------
     os.makedirs(args.cache_dir, exist_ok=True)
-    kw = dict(n=args.n, nq=args.nq, d=128, d_low=32, d_hidden=256, seed=1234,
-              cache_dir=args.cache_dir)
+    kw = dict(n=cfg["n"], nq=cfg["nq"], d=cfg["d"], d_low=cfg["d_low"], d_hidden=cfg["d_hidden"], seed=1234,
+              cache_dir=args.cache_dir, native_knn=bool(cfg.get("native_knn")) and cfg["n"] > 2_000_000)
+    if cfg.get("strong"):
+        kw["gt_queries"] = 20_000  # exact ground truth for the first 20 000 queries of the 1M batch (recall sample)
     if rank == 0:
-        ds = synth.make_dataset(device=str(dev), verbose=False, **kw)
+        ds = synth.make_dataset(device=str(dev), verbose=args.config == "deep", **kw)
     if world > 1:
         dist.barrier()
     if rank != 0:
         ds = synth.make_dataset(device=str(dev), **kw)
-    ix = ds.index(device_index=local)
-    # every rank searches the same query pool in a different rotation (its own 10k batch)
-    shift = (rank * args.nq) // world
-    q = torch.roll(ds.queries, shifts=-shift, dims=0).contiguous()
-    gt = torch.roll(ds.gt, shifts=-shift, dims=0)
-    gt2 = torch.roll(ds.gt2[:, 1], shifts=-shift, dims=0)
-    dup = ((ds.base[ds.gt2[:, 0]] - ds.base[ds.gt2[:, 1]]) ** 2).sum(1) == 0
-    dup = torch.roll(dup, shifts=-shift, dims=0)
+    metric_id = g.METRIC_NEG_DOT if cfg.get("negdot") else g.METRIC_L2
+    ix = ds.index(device_index=local, metric=metric_id)
+    strong = bool(cfg.get("strong"))
+    if strong:
+        # ONE batch, contiguous blocks per rank; entry points would shard with it
+        lo, hi = sharding.shard_bounds(ds.nq, world, rank)
+        q = ds.queries[lo:hi].contiguous()
+        n_gt = min(len(ds.gt), ds.nq)
+        g_lo, g_hi = min(lo, n_gt), min(hi, n_gt)   # the part of this rank's block that has ground truth
+        gt, gt2 = ds.gt[g_lo:g_hi], ds.gt2[g_lo:g_hi, 1]
+        dup = ((ds.base[ds.gt2[g_lo:g_hi, 0]] - ds.base[ds.gt2[g_lo:g_hi, 1]]) ** 2).sum(1) == 0
+        n_scored = g_hi - g_lo
+    else:
+        # every rank searches the same query pool in a different rotation (its own batch)
+        shift = (rank * ds.nq) // world
+        q = torch.roll(ds.queries, shifts=-shift, dims=0).contiguous()
+        gt = torch.roll(ds.gt, shifts=-shift, dims=0)
+        gt2 = torch.roll(ds.gt2[:, 1], shifts=-shift, dims=0)
+        dup = ((ds.base[ds.gt2[:, 0]] - ds.base[ds.gt2[:, 1]]) ** 2).sum(1) == 0
+        dup = torch.roll(dup, shifts=-shift, dims=0)
+        n_scored = len(gt)
+    nq_rank = int(q.shape[0])
+    nq_total = ds.nq if strong else world * ds.nq
 
     def recall_of(ids):
         # search_function.h:391-400: hit on GT[0], or on GT[1] when the two are exact duplicates
-        ids = ids.long()
+        if n_scored == 0:
+            return float("nan")
+        ids = ids.long()[:n_scored]
         return ((ids == gt) | (dup & (ids == gt2))).float().mean().item()
 
     # ---- recall sweep (untimed) ------------------------------------------------------------
+    ef = args.ef or cfg["ef"]
     sweep = {}
-    for ef in sorted(set([16, 32, 64, 128, args.ef])):
-        r = ix.search(q, ef, want=())
+    for e in sorted(set(([16, 32, 64, 128] if args.config == "sift" else []) + [ef] + cfg["efs"])):
+        r = ix.search(q, e, want=())
         torch.cuda.synchronize()
-        sweep[ef] = recall_of(r["ids"])
-    ef = args.ef
+        sweep[e] = recall_of(r["ids"])
+    gate_failed = False
     if sweep[ef] < 0.95:
-        cands = [e for e in REF_EFS + [256, 512] if e > ef]
-        for e in cands:
-            r = ix.search(q, e, want=())
-            torch.cuda.synchronize()
-            sweep[e] = recall_of(r["ids"])
+        for e in [e for e in REF_EFS + [200, 256, 300, 400, 512, 600, 800, 1000] if e > ef]:
+            if e not in sweep:
+                r = ix.search(q, e, want=())
+                torch.cuda.synchronize()
+                sweep[e] = recall_of(r["ids"])
             if sweep[e] >= 0.95:
                 ef = e
                 break
+        else:
+            gate_failed = True  # no ef up to 1000 reaches the metric's recall threshold on this data
     recall = sweep[ef]
 
     # ---- timed region -----------------------------------------------------------------------
@@ -122,6 +179,7 @@ def main():
     gathered = [None, None]
     pending = [None, None]
     nstep = 0
+    pad = sharding.shard_pad(nq_total, world) if strong else nq_rank  # equal-sized pieces for the all-gather
 
     def step():
         nonlocal nstep
@@ -134,8 +192,14 @@ def main():
         if world > 1:
             # the path's only exchange step: all-gather of the int32 answer ids over RCCL/xGMI
             if gathered[b] is None:
-                gathered[b] = torch.empty(world * args.nq, dtype=r["ids"].dtype, device=dev)
-            pending[b] = dist.all_gather_into_tensor(gathered[b], r["ids"], async_op=True)
+                gathered[b] = torch.empty(world * pad, dtype=r["ids"].dtype, device=dev)
+            piece = r["ids"]
+            if pad != nq_rank:
+                if "ids_pad" not in outs[b]:
+                    outs[b]["ids_pad"] = torch.full((pad,), -1, dtype=piece.dtype, device=dev)
+                outs[b]["ids_pad"][:nq_rank] = piece
+                piece = outs[b]["ids_pad"]
+            pending[b] = dist.all_gather_into_tensor(gathered[b], piece, async_op=True)
         return r
 
     def drain():
@@ -146,7 +210,7 @@ def main():
 
     # The library sizes its visited sets from the walks it has seen and drops the retry launch once a few batches
     # of a configuration were quiet: let that settle before the W warm-up steps, whatever W is.
-    for _ in range(8):
+    for _ in range(8 if nq_rank <= 20_000 else 3):
         ix.search(q, ef, want=(), hash_capacity=args.hash_capacity)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -175,40 +239,16 @@ def main():
     ix.profile_enable(False)
 
     ms_per_step = elapsed * 1e3 / args.steps
-    qps = world * args.nq * args.steps / elapsed
+    qps = nq_total * args.steps / elapsed
 
     # ---- algorithmic bytes of the dominant kernel (the beam walk), SURVEY.md section 8d ------
-    dc = res["dist_calc"].double()
-    hops = res["hops"].double()
-    if rank == 0:
-        qs = torch.tensor([0.5, 0.9, 0.99, 0.999, 1.0], dtype=torch.float64, device=dev)
-        log("dist_calc quantiles 50/90/99/99.9/max:", [int(v) for v in torch.quantile(dc, qs).tolist()],
-            "hops max", int(hops.max().item()))
-    edges = res["edges"].double()
-    d_low, d = ds.d_low, ds.d
-    walk_bytes = (dc * 4 * d_low + edges * 4 + hops * 8 + 4 * d_low + 4 * ef).sum().item()
-    rerank_bytes = args.nq * (ef * 4.0 * d + 4 * d + 4 + 4 * ef)
-    walk_ms = prof["walk_ms"] / max(prof["calls"], 1)
-    rerank_ms = prof["rerank_ms"] / max(prof["calls"], 1)
-    project_ms = prof["project_ms"] / max(prof["calls"], 1)
     max_degree = int(np.diff(np.asarray(ds.graph_off).astype(np.int64)).max())
-    # ef <= 64, 128-B rows, adjacency rows of <= 32 slots: the hand-laid-out instance, which also re-ranks
-    # each query at the end of its walk (no re-rank launch) -- its algorithmic bytes are SURVEY 8d's full B(q)
-    hot_shape = ds.d_low == 32 and max_degree <= 32
-    hot = ef <= 64 and hot_shape
-    fused = ef <= 512 and ds.d % 8 == 0   # every register-list first pass re-ranks at the end of the walk
-    kernel_bytes = walk_bytes + (rerank_bytes if fused else 0.0)
-    achieved = kernel_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("walk_fast_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    rl = roofline_of(ds, res, prof, ef, nq_rank, max_degree, cfg, rank)
+    hops = res["hops"].double()
+    dc = res["dist_calc"].double()
 
     result = {
-        "metric": "queries/sec @ recall@1>=0.95, SIFT1M 128->32",
+        "metric": "queries/sec @ recall@1>=0.95, %s" % cfg["label"].split(" (")[0].replace(", 1M-query batch", ""),
         "value": round(qps, 1),
         "unit": "queries/s",
         "n_gpus": world,
@@ -216,50 +256,52 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "SIFT1M-shaped synthetic 128->32 (d_hidden 256), n=%d, %d-query batch per GPU, "
-                        "ef=%d, two-stage (project+walk+rerank), index resident in HBM" % (args.n, args.nq, ef),
+            "workload": "%s synthetic %d->%d (d_hidden %d), n=%d, %s, ef=%d, two-stage (project+walk+rerank), "
+                        "index resident in HBM%s" % (
+                            cfg["shape"], ds.d, ds.d_low, ds.d_hidden, ds.n,
+                            ("one %d-query batch block-sharded over %d GPU(s)" % (nq_total, world)) if strong
+                            else "%d-query batch per GPU" % nq_rank,
+                            ef, ", negative-dot metric in walk and re-rank" if cfg.get("negdot") else ""),
+            "name": args.config,
             "ef": ef,
             "recall_at_1": round(recall, 4),
+            "recall_scored_queries": int(n_scored),
             "recall_sweep": {str(k): round(v, 4) for k, v in sorted(sweep.items())},
             "mean_hops": round(hops.mean().item(), 1),
             "mean_dist_calc": round(dc.mean().item(), 1),
-            "graph": "kNN(%d)->GD(M=%d,reverse), avg degree %.1f" % (
-                ds.recipe["knn_k"], ds.recipe["M"], len(ds.graph_nbr) / ds.n),
+            "graph": "kNN(%d)->GD(M=%d,reverse), avg degree %.1f, max %d" % (
+                ds.recipe["knn_k"], ds.recipe["M"], len(ds.graph_nbr) / ds.n, max_degree),
             "parallelism": "query-sharded replicas x%d" % world,
             "recipe": ds.recipe,
         },
-        "roofline": {
-            "bound": "hbm",
-            # ef <= 64, 128-B rows, adjacency rows of <= 32 slots: the hand-laid-out instance
-            "kernel": (("walk_hot_kernel" if hot else
-                        ("walk_hot%d_kernel" % ((ef + 63) // 64) if ef <= 256 else "walk_hotN_kernel<%d>" % ((ef + 63) // 64))
-                        if hot_shape and ef <= 512 else "walk_reg_kernel" if ef <= 512 else "walk_fast_kernel")
-                       + (" (walk + fused re-rank)" if fused else "")),
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": round(kernel_bytes),
-            "algorithmic_bytes_walk_part": round(walk_bytes),
-            "algorithmic_bytes_rerank_part": round(rerank_bytes if fused else 0),
-            "kernel_ms": round(walk_ms, 4),
-        },
-        "kernels_ms": {"project": round(project_ms, 4), "walk": round(walk_ms, 4),
-                       "walk_general": round(prof["walk_general_ms"] / max(prof["calls"], 1), 4),
-                       "rerank": None if fused else round(rerank_ms, 4),  # fused: inside the walk kernel
-                       "rerank_GBps": (round(rerank_bytes / (rerank_ms * 1e-3) / 1e9, 1)
-                                       if rerank_ms > 0 and not fused else None),
-                       "general_queries": prof["general_queries"]},
+        "roofline": rl["roofline"],
+        "kernels_ms": rl["kernels_ms"],
+        # what `value` leaves out, per SURVEY 8d's definition (one gbnns_search_batch incl. H2D / D2H): see
+        # host_buffers_qps below (filled at N = 1 unless --no-extras)
+        "value_definition": "queries of all ranks / wall time of K steps, inputs and outputs resident in HBM "
+                            "(device buffers); the PCIe-inclusive rate of the host-buffer call is host_buffers_qps",
     }
+    if gate_failed:
+        result["recall_gate_failed"] = True  # `value` is NOT a figure at recall >= 0.95
+
+    extras = world == 1 and not args.no_extras
+    small = nq_rank <= 20_000
+
+    # ---- other efs of this configuration: kernel time and roofline fraction each -------------------
+    if extras:
+        result["ef_sweep"] = ef_sweep(ix, ds, q, cfg, ef, sweep, recall_of, nq_rank, max_degree, rank)
+        ok = [e for e in result["ef_sweep"] if e["recall_at_1"] >= 0.95]
+        if ok:
+            best = max(ok, key=lambda e: e["queries_per_s"])
+            result["best_ef_at_recall_gate"] = {k: best[k] for k in ("ef", "recall_at_1", "queries_per_s", "ms_per_step")}
 
     # ---- the same step with the re-rank in its own launch (diagnostic flag): per-stage kernel times -------
-    if world == 1 and fused and not args.no_extras:
+    if extras and small and rl["fused"]:
         for _ in range(3):
             ix.search(q, ef, want=(), flags=g.FLAG_NO_FUSED_RERANK)
         torch.cuda.synchronize()
@@ -275,13 +317,13 @@ def main():
         wu, ru_ms = pu["walk_ms"] / max(pu["calls"], 1), pu["rerank_ms"] / max(pu["calls"], 1)
         result["separate_stages"] = {
             "ms_per_step": round(dtu * 1e3, 4), "walk_ms": round(wu, 4), "rerank_ms": round(ru_ms, 4),
-            "walk_GBps": round(walk_bytes / (wu * 1e-3) / 1e9, 1) if wu > 0 else None,
-            "rerank_GBps": round(rerank_bytes / (ru_ms * 1e-3) / 1e9, 1) if ru_ms > 0 else None,
+            "walk_GBps": round(rl["walk_bytes"] / (wu * 1e-3) / 1e9, 1) if wu > 0 else None,
+            "rerank_GBps": round(rl["rerank_bytes"] / (ru_ms * 1e-3) / 1e9, 1) if ru_ms > 0 else None,
             "answers_identical": bool((ru["ids"] == res["ids"]).all().item()),
         }
 
     # ---- opt-in matrix-core projection (not bit-exact): how fast, and how many answers change --------
-    if world == 1 and not args.no_extras:
+    if extras and small:
         for _ in range(3):
             rm = ix.search(q, ef, want=(), flags=g.FLAG_MFMA_PROJECT)
         torch.cuda.synchronize()
@@ -303,8 +345,8 @@ def main():
     # alternately, so the tail of batch i (a 10 k batch is < 2 "rounds" of resident wavefronts) runs
     # beside the projection and the first round of batch i+1.  A serving-throughput figure; never `value`
     # (which keeps one batch at a time on one stream).
-    if world == 1 and not args.no_extras:
-        ix2 = ds.index(device_index=local)
+    if extras and small:
+        ix2 = ds.index(device_index=local, metric=metric_id)
         handles = (ix, ix2)
         streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
         outs2 = ({}, {})
@@ -319,25 +361,26 @@ def main():
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t1
         result["two_batches_in_flight"] = {
-            "queries_per_s": round(nrep * args.nq / dt2, 1),
+            "queries_per_s": round(nrep * nq_rank / dt2, 1),
             "ms_per_batch": round(dt2 * 1e3 / nrep, 4),
             "answers_identical": bool(((outs2[0]["ids"] == res["ids"]) & (outs2[1]["ids"] == res["ids"])).all().item()),
             "note": "two index handles (shared resident tensors) on two HIP streams, batches alternate",
         }
         ix2.close()
 
-    # ---- PCIe-inclusive rate (host buffers in, ids out: what the C++ drop-in times); never `value`
-    if world == 1 and not args.no_extras:
+    # ---- PCIe-inclusive rate (host buffers in, ids out: what the C++ drop-in times, and SURVEY 8d's
+    # "one gbnns_search_batch incl. H2D of queries and D2H of ids"); never `value`
+    if extras and small:
         qh = q.cpu().numpy()
         ix.search(qh, ef, want=())
         t1 = time.perf_counter()
         for _ in range(5):
             ix.search(qh, ef, want=())
-        result["host_buffers_qps"] = round(5 * args.nq / (time.perf_counter() - t1), 1)
+        result["host_buffers_qps"] = round(5 * nq_rank / (time.perf_counter() - t1), 1)
 
     # ---- CPU baseline (rank 0, N = 1 only): the compiled reference if present, else the port ----
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(ds, q, ef, res["ids"])
+        result["cpu_baseline"] = cpu_baseline(ds, q, ef, res["ids"], metric_id)
 
     if args.sweep and rank == 0:
         for e in REF_EFS:
@@ -348,7 +391,7 @@ def main():
                 r = ix.search(q, e, want=())
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / 5
-            log(f"sweep ef={e}: recall={recall_of(r['ids']):.4f} qps={args.nq / dt:.0f}")
+            log(f"sweep ef={e}: recall={recall_of(r['ids']):.4f} qps={nq_rank / dt:.0f}")
 
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -357,7 +400,127 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(ds, q, ef, gpu_ids):
+def kernel_name(ds, ef, max_degree, negdot, fused):
+    """The first-pass walk kernel api.cpp picks for this shape (launch_fast_t / launch_reg_t in kernels.hip)."""
+    regs = (ef + 63) // 64
+    hot_shape = ds.d_low == 32 and max_degree <= 32 and not negdot
+    if ef > 512:
+        name = "walk_bitmap_kernel / walk_fast_kernel (LDS result list)"
+    elif hot_shape:
+        name = "walk_hot_kernel" if regs == 1 else ("walk_hot%d_kernel" % regs if regs <= 4 else "walk_hotN_kernel<%d>" % regs)
+    else:
+        name = "walk_reg_kernel<R=%d>" % (regs if ds.d_low == 32 else (1 if regs == 1 else 2 if regs == 2 else 4 if regs <= 4 else 8))
+    return name + (" (walk + fused re-rank)" if fused else "")
+
+
+def counters_for(config, ef):
+    """Committed PMC figures of this configuration's dominant kernel (profiles/counters_latest.json, written from
+    the rocprofv3 --pmc passes by tools/digest_profile.py); bench.py cannot read hardware counters itself."""
+    path = os.path.join(ROOT, "profiles", "counters_latest.json")
+    try:
+        return json.load(open(path)).get("%s:ef%d" % (config, ef))
+    except Exception:
+        return None
+
+
+def roofline_of(ds, res, prof, ef, nq, max_degree, cfg, rank):
+    dc = res["dist_calc"].double()
+    hops = res["hops"].double()
+    edges = res["edges"].double()
+    if rank == 0:
+        qs = torch.tensor([0.5, 0.9, 0.99, 0.999, 1.0], dtype=torch.float64, device=dc.device)
+        log("ef", ef, "dist_calc quantiles 50/90/99/99.9/max:", [int(v) for v in torch.quantile(dc[:1 << 20], qs).tolist()],
+            "hops max", int(hops.max().item()))
+    d_low, d = ds.d_low, ds.d
+    calls = max(prof["calls"], 1)
+    walk_bytes = (dc * 4 * d_low + edges * 4 + hops * 8 + 4 * d_low + 4 * ef).sum().item()
+    rerank_bytes = nq * (ef * 4.0 * d + 4 * d + 4 + 4 * ef)
+    walk_ms = prof["walk_ms"] / calls
+    rerank_ms = prof["rerank_ms"] / calls
+    project_ms = prof["project_ms"] / calls
+    general_ms = prof["walk_general_ms"] / calls
+    fused = ef <= 512 and ds.d % 8 == 0   # every register-list first pass re-ranks at the end of the walk
+    kernel_bytes = walk_bytes + (rerank_bytes if fused else 0.0)
+    achieved = kernel_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
+    pmc = counters_for(cfg["name"], ef)
+    roof = {
+        "bound": "hbm",
+        # the walked tables (db_low + adjacency) of the 10^6-node shapes fit the 256 MB Infinity Cache: the peak the
+        # fraction is taken against is still the HBM spec figure (8 TB/s), i.e. a ceiling for any mix of the two
+        "served_from": "HBM + Infinity Cache (MALL)",
+        "kernel": kernel_name(ds, ef, max_degree, bool(cfg.get("negdot")), fused),
+        "achieved": round(achieved, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        # PMC bytes per launch: FETCH_SIZE x2 + WRITE_SIZE (the guide's gfx950 correction, calibrated for wide
+        # coalesced streams only); the raw sum is given beside it -- the truth lies between the two
+        "traffic": pmc.get("hbm_bytes_corrected") if pmc else None,
+        "traffic_raw": pmc.get("hbm_bytes_raw") if pmc else None,
+        "traffic_source": pmc.get("source") if pmc else None,
+        "algorithmic_bytes_per_launch": round(kernel_bytes),
+        "algorithmic_bytes_walk_part": round(walk_bytes),
+        "algorithmic_bytes_rerank_part": round(rerank_bytes if fused else 0),
+        "kernel_ms": round(walk_ms, 4),
+    }
+    if pmc and pmc.get("valu_insts"):
+        # second roofline: vector-instruction issue.  One VALU instruction occupies its SIMD's issue port for 4
+        # cycles (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"); 1024 SIMDs; cycles from the kernel time
+        # at the clock the PMC pass observed (GRBM_GUI_ACTIVE / 8 per launch).
+        cyc = pmc.get("gpu_cycles") or walk_ms * 1e-3 * 2.4e9
+        roof["valu_issue"] = {"insts_per_launch": pmc["valu_insts"], "issue_cycles_each": 4,
+                              "busy_frac": round(pmc["valu_insts"] * 4.0 / (1024.0 * cyc), 4),
+                              "kernel_cycles": round(cyc)}
+    kernels = {"project": round(project_ms, 4), "walk": round(walk_ms, 4), "walk_general": round(general_ms, 4),
+               "rerank": None if fused else round(rerank_ms, 4),  # fused: inside the walk kernel
+               "rerank_GBps": (round(rerank_bytes / (rerank_ms * 1e-3) / 1e9, 1) if rerank_ms > 0 and not fused else None),
+               "general_queries": prof["general_queries"]}
+    return dict(roofline=roof, kernels_ms=kernels, fused=fused, walk_bytes=walk_bytes, rerank_bytes=rerank_bytes)
+
+
+def ef_sweep(ix, ds, q, cfg, ef0, recalls, recall_of, nq, max_degree, rank):
+    """Every ef of the configuration (and, for sift, the reference's top efs): wall time per step, kernel time,
+    algorithmic bytes and the roofline fraction -- the same derivation as the headline's, 3 + 8 steps each."""
+    out = []
+    reps = 8 if nq <= 20_000 else 2
+    for e in sorted(set([ef0] + cfg["efs"])):
+        for _ in range(3 if nq <= 20_000 else 1):
+            ix.search(q, e, want=())
+        torch.cuda.synchronize()
+        ix.profile_read(reset=True)
+        ix.profile_enable(True)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            r = ix.search(q, e, want=("hops", "dist_calc", "edges"))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / reps
+        p = ix.profile_read(reset=True)
+        ix.profile_enable(False)
+        rl = roofline_of(ds, r, p, e, nq, max_degree, cfg, rank)
+        rec = recalls.get(e)
+        if rec is None:
+            rec = recall_of(r["ids"])
+        out.append({"ef": e, "recall_at_1": round(rec, 4), "queries_per_s": round(nq / dt, 1),
+                    "ms_per_step": round(dt * 1e3, 4), "kernel": rl["roofline"]["kernel"],
+                    "kernel_ms": rl["roofline"]["kernel_ms"], "rerank_ms": rl["kernels_ms"]["rerank"],
+                    "algorithmic_bytes_per_launch": rl["roofline"]["algorithmic_bytes_per_launch"],
+                    "achieved_GBps": rl["roofline"]["achieved"], "frac": rl["roofline"]["frac"],
+                    "mean_dist_calc": round(r["dist_calc"].double().mean().item(), 1),
+                    "mean_hops": round(r["hops"].double().mean().item(), 1)})
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(ds, q, ef, gpu_ids, metric_id):
     """Times the reference's per-query body on host cores over the SAME batch and checks that the
     GPU answers are identical.  oracle/ is used here only as the reported baseline / checker."""
     import oracle
@@ -369,29 +532,61 @@ def cpu_baseline(ds, q, ef, gpu_ids):
     if oracle.have_ref():
         impl, kind = oracle.Ref(), "reference"
         impl.prepare(base)
-        impl.search_batch(oracle.MODE_NET, qh[:8], base, off, nbr, ef, db_low=dbl, net=net)  # graph conv
+        impl.search_batch(oracle.MODE_NET, qh[:8], base, off, nbr, ef, db_low=dbl, net=net, metric=metric_id)  # graph conv
+        flags = "g++ -O2 -std=c++11 -fopenmp -mavx2 -mfma -ffp-contract=off (oracle/Makefile REF_FLAGS: the strict-IEEE " \
+                "build the golden vectors come from; ~10 % slower than the README's -Ofast -march=native, BASELINE.md 2)"
     else:
         impl, kind = oracle.Oracle(), "port"
-    cores = impl.max_threads()
-    # 1 thread (what final_test.cpp ships, :71) on a bounded sample, then all cores on the batch
-    ns = min(len(qh), 2000)
-    t0 = time.perf_counter()
-    impl.search_batch(oracle.MODE_NET, qh[:ns], base, off, nbr, ef, db_low=dbl, net=net, threads=1)
-    t1 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    r = impl.search_batch(oracle.MODE_NET, qh, base, off, nbr, ef, db_low=dbl, net=net, threads=cores)
-    tn = time.perf_counter() - t0
-    same = int((r["ids"].astype(np.int64) == gpu_ids.cpu().numpy().astype(np.int64)).sum())
+        flags = "g++ -O2 -std=c++17 -fopenmp -ffp-contract=off -fno-fast-math (oracle/Makefile ORACLE_FLAGS)"
+    omp_max = impl.max_threads()
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+    avail = max(1, min(omp_max, affinity))
+
+    def run(nqs, threads):
+        t0 = time.perf_counter()
+        r = impl.search_batch(oracle.MODE_NET, qh[:nqs], base, off, nbr, ef, db_low=dbl, net=net, threads=threads,
+                              metric=metric_id)
+        return time.perf_counter() - t0, r
+
+    # 1 thread (what final_test.cpp ships, :71) on a bounded sample sized from a probe (~5 s of work) ...
+    probe = min(len(qh), 200)
+    t_probe, _ = run(probe, 1)
+    per_q = t_probe / probe
+    ns = int(max(probe, min(len(qh), 5.0 / max(per_q, 1e-9))))
+    t1, _ = run(ns, 1)
+    # ... then the OpenMP form (search_function.h:152) at 2, 4, ... up to the cores this process may use, each on a
+    # sample of ~4 s; the widest run covers the whole batch when that fits ~15 s and is the id check
+    scaling = {"1": round(ns / t1, 1)}
+    th = 2
+    while th < avail:
+        nst = int(max(probe, min(len(qh), 4.0 * th / max(per_q, 1e-9))))
+        tt, _ = run(nst, th)
+        scaling[str(th)] = round(nst / tt, 1)
+        th *= 2
+    nfull = int(max(probe, min(len(qh), 15.0 * avail / max(per_q, 1e-9))))
+    tn, r = run(nfull, avail)
+    scaling[str(avail)] = round(nfull / tn, 1)
+    same = int((r["ids"].astype(np.int64) == gpu_ids[:nfull].cpu().numpy().astype(np.int64)).sum())
     return {
-        "value": round(len(qh) / tn, 1),
+        "value": round(nfull / tn, 1),
         "unit": "queries/s",
-        "cores": cores,
+        "cores": avail,
         "kind": kind,
-        "sample": "the full %d-query batch at ef=%d, OpenMP over queries (search_function.h:152) on %d "
-                  "threads; 1-thread figure on the first %d queries" % (len(qh), ef, cores, ns),
+        "sample": "the first %d queries of the batch at ef=%d, OpenMP over queries (search_function.h:152) on %d "
+                  "thread(s); 1-thread figure on the first %d queries" % (nfull, ef, avail, ns),
         "value_1thread": round(ns / t1, 1),
-        "gpu_ids_identical": same == len(qh),
-        "gpu_id_mismatches": len(qh) - same,
+        "queries_per_s_by_threads": scaling,
+        "cpu_model": cpu_model(),
+        "os_cpu_count": os.cpu_count(),
+        "sched_affinity_cpus": affinity,
+        "omp_max_threads": omp_max,
+        "cores_available": avail,
+        "build_flags": flags,
+        "gpu_ids_identical": same == nfull,
+        "gpu_id_mismatches": nfull - same,
     }
 
 

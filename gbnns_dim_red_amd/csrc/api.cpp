@@ -104,7 +104,7 @@ struct gbnns_index {
     uint32_t ws1 = 0, ws2 = 0, ws3 = 0;
     // workspace
     DevBuf q_in, q_low, h1, h2, cand, cand_dist, cnt, hops, dc, edges, out, entries, ovf_list, ovf2_list, ctrl;
-    DevBuf g_bitmap, g_keys, g_tie, fp_bitmap;
+    DevBuf g_bitmap, g_keys, fp_bitmap;
     // profiling
     bool profiling = false;
     std::vector<ProfCall> pending;
@@ -123,6 +123,11 @@ struct gbnns_index {
     // which of the two control-word blocks the next call uses, and whether each is known to be zero
     int ctrl_phase = 0;
     bool ctrl_clean[2] = {true, true};
+    // stream of the last call that left work in flight (the workspace and the control words are ordered by
+    // stream order only: a call on another stream first waits for that work, see enter_stream)
+    hipStream_t last_stream = nullptr;
+    bool in_flight = false;
+    hipEvent_t order_ev = nullptr;
 };
 
 namespace {
@@ -204,6 +209,26 @@ int build_ell(const uint64_t* off, const uint32_t* nbr, uint64_t n, std::vector<
 }
 
 constexpr size_t kMaxLds = 160 * 1024;
+
+// A handle's workspace (projected queries, candidate lists, hand-over lists, control words) is shared by its
+// calls and ordered by stream order.  When a call names another stream than the last one that left work in
+// flight, the new stream first waits for that work (an event recorded on the old stream now covers everything
+// enqueued there so far).  Should the old stream be gone, the device is synchronised instead.
+int enter_stream(gbnns_index* ix, hipStream_t s) {
+    if (ix->in_flight && ix->last_stream != s) {
+        hipError_t e = hipSuccess;
+        if (!ix->order_ev) e = hipEventCreateWithFlags(&ix->order_ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(ix->order_ev, ix->last_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, ix->order_ev, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipDeviceSynchronize());
+        }
+    }
+    ix->last_stream = s;
+    ix->in_flight = true;
+    return GBNNS_OK;
+}
 
 }  // namespace
 
@@ -475,11 +500,11 @@ int gbnns_index_destroy(gbnns_index* ix) {
     for (auto& pc : ix->pending)
         for (auto& e : pc.ev) (void)hipEventDestroy(e);
     if (ix->stats_ev) (void)hipEventDestroy(ix->stats_ev);
+    if (ix->order_ev) (void)hipEventDestroy(ix->order_ev);
     if (ix->h_stats) (void)hipHostFree(ix->h_stats);
     DevBuf* bufs[] = {&ix->db_own, &ix->db_low_own, &ix->ell, &ix->aux_ell, &ix->net, &ix->q_in, &ix->q_low,
                       &ix->h1, &ix->h2, &ix->cand, &ix->cand_dist, &ix->cnt, &ix->hops, &ix->dc, &ix->edges,
-                      &ix->out, &ix->entries, &ix->ovf_list, &ix->ovf2_list, &ix->ctrl, &ix->g_bitmap, &ix->fp_bitmap, &ix->g_keys,
-                      &ix->g_tie};
+                      &ix->out, &ix->entries, &ix->ovf_list, &ix->ovf2_list, &ix->ctrl, &ix->g_bitmap, &ix->fp_bitmap, &ix->g_keys};
     for (DevBuf* b : bufs) b->release();
     delete ix;
     return GBNNS_OK;
@@ -600,7 +625,9 @@ int gbnns_project(gbnns_index* ix, const float* x, uint64_t n_x, float* out, int
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t chunk = 1u << 16;
-    int rc = ix->q_low.ensure((size_t)std::min<uint64_t>(chunk, n_x) * ix->dl_pad * 4);
+    int rc = enter_stream(ix, s);
+    if (rc) return rc;
+    rc = ix->q_low.ensure((size_t)std::min<uint64_t>(chunk, n_x) * ix->dl_pad * 4);
     if (rc) return rc;
     if (mem_kind == GBNNS_MEM_HOST) {
         rc = ix->q_in.ensure((size_t)std::min<uint64_t>(chunk, n_x) * ix->d * 4);
@@ -639,6 +666,7 @@ int gbnns_rerank(gbnns_index* ix, const float* queries, uint64_t n_q, const uint
     const uint32_t nq = (uint32_t)n_q;
     const bool host = mem_kind == GBNNS_MEM_HOST;
     int rc;
+    if ((rc = enter_stream(ix, s))) return rc;
     RerankParams r{};
     r.db = ix->db; r.dstride = ix->d_pad; r.dim = ix->d; r.qstride = ix->d; r.cand_stride = cand_stride;
     r.nq = nq; r.n = (uint32_t)ix->n;
@@ -669,6 +697,7 @@ int gbnns_rerank(gbnns_index* ix, const float* queries, uint64_t n_q, const uint
     if (host) {
         HIP_TRY(hipMemcpyAsync(out_ids, r.out, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        ix->in_flight = false;
     }
     return GBNNS_OK;
 }
@@ -694,15 +723,19 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         return fail(GBNNS_ERR_INVALID, "GBNNS_FLAG_AUX_GRAPH without gbnns_index_set_aux_graph");
     if (a->hash_capacity != 0 && a->hash_capacity < 128)
         return fail(GBNNS_ERR_INVALID, "hash_capacity must be 0 (auto) or >= 128");
+    const uint32_t n_ent = a->n_entries ? a->n_entries : 1u;
+    if (n_ent > 1 && !a->entry_ids) return fail(GBNNS_ERR_INVALID, "n_entries > 1 needs entry_ids");
+    if (n_ent > 4096) return fail(GBNNS_ERR_INVALID, "n_entries too large");
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = static_cast<hipStream_t>(a->stream);
+    int rc;
+    if ((rc = enter_stream(ix, s))) return rc;
     const bool host = a->mem_kind == GBNNS_MEM_HOST;
     const uint32_t nq = (uint32_t)a->n_q;
     const int ef = a->ef;
     const bool plain = a->mode == GBNNS_MODE_PLAIN;
     const int k = plain ? std::max(1, std::min(a->k > 0 ? a->k : 1, ef)) : ef;
     const uint32_t cstride = (uint32_t)k;
-    int rc;
 
     // ---- workspace ----------------------------------------------------------------------
     if ((rc = ix->cnt.ensure((size_t)nq * 4))) return rc;
@@ -718,10 +751,11 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         if ((rc = ix->out.ensure((size_t)nq * 4))) return rc;
     if (host && a->out_edges)
         if ((rc = ix->edges.ensure((size_t)nq * 4))) return rc;
+    // general-kernel slots: visited bits + tie bits (n / 4 bytes per slot) and the result list -- 16 n bytes + 512 ef
+    // per handle in all (see gbnns.h, "Device memory")
     const uint32_t bitmap_words = (uint32_t)((ix->n + 31) / 32);
-    if ((rc = ix->g_bitmap.ensure((size_t)kGeneralSlots * bitmap_words * 4))) return rc;
-    if ((rc = ix->g_keys.ensure((size_t)kGeneralSlots * ((size_t)ef + (a->n_entries ? a->n_entries : 1u) - 1) * 8))) return rc;
-    if ((rc = ix->g_tie.ensure((size_t)kGeneralSlots * ix->n * 8))) return rc;
+    if ((rc = ix->g_bitmap.ensure((size_t)kGeneralSlots * 2 * bitmap_words * 4))) return rc;
+    if ((rc = ix->g_keys.ensure((size_t)kGeneralSlots * ((size_t)ef + n_ent - 1) * 8))) return rc;
 
     // ---- inputs -------------------------------------------------------------------------
     const float* q_dev = a->queries;
@@ -730,9 +764,6 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         HIP_TRY(hipMemcpyAsync(ix->q_in.p, a->queries, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice, s));
         q_dev = ix->q_in.as<float>();
     }
-    const uint32_t n_ent = a->n_entries ? a->n_entries : 1u;
-    if (n_ent > 1 && !a->entry_ids) return fail(GBNNS_ERR_INVALID, "n_entries > 1 needs entry_ids");
-    if (n_ent > 4096) return fail(GBNNS_ERR_INVALID, "n_entries too large");
     const uint32_t* entries_dev = a->entry_ids;
     if (a->entry_ids && host) {
         if ((rc = ix->entries.ensure((size_t)nq * n_ent * 4))) return rc;
@@ -808,7 +839,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     w.ovf_count = ctrl; w.g_cursor = ctrl + 1; w.max_dc = ctrl + 2; w.ovf2_count = ctrl + 3; w.r_cursor = ctrl + 4;
     w.g_total = ctrl_base + 5; w.ovf_list = ix->ovf_list.as<uint32_t>(); w.ovf2_list = ix->ovf2_list.as<uint32_t>();
     w.g_bitmap = ix->g_bitmap.as<uint32_t>(); w.g_keys = ix->g_keys.as<uint64_t>();
-    w.g_tie = ix->g_tie.as<uint64_t>(); w.bitmap_words = bitmap_words;
+    w.bitmap_words = bitmap_words;
 
     // Visited-set capacity.  The walk kernel's occupancy is LDS-bound, and a 10k-query batch is only
     // a few "rounds" deep (queries / (256 CUs x resident wavefronts)), so the table is sized from
@@ -982,6 +1013,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
             HIP_TRY(hipMemcpyAsync(a->out_cand_dist, w.cand_dist, (size_t)nq * cstride * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(&ix->last_general, ctrl, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        ix->in_flight = false;
         if (w.all_general) ix->last_general = nq;
     }
     return GBNNS_OK;

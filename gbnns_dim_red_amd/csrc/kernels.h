@@ -47,7 +47,7 @@ struct WalkParams {
     uint32_t* ovf2_count;    // [1]   list B
     uint32_t* ovf2_list;     // [nq]
     uint32_t* r_cursor;      // [1]   work-queue head of the retry pass
-    // general kernel workspace: per slot [bitmap words][keys ef][tie n]
+    // general kernel workspace: per slot [visited bits | tie bits: 2 x bitmap_words][keys ef]
     // first pass with the visited set in HBM (large ef): per-slot bitmaps and the work-queue head
     uint32_t* fp_bitmap;     // [slots x bitmap_words]
     uint32_t* fp_cursor;     // [1]
@@ -55,9 +55,8 @@ struct WalkParams {
     uint32_t* g_total;       // [1] running count of queries the general kernel processed
     uint32_t* max_dc;        // [1] max dist_calc over the batch (feeds the host's visited-set sizing)
     uint32_t* next_ctrl;     // [5] control words of the NEXT call: the general kernel clears them
-    uint32_t* g_bitmap;      // [slots x bitmap_words]
-    uint64_t* g_keys;        // [slots x ef]
-    uint64_t* g_tie;         // [slots x n]
+    uint32_t* g_bitmap;      // [slots x 2 x bitmap_words]: visited bits, then the tie set (one bit per node)
+    uint64_t* g_keys;        // [slots x (ef + n_entries - 1)]
     uint32_t bitmap_words;
     int32_t all_general;     // 1: the general kernel takes every query (fast kernel skipped)
     // fused re-rank (rr_db != nullptr): every walk kernel re-ranks its own query at the end of the walk

@@ -550,10 +550,96 @@ struct WalkState {
 // distance can never be expanded again (the worst distance only decreases), so only exact ties
 // need to be kept; the list is flushed whenever the worst distance strictly decreases.
 
+// Two containers for it.  TieList: a small array of evicted keys (LDS; the fast kernels hand a query over when it
+// overflows).  TieBits: one bit per node in global memory (general kernel: exact for any number of ties at
+// n / 8 bytes per wavefront slot) with the word range that may hold bits; ids in the set are distinct (an
+// unexpanded entry was claimed in the visited set of the current entry point's walk exactly once).
+struct TieList {
+    uint64_t* a;
+    int cap;
+    __device__ __forceinline__ bool push(uint64_t ev, int& tsize, int lane) {
+        if (tsize >= cap) return false;
+        if (lane == 0) a[tsize] = ev;
+        tsize += 1;
+        wave_sync();
+        return true;
+    }
+    __device__ __forceinline__ void clear(int& tsize, int) { tsize = 0; }
+    // id + 1 of the largest id in the set (0 = empty); `pos` = its slot
+    __device__ __forceinline__ uint32_t max_plus1(int tsize, int lane, int& pos) const {
+        uint32_t tbest = 0;
+        pos = -1;
+        for (int base = 0; base < tsize; base += 64) {
+            const int idx = base + lane;
+            uint32_t v = (idx < tsize) ? key_id(a[idx]) + 1u : 0u;
+            int w = idx;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {  // wave arg-max (ids are distinct)
+                const uint32_t ov = (uint32_t)__shfl_xor((int)v, off);
+                const int ow = __shfl_xor(w, off);
+                if (ov > v) { v = ov; w = ow; }
+            }
+            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            w = __builtin_amdgcn_readfirstlane(w);
+            if (v > tbest) { tbest = v; pos = w; }
+        }
+        return tbest;
+    }
+    __device__ __forceinline__ void remove(int pos, uint32_t, int& tsize, int lane) {
+        if (lane == 0) a[pos] = a[tsize - 1];  // unordered remove
+        tsize -= 1;
+        wave_sync();
+    }
+};
+
+struct TieBits {
+    uint32_t* bm;       // [ceil(n / 32)] words, all zero whenever the set is empty
+    uint32_t lo, hi;    // words that may hold bits: lo..hi (lo > hi: none)
+    __device__ __forceinline__ void reset_range() { lo = 0xFFFFFFFFu; hi = 0u; }
+    __device__ __forceinline__ bool push(uint64_t ev, int& tsize, int lane) {
+        const uint32_t id = key_id(ev), w = id >> 5;
+        if (lane == 0) bm[w] |= 1u << (id & 31u);
+        lo = w < lo ? w : lo;
+        hi = w > hi ? w : hi;
+        tsize += 1;
+        wave_sync();
+        return true;
+    }
+    __device__ __forceinline__ void clear(int& tsize, int lane) {
+        if (tsize > 0) {
+            for (uint64_t w = (uint64_t)lo + lane; w <= hi; w += 64) bm[w] = 0u;
+            wave_sync();
+        }
+        tsize = 0;
+        reset_range();
+    }
+    __device__ __forceinline__ uint32_t max_plus1(int tsize, int lane, int& pos) const {
+        pos = -1;
+        if (tsize <= 0) return 0u;
+        for (int64_t base = hi; base >= (int64_t)lo; base -= 64) {  // from the top word down, 64 words per pass
+            const int64_t w = base - lane;
+            const uint32_t v = w >= (int64_t)lo ? bm[w] : 0u;
+            const uint64_t m = __ballot(v != 0u);
+            if (m) {
+                const int l = __ffsll((unsigned long long)m) - 1;
+                const uint32_t vv = (uint32_t)__shfl((int)v, l);
+                pos = 0;
+                return (uint32_t)(base - l) * 32u + (31u - (uint32_t)__clz((int)vv)) + 1u;
+            }
+        }
+        return 0u;
+    }
+    __device__ __forceinline__ void remove(int, uint32_t id, int& tsize, int lane) {
+        if (lane == 0) bm[id >> 5] &= ~(1u << (id & 31u));
+        tsize -= 1;
+        wave_sync();
+    }
+};
+
 // Picks the next node to expand (closest unexpanded; ties -> LARGEST id, because the candidate
 // heap is keyed (-dist, id)).  Returns false when nothing is left (the reference's loop exit).
 template <typename KP, typename TP>
-__device__ __forceinline__ bool select_candidate(KP keys, TP tie, WalkState& st, uint32_t& node,
+__device__ __forceinline__ bool select_candidate(KP keys, TP& tie, WalkState& st, uint32_t& node,
                                                  int lane) {
     int p = -1, best = -1;
     uint32_t hi_p = 0;
@@ -580,29 +666,13 @@ __device__ __forceinline__ bool select_candidate(KP keys, TP tie, WalkState& st,
         const uint32_t worst_hi = key_hi(keys[st.size - 1]);
         if (p < 0 || hi_p == worst_hi) {
             // all tie entries sit at the worst distance: the largest id among them competes
-            uint32_t tbest = 0;  // id + 1 of the largest tie id, 0 = none
-            int tpos = -1;
-            for (int base = 0; base < st.tsize; base += 64) {
-                const int idx = base + lane;
-                uint32_t v = (idx < st.tsize) ? key_id(tie[idx]) + 1u : 0u;
-                int w = idx;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {  // wave arg-max (ids are distinct)
-                    const uint32_t ov = (uint32_t)__shfl_xor((int)v, off);
-                    const int ow = __shfl_xor(w, off);
-                    if (ov > v) { v = ov; w = ow; }
-                }
-                v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-                w = __builtin_amdgcn_readfirstlane(w);
-                if (v > tbest) { tbest = v; tpos = w; }
-            }
+            int tpos;
+            const uint32_t tbest = tie.max_plus1(st.tsize, lane, tpos);  // id + 1, 0 = none
             const uint32_t tmax = tbest - 1u;
             const uint32_t lid = (best >= 0) ? key_id(keys[best]) : 0u;
             if (tpos >= 0 && (best < 0 || tmax > lid)) {
                 node = tmax;
-                if (lane == 0) tie[tpos] = tie[st.tsize - 1];  // unordered remove
-                st.tsize -= 1;
-                wave_sync();
+                tie.remove(tpos, tmax, st.tsize, lane);
                 return true;
             }
         }
@@ -618,7 +688,7 @@ __device__ __forceinline__ bool select_candidate(KP keys, TP tie, WalkState& st,
 // (search_function.h:31-37): insert when worst.dist > dist || size < ef (strict, distance only),
 // then evict the largest pair if size > ef.  Returns false if the tie list overflowed.
 template <typename KP, typename TP>
-__device__ __forceinline__ bool offer(KP keys, TP tie, int tie_cap, WalkState& st, int ef,
+__device__ __forceinline__ bool offer(KP keys, TP& tie, WalkState& st, int ef,
                                       uint32_t dk, uint32_t id, int lane) {
     if (st.size >= ef && !(dk < key_hi(keys[st.size - 1]))) return true;
     uint64_t ev;
@@ -628,14 +698,9 @@ __device__ __forceinline__ bool offer(KP keys, TP tie, int tie_cap, WalkState& s
     if (did) {
         const uint32_t nw = key_hi(keys[st.size - 1]);
         if (key_hi(ev) == nw) {
-            if (!(ev & 1ull)) {
-                if (st.tsize >= tie_cap) return false;
-                if (lane == 0) tie[st.tsize] = ev;
-                st.tsize += 1;
-                wave_sync();
-            }
+            if (!(ev & 1ull) && !tie.push(ev, st.tsize, lane)) return false;
         } else {
-            st.tsize = 0;
+            tie.clear(st.tsize, lane);
         }
     }
     return true;
@@ -664,7 +729,25 @@ __device__ __forceinline__ void write_results(const WalkParams& p, uint32_t qi, 
         p.dist_calc[qi] = st.dist_calc;
         atomicMax(p.max_dc, (uint32_t)st.dist_calc);
         if (p.edges) p.edges[qi] = st.edges;
-        if (p.best) p.best[qi] = key_id(keys[0]);
+        // PLAIN answer = topk.top() after trimming the heap to k (search_function.h:174-181): the k-th best
+        if (p.best) p.best[qi] = kept > 0 ? key_id(keys[kept - 1]) : kInvalidId;
+    }
+}
+
+// An entry id outside the index (device buffers are not validated on the host, host buffers are): no row of it may
+// be touched.  The query gets an empty result -- answer 0xFFFFFFFF, no candidates, zero counters (gbnns.h).
+__device__ __forceinline__ void write_bad_entry(const WalkParams& p, uint32_t qi, int lane) {
+    for (int r = lane; r < (int)p.cand_stride; r += 64) {
+        p.cand[(size_t)qi * p.cand_stride + r] = kInvalidId;
+        if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + r] = __builtin_inff();
+    }
+    if (lane == 0) {
+        p.count[qi] = 0;
+        p.hops[qi] = 0;
+        p.dist_calc[qi] = 0;
+        if (p.edges) p.edges[qi] = 0;
+        if (p.best) p.best[qi] = kInvalidId;
+        if (p.rr_db) p.rr_out[qi] = kInvalidId;
     }
 }
 
@@ -692,8 +775,8 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
     const int ef = p.ef;
     const int ef_pad = (ef + 63) & ~63;
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-    uint64_t* tie = keys + ef_pad;
-    float* qf = reinterpret_cast<float*>(tie + kTieCap);
+    TieList tie{keys + ef_pad, kTieCap};
+    float* qf = reinterpret_cast<float*>(tie.a + kTieCap);
     uint32_t* hash = reinterpret_cast<uint32_t*>(qf + p.dstride);
     const float4* qs = reinterpret_cast<const float4*>(qf);
     const uint32_t cap = p.hash_cap;  // any size: slot = mulhi(id * C, cap)
@@ -713,6 +796,7 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
     st.size = 0; st.tsize = 0; st.first_un = 0; st.hops = 0; st.dist_calc = 1; st.edges = 0;
 
     const uint32_t entry = p.entries ? p.entries[qi] : 0u;
+    if (entry >= p.n) { write_bad_entry(p, qi, lane); return; }
     {
         const float d0 = walk_dist<METRIC, STEPS>(qs, p.db + (size_t)entry * p.dstride, p.dim);
         if (lane == 0) {
@@ -759,7 +843,7 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
                 m &= m - 1;
                 const uint32_t dl = (uint32_t)__shfl((int)dk, l);
                 const uint32_t il = (uint32_t)__shfl((int)nb, l);
-                if (!offer(keys, tie, kTieCap, st, ef, dl, il, lane)) { handed_over = true; break; }
+                if (!offer(keys, tie, st, ef, dl, il, lane)) { handed_over = true; break; }
             }
             if (handed_over) break;
         }
@@ -1265,6 +1349,8 @@ template <int R>
 __device__ __forceinline__ void reg_write_results(const WalkParams& p, uint32_t qi, const RegList<R>& L, int size, int hops,
                                                   int dist_calc, int edges, int lane) {
     const int kept = size < p.k ? size : p.k;
+    // PLAIN answer = topk.top() after trimming the heap to k (search_function.h:174-181): the k-th best
+    const uint32_t kth = L.lo_at(kept > 0 ? kept - 1 : 0) >> 1;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int rank = r * 64 + lane;
@@ -1284,7 +1370,7 @@ __device__ __forceinline__ void reg_write_results(const WalkParams& p, uint32_t 
         p.dist_calc[qi] = dist_calc;
         atomicMax(p.max_dc, (uint32_t)dist_calc);
         if (p.edges) p.edges[qi] = edges;
-        if (p.best) p.best[qi] = L.lo[0] >> 1;
+        if (p.best) p.best[qi] = kth;
     }
 }
 
@@ -1356,6 +1442,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     int size = 1, tsize = 0, hops = 0, dist_calc = 1, edges = 0;
     uint32_t worst;                                // hi of lane size-1 (wave-uniform)
     const uint32_t entry = p.entries ? p.entries[qi] : 0u;
+    if (entry >= p.n) { write_bad_entry(p, qi, lane); return; }
     {
         const float d0 = walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, entry, p.dstride), p.dim);
         worst = fkey(d0);
@@ -1902,6 +1989,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     int size = 1, tsize = 0, hops = 0, dist_calc = 1, edges = 0;
     uint32_t worst;
     const uint32_t entry = p.entries ? p.entries[qi] : 0u;
+    if (entry >= p.n) { write_bad_entry(p, qi, lane); return; }
     {
         const float d0 = walk_dist<0, 8>(qs, row_ptr<true>(p.db, entry, 32u), 32u);
         worst = fkey(d0);
@@ -2177,10 +2265,12 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
     const uint32_t slot = blockIdx.x;
     float* qf = reinterpret_cast<float*>(smem);
     const float4* qs = reinterpret_cast<const float4*>(qf);
-    uint32_t* bitmap = p.g_bitmap + (size_t)slot * p.bitmap_words;
+    uint32_t* bitmap = p.g_bitmap + (size_t)slot * 2u * p.bitmap_words;  // [visited bits][tie bits]
     const uint32_t n_ent = p.n_entries ? p.n_entries : 1u;
     uint64_t* keys = p.g_keys + (size_t)slot * ((size_t)p.ef + n_ent - 1u);  // one extra slot per extra entry point
-    uint64_t* tie = p.g_tie + (size_t)slot * (size_t)p.n;
+    // tie set: one bit per node (second half of the slot's bitmap block), zeroed here once and kept clean by clear()
+    TieBits tie{bitmap + p.bitmap_words, 0xFFFFFFFFu, 0u};
+    for (uint32_t i = lane; i < p.bitmap_words; i += 64) tie.bm[i] = 0u;
     const int ef = p.ef;
     const uint32_t total = p.all_general ? p.nq : *p.ovf2_count;
     if (slot == 0 && lane == 0 && total) atomicAdd(p.g_total, total);
@@ -2197,6 +2287,15 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
             qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
         wave_sync();
 
+        {
+            bool bad = false;  // an entry id outside the index: empty result, no row is touched
+            for (uint32_t e = 0; e < n_ent; ++e) bad |= (p.entries ? p.entries[(size_t)qi * n_ent + e] : 0u) >= p.n;
+            if (bad) {
+                write_bad_entry(p, qi, lane);
+                wave_sync();
+                continue;
+            }
+        }
         WalkState st;
         st.size = 0; st.tsize = 0; st.first_un = 0; st.hops = 0; st.dist_calc = 1; st.edges = 0;
         // search_function.h:54-64: one walk per entry point -- fresh candidate set (every result so far counts as
@@ -2207,7 +2306,7 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
         for (uint32_t i = lane; i < p.bitmap_words; i += 64) bitmap[i] = 0u;
         if (e > 0) {
             for (int i = lane; i < st.size; i += 64) keys[i] = keys[i] | 1ull;
-            st.tsize = 0;
+            tie.clear(st.tsize, lane);
         }
         wave_sync();
         const uint32_t entry = p.entries ? p.entries[(size_t)qi * n_ent + e] : 0u;
@@ -2254,7 +2353,7 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
                     m &= m - 1;
                     const uint32_t dl = (uint32_t)__shfl((int)dk, l);
                     const uint32_t il = (uint32_t)__shfl((int)nb, l);
-                    offer(keys, tie, (int)p.n, st, ef, dl, il, lane);
+                    offer(keys, tie, st, ef, dl, il, lane);
                 }
             }
         };
@@ -2267,6 +2366,7 @@ __global__ __launch_bounds__(64) void walk_general_kernel(WalkParams p) {
             st.hops += 1;
         }
         }  // entry points
+        tie.clear(st.tsize, lane);  // leaves the tie bits all zero for the next query
         write_results(p, qi, keys, st, lane);
         if (p.rr_db) {
             const int kept = st.size < p.k ? st.size : p.k;

@@ -121,7 +121,7 @@ inline vector<uint32_t> gbnnsEntries(const vector<vector<uint32_t>>& inter_point
 }
 
 // One batch on the device.  mode NET / LOWQ: two-stage with ef = recheck_size;
-// mode PLAIN: walk in the space of the index's `db` with (ef, k), answer = best.
+// mode PLAIN: walk in the space of the index's `db` with (ef, k), answer = top of the heap trimmed to k (:174-181).
 inline void gbnnsBatch(gbnns_index* ix, int mode, const float* queries, const float* queries_low,
                        size_t n_q, int ef, int k, const vector<uint32_t>& entries, vector<uint32_t>& ans,
                        vector<int32_t>& hops, vector<int32_t>& dist_calc, const GbnnsAux& aux, uint32_t n_entries = 1) {

@@ -16,6 +16,11 @@ def shard_bounds(n_q, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def shard_pad(n_q, world):
+    """Size of the largest block: every rank pads its answers to this many entries for the all-gather."""
+    return (n_q + world - 1) // world
+
+
 def gather_ids(local_ids, n_q, group=None):
     """All-gathers per-rank answer blocks (int32 tensors, block r = shard_bounds(n_q, W, r)) into
     the full [n_q] vector on every rank.  Blocks are padded to the largest shard so a single
@@ -24,7 +29,7 @@ def gather_ids(local_ids, n_q, group=None):
     if world == 1:
         return local_ids
     rank = dist.get_rank(group)
-    width = (n_q + world - 1) // world
+    width = shard_pad(n_q, world)
     lo, hi = shard_bounds(n_q, world, rank)
     assert local_ids.numel() == hi - lo
     send = torch.full((width,), -1, dtype=local_ids.dtype, device=local_ids.device)

@@ -112,11 +112,14 @@ def ground_truth(base, queries, k=2, chunk=2048):
 
 def make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=1234,
                  device="cuda:0", intrinsic=16, n_clusters=1000, cluster_scale=0.5, sigma=0.03,
-                 knn_k=48, M=16, threads=0, cache_dir=None, projector=None, verbose=False, native_knn=False):
+                 knn_k=48, M=16, threads=0, cache_dir=None, projector=None, verbose=False, native_knn=False,
+                 gt_queries=None):
     """Builds (or loads from `cache_dir`) the synthetic workload.  Returns a Dataset whose tensors
     live on `device`; graph arrays are numpy (host), as gbnns_index_create wants them."""
     recipe = dict(n=n, nq=nq, d=d, d_low=d_low, d_hidden=d_hidden, seed=seed, intrinsic=intrinsic,
                   n_clusters=n_clusters, cluster_scale=cluster_scale, sigma=sigma, knn_k=knn_k, M=M)
+    if gt_queries is not None and gt_queries < nq:
+        recipe["gt_queries"] = gt_queries  # exact ground truth for the first gt_queries queries only (huge batches)
     if native_knn:
         # kNN lists and ground truth from gbnns_exact_knn (the reference's distance arithmetic) instead of torch's
         # formula-based top-k: what large n needs (torch's n x chunk distance matrices do not scale to 10^7)
@@ -180,10 +183,11 @@ def make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=123
     timings["gd_s"] = time.time() - t1
 
     t1 = time.time()
+    gq = queries if gt_queries is None or gt_queries >= nq else queries[:gt_queries]
     if native_knn and d <= 128:
-        gt2 = binding.exact_knn(base, queries, 2).to(torch.int64)
+        gt2 = binding.exact_knn(base, gq, 2).to(torch.int64)
     else:
-        gt2 = ground_truth(base, queries, 2)
+        gt2 = ground_truth(base, gq, 2)
     timings["gt_s"] = time.time() - t1
     timings["total_s"] = time.time() - t0
     if verbose:

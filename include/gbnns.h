@@ -12,6 +12,21 @@
  * may be used by one host thread at a time; distinct handles are independent.  All vectors are
  * IEEE binary32, row-major; ids are uint32 (n < 2^31).  There is NO CPU fallback: without a
  * usable gfx950 device gbnns_index_create fails with GBNNS_ERR_NO_DEVICE.
+ *
+ * Streams: the calls of one handle share its workspace and are ordered by stream order.  A call that names
+ * another stream than the handle's previous call first makes the new stream wait for what that call left in
+ * flight (the previous stream must still exist, or the device is synchronised) -- results never depend on
+ * which stream a call was given.  To overlap batches use one handle per stream (handles may share borrowed
+ * device tensors).
+ *
+ * Device memory per handle besides the index data: per-batch buffers (n_q x (d_low + ef + 6) x 4 bytes at
+ * most) plus the exact fall-back walk's 64 slots of two n-bit sets and an ef-entry list: 16 n + 512 ef bytes
+ * (16 MB at n = 10^6, 160 MB at 10^7).  The large-ef first pass (ef >= 385, deep batches) adds one n-bit set
+ * per resident wavefront, capped at 8 GiB.
+ *
+ * Ids in DEVICE buffers are not validated on the host.  An entry id >= n is never dereferenced: that query
+ * gets answer 0xFFFFFFFF, an all-0xFFFFFFFF candidate row and zero counters.  Candidate ids >= n passed to
+ * gbnns_rerank read row 0 instead.  HOST buffers are validated (GBNNS_ERR_INVALID).
  */
 #ifndef GBNNS_H_
 #define GBNNS_H_
@@ -43,7 +58,8 @@ typedef enum { GBNNS_MEM_HOST = 0, GBNNS_MEM_DEVICE = 1 } gbnns_mem_kind;
 /* Which per-query body of the reference harness one batch call reproduces:
  *   NET   search_function.h:353-362  MLP projection -> walk(ef,k=ef) in low-dim space -> re-rank
  *   LOWQ  search_function.h:158-164  same with caller-supplied low-dim queries (performTest)
- *   PLAIN search_function.h:174-181  walk(ef,k) directly in the space of `db`, answer = best */
+ *   PLAIN search_function.h:174-181  walk(ef,k) directly in the space of `db`, answer = top of the heap trimmed
+ *         to k, i.e. the k-th best (the best for k = 1, which is what the reference's drivers pass) */
 typedef enum { GBNNS_MODE_NET = 0, GBNNS_MODE_LOWQ = 1, GBNNS_MODE_PLAIN = 2 } gbnns_mode;
 
 typedef struct gbnns_index gbnns_index;
@@ -87,7 +103,7 @@ typedef struct {
     uint32_t struct_size;      /* = sizeof(gbnns_search_args) */
     int32_t mode;              /* gbnns_mode */
     int32_t ef;                /* beam width (= recheck_size in NET/LOWQ, search_function.h:432-434) */
-    int32_t k;                 /* PLAIN: heap is trimmed to k, answer = its top (reference uses 1) */
+    int32_t k;                 /* PLAIN: heap is trimmed to k, answer = its top = the k-th best (reference uses 1) */
     int32_t mem_kind;          /* gbnns_mem_kind of every buffer below */
     int32_t hash_capacity;     /* 0 = auto (sized from the LDS budget and earlier batches); else entries
                                   (>= 128) of the per-query LDS visited set */

@@ -1,0 +1,110 @@
+"""The arithmetic contract, checked on the shipped code object (CPU test: no GPU needed).
+
+DESIGN.md section 2: every distance the walk / re-rank / kNN / graph-pruning kernels compute is a chain of
+separately rounded IEEE binary32 multiplies and adds in the reference's order (support_func.h:107-163) --
+a fused multiply-add anywhere in them would change bits and, through compare-driven control flow, answers.
+The compiler flags (-ffp-contract=off) promise that; this test verifies it on the gfx950 machine code inside
+lib/libgbnns_hip.so: it unbundles the device code objects, disassembles them and fails on any floating-point
+fused / multiply-accumulate instruction in those kernels.  It also pins one scheduling property of the
+hand-laid-out walk_hot kernels that cost 10 % when it broke (tools/check_isa.sh): the row gather of a hop
+must not wait for the adjacency prefetch issued just before it (no `s_waitcnt vmcnt(0)` in between).
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "gbnns_dim_red_amd", "lib", "libgbnns_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+# kernels under the bit-exact distance contract (mangled-name substrings)
+CONTRACT = ("walk_", "rerank_", "knn_scan", "gd_prune")
+# floating-point instructions that fuse or chain a multiply with an add (integer v_mad_u32_u24 etc. are fine)
+FUSED = re.compile(r"^v_(fma_|fmac_|fmaak_|fmamk_|mac_f|mad_f|madak_f|madmk_f|pk_fma_|fma_mix|mad_mix|dot\d)")
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    """{mangled kernel name: [instruction lines]} of every gfx950 code object in the library."""
+    if not os.path.exists(LIB):
+        pytest.fail(LIB + " is missing: run __graft_entry__.build() first")
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    work = tmp_path_factory.mktemp("isa")
+    lib = shutil.copy(LIB, work)  # llvm-objdump --offloading writes the bundles next to its input
+    subprocess.run([OBJDUMP, "--offloading", lib], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = {}
+    objs = [f for f in os.listdir(work) if f.endswith("gfx950")]
+    assert objs, "no gfx950 code object inside the library"
+    for f in objs:
+        text = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", os.path.join(work, f)], check=True,
+                              capture_output=True, text=True).stdout
+        name = None
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                name = m.group(1)
+                out.setdefault(name, [])
+                continue
+            if name and line.startswith("\t"):
+                out[name].append(line.strip().split("//")[0].strip())
+    return out
+
+
+def test_no_fused_multiply_add_in_the_distance_kernels(kernels):
+    checked = 0
+    bad = []
+    for name, insts in kernels.items():
+        if not any(k in name for k in CONTRACT):
+            continue
+        checked += 1
+        for ins in insts:
+            if FUSED.match(ins):
+                bad.append((name[:90], ins))
+    assert checked >= 20, "expected the walk / re-rank / kNN / pruning kernels in the code objects, found %d" % checked
+    assert not bad, "fused multiply-add inside a bit-exact kernel: %s" % bad[:5]
+
+
+def test_distance_kernels_use_separate_mul_and_add(kernels):
+    """Sanity of the check itself: the kernels do contain the separately rounded forms."""
+    hot = [v for k, v in kernels.items() if "walk_hot_kernel" in k]
+    assert hot, "walk_hot_kernel not found"
+    text = "\n".join(hot[0])
+    assert "v_pk_mul_f32" in text and "v_pk_add_f32" in text
+
+
+def test_projection_kernels_fma_only_in_div_sqrt_expansion(kernels):
+    """The MLP layers (support_func.h:624-633) are under the same contract; the correctly rounded divide / sqrt of
+    normalizeVector (:636-642) legitimately expand to fma sequences -- only the NORM variants may contain any."""
+    for name, insts in kernels.items():
+        if "mlp_" not in name or "mfma" in name:  # the opt-in matrix-core variant is outside the contract
+            continue
+        n_fma = sum(1 for i in insts if FUSED.match(i))
+        if n_fma:
+            # NORM = last template argument true (mlp_layer*_kernel<RELU, NORM>, mlp_narrow_kernel<RELU, NORM>)
+            assert re.search(r"Lb[01]ELb1E", name), "fma in a projection kernel without the normalise step: " + name
+            assert n_fma < 64, (name, n_fma)  # a div + a sqrt expansion, not a dot-product loop
+
+
+def test_hot_kernel_gather_does_not_wait_for_the_prefetch(kernels):
+    hot = {k: v for k, v in kernels.items() if re.search(r"walk_hot(\d|N)?_kernel", k)}
+    assert len(hot) >= 5
+    seen = set()
+    for name, insts in hot.items():
+        key = tuple(insts[:50])
+        if key in seen:  # the same kernel is present in every compilation unit's code object
+            continue
+        seen.add(key)
+        # hot_expand's block: four row loads into the fixed registers v[48:63], offsets 0 / 16 / 32 / 48
+        gathers = [i for i, s in enumerate(insts[:-1]) if s.startswith("global_load_dwordx4 v[48:51]") and "offset" not in s
+                   and insts[i + 1].startswith("global_load_dwordx4 v[52:55]") and "offset:16" in insts[i + 1]]
+        assert gathers, name
+        for gi in gathers:
+            back = [j for j in range(max(0, gi - 60), gi) if re.match(r"global_load_dword\s", insts[j])]
+            assert back, "no adjacency prefetch in front of the gather in " + name
+            between = insts[back[-1] + 1:gi]
+            assert not any(re.match(r"s_waitcnt vmcnt\(0\)", s) for s in between), \
+                "the gather waits for the adjacency prefetch (vmcnt(0)) in " + name

@@ -1,15 +1,19 @@
 #!/bin/bash
-# Prints the vmcnt waits of the hot walk kernel instance (L2, 8 steps, 32-bit offsets, ef <= 64) with
-# context.  A `s_waitcnt vmcnt(0)` right before the row gather's address computation means the
-# register allocator reused a load destination for the address: the adjacency prefetch is then
-# serialised with the gather (costs ~10 % of the walk time) -- perturb the source until it is gone.
+# The arithmetic / scheduling contract of the shipped code object, checked on its disassembly:
+# no fused multiply-add in walk_* / rerank_* / knn_scan / gd_prune, and no `s_waitcnt vmcnt(0)` between the
+# adjacency prefetch and the row gather of the walk_hot kernels.  Same checks as the CPU test suite runs
+# (tests/test_isa_contract.py); pass a kernel-name pattern to also dump that kernel's instructions.
+#   tools/check_isa.sh [pattern, e.g. walk_hot_kernel] [out.s]
 set -e
-cd "$(dirname "$0")/../gbnns_dim_red_amd/csrc"
-OUT=${1:-/tmp/gbnns_isa.s}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math \
-    -fhip-fp32-correctly-rounded-divide-sqrt --cuda-device-only -S -o $OUT.full kernels.hip 2>/dev/null
-awk '/^_ZN5gbnns12_GLOBAL__N_115walk_reg_kernelILi0ELi8ELb1ELb0ELi1ELb1EEEvNS_10WalkParamsE:/{f=1} f{print} /^.Lfunc_end/{if(f){exit}}' $OUT.full \
-    | grep -v "^\s*;" | grep -v "^\s*\.\(p2align\|loc\|cfi\)" > $OUT
-echo "instructions: $(grep -c "^\s[a-z]" $OUT)   vgprs: $(grep "walk_reg_kernelILi0ELi8ELb1ELb0ELi1ELb1EEEvNS_10WalkParamsE.num_vgpr" $OUT.full | awk '{print $NF}')"
-if grep -B1 -A1 "vmcnt(0)" $OUT | grep -A1 "vmcnt(0)" | grep -q "v_mul_lo_u32.*s3"; then echo "ARTIFACT: vmcnt(0) before the gather address"; else echo "gather address: no forced wait"; fi
-grep -n -A1 "vmcnt" $OUT | grep -v "^--" | paste - - | head -20
+cd "$(dirname "$0")/.."
+python -m pytest tests/test_isa_contract.py -q
+if [ -n "$1" ]; then
+  OUT=${2:-/tmp/gbnns_isa.s}
+  W=$(mktemp -d)
+  cp gbnns_dim_red_amd/lib/libgbnns_hip.so $W/
+  /opt/rocm/lib/llvm/bin/llvm-objdump --offloading $W/libgbnns_hip.so > /dev/null 2>&1
+  O=$(ls $W/*gfx950 | head -1)
+  /opt/rocm/lib/llvm/bin/llvm-objdump -d --no-show-raw-insn $O | awk -v pat="$1" '/^[0-9a-f]+ <.*>:$/{f = ($0 ~ pat)} f{print}' | sed 's,[[:space:]]*//.*,,' > $OUT
+  echo "$(grep -c '^\s' $OUT) instructions of kernels matching '$1' written to $OUT"
+  rm -rf $W
+fi
