@@ -43,9 +43,9 @@ CONFIGS = {
                  label="SIFT1M 128->32", shape="SIFT1M-shaped"),
     "gist": dict(n=1_000_000, nq=1_000, d=960, d_low=64, d_hidden=1024, ef=200, efs=[400],
                  label="GIST1M 960->64", shape="GIST1M-shaped"),
-    "glove": dict(n=1_200_000, nq=10_000, d=200, d_low=32, d_hidden=256, ef=64, efs=[300],
+    "glove": dict(n=1_200_000, nq=10_000, d=200, d_low=32, d_hidden=256, ef=64, efs=[300], unit_norm=True,
                   label="GloVe-1.2M 200->32 (L2 on normalised data)", shape="GloVe-1.2M-shaped"),
-    "glove-dot": dict(n=1_200_000, nq=10_000, d=200, d_low=32, d_hidden=256, ef=64, efs=[300], negdot=True,
+    "glove-dot": dict(n=1_200_000, nq=10_000, d=200, d_low=32, d_hidden=256, ef=64, efs=[300], negdot=True, unit_norm=True,
                       label="GloVe-1.2M 200->32 (negative-dot metric)", shape="GloVe-1.2M-shaped"),
     "deep": dict(n=10_000_000, nq=1_000_000, d=96, d_low=32, d_hidden=128, ef=40, efs=[60, 120], strong=True,
                  native_knn=True, label="DEEP10M 96->32, 1M-query batch", shape="DEEP10M-shaped"),
@@ -110,6 +110,8 @@ def main():
     os.makedirs(args.cache_dir, exist_ok=True)
     kw = dict(n=cfg["n"], nq=cfg["nq"], d=cfg["d"], d_low=cfg["d_low"], d_hidden=cfg["d_hidden"], seed=1234,
               cache_dir=args.cache_dir, native_knn=bool(cfg.get("native_knn")) and cfg["n"] > 2_000_000)
+    if cfg.get("unit_norm"):
+        kw["unit_norm"] = True  # GloVe vectors are normalised before anything else (train_naive_triplet.py:233-237)
     if cfg.get("strong"):
         kw["gt_queries"] = 20_000  # exact ground truth for the first 20 000 queries of the 1M batch (recall sample)
     if rank == 0:
@@ -538,12 +540,20 @@ def cpu_baseline(ds, q, ef, gpu_ids, metric_id):
     else:
         impl, kind = oracle.Oracle(), "port"
         flags = "g++ -O2 -std=c++17 -fopenmp -ffp-contract=off -fno-fast-math (oracle/Makefile ORACLE_FLAGS)"
-    omp_max = impl.max_threads()
+    omp_max = impl.max_threads()   # honours OMP_NUM_THREADS (the GPU boxes export 1); explicit counts below override it
     try:
         affinity = len(os.sched_getaffinity(0))
     except AttributeError:
         affinity = os.cpu_count() or 1
-    avail = max(1, min(omp_max, affinity))
+    quota = None  # cgroup v2 CPU quota of this container, in cores
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            quota = float(a) / float(b)
+    except (OSError, ValueError):
+        pass
+    # cores this process may really use: affinity mask, cgroup quota, and the pool's share of 16 per GPU
+    avail = max(1, min(affinity, int(quota) if quota and quota >= 1 else affinity, 16))
 
     def run(nqs, threads):
         t0 = time.perf_counter()
@@ -551,22 +561,22 @@ def cpu_baseline(ds, q, ef, gpu_ids, metric_id):
                               metric=metric_id)
         return time.perf_counter() - t0, r
 
-    # 1 thread (what final_test.cpp ships, :71) on a bounded sample sized from a probe (~5 s of work) ...
+    # 1 thread (what final_test.cpp ships, :71) on a bounded sample sized from a probe (~4 s of work) ...
     probe = min(len(qh), 200)
     t_probe, _ = run(probe, 1)
     per_q = t_probe / probe
-    ns = int(max(probe, min(len(qh), 5.0 / max(per_q, 1e-9))))
+    ns = int(max(probe, min(len(qh), 4.0 / max(per_q, 1e-9))))
     t1, _ = run(ns, 1)
     # ... then the OpenMP form (search_function.h:152) at 2, 4, ... up to the cores this process may use, each on a
-    # sample of ~4 s; the widest run covers the whole batch when that fits ~15 s and is the id check
+    # sample of ~2.5 s; the widest run covers the whole batch when that fits ~10 s and is the id check
     scaling = {"1": round(ns / t1, 1)}
     th = 2
     while th < avail:
-        nst = int(max(probe, min(len(qh), 4.0 * th / max(per_q, 1e-9))))
+        nst = int(max(probe, min(len(qh), 2.5 * th / max(per_q, 1e-9))))
         tt, _ = run(nst, th)
         scaling[str(th)] = round(nst / tt, 1)
         th *= 2
-    nfull = int(max(probe, min(len(qh), 15.0 * avail / max(per_q, 1e-9))))
+    nfull = int(max(probe, min(len(qh), 10.0 * avail / max(per_q, 1e-9))))
     tn, r = run(nfull, avail)
     scaling[str(avail)] = round(nfull / tn, 1)
     same = int((r["ids"].astype(np.int64) == gpu_ids[:nfull].cpu().numpy().astype(np.int64)).sum())
@@ -583,7 +593,11 @@ def cpu_baseline(ds, q, ef, gpu_ids, metric_id):
         "os_cpu_count": os.cpu_count(),
         "sched_affinity_cpus": affinity,
         "omp_max_threads": omp_max,
+        "env_OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"),
+        "cgroup_cpu_quota_cores": quota,
         "cores_available": avail,
+        "cores_rule": "min(sched affinity, cgroup cpu.max, 16 = the GPU pool's CPU share per GPU); thread counts are set "
+                      "explicitly (omp_set_num_threads), whatever OMP_NUM_THREADS says",
         "build_flags": flags,
         "gpu_ids_identical": same == nfull,
         "gpu_id_mismatches": nfull - same,

@@ -26,6 +26,10 @@ SYMBOLS = [
     "gbnns_index_create", "gbnns_index_destroy", "gbnns_index_set_aux_graph", "gbnns_search_ex", "gbnns_search_batch",
     "gbnns_project", "gbnns_rerank", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd", "gbnns_build_graph_gd_device",
     "gbnns_free", "gbnns_exact_knn", "gbnns_device_count", "gbnns_version", "gbnns_last_error",
+    "gbnns_index_n", "gbnns_index_d", "gbnns_index_d_low", "gbnns_index_device",
+    "gbnns_multi_create", "gbnns_multi_destroy", "gbnns_multi_size", "gbnns_multi_replica", "gbnns_multi_device_of",
+    "gbnns_multi_stream", "gbnns_multi_set_aux_graph", "gbnns_shard_bounds", "gbnns_multi_search_ex",
+    "gbnns_multi_search_device", "gbnns_multi_synchronize", "gbnns_multi_last_error",
 ]
 
 
@@ -108,6 +112,23 @@ def load_library():
                                                 C.POINTER(C.c_uint64)]
     lib.gbnns_exact_knn.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32,
                                     C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.gbnns_multi_last_error.restype = C.c_char_p
+    lib.gbnns_multi_create.argtypes = [C.POINTER(_IndexDesc), C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.gbnns_multi_destroy.argtypes = [C.c_void_p]
+    lib.gbnns_multi_size.argtypes = [C.c_void_p]
+    lib.gbnns_multi_replica.argtypes = [C.c_void_p, C.c_int32]
+    lib.gbnns_multi_replica.restype = C.c_void_p
+    lib.gbnns_multi_stream.argtypes = [C.c_void_p, C.c_int32]
+    lib.gbnns_multi_stream.restype = C.c_void_p
+    lib.gbnns_multi_device_of.argtypes = [C.c_void_p, C.c_int32]
+    lib.gbnns_multi_set_aux_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gbnns_multi_search_ex.argtypes = [C.c_void_p, C.POINTER(_SearchArgs)]
+    lib.gbnns_multi_search_device.argtypes = [C.c_void_p, C.POINTER(_SearchArgs), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gbnns_multi_synchronize.argtypes = [C.c_void_p]
+    lib.gbnns_shard_bounds.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.gbnns_shard_bounds.restype = None
+    lib.gbnns_index_d_low.argtypes = [C.c_void_p]
+    lib.gbnns_index_d_low.restype = C.c_uint32
     _lib = lib
     return lib
 
@@ -224,6 +245,100 @@ def exact_knn(base, queries, k, metric=METRIC_L2, self_offset=-1, want_dist=Fals
     _check(lib.gbnns_exact_knn(device, _ptr(base), n, _ptr(queries), nq, d, k, metric, self_offset, _ptr(ids),
                                _ptr(dist), MEM_DEVICE if dev else MEM_HOST, sptr))
     return (ids, dist) if want_dist else ids
+
+
+def _check_multi(rc):
+    if rc != 0:
+        raise GbnnsError(rc, load_library().gbnns_multi_last_error().decode(errors="replace"))
+
+
+class MultiIndex:
+    """gbnns_multi: one replica of the index per entry of `devices` (host arrays in), a batch is cut into contiguous
+    blocks, one per replica, each on its own host thread and HIP stream."""
+
+    def __init__(self, db, graph_offsets, graph_nbrs, db_low=None, net=None, metric=METRIC_L2, devices=None):
+        lib = load_library()
+        self._lib = lib
+        self._h = C.c_void_p()
+        db = _host(db, np.float32)
+        db_low = None if db_low is None else _host(db_low, np.float32)
+        net = None if net is None else tuple(_host(x, np.float32) for x in net)
+        off, nbr = _host(graph_offsets, np.uint64), _host(graph_nbrs, np.uint32)
+        self.n, self.d = int(db.shape[0]), int(db.shape[1])
+        self.d_low = int(db_low.shape[1]) if db_low is not None else 0
+        self.d_hidden = int(net[0].shape[0]) if net is not None else 0
+        desc = _IndexDesc(
+            struct_size=C.sizeof(_IndexDesc), device=0, metric=metric, mem_kind=MEM_HOST, n=self.n, d=self.d,
+            d_low=self.d_low, d_hidden=self.d_hidden, db=_ptr(db), db_low=_ptr(db_low), graph_offsets=_ptr(off),
+            graph_nbrs=_ptr(nbr), net_l1=_ptr(net[0]) if net else None, net_l2=_ptr(net[1]) if net else None,
+            net_l3=_ptr(net[2]) if net else None)
+        devs = None if devices is None else np.ascontiguousarray(devices, np.int32)
+        _check_multi(lib.gbnns_multi_create(C.byref(desc), _ptr(devs), 0 if devs is None else len(devs), C.byref(self._h)))
+        self.size = lib.gbnns_multi_size(self._h)
+        self.devices = [lib.gbnns_multi_device_of(self._h, i) for i in range(self.size)]
+
+    def close(self):
+        if self._h:
+            self._lib.gbnns_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard_bounds(self, n_q, part):
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self._lib.gbnns_shard_bounds(n_q, self.size, part, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def set_aux_graph(self, offsets, nbrs):
+        off = None if offsets is None else _host(offsets, np.uint64)
+        nbr = None if nbrs is None else _host(nbrs, np.uint32)
+        _check_multi(self._lib.gbnns_multi_set_aux_graph(self._h, _ptr(off), _ptr(nbr)))
+
+    def search(self, queries, ef, mode=MODE_NET, k=1, queries_low=None, entry_ids=None, want=("hops", "dist_calc"),
+               flags=0, hops_bound=0):
+        """gbnns_multi_search_ex: host arrays holding the whole batch in, numpy results out."""
+        q = _host(queries, np.float32)
+        ql = None if queries_low is None else _host(queries_low, np.float32)
+        ent = None if entry_ids is None else _host(entry_ids, np.uint32)
+        nq = q.shape[0]
+        kk = ef if mode != MODE_PLAIN else max(1, min(k, ef))
+        res = {"ids": np.empty(nq, np.uint32)}
+        a = _SearchArgs(struct_size=C.sizeof(_SearchArgs), mode=mode, ef=ef, k=kk, mem_kind=MEM_HOST, n_q=nq,
+                        queries=_ptr(q), queries_low=_ptr(ql), entry_ids=_ptr(ent), out_ids=_ptr(res["ids"]),
+                        flags=flags, hops_bound=hops_bound,
+                        n_entries=int(ent.shape[1]) if ent is not None and ent.ndim == 2 else 0)
+        if "hops" in want:
+            res["hops"] = np.empty(nq, np.int32); a.out_hops = _ptr(res["hops"])
+        if "dist_calc" in want:
+            res["dist_calc"] = np.empty(nq, np.int32); a.out_dist_calc = _ptr(res["dist_calc"])
+        if "cand" in want:
+            res["cand"] = np.empty((nq, kk), np.uint32); a.out_cand = _ptr(res["cand"])
+        if "cand_dist" in want:
+            res["cand_dist"] = np.empty((nq, kk), np.float32); a.out_cand_dist = _ptr(res["cand_dist"])
+        if "q_low" in want:
+            res["q_low"] = np.empty((nq, self.d_low), np.float32); a.out_q_low = _ptr(res["q_low"])
+        _check_multi(self._lib.gbnns_multi_search_ex(self._h, C.byref(a)))
+        return res
+
+    def search_device(self, query_blocks, ef, n_q, mode=MODE_NET, entry_blocks=None, flags=0):
+        """gbnns_multi_search_device: query_blocks[r] = torch tensor on replica r's device; returns one [n_q] int32
+        tensor per replica (every one holds all answers once synchronize() has returned)."""
+        import torch
+        outs = [torch.empty(n_q, dtype=torch.int32, device=b.device) for b in query_blocks]
+        qp = (C.c_void_p * self.size)(*[b.data_ptr() for b in query_blocks])
+        op = (C.c_void_p * self.size)(*[o.data_ptr() for o in outs])
+        ep = None if entry_blocks is None else (C.c_void_p * self.size)(*[e.data_ptr() for e in entry_blocks])
+        a = _SearchArgs(struct_size=C.sizeof(_SearchArgs), mode=mode, ef=ef, k=1, flags=flags)
+        _check_multi(self._lib.gbnns_multi_search_device(self._h, C.byref(a), n_q, qp, ep, op))
+        self._keep = (query_blocks, entry_blocks, outs)
+        return outs
+
+    def synchronize(self):
+        _check_multi(self._lib.gbnns_multi_synchronize(self._h))
 
 
 class Index:

@@ -494,6 +494,11 @@ int gbnns_index_set_aux_graph(gbnns_index* ix, const uint64_t* offsets, const ui
     return GBNNS_OK;
 }
 
+uint32_t gbnns_index_d_low(const gbnns_index* ix) { return ix ? ix->d_low : 0u; }
+uint64_t gbnns_index_n(const gbnns_index* ix) { return ix ? ix->n : 0u; }
+uint32_t gbnns_index_d(const gbnns_index* ix) { return ix ? ix->d : 0u; }
+int gbnns_index_device(const gbnns_index* ix) { return ix ? ix->device : -1; }
+
 int gbnns_index_destroy(gbnns_index* ix) {
     if (!ix) return GBNNS_OK;
     (void)hipSetDevice(ix->device);

@@ -18,6 +18,7 @@
 // makeStep (:15-40) is an internal step of the walk and has no host-visible counterpart.
 #pragma once
 
+#include <cstring>
 #include <queue>
 #include <tuple>
 
@@ -36,18 +37,62 @@ struct TripleResult {
 // ---- device index cache ----------------------------------------------------------------------
 // The reference passes raw vectors to every call; the device copy is created on first use and
 // reused while the same buffers are passed again (performRealNetTests calls performNetTest once
-// per ef with identical data).
-typedef std::tuple<const void*, const void*, const void*, const void*, size_t, size_t, size_t, int> GbnnsKey;
+// per ef with identical data).  The key holds the buffers' addresses, their sizes and a fingerprint of a strided
+// sample of their contents, so a caller that refills a vector in place gets a fresh device copy.
+typedef std::tuple<const void*, const void*, const void*, const void*, size_t, size_t, size_t, int, uint64_t> GbnnsKey;
 
 inline std::map<GbnnsKey, gbnns_index*>& gbnnsCache() {
     static std::map<GbnnsKey, gbnns_index*> cache;
     return cache;
 }
 
+// Several devices (GBNNS_DEVICES=0,1,...): the handle of the cache is replica 0 of a gbnns_multi; this map finds
+// the multi handle of such a replica (single-device handles are absent from it).
+inline std::map<gbnns_index*, gbnns_multi*>& gbnnsMultiOf() {
+    static std::map<gbnns_index*, gbnns_multi*> m;
+    return m;
+}
+
+// devices the drop-in searches on: GBNNS_DEVICES (comma list; "all" = every visible device), else GBNNS_DEVICE, else 0
+inline vector<int32_t> gbnnsDevices() {
+    vector<int32_t> devs;
+    if (const char* list = getenv("GBNNS_DEVICES")) {
+        if (string(list) == "all") {
+            for (int i = 0; i < gbnns_device_count(); ++i) devs.push_back(i);
+        } else {
+            for (const string& tok : splitString(list, ','))
+                if (!tok.empty()) devs.push_back((int32_t)atoi(tok.c_str()));
+        }
+    }
+    if (devs.empty()) {
+        const char* dev = getenv("GBNNS_DEVICE");
+        devs.push_back(dev ? atoi(dev) : 0);
+    }
+    return devs;
+}
+
+inline uint64_t gbnnsFingerprint(const float* p, size_t count) {
+    // FNV-1a over <= 4096 evenly spaced elements (bit patterns) and the length
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)count;
+    if (!p || count == 0) return h;
+    const size_t step = count / 4096 + 1;
+    for (size_t i = 0; i < count; i += step) {
+        uint32_t b;
+        std::memcpy(&b, p + i, 4);
+        h = (h ^ b) * 1099511628211ull;
+    }
+    return h;
+}
+
 inline gbnns_index* gbnnsIndexFor(vector<vector<uint32_t>>& graph, const float* db, size_t n, size_t d,
                                   const float* db_low, size_t d_low, const Net* net, size_t d_hidden,
                                   Metric* metric) {
-    const GbnnsKey key(db, db_low, &graph, net, n, d, d_low, metric->gbnnsMetric());
+    uint64_t fp = gbnnsFingerprint(db, n * d) ^ (gbnnsFingerprint(db_low, n * d_low) << 1);
+    size_t edges = 0;
+    for (size_t i = 0; i < graph.size(); i += graph.size() / 1024 + 1) edges = edges * 31 + graph[i].size() + (graph[i].empty() ? 0 : graph[i][0]);
+    fp ^= (uint64_t)edges * 0x9E3779B97F4A7C15ull;
+    if (net) fp ^= gbnnsFingerprint(net->layerFirst.data(), net->layerFirst.size()) + gbnnsFingerprint(net->layerFinal.data(), net->layerFinal.size());
+    const GbnnsKey key(db, db_low, &graph, net, n, d, d_low, metric->gbnnsMetric(), fp);
     auto it = gbnnsCache().find(key);
     if (it != gbnnsCache().end()) return it->second;
     const GbnnsCsr csr = gbnnsToCsr(graph);
@@ -70,10 +115,21 @@ inline gbnns_index* gbnnsIndexFor(vector<vector<uint32_t>>& graph, const float* 
         desc.net_l2 = net->layerSecond.data();
         desc.net_l3 = net->layerFinal.data();
     }
-    const char* dev = getenv("GBNNS_DEVICE");
-    desc.device = dev ? atoi(dev) : 0;
+    const vector<int32_t> devs = gbnnsDevices();
     gbnns_index* ix = nullptr;
-    if (gbnns_index_create(&desc, &ix)) gbnnsDie("gbnns_index_create");
+    if (devs.size() > 1) {
+        // one replica per device, the query loop (:152 / :346) is cut into contiguous blocks (gbnns_multi_search_ex)
+        gbnns_multi* multi = nullptr;
+        if (gbnns_multi_create(&desc, devs.data(), (int32_t)devs.size(), &multi)) {
+            std::cerr << "gbnns_multi_create: " << gbnns_multi_last_error() << std::endl;
+            exit(1);
+        }
+        ix = gbnns_multi_replica(multi, 0);
+        gbnnsMultiOf()[ix] = multi;
+    } else {
+        desc.device = devs[0];
+        if (gbnns_index_create(&desc, &ix)) gbnnsDie("gbnns_index_create");
+    }
     gbnnsCache()[key] = ix;
     return ix;
 }
@@ -94,7 +150,12 @@ inline uint32_t gbnnsAttachAux(gbnns_index* ix, const GbnnsAux& aux) {
     static std::map<gbnns_index*, const void*> attached;
     if (attached[ix] != (const void*)aux.graph) {
         const GbnnsCsr csr = gbnnsToCsr(*aux.graph);
-        if (gbnns_index_set_aux_graph(ix, csr.offsets.data(), csr.nbrs.data())) gbnnsDie("gbnns_index_set_aux_graph");
+        auto mi = gbnnsMultiOf().find(ix);
+        if (mi != gbnnsMultiOf().end()) {
+            if (gbnns_multi_set_aux_graph(mi->second, csr.offsets.data(), csr.nbrs.data())) gbnnsDie("gbnns_multi_set_aux_graph");
+        } else if (gbnns_index_set_aux_graph(ix, csr.offsets.data(), csr.nbrs.data())) {
+            gbnnsDie("gbnns_index_set_aux_graph");
+        }
         attached[ix] = (const void*)aux.graph;
     }
     return GBNNS_FLAG_AUX_GRAPH | (aux.llf ? GBNNS_FLAG_LLF : 0u);
@@ -141,7 +202,15 @@ inline void gbnnsBatch(gbnns_index* ix, int mode, const float* queries, const fl
     a.out_ids = ans.data();
     a.out_hops = hops.data();
     a.out_dist_calc = dist_calc.data();
-    if (gbnns_search_ex(ix, &a)) gbnnsDie("gbnns_search_ex");
+    auto mi = gbnnsMultiOf().find(ix);
+    if (mi != gbnnsMultiOf().end()) {  // GBNNS_DEVICES: contiguous query blocks, one per replica / device
+        if (gbnns_multi_search_ex(mi->second, &a)) {
+            std::cerr << "gbnns_multi_search_ex: " << gbnns_multi_last_error() << std::endl;
+            exit(1);
+        }
+    } else if (gbnns_search_ex(ix, &a)) {
+        gbnnsDie("gbnns_search_ex");
+    }
 }
 
 // ---- per-query entry points (single-query device calls; the batch functions below are the fast

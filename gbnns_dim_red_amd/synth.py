@@ -113,13 +113,15 @@ def ground_truth(base, queries, k=2, chunk=2048):
 def make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=1234,
                  device="cuda:0", intrinsic=16, n_clusters=1000, cluster_scale=0.5, sigma=0.03,
                  knn_k=48, M=16, threads=0, cache_dir=None, projector=None, verbose=False, native_knn=False,
-                 gt_queries=None):
+                 gt_queries=None, unit_norm=False):
     """Builds (or loads from `cache_dir`) the synthetic workload.  Returns a Dataset whose tensors
     live on `device`; graph arrays are numpy (host), as gbnns_index_create wants them."""
     recipe = dict(n=n, nq=nq, d=d, d_low=d_low, d_hidden=d_hidden, seed=seed, intrinsic=intrinsic,
                   n_clusters=n_clusters, cluster_scale=cluster_scale, sigma=sigma, knn_k=knn_k, M=M)
     if gt_queries is not None and gt_queries < nq:
         recipe["gt_queries"] = gt_queries  # exact ground truth for the first gt_queries queries only (huge batches)
+    if unit_norm:
+        recipe["unit_norm"] = True  # vectors scaled to unit length (the reference does this to GloVe): L2 and dot orders agree
     if native_knn:
         # kNN lists and ground truth from gbnns_exact_knn (the reference's distance arithmetic) instead of torch's
         # formula-based top-k: what large n needs (torch's n x chunk distance matrices do not scale to 10^7)
@@ -149,6 +151,8 @@ def make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=123
         z = centers[j] + cluster_scale * torch.randn(count, m, generator=gen, device=dev)
         z = z / z.norm(dim=1, keepdim=True)
         x = z @ A[:m] + sigma * torch.randn(count, d, generator=gen, device=dev)
+        if unit_norm:
+            x = x / x.norm(dim=1, keepdim=True)
         return x.contiguous()
 
     base = sample(n)

@@ -92,6 +92,11 @@ typedef struct {
  * VisitedListPool allocation (search_function.h:331). */
 int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out);
 int gbnns_index_destroy(gbnns_index* index);
+/* what the handle was created with */
+uint64_t gbnns_index_n(const gbnns_index* index);
+uint32_t gbnns_index_d(const gbnns_index* index);
+uint32_t gbnns_index_d_low(const gbnns_index* index);
+int gbnns_index_device(const gbnns_index* index);
 
 /* The `auxiliary_graph` argument of getOneSearchResults (search_function.h:44; naive_test.cpp:103-105
  * passes the KL graph): host CSR over the same n nodes, neighbour order preserved, copied to the device
@@ -235,6 +240,42 @@ int gbnns_build_graph_gd_device(int device, const uint64_t* knn_offsets, const u
 int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* queries, uint64_t n_q,
                     uint32_t d, int k, int metric, int64_t self_offset, uint32_t* out_ids, float* out_dist,
                     int mem_kind, void* stream);
+
+/* ---- several devices of one node: query-sharded replicas ----------------------------------------------------
+ * The reference's only parallelism on this path is `#pragma omp parallel for` over the queries of a batch
+ * (search_function.h:152; the loop body :348-385 is pure per query).  Here that loop is cut into contiguous blocks,
+ * one per replica of the index: one gbnns_index per entry of `devices` (NULL / 0 = every visible device; an ordinal
+ * may repeat: the replicas then share that device), each driven by its own host thread on its own HIP stream.
+ * Nothing is exchanged while searching; results are combined as described per call.  desc as for
+ * gbnns_index_create (HOST buffers; desc->device is ignored).  What the drop-in uses when GBNNS_DEVICES=0,1,...
+ * names more than one device. */
+typedef struct gbnns_multi gbnns_multi;
+int gbnns_multi_create(const gbnns_index_desc* desc, const int32_t* devices, int32_t n_devices, gbnns_multi** out);
+int gbnns_multi_destroy(gbnns_multi* multi);
+int gbnns_multi_size(const gbnns_multi* multi);                    /* replicas */
+gbnns_index* gbnns_multi_replica(gbnns_multi* multi, int32_t i);   /* borrowed */
+int gbnns_multi_device_of(const gbnns_multi* multi, int32_t i);
+void* gbnns_multi_stream(gbnns_multi* multi, int32_t i);           /* hipStream_t of replica i */
+int gbnns_multi_set_aux_graph(gbnns_multi* multi, const uint64_t* offsets, const uint32_t* nbrs);
+/* Block of part `part` of `parts` parts of a batch: [*lo, *hi), contiguous, sizes differ by at most one. */
+void gbnns_shard_bounds(uint64_t n_q, int32_t parts, int32_t part, uint64_t* lo, uint64_t* hi);
+/* One batch over all replicas, HOST buffers holding the WHOLE batch (args as gbnns_search_ex; args->stream is
+ * ignored): replica r searches rows gbnns_shard_bounds(n_q, R, r) and writes its answers, counters and candidate
+ * rows straight into the caller's arrays -- identical to what one gbnns_search_ex call would have written.
+ * Returns when every replica has finished. */
+int gbnns_multi_search_ex(gbnns_multi* multi, const gbnns_search_args* args);
+/* Device-resident form (NET / PLAIN): query_blocks[r] = rows gbnns_shard_bounds(n_q, R, r) of the batch, resident on
+ * replica r's device ([rows x d]); entry_blocks likewise or NULL; out_ids_all[r] = [n_q] uint32 on replica r's
+ * device.  Every replica searches its block, then the answer ids are all-gathered (ONE ncclAllGather of uint32
+ * per batch over RCCL / xGMI, sends padded to the largest block; librccl is loaded on first use; replicas must then
+ * sit on distinct devices) so that every out_ids_all[r] holds the whole answer vector.  `args` supplies mode, ef,
+ * k, flags, hops_bound, hash_capacity; its buffers and n_q are ignored.  Enqueued on the replicas' streams:
+ * gbnns_multi_synchronize waits for them. */
+int gbnns_multi_search_device(gbnns_multi* multi, const gbnns_search_args* args, uint64_t n_q,
+                              const float* const* query_blocks, const uint32_t* const* entry_blocks,
+                              uint32_t* const* out_ids_all);
+int gbnns_multi_synchronize(gbnns_multi* multi);
+const char* gbnns_multi_last_error(void);
 
 int gbnns_device_count(void);
 int gbnns_version(void);

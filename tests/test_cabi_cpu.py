@@ -23,7 +23,8 @@ def lib():
 
 def test_exports_every_declared_symbol(lib):
     header = open(os.path.join(ROOT, "include", "gbnns.h")).read()
-    declared = set(re.findall(r"^(?:int|void|const char\*)\s+(gbnns_[a-z_]+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|void|void\*|const char\*|uint64_t|uint32_t|gbnns_index\*)\s+(gbnns_[a-z_0-9]+)\s*\(",
+                              header, re.M))
     assert declared == set(binding.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
@@ -35,6 +36,44 @@ def test_struct_sizes_match_header(lib):
     assert ctypes.sizeof(binding._IndexDesc) == 96
     assert ctypes.sizeof(binding._SearchArgs) == 136  # + n_entries, reserved2
     assert ctypes.sizeof(binding.Profile) == 64
+
+
+def test_shard_bounds_arithmetic(lib):
+    """gbnns_shard_bounds (the block arithmetic of gbnns_multi_* and of the C++ drop-in) = sharding.shard_bounds
+    (what bench.py and the gloo tests use): contiguous, covering, sizes differ by at most one."""
+    from gbnns_dim_red_amd import sharding
+    lib.gbnns_shard_bounds.argtypes = [ctypes.c_uint64, ctypes.c_int32, ctypes.c_int32,
+                                       ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    lib.gbnns_shard_bounds.restype = None
+    lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+    for n_q in (0, 1, 7, 8, 9, 1000, 10_000, 1_000_000, 999_999, (1 << 33) + 5):
+        for parts in (1, 2, 3, 4, 7, 8, 64):
+            prev = 0
+            sizes = []
+            for part in range(parts):
+                lib.gbnns_shard_bounds(n_q, parts, part, ctypes.byref(lo), ctypes.byref(hi))
+                assert (lo.value, hi.value) == sharding.shard_bounds(n_q, parts, part)
+                assert lo.value == prev and hi.value >= lo.value
+                prev = hi.value
+                sizes.append(hi.value - lo.value)
+            assert prev == n_q and max(sizes) - min(sizes) <= 1
+            assert max(sizes) == sharding.shard_pad(n_q, parts)
+    lib.gbnns_shard_bounds(10, 4, 9, ctypes.byref(lo), ctypes.byref(hi))  # part out of range: empty block
+    assert (lo.value, hi.value) == (0, 0)
+
+
+def test_multi_argument_validation(lib):
+    h = ctypes.c_void_p()
+    assert lib.gbnns_multi_create(None, None, 0, ctypes.byref(h)) == 1
+    d = binding._IndexDesc(struct_size=ctypes.sizeof(binding._IndexDesc), mem_kind=binding.MEM_DEVICE)
+    assert lib.gbnns_multi_create(ctypes.byref(d), None, 0, ctypes.byref(h)) == 1   # device tensors cannot be replicated
+    lib.gbnns_multi_last_error.restype = ctypes.c_char_p
+    assert b"HOST" in lib.gbnns_multi_last_error()
+    assert lib.gbnns_multi_size(None) == 0
+    assert lib.gbnns_multi_search_ex(None, None) == 1
+    if _no_gpu():
+        d.mem_kind = binding.MEM_HOST
+        assert lib.gbnns_multi_create(ctypes.byref(d), None, 0, ctypes.byref(h)) == 2  # no device, no CPU path
 
 
 def _no_gpu():

@@ -32,8 +32,11 @@ def write_edges(path, off, nbr):
             row.astype(np.uint32).tofile(f)
 
 
-@pytest.mark.parametrize("name", ["sift_toy", "tail_toy", "ties_toy"])
-def test_final_test_result_lines(tmp_path, orc, name):
+@pytest.mark.parametrize("name,devices", [("sift_toy", None), ("tail_toy", None), ("ties_toy", None),
+                                          # GBNNS_DEVICES: query blocks over several replicas (gbnns_multi_*); a one-GPU
+                                          # box lists its device twice -- same result lines
+                                          ("sift_toy", "0,0"), ("ties_toy", "0,0,0")])
+def test_final_test_result_lines(tmp_path, orc, name, devices):
     assert os.path.exists(BIN), "build() must produce the drop-in driver"
     gd = gu.load(name)
     c = gd.case
@@ -59,6 +62,8 @@ def test_final_test_result_lines(tmp_path, orc, name):
         f"{ds} d_low {c.dlow}", f"{ds} d_hidden {c.dh}", f"{ds} efs {efs}", f"{ds} efs_hnsw {efs}",
         f"{ds} hnsw_name toygraph", "other n 5", "# comment line with three tokens"]) + "\n")
     env = dict(os.environ, GBNNS_NUM_EXPER="2")
+    if devices:
+        env["GBNNS_DEVICES"] = devices
     p = subprocess.run([BIN, ds, str(data), str(models), str(tmp_path), str(params)], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
