@@ -248,7 +248,7 @@ int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* quer
     if (d == 0) return fail(GBNNS_ERR_INVALID, "d must be >= 1");
     if (metric != GBNNS_METRIC_L2 && metric != GBNNS_METRIC_NEG_DOT) return fail(GBNNS_ERR_INVALID, "unknown metric %d", metric);
     if (mem_kind != GBNNS_MEM_HOST && mem_kind != GBNNS_MEM_DEVICE) return fail(GBNNS_ERR_INVALID, "unknown mem_kind %d", mem_kind);
-    if (d > 128) return fail(GBNNS_ERR_UNSUPPORTED, "gbnns_exact_knn holds a query in registers: d <= 128 (got %u)", d);
+    if (d > 8192) return fail(GBNNS_ERR_UNSUPPORTED, "gbnns_exact_knn: d <= 8192 (a tile of base rows is staged in LDS; got %u)", d);
     if (metric == GBNNS_METRIC_NEG_DOT && d % 8 != 0)
         return fail(GBNNS_ERR_UNSUPPORTED, "gbnns_exact_knn: the negative-dot form needs d %% 8 == 0 (got %u)", d);
     if (self_offset < -1) return fail(GBNNS_ERR_INVALID, "self_offset must be >= -1");

@@ -48,8 +48,9 @@ int main(int argc, char** argv) {
     const string hnsw_name = params["hnsw_name"];
 
     const string pathData = dataDir + "/" + datasetName;
-    vector<float> db = loadXvecs<float>(pathData + "_base.fvecs", d, n);
-    vector<float> queries = loadXvecs<float>(pathData + "_query.fvecs", d, n_q);
+    // <name>_base.fvecs, or <name>_base.bvecs when only the byte-vector file exists (graph_utils.h: loadVectorsAny)
+    vector<float> db = loadVectorsAny(pathData + "_base", d, n);
+    vector<float> queries = loadVectorsAny(pathData + "_query", d, n_q);
     vector<uint32_t> truth = loadXvecs<uint32_t>(pathData + "_groundtruth.ivecs", n_tr, n_q);
     vector<float> db_ar = loadXvecs<float>(pathData + "_base_angular_optimal.fvecs", d_low, n);
 

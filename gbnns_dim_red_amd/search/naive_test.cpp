@@ -7,13 +7,16 @@
 // sweeps of naive_test.cpp:98-105 -- "hnsw", "knn", "knn_lk" (knn + KL as auxiliary graph, llf) and
 // "knn_lk_low" (the same in the low-dim space with re-rank) -- appending result lines to
 // <results_dir>/naive_results_<dataset>.txt.  Paths come from argv / the environment as in final_test.cpp.
-// Differences from the reference, both stated on stdout when they matter:
-//   * the KL graphs must exist (files <dataset>_kl_sqrt_style.ivecs / _kl_llow_sqrt_style.ivecs): building
-//     them (KLgraph::BuildByNumberCustom, support_classes.h:82-133) is outside this build's scope;
+// The KL graphs are built when their files are missing (KLgraph::BuildByNumberCustom, naive_test.cpp:77-88: L =
+// `kl_size` of the parameter table, candidates = sqrt(n) random nodes) and kept, exactly as the reference does.
+// One difference from the reference:
 //   * the low-dim query file is read with dimension d_low (the reference passes d, naive_test.cpp:59, which
 //     only works when its file happens to be d wide).
-// GBNNS_SEED fixes the entry-point generator (the reference seeds it from random_device, :22-23);
+// GBNNS_SEED fixes the generator of the entry points and of the KL builder (the reference seeds it from
+// random_device, :22-23); GBNNS_KL_SIZE overrides kl_size;
 // GBNNS_NUM_EXPER overrides the repeat count.
+#include <cmath>
+
 #include "search_function.h"
 
 static string pickPath(int argc, char** argv, int pos, const char* env, const string& fallback) {
@@ -63,10 +66,24 @@ int main(int argc, char** argv) {
 
     const string kl_dir = modelsDir + "/" + datasetName + "_kl_sqrt_style.ivecs";
     const string kl_dir_low = modelsDir + "/" + datasetName + "_kl_llow_sqrt_style.ivecs";
-    if (!std::ifstream(kl_dir).good() || !std::ifstream(kl_dir_low).good()) {
-        cout << "KL graph files missing (" << kl_dir << ", " << kl_dir_low
-             << "): build them with the reference's KLgraph first" << endl;
-        return 1;
+    L2Metric l2 = L2Metric();
+    std::mt19937 random_gen;
+    if (const char* e = getenv("GBNNS_SEED")) {
+        random_gen.seed((unsigned)strtoul(e, nullptr, 10));
+    } else {
+        std::random_device device;
+        random_gen.seed(device());
+    }
+    // naive_test.cpp:77-88: the long-link graphs are built (and kept as files) when they are missing
+    if (!checkFileExistence(kl_dir)) {
+        int kl_size = atoi(params["kl_size"].c_str());  // naive_test.cpp:35 (`<dataset> kl_size <L>` in the table)
+        if (const char* e = getenv("GBNNS_KL_SIZE")) kl_size = atoi(e);
+        KLgraph kl_sqrt;
+        kl_sqrt.BuildByNumberCustom(kl_size, db, n, d, pow(n, 0.5), random_gen, &l2);
+        writeEdges(kl_dir, kl_sqrt.longmatrixNN);
+        KLgraph kl_sqrt_low;
+        kl_sqrt_low.BuildByNumberCustom(kl_size, db_low, n, d_low, pow(n, 0.5), random_gen, &l2);
+        writeEdges(kl_dir_low, kl_sqrt_low.longmatrixNN);
     }
     vector<vector<uint32_t>> kl = loadEdges(kl_dir, n, "kl");
     vector<vector<uint32_t>> kl_low = loadEdges(kl_dir_low, n, "kl_low");
@@ -78,15 +95,6 @@ int main(int argc, char** argv) {
     const string output_s = resultsDir + "/naive_results_" + datasetName + ".txt";
     const char* output = output_s.c_str();
     remove(output);
-
-    L2Metric l2 = L2Metric();
-    std::mt19937 random_gen;
-    if (const char* e = getenv("GBNNS_SEED")) {
-        random_gen.seed((unsigned)strtoul(e, nullptr, 10));
-    } else {
-        std::random_device device;
-        random_gen.seed(device());
-    }
 
     performRealTests(n, d, d, n_q, n_tr, efs_hnsw_origin, random_gen, hnsw, hnsw, db, queries, db, queries, truth,
                      output, &l2, "hnsw", false, false, numberExper, numberThreads);

@@ -70,7 +70,10 @@ int main(int argc, char** argv) {
 
     int M = 30;
     if (const char* e = getenv("GBNNS_GD_M")) M = atoi(e);
-    vector<vector<uint32_t>> gd_knn_low = hnswlikeGD(knn_low, db_low.data(), M, n, d_low, &l2, true, false);
+    // prepare_graph.cpp:70 passes need_const_degree = false; GBNNS_CONST_DEGREE=1 turns the builder's last argument on
+    // (lists padded to 2M from the kNN candidates, support_func.h:466-485)
+    const bool const_degree = getenv("GBNNS_CONST_DEGREE") && atoi(getenv("GBNNS_CONST_DEGREE"));
+    vector<vector<uint32_t>> gd_knn_low = hnswlikeGD(knn_low, db_low.data(), M, n, d_low, &l2, true, const_degree);
     cout << "GD_knn " << findGraphAverageDegree(gd_knn_low) << endl;
     writeEdges(modelsDir + "/" + datasetName + "_gd_knn_" + fileLatName + ".ivecs", gd_knn_low);
     return 0;

@@ -15,7 +15,10 @@
 // (gbnns_index_set_aux_graph) and the call sets GBNNS_FLAG_AUX_GRAPH / GBNNS_FLAG_LLF.
 // Several entry points per query (:54) are served too (same count for every query of a batch; exact, on the
 // general kernel -- no driver of the reference uses them).
-// makeStep (:15-40) is an internal step of the walk and has no host-visible counterpart.
+// makeStep (:15-40) keeps its signature for callers that drive a walk step by step on host containers; the batch
+// functions never call it (on the device the step is part of the walk kernels).
+// Besides the result line, every sweep point is appended as one JSON object to <output_txt>.json (queries/s,
+// recall, hops, dist_calc, ef, devices) -- the machine-readable sidecar SURVEY.md section 5 asks for.
 #pragma once
 
 #include <cstring>
@@ -33,6 +36,29 @@ struct TripleResult {
     int dist_calc;
     int degree;
 };
+
+// makeStep (search_function.h:15-40): offers the not-yet-visited neighbours of one node, in list order, to the two
+// heaps with the reference's strict rule.  Host containers in, host containers out -- a compatibility entry for
+// code that steps a walk itself; it is NOT how this build searches (getOneSearchResults and the perform*
+// functions run whole walks on the device, where this step lives inside the walk kernels).
+void makeStep(vector<uint32_t>& graph_level, const float* query, const float* db,
+              priority_queue<pair<float, int>>& topResults, priority_queue<std::pair<float, int>>& candidateSet,
+              Metric* metric, uint32_t d, int& query_dist_calc, bool& found, int& ef, int& k, VisitedList* vl) {
+    (void)k;
+    for (size_t j = 0; j < graph_level.size(); ++j) {
+        const int id = (int)graph_level[j];
+        if (vl->mass[id] == vl->curV) continue;
+        vl->mass[id] = vl->curV;
+        const float dist = metric->Dist(query, db + (size_t)id * d, d);
+        query_dist_calc++;
+        if (topResults.top().first > dist || (int)topResults.size() < ef) {
+            candidateSet.emplace(-dist, id);
+            found = true;
+            topResults.emplace(dist, id);
+            if ((int)topResults.size() > ef) topResults.pop();
+        }
+    }
+}
 
 // ---- device index cache ----------------------------------------------------------------------
 // The reference passes raw vectors to every call; the device copy is created on first use and
@@ -292,6 +318,23 @@ inline void gbnnsScore(const vector<uint32_t>& ans, vector<float>& ds, vector<ui
     }
 }
 
+// one JSON object per sweep point, appended to <output_txt>.json
+inline void gbnnsSidecar(const char* output_txt, const string& graph_name, int ef, int k, int recheck_size, double acc,
+                         double hops, double dist_calc, double sec_per_query, int num_exp, int n_q, int n, int d, int d_low) {
+    if (!output_txt) return;
+    std::ofstream js((string(output_txt) + ".json").c_str(), std::ios_base::app);
+    const vector<int32_t> devs = gbnnsDevices();
+    js << "{\"graph_type\": \"" << graph_name << "\", \"ef\": " << ef << ", \"k\": " << k << ", \"recheck_size\": " << recheck_size
+       << ", \"n\": " << n << ", \"n_q\": " << n_q << ", \"d\": " << d << ", \"d_low\": " << d_low
+       << ", \"repeats\": " << num_exp << ", \"recall_at_1\": " << acc << ", \"mean_hops\": " << hops
+       << ", \"mean_dist_calc\": " << dist_calc << ", \"sec_per_query\": " << sec_per_query
+       << ", \"queries_per_s\": " << (sec_per_query > 0 ? 1.0 / sec_per_query : 0.0)
+       << ", \"timed_region\": \"host buffers in, answers out (H2D + kernels + D2H), as search_function.h:346-387\""
+       << ", \"devices\": [";
+    for (size_t i = 0; i < devs.size(); ++i) js << (i ? ", " : "") << devs[i];
+    js << "], \"backend\": \"libgbnns_hip (gfx950)\"}" << std::endl;
+}
+
 inline void gbnnsReport(std::ofstream& outfile, const string& graph_name, float acc, long long hops,
                         long long dist_calc, float work_time, int num_exp, int n_q) {
     // same expression shapes as the reference: float / int, integer / integer, float / double
@@ -354,6 +397,9 @@ void performTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>>& 
         gbnnsScore(ans, ds, truth, d, n_q, n_tr, metric, acc);
     }
     gbnnsReport(outfile, graph_name, acc, hops, dist_calc, work_time, num_exp, n_q);
+    gbnnsSidecar(output_txt, graph_name, run_ef, run_k, recheck_size, acc / ((double)num_exp * n_q),
+                 (double)hops / ((double)num_exp * n_q), (double)dist_calc / ((double)num_exp * n_q),
+                 work_time / (num_exp * 1e6 * n_q), num_exp, n_q, n, d, d_low);
 }
 
 inline vector<vector<uint32_t>> gbnnsInterPoints(int n, int n_q, std::mt19937& random_gen, const string& graph_name) {
@@ -376,6 +422,46 @@ void performRealTests(int n, int d, int d_low, int n_q, int n_tr, vector<int> ef
         performTest(main_graph, kl, db, queries, db_low, queries_low, truth, n, d, d_low, n_q, n_tr, efs[i], 1,
                     graph_name, metric, output_txt, inter_points, use_second_graph, llf, hops_bound, 0, efs[i],
                     number_exper, number_of_threads);
+}
+
+// performSyntheticTests (search_function.h:214-287): the leftover synthetic-sphere harness (d in {3, 5, 9, 17}; no
+// caller in the reference).  Same sweep tables; each point is one performTest call on a kNN graph cut to k_coeff
+// neighbours.  The reference leaves every query WITHOUT an entry point (the lines that draw one are commented out,
+// :219-223), which makes its getOneSearchResults read an empty heap; here the queries start at node 0 -- the only
+// deviation, stated on stdout.
+void performSyntheticTests(int n, int d, int n_q, int n_tr, std::mt19937 random_gen, vector<vector<uint32_t>>& knn,
+                           vector<vector<uint32_t>>& kl, vector<float>& db, vector<float>& queries,
+                           vector<uint32_t>& truth, const char* output_txt, Metric* metric, string graph_name,
+                           bool use_second_graph, bool llf, bool beam_search) {
+    (void)random_gen;
+    cout << "performSyntheticTests: entry point = node 0 for every query (the reference passes none)" << endl;
+    vector<vector<uint32_t>> inter_points(n_q, vector<uint32_t>(1, 0u));
+    vector<int> ef_coeff, k_coeff;
+    uint32_t hops_bound = 11;
+    const int recheck_size = -1;
+    const int knn_size = findGraphAverageDegree(knn);
+    if (beam_search) k_coeff.assign(6, knn_size);
+    else ef_coeff.assign(6, 1);
+    vector<int>& swept = beam_search ? ef_coeff : k_coeff;
+    if (d == 3) {
+        swept = beam_search ? vector<int>{10, 15, 20, 25, 30} : vector<int>{12, 14, 16, 18, 20};
+        hops_bound = 11;
+    } else if (d == 5) {
+        swept = beam_search ? vector<int>{7, 10, 15, 22, 25, 30} : vector<int>{15, 20, 25, 30, 40, 60};
+        hops_bound = 7;
+    } else if (d == 9) {
+        swept = beam_search ? vector<int>{5, 8, 15, 25, 30, 35} : vector<int>{60, 100, 150, 200, 250, 300};
+        hops_bound = 5;
+    } else if (d == 17) {
+        swept = beam_search ? vector<int>{10, 40, 70, 100, 130, 160} : vector<int>{750, 1000, 1250, 1500, 1750, 2000};
+        hops_bound = 4;
+    }
+    const size_t exp_size = std::min(ef_coeff.size(), k_coeff.size());
+    for (size_t i = 0; i < exp_size; ++i) {
+        vector<vector<uint32_t>> knn_cur = cutKNNbyK(knn, db.data(), k_coeff[i], n, d, metric);
+        performTest(knn_cur, kl, db, queries, db, queries, truth, n, d, d, n_q, n_tr, ef_coeff[i], 1, graph_name, metric,
+                    output_txt, inter_points, use_second_graph, llf, hops_bound, 0, recheck_size, 1, 1);
+    }
 }
 
 void performNetTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>>& kl_graph, vector<float>& ds,
@@ -429,6 +515,9 @@ void performNetTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>
         gbnnsScore(ans, ds, truth, d, n_q, n_tr, metric, acc);
     }
     gbnnsReport(outfile, graph_name, acc, hops, dist_calc, work_time, num_exp, n_q);
+    gbnnsSidecar(output_txt, graph_name, two_stage ? recheck_size : ef, two_stage ? recheck_size : k, recheck_size,
+                 acc / ((double)num_exp * n_q), (double)hops / ((double)num_exp * n_q),
+                 (double)dist_calc / ((double)num_exp * n_q), work_time / (num_exp * 1e6 * n_q), num_exp, n_q, n, d, d_low);
 }
 
 void performRealNetTests(int n, int d, int d_low, int n_q, int n_tr, vector<int> efs, std::mt19937 random_gen,

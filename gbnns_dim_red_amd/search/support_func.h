@@ -3,7 +3,8 @@
 //   Net (:45-49), Metric / L2Metric / Angular (:87-163), findGraphAverageDegree (:166),
 //   readXvec / writeXvec / loadXvecs (:176-228), writeEdges / loadEdges (:205-249),
 //   splitString / addMapFromStr / readSearchParams / getVectorFromString (:578-621),
-//   hnswlikeGD (:521-575), GetLowQueryFromNet (:645-658).
+//   hnswlikeGD (:521-575), GetLowQueryFromNet (:645-658); the remaining graph utilities, the synthetic-data helpers
+//   and the mmap / bvecs loaders live in graph_utils.h, included at the end of this file.
 // Like the reference's header it holds non-inline definitions: include it from one .cpp only.
 //
 // The Metric classes here are plain scalar code in the reference's operation order (4 running
@@ -204,13 +205,13 @@ inline void gbnnsDie(const char* what) {
 // device when there is one (gbnns_build_graph_gd_device: nodes with equal candidate distances and the reverse
 // pass are finished on the host, so the graph is the host builder's bit for bit), else -- or with
 // GBNNS_GD_HOST=1 -- on the host (gbnns_build_graph_gd, OpenMP, reference operation order).
-// need_const_degree = true (getConstantDegreeForGD, :466-485) is not implemented.
+// need_const_degree = true pads the lists to 2M afterwards (getConstantDegreeForGD, :466-485, graph_utils.h).
+vector<vector<uint32_t>> getConstantDegreeForGD(vector<vector<uint32_t>>& graph, const float* ds,
+                                                vector<vector<uint32_t>>& gd_graph, int M, size_t N, size_t d,
+                                                Metric* metric);
+
 vector<vector<uint32_t>> hnswlikeGD(vector<vector<uint32_t>>& graph, const float* ds, int M, size_t N, size_t d,
                                     Metric* metric, bool reverse, bool need_const_degree) {
-    if (need_const_degree) {
-        std::cerr << "gbnns: hnswlikeGD(need_const_degree = true) is not implemented" << std::endl;
-        exit(2);
-    }
     const GbnnsCsr knn = gbnnsToCsr(graph);
     uint64_t* off = nullptr;
     uint32_t* nbr = nullptr;
@@ -233,6 +234,7 @@ vector<vector<uint32_t>> hnswlikeGD(vector<vector<uint32_t>>& graph, const float
     for (size_t i = 0; i < N; ++i) out[i].assign(nbr + off[i], nbr + off[i + 1]);
     gbnns_free(off);
     gbnns_free(nbr);
+    if (need_const_degree) out = getConstantDegreeForGD(graph, ds, out, M, N, d, metric);  // :570-572
     return out;
 }
 
@@ -273,3 +275,5 @@ void GetLowQueryFromNet(const Net* net, const float* query, vector<float>& ans, 
     ans.resize(d_low);
     if (gbnns_project(cached, query, 1, ans.data(), GBNNS_MEM_HOST, nullptr)) gbnnsDie("gbnns_project");
 }
+
+#include "graph_utils.h"

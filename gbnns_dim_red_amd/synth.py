@@ -188,7 +188,7 @@ def make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=123
 
     t1 = time.time()
     gq = queries if gt_queries is None or gt_queries >= nq else queries[:gt_queries]
-    if native_knn and d <= 128:
+    if native_knn:
         gt2 = binding.exact_knn(base, gq, 2).to(torch.int64)
     else:
         gt2 = ground_truth(base, gq, 2)

@@ -234,7 +234,8 @@ int gbnns_build_graph_gd_device(int device, const uint64_t* knn_offsets, const u
  * pair order, ties towards the lower id; 0xFFFFFFFF / +inf where fewer than k rows qualify.
  * self_offset >= 0 says query i IS base row i + self_offset and must not be reported as its own neighbour
  * (kNN graph of a set over itself, possibly computed in slices of queries); -1 turns that off.
- * d <= 128; GBNNS_METRIC_NEG_DOT needs d % 8 == 0 (else GBNNS_ERR_UNSUPPORTED).  Buffers are all host or all
+ * d <= 8192 (d > 128 runs a kernel that streams the query through in chunks); GBNNS_METRIC_NEG_DOT needs
+ * d % 8 == 0 (else GBNNS_ERR_UNSUPPORTED).  Buffers are all host or all
  * device (mem_kind); the work runs on `stream` and the call returns when it has finished (a k x n_q x 8-byte
  * workspace lives for the duration of the call). */
 int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* queries, uint64_t n_q,

@@ -364,6 +364,63 @@ class Ref(_Base):
         self._gd_fetch(_p(off, _u64p), _p(nbr, _u32p))
         return off, nbr[:int(total)]
 
+    # ---- graph utilities around the search path (golden vectors for the drop-in's host helpers) ----
+    def _fetch(self, n, total):
+        off = np.empty(n + 1, np.uint64)
+        nbr = np.empty(max(int(total), 1), np.uint32)
+        self._gd_fetch(_p(off, _u64p), _p(nbr, _u32p))
+        return off, nbr[:int(total)]
+
+    def _util(self, name, argtypes):
+        f = getattr(self.lib, "ref_" + name)
+        f.restype = C.c_uint64
+        f.argtypes = argtypes
+        return f
+
+    def hnswlike_gd_const(self, koff, knbr, ds, M, metric=L2, reverse=True):
+        koff, knbr, ds = _u64(koff), _u32(knbr), _f32(ds)
+        n, d = ds.shape
+        f = self._util("hnswlike_gd_const", [_u64p, _u32p, _f32p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int])
+        return self._fetch(n, f(_p(koff, _u64p), _p(knbr, _u32p), _p(ds, _f32p), M, n, d, metric, int(reverse)))
+
+    def cut_knn_by_k(self, koff, knbr, ds, k, metric=L2):
+        koff, knbr, ds = _u64(koff), _u32(knbr), _f32(ds)
+        n, d = ds.shape
+        f = self._util("cut_knn_by_k", [_u64p, _u32p, _f32p, C.c_int, C.c_uint64, C.c_int, C.c_int])
+        return self._fetch(n, f(_p(koff, _u64p), _p(knbr, _u32p), _p(ds, _f32p), k, n, d, metric))
+
+    def cut_knn_by_threshold(self, koff, knbr, ds, thr, metric=L2):
+        koff, knbr, ds = _u64(koff), _u32(knbr), _f32(ds)
+        n, d = ds.shape
+        f = self._util("cut_knn_by_threshold", [_u64p, _u32p, _f32p, C.c_float, C.c_uint64, C.c_int, C.c_int])
+        return self._fetch(n, f(_p(koff, _u64p), _p(knbr, _u32p), _p(ds, _f32p), thr, n, d, metric))
+
+    def merge_graph(self, aoff, anbr, boff, bnbr):
+        aoff, anbr, boff, bnbr = _u64(aoff), _u32(anbr), _u64(boff), _u32(bnbr)
+        n = len(aoff) - 1
+        f = self._util("merge_graph", [_u64p, _u32p, _u64p, _u32p, C.c_uint64])
+        return self._fetch(n, f(_p(aoff, _u64p), _p(anbr, _u32p), _p(boff, _u64p), _p(bnbr, _u32p), n))
+
+    def fill_const_degree(self, aoff, anbr, boff, bnbr, degree):
+        aoff, anbr, boff, bnbr = _u64(aoff), _u32(anbr), _u64(boff), _u32(bnbr)
+        n = len(aoff) - 1
+        f = self._util("fill_const_degree", [_u64p, _u32p, _u64p, _u32p, C.c_uint64, C.c_int])
+        return self._fetch(n, f(_p(aoff, _u64p), _p(anbr, _u32p), _p(boff, _u64p), _p(bnbr, _u32p), n, degree))
+
+    def kl_build(self, which, l, ds, sqrt_n, seed, metric=L2):
+        ds = _f32(ds)
+        n, d = ds.shape
+        f = self._util("kl_build", [C.c_int, C.c_int, _f32p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint32, C.c_int])
+        return self._fetch(n, f(which, l, _p(ds, _f32p), n, d, sqrt_n, seed, metric))
+
+    def create_uniform_data(self, n, d, seed):
+        out = np.empty((n, d), np.float32)
+        f = self.lib.ref_create_uniform_data
+        f.restype = None
+        f.argtypes = [C.c_int, C.c_int, C.c_uint32, _f32p]
+        f(n, d, seed, _p(out, _f32p))
+        return out
+
     def perform_real_net_tests(self, db, queries, db_low, net, off, nbr, truth, efs, out_path,
                                graph_name="hnsw_new_ar", number_exper=1, threads=1):
         db, queries, db_low = _f32(db), _f32(queries), _f32(db_low)

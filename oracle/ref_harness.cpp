@@ -289,4 +289,70 @@ void ref_get_truth(const float* base, uint64_t n, const float* queries, uint64_t
 
 int ref_max_threads() { return omp_get_max_threads(); }
 
+// ---- graph utilities around the search path (golden vectors for the drop-in's graph_utils.h / support_classes.h) ----
+// Each call leaves its adjacency-list result in g_gd_result; ref_hnswlike_gd_fetch copies it out as CSR.
+static uint64_t keep_lists(vector<vector<uint32_t>> lists) {
+    g_gd_result = lists;
+    uint64_t total = 0;
+    for (auto& l : g_gd_result) total += l.size();
+    return total;
+}
+
+// hnswlikeGD with need_const_degree = true (support_func.h:570-572 -> getConstantDegreeForGD :466-485)
+uint64_t ref_hnswlike_gd_const(const uint64_t* koff, const uint32_t* knbr, const float* ds, int M, uint64_t n, int d,
+                               int metric, int reverse) {
+    vector<vector<uint32_t>> knn = csr_to_lists(koff, knbr, n);
+    omp_set_num_threads(1);
+    return keep_lists(hnswlikeGD(knn, ds, M, n, d, pick_metric(metric), reverse != 0, true));
+}
+
+uint64_t ref_cut_knn_by_k(const uint64_t* koff, const uint32_t* knbr, const float* ds, int knn_size, uint64_t n, int d,
+                          int metric) {
+    vector<vector<uint32_t>> knn = csr_to_lists(koff, knbr, n);
+    omp_set_num_threads(1);
+    return keep_lists(cutKNNbyK(knn, ds, knn_size, (int)n, d, pick_metric(metric)));
+}
+
+uint64_t ref_cut_knn_by_threshold(const uint64_t* koff, const uint32_t* knbr, const float* ds, float thr, uint64_t n,
+                                  int d, int metric) {
+    vector<vector<uint32_t>> knn = csr_to_lists(koff, knbr, n);
+    vector<float> v(ds, ds + n * d);
+    omp_set_num_threads(1);
+    return keep_lists(cutKNNbyThreshold(knn, v, thr, (int)n, d, pick_metric(metric)));
+}
+
+uint64_t ref_merge_graph(const uint64_t* aoff, const uint32_t* anbr, const uint64_t* boff, const uint32_t* bnbr,
+                         uint64_t n) {
+    vector<vector<uint32_t>> a = csr_to_lists(aoff, anbr, n), b = csr_to_lists(boff, bnbr, n);
+    omp_set_num_threads(1);
+    return keep_lists(mergeGraph(a, b));
+}
+
+uint64_t ref_fill_const_degree(const uint64_t* aoff, const uint32_t* anbr, const uint64_t* boff, const uint32_t* bnbr,
+                               uint64_t n, int degree_needed) {
+    vector<vector<uint32_t>> a = csr_to_lists(aoff, anbr, n), b = csr_to_lists(boff, bnbr, n);
+    omp_set_num_threads(1);
+    return keep_lists(fillGraphToConstantDegree(a, b, degree_needed));
+}
+
+// KLgraph builders (support_classes.h:38-175) with a generator seeded `seed`, one thread (the reference shares the
+// generator between OpenMP threads: only the single-thread sequence is defined).  which: 0 BuildByNumber,
+// 1 BuildByNumberCustom (sqrtN candidates), 2 BuildByDist.
+uint64_t ref_kl_build(int which, int l, const float* ds, uint64_t n, int d, uint64_t sqrtN, uint32_t seed, int metric) {
+    vector<float> v(ds, ds + n * d);
+    std::mt19937 gen(seed);
+    omp_set_num_threads(1);
+    KLgraph kl;
+    if (which == 0) kl.BuildByNumber(l, v, n, d, gen, pick_metric(metric));
+    else if (which == 1) kl.BuildByNumberCustom(l, v, n, d, sqrtN, gen, pick_metric(metric));
+    else kl.BuildByDist(l, v, n, d, gen, pick_metric(metric));
+    return keep_lists(kl.longmatrixNN);
+}
+
+void ref_create_uniform_data(int n, int d, uint32_t seed, float* out) {
+    std::mt19937 gen(seed);
+    vector<float> v = createUniformData(n, d, gen);
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+}
+
 }  // extern "C"

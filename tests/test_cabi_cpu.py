@@ -112,8 +112,8 @@ def test_exact_knn_argument_validation(lib):
     assert call(8, 8, 16, 3, 7) == 1                  # unknown metric
     assert call(8, 8, 16, 3, 0, mem=5) == 1           # unknown memory kind
     assert call(8, 8, 16, 3, 0, self_offset=-2) == 1
-    assert call(8, 8, 200, 3, 0) == 5                 # d > 128: GBNNS_ERR_UNSUPPORTED
-    assert b"d <= 128" in lib.gbnns_last_error()
+    assert call(8, 8, 9000, 3, 0) == 5                # d > 8192: GBNNS_ERR_UNSUPPORTED
+    assert b"d <= 8192" in lib.gbnns_last_error()
     assert call(8, 8, 12, 3, 1) == 5                  # dot form needs d % 8 == 0
     if _no_gpu():
         assert call(8, 8, 16, 3, 0) == 2              # valid request, no device: no CPU path

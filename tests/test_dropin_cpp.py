@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import golden_util as gu
+import oracle as orc_mod
 
 pytestmark = pytest.mark.gpu
 
@@ -129,11 +130,32 @@ def test_naive_test_result_lines(tmp_path, orc):
     lines = open(tmp_path / f"naive_results_{ds}.txt").read().splitlines()
     got = [ln.split(" work_time ")[0] for ln in lines]
     assert got == meta["naive_result_lines"]
-    # missing KL files: a message and exit(1), nothing silently different
+    # the JSON sidecar: one object per result line, same order, same recall / counters
+    side = [json.loads(ln) for ln in open(str(tmp_path / f"naive_results_{ds}.txt") + ".json").read().splitlines()]
+    assert len(side) == len(lines)
+    for ln, js in zip(lines, side):
+        tok = ln.split()
+        assert js["graph_type"] == tok[1] and js["n_q"] == c.nq and js["repeats"] == 2
+        assert abs(js["recall_at_1"] - float(tok[3])) < 1e-5 and int(js["mean_hops"]) == int(tok[5])
+        assert js["queries_per_s"] > 0 and js["devices"] == [0]
+    # missing KL files (naive_test.cpp:77-88): both long-link graphs are built -- L = kl_size, sqrt(n) candidates,
+    # the generator seeded like the entry points' -- written, and used; with the compiled reference at hand the files
+    # must equal its KLgraph::BuildByNumberCustom for that seed (one thread), link for link
     os.remove(models / f"{ds}_kl_sqrt_style.ivecs")
+    os.remove(models / f"{ds}_kl_llow_sqrt_style.ivecs")
     p = subprocess.run([nbin, ds, str(data), str(models), str(tmp_path), str(params)], env=env,
                        capture_output=True, text=True, timeout=300)
-    assert p.returncode == 1 and "KL graph files missing" in p.stdout
+    assert p.returncode == 0, p.stdout + p.stderr
+    sq = int(c.n ** 0.5)  # pow(n, 0.5) converted to size_t
+    for fn, vecs in ((f"{ds}_kl_sqrt_style.ivecs", c.base), (f"{ds}_kl_llow_sqrt_style.ivecs", db_low)):
+        raw = np.fromfile(models / fn, np.uint32).reshape(c.n, 6)
+        assert (raw[:, 0] == 5).all() and (raw[:, 1:] < c.n).all()
+        assert all(len(set(r[1:])) == 5 and i not in r[1:] for i, r in enumerate(raw))
+        if orc_mod.have_ref():
+            ref = orc_mod.Ref()
+            _, want = ref.kl_build(1, 5, vecs, sq, meta["naive_seed"])
+            assert np.array_equal(raw[:, 1:].reshape(-1), want), fn
+    assert len(open(tmp_path / f"naive_results_{ds}.txt").read().splitlines()) == len(lines)
 
 
 def test_prepare_graph_builds_missing_knn_on_device(tmp_path, orc):
