@@ -522,6 +522,23 @@ namespace {
 // MLP over rows x [nx x xstride] (device) -> out [nx x dl_pad] (device); h1/h2 are scratch.
 int run_project(gbnns_index* ix, const float* x, uint32_t xstride, uint32_t nx, float* out,
                 hipStream_t s, bool mfma = false) {
+    // one launch for the whole net when its activations fit the LDS (project.hip); GBNNS_NO_FUSED_MLP=1 keeps the
+    // per-layer kernels (diagnostic: identical outputs)
+    static const bool no_fused = getenv("GBNNS_NO_FUSED_MLP") && atoi(getenv("GBNNS_NO_FUSED_MLP"));
+    if (!mfma && !no_fused) {
+        FusedMlpParams f{};
+        size_t lds = 0;
+        f.rows_per_wave = mlp_fused_plan(ix->d, ix->d_hidden, ix->d_low, nx, &f.lda, &f.ldb, &lds);
+        if (f.rows_per_wave) {
+            f.x = x; f.xstride = xstride; f.nq = nx; f.d = ix->d; f.dh = ix->d_hidden; f.dl = ix->d_low;
+            f.xvec = (xstride % 4 == 0 && ix->d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1u : 0u;
+            f.w1 = ix->w1; f.b1 = ix->b1; f.w2 = ix->w2; f.b2 = ix->b2; f.w3 = ix->w3; f.b3 = ix->b3;
+            f.ws1 = ix->ws1; f.ws2 = ix->ws2; f.ws3 = ix->ws3;
+            f.out = out; f.ostride = ix->dl_pad;
+            HIP_TRY(launch_mlp_fused(f, lds, s));
+            return GBNNS_OK;
+        }
+    }
     int rc = ix->h1.ensure((size_t)nx * ix->d_hidden * 4);
     if (!rc) rc = ix->h2.ensure((size_t)nx * ix->d_hidden * 4);
     if (rc) return rc;
@@ -759,7 +776,12 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     // general-kernel slots: visited bits + tie bits (n / 4 bytes per slot) and the result list -- 16 n bytes + 512 ef
     // per handle in all (see gbnns.h, "Device memory")
     const uint32_t bitmap_words = (uint32_t)((ix->n + 31) / 32);
-    if ((rc = ix->g_bitmap.ensure((size_t)kGeneralSlots * 2 * bitmap_words * 4))) return rc;
+    {
+        const size_t before = ix->g_bitmap.bytes;  // (re)allocation always changes the size
+        if ((rc = ix->g_bitmap.ensure((size_t)kGeneralSlots * 2 * bitmap_words * 4))) return rc;
+        // the tie bits must start out all zero (the kernel keeps them so); the visited bits are cleared per query
+        if (ix->g_bitmap.bytes != before) HIP_TRY(hipMemsetAsync(ix->g_bitmap.p, 0, ix->g_bitmap.bytes, s));
+    }
     if ((rc = ix->g_keys.ensure((size_t)kGeneralSlots * ((size_t)ef + n_ent - 1) * 8))) return rc;
 
     // ---- inputs -------------------------------------------------------------------------
@@ -934,9 +956,11 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
                 bitmap_per_cu = per_cu;
         }
     }
+    // (the ef > 64 hot instance keeps its result list in LDS and stages the re-rank query in the visited-set area)
+    const size_t rr_room = bitmap_per_cu ? walk_bitmap_lds_bytes(w, ix->metric)
+                           : (hot && ef > 64 ? walk_hash_bytes(w.hash_cap, packed) : walk_fast_lds_bytes(w, hot));
     const bool fuse = !walk_uses_lds_list(w) && (!bitmap_per_cu || walk_bitmap_uses_reg(w, ix->metric)) && !plain && !w.all_general && ix->d % 8 == 0 &&
-                      (size_t)ix->d_pad * 4 <= (bitmap_per_cu ? walk_bitmap_lds_bytes(w, ix->metric) : walk_fast_lds_bytes(w, hot)) &&
-                      !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
+                      (size_t)ix->d_pad * 4 <= rr_room && !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
     if (fuse) {
         w.rr_q = q_dev; w.rr_qstride = ix->d; w.rr_db = ix->db; w.rr_dstride = ix->d_pad; w.rr_dim = ix->d;
         w.rr_n = (uint32_t)ix->n; w.rr_out = out_dev; w.rr_metric = ix->metric;

@@ -12,8 +12,12 @@ if [ -n "$1" ]; then
   W=$(mktemp -d)
   cp gbnns_dim_red_amd/lib/libgbnns_hip.so $W/
   /opt/rocm/lib/llvm/bin/llvm-objdump --offloading $W/libgbnns_hip.so > /dev/null 2>&1
-  O=$(ls $W/*gfx950 | head -1)
-  /opt/rocm/lib/llvm/bin/llvm-objdump -d --no-show-raw-insn $O | awk -v pat="$1" '/^[0-9a-f]+ <.*>:$/{f = ($0 ~ pat)} f{print}' | sed 's,[[:space:]]*//.*,,' > $OUT
+  : > $OUT
+  for O in $W/*gfx950; do   # one code object per compilation unit; a kernel present in several is dumped once
+    /opt/rocm/lib/llvm/bin/llvm-objdump -d --no-show-raw-insn $O | awk -v pat="$1" '/^[0-9a-f]+ <.*>:$/{f = ($0 ~ pat)} f{print}' | sed 's,[[:space:]]*//.*,,' > $OUT.part
+    if [ -s $OUT.part ] && [ ! -s $OUT ]; then mv $OUT.part $OUT; fi
+  done
+  rm -f $OUT.part
   echo "$(grep -c '^\s' $OUT) instructions of kernels matching '$1' written to $OUT"
   rm -rf $W
 fi
