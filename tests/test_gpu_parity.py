@@ -910,6 +910,56 @@ def test_wide_index_kernels(g, orc):
             ix.close()
 
 
+def test_index_beyond_2pow24_nodes(g, orc):
+    """A REAL large index (n = 2^24 + 2 048 nodes: ids need more than 24 bits, so every walk runs the 64-bit-offset /
+    4-byte-slot instantiations without the diagnostic flag): cheap synthetic vectors, a random fixed-degree graph
+    (duplicates and self loops left in: the index drops / the walk skips them exactly as the reference's visited test
+    does), a few hundred queries against the oracle -- plain walks over 128-byte rows at small and multi-register ef,
+    high entry ids, the two-stage path through a small net, and the general kernel.  Sized to finish in about a minute."""
+    import time
+    t0 = time.time()
+    n, d, nq, deg = (1 << 24) + 2048, 32, 192, 6
+    rng = np.random.Generator(np.random.PCG64(20261004))
+    base = rng.random((n, d), dtype=np.float32)   # (both sides of the comparison read this very array)
+    queries = rng.random((nq, d), dtype=np.float32)
+    nbr = rng.integers(0, n, size=(n, deg), dtype=np.int64).astype(np.uint32)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(deg)
+    ent = np.concatenate([rng.integers(0, n, size=nq - 4), [n - 1, n - 2, 1 << 24, (1 << 24) - 1]]).astype(np.uint32)
+    ix = g.Index(base, off, nbr.reshape(-1))
+    for ef, k in ((1, 1), (16, 16), (64, 64), (150, 150), (200, 7)):
+        w = orc.walk(queries, base, off, nbr.reshape(-1), ef, k=k, entries=ent, threads=8)
+        r = ix.search(queries, ef, mode=g.MODE_PLAIN, k=k, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"))
+        assert np.array_equal(r["cand"], w["ids"]), ef
+        assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), ef
+        assert np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]), ef
+        assert np.array_equal(r["ids"], w["ids"][:, 0]), ef
+        assert r["cand"].max() >= (1 << 24) or ef < 64   # ids beyond 24 bits really occur in the results
+    # the general kernel on the large index (two entry points per query), and a forced hand-over chain
+    ent2 = np.stack([ent, ent[::-1]], axis=1).copy()
+    w = orc.walk(queries[:48], base, off, nbr.reshape(-1), 32, entries=ent2[:48], threads=8)
+    r = ix.search(queries[:48], 32, mode=g.MODE_PLAIN, k=32, entry_ids=ent2[:48], want=("hops", "dist_calc", "cand"))
+    assert np.array_equal(r["cand"], w["ids"]) and np.array_equal(r["hops"], w["hops"])
+    w = orc.walk(queries, base, off, nbr.reshape(-1), 64, entries=ent, threads=8)
+    r = ix.search(queries, 64, mode=g.MODE_PLAIN, k=64, entry_ids=ent, want=("hops", "dist_calc", "cand"), hash_capacity=128)
+    assert np.array_equal(r["cand"], w["ids"]) and np.array_equal(r["dist_calc"], w["dist_calc"])
+    ix.close()
+    # two-stage: 32 -> 8 through a small net; the low-dim base set comes from the product's own projection kernel
+    # (bit-identical to the reference's GetLowQueryFromNet: test_golden_two_stage), the oracle then walks the same bytes
+    c = datagen.Case("big", 4242, 8, 4, d, 8, 16)
+    ixp = g.Index(base[:1], np.array([0, 0], np.uint64), np.zeros(0, np.uint32), db_low=np.zeros((1, 8), np.float32), net=c.net)
+    db_low = ixp.project(base)
+    ixp.close()
+    assert np.array_equal(gu.bits(db_low[:4096]), gu.bits(orc.project(c.net, base[:4096], threads=8)))
+    ix = g.Index(base, off, nbr.reshape(-1), db_low=db_low, net=c.net)
+    for ef in (8, 64, 100):
+        s = orc.search_batch(orc_mod.MODE_NET, queries, base, off, nbr.reshape(-1), ef, db_low=db_low, net=c.net, entries=ent, threads=8)
+        r = ix.search(queries, ef, entry_ids=ent, want=("hops", "dist_calc"))
+        assert np.array_equal(r["ids"], s["ids"]), ef
+        assert np.array_equal(r["hops"], s["hops"]) and np.array_equal(r["dist_calc"] + ef, s["dist_calc"]), ef
+    ix.close()
+    print("large-index test: %.1f s" % (time.time() - t0))
+
+
 def test_several_entry_points(g, orc):
     """inter_points with more than one entry per query (search_function.h:54-93): one walk per entry point over a
     shared result heap -- fresh candidates and visited set per entry, the heap one longer per extra entry,
