@@ -409,7 +409,7 @@ def kernel_name(ds, ef, max_degree, negdot, fused):
     if ef > 512:
         name = "walk_bitmap_kernel / walk_fast_kernel (LDS result list)"
     elif hot_shape:
-        name = "walk_hot_kernel" if regs == 1 else "walk_hot_big_kernel"
+        name = "walk_hot_kernel" if regs == 1 else ("walk_hot2_kernel" if regs == 2 else "walk_hot_big_kernel")
     else:
         name = "walk_reg_kernel<R=%d>" % (regs if ds.d_low == 32 else (1 if regs == 1 else 2 if regs == 2 else 4 if regs <= 4 else 8))
     return name + (" (walk + fused re-rank)" if fused else "")

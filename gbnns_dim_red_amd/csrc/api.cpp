@@ -522,10 +522,11 @@ namespace {
 // MLP over rows x [nx x xstride] (device) -> out [nx x dl_pad] (device); h1/h2 are scratch.
 int run_project(gbnns_index* ix, const float* x, uint32_t xstride, uint32_t nx, float* out,
                 hipStream_t s, bool mfma = false) {
-    // one launch for the whole net when its activations fit the LDS (project.hip); GBNNS_NO_FUSED_MLP=1 keeps the
-    // per-layer kernels (diagnostic: identical outputs)
-    static const bool no_fused = getenv("GBNNS_NO_FUSED_MLP") && atoi(getenv("GBNNS_NO_FUSED_MLP"));
-    if (!mfma && !no_fused) {
+    // GBNNS_FUSED_MLP=1: one launch for the whole net when its activations fit the LDS (project.hip; identical
+    // outputs).  Off by default: measured 0.084 ms against 0.071 ms for the three per-layer launches on the SIFT
+    // shape -- two wavefronts per SIMD do not hide the LDS latency of its 3 x 4-output register tile.
+    static const bool fused = getenv("GBNNS_FUSED_MLP") && atoi(getenv("GBNNS_FUSED_MLP"));
+    if (!mfma && fused) {
         FusedMlpParams f{};
         size_t lds = 0;
         f.rows_per_wave = mlp_fused_plan(ix->d, ix->d_hidden, ix->d_low, nx, &f.lda, &f.ldb, &lds);
@@ -956,9 +957,9 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
                 bitmap_per_cu = per_cu;
         }
     }
-    // (the ef > 64 hot instance keeps its result list in LDS and stages the re-rank query in the visited-set area)
+    // (the ef > 128 hot instance keeps its result list in LDS and stages the re-rank query in the visited-set area)
     const size_t rr_room = bitmap_per_cu ? walk_bitmap_lds_bytes(w, ix->metric)
-                           : (hot && ef > 64 ? walk_hash_bytes(w.hash_cap, packed) : walk_fast_lds_bytes(w, hot));
+                           : (hot && ef > 128 ? walk_hash_bytes(w.hash_cap, packed) : walk_fast_lds_bytes(w, hot));
     const bool fuse = !walk_uses_lds_list(w) && (!bitmap_per_cu || walk_bitmap_uses_reg(w, ix->metric)) && !plain && !w.all_general && ix->d % 8 == 0 &&
                       (size_t)ix->d_pad * 4 <= rr_room && !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
     if (fuse) {

@@ -1386,6 +1386,465 @@ __device__ __forceinline__ uint32_t reg_id_at_rank(const RegList<R>& L, int rank
     return v;
 }
 
+// ---- hot instance for 64 < ef <= 512: the result list as a sorted BASE list in LDS + a sorted FRONT list in a register
+//
+// With the whole list in R = ceil(ef / 64) registers per lane (walk_hot_one<R>, reg_merge_multi), finding the next node
+// costs ~16 R instructions EVERY hop and a merge rewrites all R registers; the walk is instruction-issue bound, so ef =
+// 300 ran at a third of the ef = 64 rate per distance -- although 2 hops in 3 insert at most one entry (measured
+// histogram: 44 % of the hops at ef = 180 have no survivor, 20 % one).  Here
+//   base  L: sorted keys in LDS, `l` live entries; between two flushes it only loses entries from its end and gets
+//            "expanded" bits set.  Its two closest unexpanded entries are cached in scalar registers (found through a
+//            per-chunk unexpanded mask kept in two vector registers), so a hop that does not pick from it pays nothing.
+//   front F: sorted, ONE register per lane, `f` <= 64 live entries: every insertion goes here, with the one-register
+//            machinery of the ef <= 64 instance (reg_merge / reg_offer), whatever ef is.
+// The reference's result heap (search_function.h:50) is the union: l + f <= ef entries; its worst element is the
+// larger of the two tails, the next node is the closer of the two first unexpanded entries.  When a hop's E = l + f
+// - ef entries have to go, they are the E largest of the two tails: one vector step finds how many come from which
+// list (lane j tests the split "j from the base list, E - j from the front list").  When the front list would
+// overflow (and at the end of the walk) it is merged into the base list in place: every front entry finds its rank by
+// bisection, every destination rank then gathers its entry (chunks of 64 ranks, top down).  Exactly the same results:
+// the union holds the same keys as the single list did, selection and eviction see the same total order; the
+// sequential fallback on a boundary tie and the tie list work as before.  Nothing depends on R any more: one kernel.
+
+constexpr int kBigMaxEf = 512;
+constexpr int kHot2MaxEf = 128;  // up to here the two-register list of walk_hot_one<2> is the faster one
+
+__device__ __forceinline__ uint64_t dpp_wave_shl1_u64(uint64_t v) {  // lane j <- lane j + 1
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x130, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x130, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// LDS of the instance besides the visited set: [tie list][front-merge buffer: 66 keys][base list: ef_pad keys]
+// [flush flags: ef_pad + 64 bytes], ef_pad = ef rounded up to 64
+__host__ __device__ __forceinline__ constexpr size_t big_list_fixed_bytes(int ef) {
+    return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (size_t)((ef + 63) / 64 * 64) * 9 + 64;
+}
+
+struct BigList {
+    uint64_t* tie;          // [kRegTieCap]
+    uint64_t* stage;        // [kRegStageSlots] scatter buffer of the front-list merge
+    uint64_t* base;         // [ef_pad] base list, ascending; ranks >= l are dead
+    unsigned char* flags;   // [ef_pad + 64] flush scratch
+    RegList<1> F;           // front list; lanes >= f hold all-ones
+    int ef, l, f, tsize;
+    uint32_t worst;         // hi of the union's worst entry (valid once l + f == ef)
+    uint32_t fworst;        // hi of the front list's last entry
+    uint32_t mu_lo, mu_hi;  // lane c: mask of the unexpanded live entries of base ranks 64 c .. 64 c + 63
+    // the two closest unexpanded base entries (c_valid: the cache reflects the masks)
+    bool c_valid;
+    int p1, p2;             // ranks, -1 = none
+    uint32_t h1, n1, h2, n2;
+
+    // NOTE on lane-dependent updates: they are written as selects / unconditional same-value stores, never as
+    // `if (lane == x) ...`.  A lane-dependent branch inside these functions lets the optimiser thread scalar list
+    // state through its two arms; the divergence analysis then takes l, f, worst ... for divergent, keeps them in
+    // vector registers and turns the list's scalar control flow into exec-masked regions (measured: 3 x the vector
+    // instructions per hop).
+    __device__ __forceinline__ void kill_front_from(int first_dead, int lane) {  // lanes >= first_dead <- all-ones
+        const bool dead = lane >= first_dead;
+        F.lo[0] = dead ? 0xFFFFFFFFu : F.lo[0];
+        F.hi[0] = dead ? 0xFFFFFFFFu : F.hi[0];
+    }
+
+    __device__ __forceinline__ uint64_t base_at(int rank) const {  // wave-uniform rank
+        const uint64_t v = base[rank];
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    }
+    __device__ __forceinline__ uint32_t union_worst() const {
+        const uint32_t lw = l > 0 ? (uint32_t)(base_at(l - 1) >> 32) : 0u;
+        const uint32_t fw = f > 0 ? readlane_u32(F.hi[0], f - 1) : 0u;
+        return lw > fw ? lw : fw;
+    }
+    // drops the mask bits of base ranks >= l (after the base list lost entries from its end)
+    __device__ __forceinline__ void trim_masks(int lane) {
+        const int left = l - 64 * lane;
+        const uint64_t keep = left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
+        mu_lo &= (uint32_t)keep;
+        mu_hi &= (uint32_t)(keep >> 32);
+        if (p1 >= l || p2 >= l) c_valid = false;
+    }
+    // the two lowest set bits of the masks -> (p1, h1, n1), (p2, h2, n2)
+    __device__ __forceinline__ void refresh_cache(int lane) {
+        p1 = p2 = -1;
+        h1 = h2 = 0xFFFFFFFFu;
+        n1 = n2 = 0u;
+        uint64_t nz = __ballot((mu_lo | mu_hi) != 0u);
+        if (nz) {
+            const int c1 = __ffsll((unsigned long long)nz) - 1;
+            uint64_t m1 = ((uint64_t)readlane_u32(mu_hi, c1) << 32) | readlane_u32(mu_lo, c1);
+            p1 = 64 * c1 + __ffsll((unsigned long long)m1) - 1;
+            m1 &= m1 - 1;
+            if (m1) {
+                p2 = 64 * c1 + __ffsll((unsigned long long)m1) - 1;
+            } else {
+                nz &= nz - 1;
+                if (nz) {
+                    const int c2 = __ffsll((unsigned long long)nz) - 1;
+                    const uint64_t m2 = ((uint64_t)readlane_u32(mu_hi, c2) << 32) | readlane_u32(mu_lo, c2);
+                    p2 = 64 * c2 + __ffsll((unsigned long long)m2) - 1;
+                }
+            }
+            const uint64_t kv = base[lane == 0 ? p1 : (p2 >= 0 ? p2 : p1)];  // lane 0: first, lane 1: second
+            h1 = readlane_u32((uint32_t)(kv >> 32), 0);
+            n1 = readlane_u32((uint32_t)kv, 0) >> 1;
+            if (p2 >= 0) {
+                h2 = readlane_u32((uint32_t)(kv >> 32), 1);
+                n2 = readlane_u32((uint32_t)kv, 1) >> 1;
+            }
+        }
+        c_valid = true;
+    }
+    // marks base rank `p` expanded: the key's flag bit in LDS and the mask bit
+    __device__ __forceinline__ void expand_base(int p, int lane) {
+        p = __builtin_amdgcn_readfirstlane(p);  // wave-uniform by construction; tell the compiler
+        reinterpret_cast<uint32_t*>(base)[2 * p] |= 1u;  // (every lane: same address, same value)
+        const int c = p >> 6;
+        uint64_t m = ((uint64_t)readlane_u32(mu_hi, c) << 32) | readlane_u32(mu_lo, c);
+        m = clear_bit64(m, p & 63);
+        mu_lo = writelane_u32(mu_lo, (uint32_t)m, c);
+        mu_hi = writelane_u32(mu_hi, (uint32_t)(m >> 32), c);
+        c_valid = false;
+    }
+
+    // Merges the front list into the base list in place (both sorted; keys are distinct).  Afterwards l += f, f = 0,
+    // the front register holds all-ones, the masks and the cache are rebuilt lazily.
+    __device__ __forceinline__ void flush(int lane) {
+        if (f == 0) return;
+        l = __builtin_amdgcn_readfirstlane(l);  // wave-uniform by construction; tell the compiler (loop counters
+        f = __builtin_amdgcn_readfirstlane(f);  // below index lanes through scalar registers)
+        const int total = l + f;
+        const int chunks = (total + 63) >> 6;
+        {   // zero the flag bytes of ranks 0 .. 64 chunks + 63 (<= 72 words): two unconditional stores per lane
+            const int words = chunks * 8 + 8;
+            reinterpret_cast<uint64_t*>(flags)[lane < words ? lane : 0] = 0ull;
+            reinterpret_cast<uint64_t*>(flags)[64 + lane < words ? 64 + lane : 0] = 0ull;
+        }
+        wave_sync();
+        // every front entry: number of base entries below it (lower bound by bisection)
+        const uint64_t fk = ((uint64_t)F.hi[0] << 32) | F.lo[0];
+        int lo = 0, hi = l;
+        const int iters = 32 - __clz(l);  // covers 0 .. l
+        for (int it = 0; it < iters; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const uint64_t v = base[mid < l ? mid : 0];
+            const bool go = lo < hi;
+            const bool less = v < fk;
+            lo = (go && less) ? mid + 1 : lo;
+            hi = (go && !less) ? mid : hi;
+        }
+        // final rank = base entries below + front entries below (= its lane); lanes without an entry hit a byte past
+        // the last chunk (zeroed again by the next flush)
+        flags[lane < f ? lo + lane : 64 * chunks + 1] = 1;
+        wave_sync();
+        // front entries below each chunk (lane c of `below`)
+        uint32_t below = 0;
+        {
+            int carry = 0;
+            for (int c = 0; c < chunks; ++c) {
+                below = writelane_u32(below, (uint32_t)__builtin_amdgcn_readfirstlane(carry), c);
+                carry += __popcll(__ballot(flags[64 * c + lane] != 0));
+            }
+        }
+        // every destination rank takes its entry, chunks top down (a chunk reads base ranks of itself and of the chunk
+        // below only, so writing in place is safe in this order)
+        mu_lo = mu_hi = 0u;
+        for (int c = chunks - 1; c >= 0; --c) {
+            const int rank = 64 * c + lane;
+            const bool flagged = flags[rank] != 0;
+            const uint64_t mk = __ballot(flagged);
+            const int cc = (int)readlane_u32(below, c) +
+                           (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            const uint32_t flo = (uint32_t)__builtin_amdgcn_ds_bpermute((cc & 63) << 2, (int)F.lo[0]);
+            const uint32_t fhi = (uint32_t)__builtin_amdgcn_ds_bpermute((cc & 63) << 2, (int)F.hi[0]);
+            const int src = rank - cc;
+            const uint64_t bv = (rank < total && src < l) ? base[src] : ~0ull;
+            const uint64_t nk = flagged ? (((uint64_t)fhi << 32) | flo) : bv;
+            base[rank] = nk;
+            const uint64_t un = __ballot(rank < total && !((uint32_t)nk & 1u));
+            mu_lo = writelane_u32(mu_lo, (uint32_t)un, c);
+            mu_hi = writelane_u32(mu_hi, (uint32_t)(un >> 32), c);
+        }
+        wave_sync();
+        l = total;
+        f = 0;
+        F.clear();
+        c_valid = false;
+    }
+
+    // One offer with the reference's rule (search_function.h:31-37): the sequential path (single survivors into a full
+    // union, boundary ties).  False: the tie list overflowed.
+    __device__ __forceinline__ bool offer_one(uint32_t dl, uint32_t nlo, int lane) {
+        const bool full = l + f >= ef;
+        if (full && !(dl < worst)) return true;
+        if (f == 64) flush(lane);
+        int ts_unused = 0;
+        reg_offer<1>(dl, nlo, F, f, fworst, ts_unused, tie, 64, lane);  // f < 64: a plain sorted insert
+        if (!full) {
+            if (l + f == ef) worst = union_worst();
+            return true;
+        }
+        // evict the union's largest entry: the larger of the two tails
+        const uint64_t lt = l > 0 ? base_at(l - 1) : 0ull;
+        const uint64_t ft = ((uint64_t)readlane_u32(F.hi[0], f - 1) << 32) | readlane_u32(F.lo[0], f - 1);
+        uint64_t ev;
+        if (lt > ft) {
+            ev = lt;
+            l -= 1;
+            trim_masks(lane);
+        } else {
+            ev = ft;
+            f -= 1;
+            kill_front_from(f, lane);
+        }
+        const uint32_t nw = union_worst();
+        if (nw != worst) {
+            tsize = 0;  // the worst distance decreased: old ties are dead
+        } else if (!(ev & 1ull)) {  // evicted unexpanded at a distance that is still the worst
+            if (tsize >= kRegTieCap) return false;
+            tie[tsize] = ev;  // (every lane stores the same value: no lane-dependent branch, see the note above)
+            tsize += 1;
+            wave_sync();
+        }
+        worst = nw;
+        return true;
+    }
+
+    // A hop's survivors (mask m, keys dk / ids nb in their lanes; at most 32) into the union.  False: hand over.
+    __device__ __forceinline__ bool insert(uint64_t m, uint32_t dk, uint32_t nb, int lane) {
+        const int ns = __popcll(m);
+        bool sequential = false;
+        if (l + f + ns <= ef || (m & (m - 1)) != 0) {
+            // ---- batch: survivors into the front list, then the E largest of the union go
+            if (f + ns > 64) flush(lane);
+            const uint32_t keep_lo = F.lo[0], keep_hi = F.hi[0], keep_fw = fworst;
+            const int keep_f = f;
+            int ts_unused = 0;
+            if ((m & (m - 1)) != 0) {
+                reg_merge(m, __builtin_amdgcn_inverse_ballot_w64(m), dk, nb, F, f, fworst, ts_unused, stage, 64, lane);
+            } else {
+                const int sl = __ffsll((unsigned long long)m) - 1;
+                reg_offer<1>(readlane_u32(dk, sl), readlane_u32(nb, sl) << 1, F, f, fworst, ts_unused, tie, 64, lane);
+            }
+            const int E = l + f - ef;
+            if (E > 0) {
+                // lane j: "the base list drops its top j entries, the front list its top E - j" (0 <= j <= E <= 32)
+                const int j = lane;
+                const int bi = l - j;  // smallest base entry dropped (j = 0: none -> all-ones; below rank 0: zero)
+                uint64_t H = base[(bi >= 0 && bi < l) ? bi : 0];
+                H = bi < 0 ? 0ull : H;
+                H = bi >= l ? ~0ull : H;
+                const int fi = f - E - 1 + j;  // largest front entry kept (< 0: none)
+                const uint32_t glo = (uint32_t)__builtin_amdgcn_ds_bpermute((fi & 63) << 2, (int)F.lo[0]);
+                const uint32_t ghi = (uint32_t)__builtin_amdgcn_ds_bpermute((fi & 63) << 2, (int)F.hi[0]);
+                uint64_t G = ((uint64_t)ghi << 32) | glo;
+                G = fi < 0 ? 0ull : G;
+                G = fi >= f ? ~0ull : G;
+                const uint64_t La = H, Lb = dpp_wave_shl1_u64(H);  // Lb = base entry of rank l - j - 1 (largest kept)
+                const uint64_t Fb = G, Fa = dpp_wave_shl1_u64(G);  // Fa = front entry of rank f - E + j (smallest dropped)
+                const bool cand = j <= E && j <= l && E - j <= f;
+                const uint64_t good = __ballot(cand && La > Fb && Fa > Lb);
+                const int x = __ffsll((unsigned long long)good) - 1;  // exactly one lane (keys are distinct)
+                const uint32_t la_hi = readlane_u32((uint32_t)(La >> 32), x), fa_hi = readlane_u32((uint32_t)(Fa >> 32), x);
+                const uint32_t lb_hi = readlane_u32((uint32_t)(Lb >> 32), x), fb_hi = readlane_u32((uint32_t)(Fb >> 32), x);
+                const uint32_t first_dropped = la_hi < fa_hi ? la_hi : fa_hi;  // distance of the smallest dropped entry
+                const uint32_t nw = lb_hi > fb_hi ? lb_hi : fb_hi;            // distance of the largest kept entry
+                if (first_dropped == nw) {
+                    // a dropped entry ties the new worst distance: order matters -> undo, go sequential
+                    F.lo[0] = keep_lo; F.hi[0] = keep_hi; f = keep_f; fworst = keep_fw;
+                    sequential = true;
+                } else {
+                    if (x > 0) {
+                        l -= x;
+                        trim_masks(lane);
+                    }
+                    f -= E - x;
+                    kill_front_from(f, lane);
+                    tsize = 0;  // something was evicted and (no tie) the worst distance decreased
+                    worst = nw;
+                }
+            } else if (E == 0) {
+                worst = union_worst();  // the union just became full
+            }
+        } else {
+            sequential = true;  // a single survivor into a full union: one offer
+        }
+        if (sequential) {
+            do {
+                const int sl = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                if (!offer_one(readlane_u32(dk, sl), readlane_u32(nb, sl) << 1, lane)) return false;
+            } while (m);
+        }
+        return true;
+    }
+
+    // The next node to expand: the closest unexpanded entry of the union, ties -> largest id (the candidate heap is
+    // keyed (-dist, id)); `pred` / `h2k` = the runner-up's id / distance key when it is well defined.  False: nothing
+    // is left (the reference's loop exit).
+    __device__ __forceinline__ bool select(uint32_t& node, uint32_t& pred, uint32_t& h2k, int lane) {
+        if (!c_valid) refresh_cache(lane);
+        // Common case as one branch-free block (the walk is instruction-issue bound; the compiler's version of this
+        // logic is twice as long): the front list's two closest unexpanded entries (dead lanes hold all-ones = read
+        // as expanded), the winner against the cached base entries, the runner-up as the prediction.
+        //   ok   = the closest distance is unique and the tie list is empty (else: slow path below)
+        //   pred = runner-up id, -1 when there is none or the two runner-up candidates have equal distances
+        uint32_t ok, fb, q1, q2, hf1, hf2, nf1, nf2, hw, ha, na, hb, nb2, hr, t0;
+        uint64_t fm;
+        asm volatile(
+            "v_and_b32 %[t0], 1, %[flo]\n\t"
+            "v_cmp_eq_u32 vcc, 0, %[t0]\n\t"
+            "s_mov_b64 %[fm], vcc\n\t"
+            "s_ff1_i32_b64 %[q1], %[fm]\n\t"               // -1 when the front list has no unexpanded entry
+            "s_bitset0_b64 %[fm], %[q1]\n\t"
+            "s_ff1_i32_b64 %[q2], %[fm]\n\t"
+            "v_readlane_b32 %[hf1], %[fhi], %[q1]\n\t"      // (lane index taken mod 64; fixed up below)
+            "v_readlane_b32 %[nf1], %[flo], %[q1]\n\t"
+            "v_readlane_b32 %[hf2], %[fhi], %[q2]\n\t"
+            "v_readlane_b32 %[nf2], %[flo], %[q2]\n\t"
+            "s_cmp_lt_i32 %[q1], 0\n\t"
+            "s_cselect_b32 %[hf1], -1, %[hf1]\n\t"
+            "s_cmp_lt_i32 %[q2], 0\n\t"
+            "s_cselect_b32 %[hf2], -1, %[hf2]\n\t"
+            "s_lshr_b32 %[nf1], %[nf1], 1\n\t"
+            "s_lshr_b32 %[nf2], %[nf2], 1\n\t"
+            "s_cmp_lt_u32 %[h1], %[hf1]\n\t"                // the base list's closest entry wins
+            "s_cselect_b32 %[fb], 1, 0\n\t"
+            "s_cselect_b32 %[hw], %[h1], %[hf1]\n\t"
+            "s_cselect_b32 %[node], %[n1], %[nf1]\n\t"
+            "s_cselect_b32 %[ha], %[h2], %[hf2]\n\t"        // second entry of the winning list
+            "s_cselect_b32 %[na], %[n2], %[nf2]\n\t"
+            "s_cselect_b32 %[hb], %[hf1], %[h1]\n\t"        // first entry of the other list
+            "s_cselect_b32 %[nb2], %[nf1], %[n1]\n\t"
+            "s_min_u32 %[hr], %[ha], %[hb]\n\t"
+            "s_cmp_lt_u32 %[ha], %[hb]\n\t"
+            "s_cselect_b32 %[pred], %[na], %[nb2]\n\t"
+            "s_cmp_lg_u32 %[h1], %[hf1]\n\t"                // equal: a tie across the lists, or both lists empty
+            "s_cselect_b32 %[ok], 1, 0\n\t"
+            "s_cmp_lg_u32 %[hr], %[hw]\n\t"                 // the runner-up ties the winner
+            "s_cselect_b32 %[ok], %[ok], 0\n\t"
+            "s_cmp_eq_u32 %[ts], 0\n\t"
+            "s_cselect_b32 %[ok], %[ok], 0\n\t"
+            "s_cmp_lg_u32 %[ha], %[hb]\n\t"                 // ambiguous runner-up: no prediction
+            "s_cselect_b32 %[pred], %[pred], -1\n\t"
+            "s_cselect_b32 %[hr], %[hr], -1\n\t"
+            "s_cmp_lg_u32 %[hr], -1\n\t"
+            "s_cselect_b32 %[pred], %[pred], -1"
+            : [ok] "=&s"(ok), [fb] "=&s"(fb), [q1] "=&s"(q1), [q2] "=&s"(q2), [hf1] "=&s"(hf1), [hf2] "=&s"(hf2),
+              [nf1] "=&s"(nf1), [nf2] "=&s"(nf2), [hw] "=&s"(hw), [ha] "=&s"(ha), [na] "=&s"(na), [hb] "=&s"(hb),
+              [nb2] "=&s"(nb2), [hr] "=&s"(hr), [t0] "=&v"(t0), [fm] "=&s"(fm), [node] "=&s"(node), [pred] "=&s"(pred)
+            : [flo] "v"(F.lo[0]), [fhi] "v"(F.hi[0]), [h1] "s"(h1), [n1] "s"(n1), [h2] "s"(h2), [n2] "s"(n2), [ts] "s"(tsize)
+            : "vcc", "scc");
+        h2k = hr;
+        if (__builtin_expect(ok != 0, 1)) {
+            if (fb) expand_base(p1, lane);
+            else F.lo[0] |= (lane == (int)q1) ? 1u : 0u;
+            return true;
+        }
+        pred = kInvalidId;
+        h2k = 0xFFFFFFFFu;
+        const int pF = (int)q1;
+        const uint32_t hF1 = hf1;
+        // rare: equal distances among the closest unexpanded entries, a non-empty tie list, or the end
+        const bool any = p1 >= 0 || pF >= 0;
+        const uint32_t hi_p = h1 < hF1 ? h1 : hF1;
+        int bestL = -1, bestF = -1;  // largest id with that distance: the last unexpanded one of its run in either list
+        uint32_t idL = 0, idF = 0;
+        if (any) {
+            if (p1 >= 0 && h1 == hi_p) {
+                for (int b0 = p1; b0 < l; b0 += 64) {  // the run of equal distances starts at p1
+                    const int r = b0 + lane;
+                    uint64_t kv = base[r < l ? r : 0];
+                    kv = r < l ? kv : ~0ull;
+                    const bool same = (uint32_t)(kv >> 32) == hi_p;
+                    const uint64_t ms = __ballot(same && !((uint32_t)kv & 1u));
+                    if (ms) {
+                        const int q = 63 - __clzll((long long)ms);
+                        bestL = b0 + q;
+                        idL = readlane_u32((uint32_t)kv, q) >> 1;
+                    }
+                    if (!((__ballot(same) >> 63) & 1ull)) break;  // the run ends inside this chunk
+                }
+            }
+            const uint64_t msf = __ballot(!(F.lo[0] & 1u) && F.hi[0] == hi_p);
+            if (msf) {
+                bestF = 63 - __clzll((long long)msf);
+                idF = readlane_u32(F.lo[0], bestF) >> 1;
+            }
+        }
+        const bool pickL = bestL >= 0 && (bestF < 0 || idL > idF);
+        const bool have = bestL >= 0 || bestF >= 0;
+        const uint32_t lid = pickL ? idL : idF;
+        if (tsize > 0 && (!have || hi_p == worst)) {
+            // tie entries all sit at the worst distance: the largest id among them competes
+            uint32_t v = (lane < tsize) ? key_id(tie[lane]) + 1u : 0u;
+            int w = lane;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t ov = (uint32_t)__shfl_xor((int)v, off);
+                const int ow = __shfl_xor(w, off);
+                if (ov > v) { v = ov; w = ow; }
+            }
+            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            w = __builtin_amdgcn_readfirstlane(w);
+            if (!have || v - 1u > lid) {
+                node = v - 1u;
+                tie[w] = tie[tsize - 1];  // (every lane: same value)
+                tsize -= 1;
+                wave_sync();
+                return true;
+            }
+        }
+        if (!have) return false;
+        node = lid;
+        if (pickL) expand_base(bestL, lane);
+        else F.lo[0] |= (lane == bestF) ? 1u : 0u;
+        return true;
+    }
+    // End of a walk: one sorted list (flush), the outputs in POP order (rank i goes to position kept - 1 - i), and --
+    // when the walk kernels re-rank -- getRealNearest on this query with the original-space query staged in
+    // `rr_scratch` (LDS that the walk no longer needs; the base list must stay readable).
+    __device__ __forceinline__ void finish(const WalkParams& p, uint32_t qi, int hops, int dist_calc, int edges,
+                                           unsigned char* rr_scratch, int lane) {
+        flush(lane);
+        const int kept = l < p.k ? l : p.k;
+        for (int rank = lane; rank < (int)p.cand_stride; rank += 64) {
+            const uint64_t kv = base[rank < kept ? rank : 0];
+            const size_t at = (size_t)qi * p.cand_stride + (rank < kept ? kept - 1 - rank : rank);
+            p.cand[at] = rank < kept ? key_id(kv) : kInvalidId;
+            if (p.cand_dist) p.cand_dist[at] = rank < kept ? fkey_inv_out(key_hi(kv), p.zero_dist_bits) : __builtin_inff();
+        }
+        if (lane == 0) {
+            p.count[qi] = kept;
+            p.hops[qi] = hops;
+            p.dist_calc[qi] = dist_calc;
+            atomicMax(p.max_dc, (uint32_t)dist_calc);
+            if (p.edges) p.edges[qi] = edges;
+            // PLAIN answer = topk.top() after trimming the heap to k (search_function.h:174-181): the k-th best
+            if (p.best) p.best[qi] = kept > 0 ? key_id(base[kept - 1]) : kInvalidId;
+        }
+        if (p.rr_db) {
+            const uint64_t* b = base;
+            fused_rerank(p, qi, kept, rr_scratch, lane, [&](int rank) { return key_id(b[rank]); });
+        }
+    }
+
+    // the state of an empty union around `entry` (the caller puts the entry's key into lane 0 of the front list)
+    __device__ __forceinline__ void init(unsigned char* smem, int ef_) {
+        const int ef_pad = (ef_ + 63) & ~63;
+        tie = reinterpret_cast<uint64_t*>(smem);
+        stage = tie + kRegTieCap;
+        base = stage + kRegStageSlots;
+        flags = reinterpret_cast<unsigned char*>(base + ef_pad);
+        F.clear();
+        ef = ef_; l = 0; f = 1; tsize = 0;
+        mu_lo = mu_hi = 0u;
+        c_valid = false; p1 = p2 = -1; h1 = h2 = 0xFFFFFFFFu; n1 = n2 = 0u;
+        worst = fworst = 0u;
+    }
+};
+
 // AUX: the auxiliary-graph walk (search_function.h:73-89): a hop expands the node's auxiliary row first (while
 // hops < hops_bound), then -- unless llf and that step inserted something -- its main row.
 // BITMAP: visited set = one bit per node in HBM (`bitmap`, this wavefront's slot), see walk_bitmap_kernel.
@@ -1734,6 +2193,182 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     if (p.rr_db) {
         const int kept = size < p.k ? size : p.k;
         fused_rerank(p, qi, kept, smem, lane, [&](int rank) { return reg_id_at_rank<R>(L, rank); });
+    }
+}
+
+// ---- generic walk for 64 < ef <= 512: walk_reg_one's hop around the two-list result structure (BigList) ---------------
+//
+// Every shape the hot instances do not take (256-byte rows, the dot metric, adjacency rows of more than one pass,
+// auxiliary graphs, large indexes, the HBM-bitmap first pass): same expansion as walk_reg_one, but the result list is
+// the base list in LDS + the front list in one register, so that selection and insertion cost what they cost at
+// ef <= 64 whatever ef is (the R-register lists spent 28 % of a hop selecting and 30 % inserting at ef = 300).
+// LDS: [BigList: big_list_fixed_bytes(ef)][query: dstride floats][visited set | (BITMAP) re-rank scratch].
+template <int METRIC, int STEPS, bool OFF32, bool AUX = false, bool BITMAP = false>
+__device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
+                                                 uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
+    constexpr bool kEarlyLoad = (STEPS > 0);
+    constexpr bool kPair = (STEPS == 8);                      // 128-byte rows: two lanes per neighbour
+    constexpr bool kAlt = (kPair && METRIC == 1);
+    constexpr int kQSteps = kPair ? 4 : STEPS;
+    constexpr uint32_t kChunk = kPair ? 32u : 64u;
+    constexpr uint64_t kSlotLanes = kPair ? 0x5555555555555555ull : ~0ull;
+    const int lane = lane_id();
+    const uint32_t slot = kPair ? (uint32_t)lane >> 1 : (uint32_t)lane;
+    const uint32_t half = kPair ? (uint32_t)lane & 1u : 0u;
+    const int ef = p.ef;
+    BigList B;
+    B.init(smem, ef);
+    float* qf = reinterpret_cast<float*>(smem + big_list_fixed_bytes(ef));
+    unsigned char* after_q = reinterpret_cast<unsigned char*>(qf + p.dstride);  // visited set, or re-rank scratch
+    uint32_t* hash = reinterpret_cast<uint32_t*>(after_q);
+    const float4* qs = reinterpret_cast<const float4*>(qf);
+    const uint32_t cap = p.hash_cap;
+    const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
+    constexpr bool packed = OFF32;
+    const uint32_t nbuckets = packed ? cap / 5u : cap >> 2;
+    if constexpr (BITMAP) { for (uint32_t i = lane; i < p.bitmap_words; i += 64) bitmap[i] = 0u; }
+    else if constexpr (packed) packed_table_init(hash, nbuckets, 0u, lane);
+    else for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
+    for (uint32_t i = lane; i < p.dstride; i += 64)
+        qf[i] = (i < p.dim) ? p.q[(size_t)qi * p.qstride + i] : 0.f;
+    wave_sync();
+    RowRegs<kQSteps> qreg;
+    if constexpr (kEarlyLoad) {
+#pragma unroll
+        for (int t = 0; t < kQSteps; ++t) qreg.v[t] = kAlt ? qs[2 * t + half] : qs[kQSteps * half + t];
+    }
+
+    int hops = 0, dist_calc = 1, edges = 0;
+    // (readfirstlane: every lane computes the same entry id / distance; the compiler must know they are wave-uniform)
+    const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p.entries ? p.entries[qi] : 0u));
+    if (entry >= p.n) { write_bad_entry(p, qi, lane); return; }
+    {
+        const float d0 = walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, entry, p.dstride), p.dim);
+        B.worst = B.fworst = (uint32_t)__builtin_amdgcn_readfirstlane((int)fkey(d0));
+        B.F.hi[0] = lane == 0 ? B.worst : B.F.hi[0];
+        B.F.lo[0] = lane == 0 ? entry << 1 : B.F.lo[0];
+        if (lane == 0) {
+            if constexpr (BITMAP) bitmap[entry >> 5] = 1u << (entry & 31u);
+            else if constexpr (packed) packed_table_put_first(hash, nbuckets, entry);
+            else hash[4u * __umulhi(entry * 0x9E3779B1u, nbuckets)] = entry;
+        }
+        wave_sync();
+    }
+
+    int status = 0;  // 0 = walking, 1 = finished, 2 = handed over
+    uint32_t pf_node = kInvalidId, pf_val = kInvalidId;
+    while (true) {
+        uint32_t node, pred, h2;
+        if (!B.select(node, pred, h2, lane)) { status = 1; break; }
+        // ---- adjacency row of `node` (prefetched or loaded now), then the prefetch for the next hop
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(
+            row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), node, p.ell_stride));
+        uint32_t nb0;
+        if (node == pf_node) nb0 = pf_val;
+        else nb0 = (slot < p.ell_stride) ? row[slot] : kInvalidId;
+        const uint64_t mv0 = __ballot(nb0 != kInvalidId);  // consumed BEFORE the prefetch is issued
+        pf_node = pred;
+        if (pred != kInvalidId)
+            pf_val = (slot < p.ell_stride) ? reinterpret_cast<const uint32_t*>(row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), pred, p.ell_stride))[slot] : kInvalidId;
+
+        bool found = false;  // makeStep's flag (:34); only read when AUX
+        for (int g = AUX ? ((uint32_t)hops < p.hops_bound ? 0 : 1) : 1; g < 2; ++g) {
+        const bool is_aux = AUX && g == 0;
+        if (AUX && g == 1 && found && p.llf) break;
+        const uint32_t* grow = row;
+        uint32_t gstride = p.ell_stride;
+        if (is_aux) {
+            grow = reinterpret_cast<const uint32_t*>(row_ptr<OFF32>(reinterpret_cast<const float*>(p.aux_ell), node, p.aux_stride));
+            gstride = p.aux_stride;
+        }
+        for (uint32_t c = 0; c < gstride; c += kChunk) {
+            uint32_t nb = nb0;
+            uint64_t mv = mv0;
+            if (c || is_aux) {
+                nb = (c + slot < gstride) ? grow[c + slot] : kInvalidId;
+                mv = __ballot(nb != kInvalidId);
+            }
+            if (!mv) break;
+            if constexpr (!BITMAP)
+                if ((uint32_t)dist_calc + 64u > p.hash_limit) { status = 2; break; }
+            const bool valid = nb != kInvalidId;
+            edges += __popcll(mv & kSlotLanes);
+            RowRegs<kQSteps> rr;
+            uint32_t roff = 0;
+            if constexpr (kEarlyLoad) {
+                if constexpr (OFF32) {
+                    roff = kPair ? (nb << 7) + half * (kAlt ? 16u : 64u) : nb * (p.dstride * 4u);
+                    const float* rp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff);
+                    if constexpr (kAlt) { if (valid) load_row_alt(rr, rp); }
+                    else { if (valid) load_row<kQSteps>(rr, rp); }
+                } else {
+                    const float* rp = row_ptr<OFF32>(p.db, nb, p.dstride) + half * (kAlt ? 4u : 16u);
+                    if constexpr (kAlt) { if (valid) load_row_alt(rr, rp); }
+                    else { if (valid) load_row<kQSteps>(rr, rp); }
+                }
+            }
+            uint64_t mclaimed;
+            if constexpr (BITMAP) {
+                bool fr = false;
+                if (valid && (!kPair || half == 0u)) {
+                    const uint32_t bit = 1u << (nb & 31u);
+                    fr = !(atomicOr(&bitmap[nb >> 5], bit) & bit);
+                }
+                mclaimed = __ballot(fr);
+            } else if constexpr (packed) mclaimed = visited_claim_mask_packed(hash_lds, nbuckets, nb, mv & kSlotLanes);
+            else mclaimed = visited_claim_mask(hash_lds, nbuckets, nb, mv & kSlotLanes);
+            const uint64_t mfresh = kPair ? (mclaimed << 1) : mclaimed;
+            const bool fresh = __builtin_amdgcn_inverse_ballot_w64(mfresh);
+            uint32_t dk = 0xFFFFFFFFu;
+            if constexpr (kEarlyLoad) {
+                if constexpr (kAlt) {
+                    const uint32_t kd = fkey(dot_pair_from_regs(rr, qreg.v));
+                    dk = fresh ? kd : 0xFFFFFFFFu;
+                } else if constexpr (kPair) {
+                    const uint32_t kd = fkey_sumsq(l2_pair_from_regs(rr, qreg.v));
+                    dk = fresh ? kd : 0xFFFFFFFFu;
+                } else {
+                    if (fresh) dk = fkey(l2_from_regs<STEPS>(rr, qreg.v));
+                }
+                asm volatile("" ::"v"(roff));  // the address register must not double as a load destination
+            } else {
+                if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, nb, p.dstride), p.dim));
+            }
+            dist_calc += __popcll(mfresh);
+            const uint64_t m = (B.l + B.f < ef) ? mfresh : __ballot(fresh && dk < B.worst);
+            if (m) {
+                if (AUX) found = true;  // the first of them is inserted whatever happens to the others
+                // BigList::insert takes up to 32 survivors (its eviction step is one lane per split): the two halves of
+                // a 64-slot pass go in one after the other -- same union, same rule (boundary ties fall back to the
+                // sequential offers either way)
+                const uint64_t ma = kPair ? m : (m & 0xFFFFFFFFull), mb = kPair ? 0ull : (m & 0xFFFFFFFF00000000ull);
+                if (ma && !B.insert(ma, dk, nb, lane)) { status = 2; break; }
+                if (mb && !B.insert(mb, dk, nb, lane)) { status = 2; break; }
+            }
+        }
+        if (status) break;
+        }
+        if (status) break;
+        hops += 1;
+    }
+
+    if (status == 2) {
+        if (lane == 0) {
+            const uint32_t s = atomicAdd(ovf_count, 1u);
+            ovf_list[s] = qi;
+        }
+        return;
+    }
+    B.finish(p, qi, hops, dist_calc, edges, after_q, lane);
+}
+
+template <int METRIC, int STEPS, bool OFF32, bool RETRY, bool AUX = false>
+__global__ __launch_bounds__(64) void walk_reg_big_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (RETRY) {
+        retry_loop(p, [&](uint32_t qi) { walk_reg_big_one<METRIC, STEPS, OFF32, AUX>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
+    } else {
+        walk_reg_big_one<METRIC, STEPS, OFF32, AUX>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
     }
 }
 
@@ -2165,406 +2800,12 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     }
 }
 
-// ---- hot instance for 64 < ef <= 512: the result list as a sorted BASE list in LDS + a sorted FRONT list in a register
-//
-// With the whole list in R = ceil(ef / 64) registers per lane (walk_hot_one<R>, reg_merge_multi), finding the next node
-// costs ~16 R instructions EVERY hop and a merge rewrites all R registers; the walk is instruction-issue bound, so ef =
-// 300 ran at a third of the ef = 64 rate per distance -- although 2 hops in 3 insert at most one entry (measured
-// histogram: 44 % of the hops at ef = 180 have no survivor, 20 % one).  Here
-//   base  L: sorted keys in LDS, `l` live entries; between two flushes it only loses entries from its end and gets
-//            "expanded" bits set.  Its two closest unexpanded entries are cached in scalar registers (found through a
-//            per-chunk unexpanded mask kept in two vector registers), so a hop that does not pick from it pays nothing.
-//   front F: sorted, ONE register per lane, `f` <= 64 live entries: every insertion goes here, with the one-register
-//            machinery of the ef <= 64 instance (reg_merge / reg_offer), whatever ef is.
-// The reference's result heap (search_function.h:50) is the union: l + f <= ef entries; its worst element is the
-// larger of the two tails, the next node is the closer of the two first unexpanded entries.  When a hop's E = l + f
-// - ef entries have to go, they are the E largest of the two tails: one vector step finds how many come from which
-// list (lane j tests the split "j from the base list, E - j from the front list").  When the front list would
-// overflow (and at the end of the walk) it is merged into the base list in place: every front entry finds its rank by
-// bisection, every destination rank then gathers its entry (chunks of 64 ranks, top down).  Exactly the same results:
-// the union holds the same keys as the single list did, selection and eviction see the same total order; the
-// sequential fallback on a boundary tie and the tie list work as before.  Nothing depends on R any more: one kernel.
-
-constexpr int kBigMaxEf = 512;
-
-__device__ __forceinline__ uint64_t dpp_wave_shl1_u64(uint64_t v) {  // lane j <- lane j + 1
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x130, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x130, 0xf, 0xf, false);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// LDS of the instance besides the visited set: [tie list][front-merge buffer: 66 keys][base list: ef_pad keys]
-// [flush flags: ef_pad + 64 bytes], ef_pad = ef rounded up to 64
-__host__ __device__ __forceinline__ constexpr size_t big_list_fixed_bytes(int ef) {
-    return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (size_t)((ef + 63) / 64 * 64) * 9 + 64;
-}
-
-struct BigList {
-    uint64_t* tie;          // [kRegTieCap]
-    uint64_t* stage;        // [kRegStageSlots] scatter buffer of the front-list merge
-    uint64_t* base;         // [ef_pad] base list, ascending; ranks >= l are dead
-    unsigned char* flags;   // [ef_pad + 64] flush scratch
-    RegList<1> F;           // front list; lanes >= f hold all-ones
-    int ef, l, f, tsize;
-    uint32_t worst;         // hi of the union's worst entry (valid once l + f == ef)
-    uint32_t fworst;        // hi of the front list's last entry
-    uint32_t mu_lo, mu_hi;  // lane c: mask of the unexpanded live entries of base ranks 64 c .. 64 c + 63
-    // the two closest unexpanded base entries (c_valid: the cache reflects the masks)
-    bool c_valid;
-    int p1, p2;             // ranks, -1 = none
-    uint32_t h1, n1, h2, n2;
-
-    __device__ __forceinline__ uint64_t base_at(int rank) const {  // wave-uniform rank
-        const uint64_t v = base[rank];
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
-               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    }
-    __device__ __forceinline__ uint32_t union_worst() const {
-        const uint32_t lw = l > 0 ? (uint32_t)(base_at(l - 1) >> 32) : 0u;
-        const uint32_t fw = f > 0 ? readlane_u32(F.hi[0], f - 1) : 0u;
-        return lw > fw ? lw : fw;
-    }
-    // drops the mask bits of base ranks >= l (after the base list lost entries from its end)
-    __device__ __forceinline__ void trim_masks(int lane) {
-        const int left = l - 64 * lane;
-        const uint64_t keep = left >= 64 ? ~0ull : (left <= 0 ? 0ull : ((1ull << left) - 1ull));
-        mu_lo &= (uint32_t)keep;
-        mu_hi &= (uint32_t)(keep >> 32);
-        if (p1 >= l || p2 >= l) c_valid = false;
-    }
-    // the two lowest set bits of the masks -> (p1, h1, n1), (p2, h2, n2)
-    __device__ __forceinline__ void refresh_cache(int lane) {
-        p1 = p2 = -1;
-        h1 = h2 = 0xFFFFFFFFu;
-        n1 = n2 = 0u;
-        uint64_t nz = __ballot((mu_lo | mu_hi) != 0u);
-        if (nz) {
-            const int c1 = __ffsll((unsigned long long)nz) - 1;
-            uint64_t m1 = ((uint64_t)readlane_u32(mu_hi, c1) << 32) | readlane_u32(mu_lo, c1);
-            p1 = 64 * c1 + __ffsll((unsigned long long)m1) - 1;
-            m1 &= m1 - 1;
-            if (m1) {
-                p2 = 64 * c1 + __ffsll((unsigned long long)m1) - 1;
-            } else {
-                nz &= nz - 1;
-                if (nz) {
-                    const int c2 = __ffsll((unsigned long long)nz) - 1;
-                    const uint64_t m2 = ((uint64_t)readlane_u32(mu_hi, c2) << 32) | readlane_u32(mu_lo, c2);
-                    p2 = 64 * c2 + __ffsll((unsigned long long)m2) - 1;
-                }
-            }
-            const uint64_t kv = base[lane == 0 ? p1 : (p2 >= 0 ? p2 : p1)];  // lane 0: first, lane 1: second
-            h1 = readlane_u32((uint32_t)(kv >> 32), 0);
-            n1 = readlane_u32((uint32_t)kv, 0) >> 1;
-            if (p2 >= 0) {
-                h2 = readlane_u32((uint32_t)(kv >> 32), 1);
-                n2 = readlane_u32((uint32_t)kv, 1) >> 1;
-            }
-        }
-        c_valid = true;
-    }
-    // marks base rank `p` expanded: the key's flag bit in LDS and the mask bit
-    __device__ __forceinline__ void expand_base(int p, int lane) {
-        p = __builtin_amdgcn_readfirstlane(p);  // wave-uniform by construction; tell the compiler
-        if (lane == 0) reinterpret_cast<uint32_t*>(base)[2 * p] |= 1u;
-        const int c = p >> 6;
-        uint64_t m = ((uint64_t)readlane_u32(mu_hi, c) << 32) | readlane_u32(mu_lo, c);
-        m = clear_bit64(m, p & 63);
-        mu_lo = writelane_u32(mu_lo, (uint32_t)m, c);
-        mu_hi = writelane_u32(mu_hi, (uint32_t)(m >> 32), c);
-        c_valid = false;
-    }
-
-    // Merges the front list into the base list in place (both sorted; keys are distinct).  Afterwards l += f, f = 0,
-    // the front register holds all-ones, the masks and the cache are rebuilt lazily.
-    __device__ __forceinline__ void flush(int lane) {
-        if (f == 0) return;
-        l = __builtin_amdgcn_readfirstlane(l);  // wave-uniform by construction; tell the compiler (loop counters
-        f = __builtin_amdgcn_readfirstlane(f);  // below index lanes through scalar registers)
-        const int total = l + f;
-        const int chunks = (total + 63) >> 6;
-        for (int i = lane; i < chunks * 8 + 8; i += 64) reinterpret_cast<uint64_t*>(flags)[i] = 0ull;
-        wave_sync();
-        // every front entry: number of base entries below it (lower bound by bisection)
-        const uint64_t fk = ((uint64_t)F.hi[0] << 32) | F.lo[0];
-        int lo = 0, hi = l;
-        const int iters = 32 - __clz(l);  // covers 0 .. l
-        for (int it = 0; it < iters; ++it) {
-            const int mid = (lo + hi) >> 1;
-            const uint64_t v = base[mid < l ? mid : 0];
-            const bool go = lo < hi;
-            const bool less = v < fk;
-            lo = (go && less) ? mid + 1 : lo;
-            hi = (go && !less) ? mid : hi;
-        }
-        if (lane < f) flags[lo + lane] = 1;  // final rank = base entries below + front entries below (= its lane)
-        wave_sync();
-        // front entries below each chunk (lane c of `below`)
-        uint32_t below = 0;
-        {
-            int carry = 0;
-            for (int c = 0; c < chunks; ++c) {
-                below = writelane_u32(below, (uint32_t)__builtin_amdgcn_readfirstlane(carry), c);
-                carry += __popcll(__ballot(flags[64 * c + lane] != 0));
-            }
-        }
-        // every destination rank takes its entry, chunks top down (a chunk reads base ranks of itself and of the chunk
-        // below only, so writing in place is safe in this order)
-        mu_lo = mu_hi = 0u;
-        for (int c = chunks - 1; c >= 0; --c) {
-            const int rank = 64 * c + lane;
-            const bool flagged = flags[rank] != 0;
-            const uint64_t mk = __ballot(flagged);
-            const int cc = (int)readlane_u32(below, c) +
-                           (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-            const uint32_t flo = (uint32_t)__builtin_amdgcn_ds_bpermute((cc & 63) << 2, (int)F.lo[0]);
-            const uint32_t fhi = (uint32_t)__builtin_amdgcn_ds_bpermute((cc & 63) << 2, (int)F.hi[0]);
-            const int src = rank - cc;
-            const uint64_t bv = (rank < total && src < l) ? base[src] : ~0ull;
-            const uint64_t nk = flagged ? (((uint64_t)fhi << 32) | flo) : bv;
-            base[rank] = nk;
-            const uint64_t un = __ballot(rank < total && !((uint32_t)nk & 1u));
-            mu_lo = writelane_u32(mu_lo, (uint32_t)un, c);
-            mu_hi = writelane_u32(mu_hi, (uint32_t)(un >> 32), c);
-        }
-        wave_sync();
-        l = total;
-        f = 0;
-        F.clear();
-        c_valid = false;
-    }
-
-    // One offer with the reference's rule (search_function.h:31-37): the sequential path (single survivors into a full
-    // union, boundary ties).  False: the tie list overflowed.
-    __device__ __forceinline__ bool offer_one(uint32_t dl, uint32_t nlo, int lane) {
-        const bool full = l + f >= ef;
-        if (full && !(dl < worst)) return true;
-        if (f == 64) flush(lane);
-        int ts_unused = 0;
-        reg_offer<1>(dl, nlo, F, f, fworst, ts_unused, tie, 64, lane);  // f < 64: a plain sorted insert
-        if (!full) {
-            if (l + f == ef) worst = union_worst();
-            return true;
-        }
-        // evict the union's largest entry: the larger of the two tails
-        const uint64_t lt = l > 0 ? base_at(l - 1) : 0ull;
-        const uint64_t ft = ((uint64_t)readlane_u32(F.hi[0], f - 1) << 32) | readlane_u32(F.lo[0], f - 1);
-        uint64_t ev;
-        if (lt > ft) {
-            ev = lt;
-            l -= 1;
-            trim_masks(lane);
-        } else {
-            ev = ft;
-            f -= 1;
-            if (lane == f) F.lo[0] = F.hi[0] = 0xFFFFFFFFu;
-        }
-        const uint32_t nw = union_worst();
-        if (nw != worst) {
-            tsize = 0;  // the worst distance decreased: old ties are dead
-        } else if (!(ev & 1ull)) {  // evicted unexpanded at a distance that is still the worst
-            if (tsize >= kRegTieCap) return false;
-            if (lane == 0) tie[tsize] = ev;
-            tsize += 1;
-            wave_sync();
-        }
-        worst = nw;
-        return true;
-    }
-
-    // A hop's survivors (mask m, keys dk / ids nb in their lanes; at most 32) into the union.  False: hand over.
-    __device__ __forceinline__ bool insert(uint64_t m, uint32_t dk, uint32_t nb, int lane) {
-        const int ns = __popcll(m);
-        bool sequential = false;
-        if (l + f + ns <= ef || (m & (m - 1)) != 0) {
-            // ---- batch: survivors into the front list, then the E largest of the union go
-            if (f + ns > 64) flush(lane);
-            const uint32_t keep_lo = F.lo[0], keep_hi = F.hi[0], keep_fw = fworst;
-            const int keep_f = f;
-            int ts_unused = 0;
-            if ((m & (m - 1)) != 0) {
-                reg_merge(m, __builtin_amdgcn_inverse_ballot_w64(m), dk, nb, F, f, fworst, ts_unused, stage, 64, lane);
-            } else {
-                const int sl = __ffsll((unsigned long long)m) - 1;
-                reg_offer<1>(readlane_u32(dk, sl), readlane_u32(nb, sl) << 1, F, f, fworst, ts_unused, tie, 64, lane);
-            }
-            const int E = l + f - ef;
-            if (E > 0) {
-                // lane j: "the base list drops its top j entries, the front list its top E - j" (0 <= j <= E <= 32)
-                const int j = lane;
-                const int bi = l - j;  // smallest base entry dropped (j = 0: none -> all-ones; below rank 0: zero)
-                uint64_t H = base[(bi >= 0 && bi < l) ? bi : 0];
-                H = bi < 0 ? 0ull : H;
-                H = bi >= l ? ~0ull : H;
-                const int fi = f - E - 1 + j;  // largest front entry kept (< 0: none)
-                const uint32_t glo = (uint32_t)__builtin_amdgcn_ds_bpermute((fi & 63) << 2, (int)F.lo[0]);
-                const uint32_t ghi = (uint32_t)__builtin_amdgcn_ds_bpermute((fi & 63) << 2, (int)F.hi[0]);
-                uint64_t G = ((uint64_t)ghi << 32) | glo;
-                G = fi < 0 ? 0ull : G;
-                G = fi >= f ? ~0ull : G;
-                const uint64_t La = H, Lb = dpp_wave_shl1_u64(H);  // Lb = base entry of rank l - j - 1 (largest kept)
-                const uint64_t Fb = G, Fa = dpp_wave_shl1_u64(G);  // Fa = front entry of rank f - E + j (smallest dropped)
-                const bool cand = j <= E && j <= l && E - j <= f;
-                const uint64_t good = __ballot(cand && La > Fb && Fa > Lb);
-                const int x = __ffsll((unsigned long long)good) - 1;  // exactly one lane (keys are distinct)
-                const uint32_t la_hi = readlane_u32((uint32_t)(La >> 32), x), fa_hi = readlane_u32((uint32_t)(Fa >> 32), x);
-                const uint32_t lb_hi = readlane_u32((uint32_t)(Lb >> 32), x), fb_hi = readlane_u32((uint32_t)(Fb >> 32), x);
-                const uint32_t first_dropped = la_hi < fa_hi ? la_hi : fa_hi;  // distance of the smallest dropped entry
-                const uint32_t nw = lb_hi > fb_hi ? lb_hi : fb_hi;            // distance of the largest kept entry
-                if (first_dropped == nw) {
-                    // a dropped entry ties the new worst distance: order matters -> undo, go sequential
-                    F.lo[0] = keep_lo; F.hi[0] = keep_hi; f = keep_f; fworst = keep_fw;
-                    sequential = true;
-                } else {
-                    if (x > 0) {
-                        l -= x;
-                        trim_masks(lane);
-                    }
-                    f -= E - x;
-                    if (lane >= f) F.lo[0] = F.hi[0] = 0xFFFFFFFFu;
-                    tsize = 0;  // something was evicted and (no tie) the worst distance decreased
-                    worst = nw;
-                }
-            } else if (E == 0) {
-                worst = union_worst();  // the union just became full
-            }
-        } else {
-            sequential = true;  // a single survivor into a full union: one offer
-        }
-        if (sequential) {
-            do {
-                const int sl = __ffsll((unsigned long long)m) - 1;
-                m &= m - 1;
-                if (!offer_one(readlane_u32(dk, sl), readlane_u32(nb, sl) << 1, lane)) return false;
-            } while (m);
-        }
-        return true;
-    }
-
-    // The next node to expand: the closest unexpanded entry of the union, ties -> largest id (the candidate heap is
-    // keyed (-dist, id)); `pred` / `h2k` = the runner-up's id / distance key when it is well defined.  False: nothing
-    // is left (the reference's loop exit).
-    // every piece of list state is wave-uniform by construction; saying so keeps it in scalar registers across the
-    // hop loop (the compiler's divergence analysis gives up on some of the merges above)
-    __device__ __forceinline__ void pin_uniform() {
-        l = __builtin_amdgcn_readfirstlane(l);
-        f = __builtin_amdgcn_readfirstlane(f);
-        tsize = __builtin_amdgcn_readfirstlane(tsize);
-        worst = (uint32_t)__builtin_amdgcn_readfirstlane((int)worst);
-        fworst = (uint32_t)__builtin_amdgcn_readfirstlane((int)fworst);
-        p1 = __builtin_amdgcn_readfirstlane(p1);
-        p2 = __builtin_amdgcn_readfirstlane(p2);
-        h1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)h1);
-        n1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n1);
-        h2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)h2);
-        n2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n2);
-    }
-
-    __device__ __forceinline__ bool select(uint32_t& node, uint32_t& pred, uint32_t& h2k, int lane) {
-        pin_uniform();
-        if (!c_valid) refresh_cache(lane);
-        pred = kInvalidId;
-        h2k = 0xFFFFFFFFu;
-        uint64_t mf = __ballot(!(F.lo[0] & 1u));  // dead front lanes hold all-ones (read as expanded)
-        int pF = -1;
-        uint32_t hF1 = 0xFFFFFFFFu, hF2 = 0xFFFFFFFFu, nF1 = 0, nF2 = 0;
-        if (mf) {
-            pF = __ffsll((unsigned long long)mf) - 1;
-            hF1 = readlane_u32(F.hi[0], pF);
-            nF1 = readlane_u32(F.lo[0], pF) >> 1;
-            mf &= mf - 1;
-            if (mf) {
-                const int q = __ffsll((unsigned long long)mf) - 1;
-                hF2 = readlane_u32(F.hi[0], q);
-                nF2 = readlane_u32(F.lo[0], q) >> 1;
-            }
-        }
-        if (tsize == 0 && (p1 >= 0 || pF >= 0)) {
-            const bool from_base = p1 >= 0 && (pF < 0 || h1 < hF1);
-            const bool cross_tie = p1 >= 0 && pF >= 0 && h1 == hF1;
-            // runner-up: the second entry of the winning list or the first of the other one
-            const uint32_t ha = from_base ? h2 : hF2, na = from_base ? n2 : nF2;
-            const uint32_t hb = from_base ? hF1 : h1, nb2 = from_base ? nF1 : n1;
-            const uint32_t hw = from_base ? h1 : hF1;
-            const uint32_t hr = ha < hb ? ha : hb;
-            if (!cross_tie && hr != hw) {  // the closest distance is unique: plain pick
-                node = from_base ? n1 : nF1;
-                if (hr != 0xFFFFFFFFu && ha != hb) {  // (equal runner-up distances: no prediction)
-                    pred = ha < hb ? na : nb2;
-                    h2k = hr;
-                }
-                if (from_base) expand_base(p1, lane);
-                else if (lane == pF) F.lo[0] |= 1u;
-                return true;
-            }
-        }
-        // rare: equal distances among the closest unexpanded entries, a non-empty tie list, or the end
-        const bool any = p1 >= 0 || pF >= 0;
-        const uint32_t hi_p = h1 < hF1 ? h1 : hF1;
-        int bestL = -1, bestF = -1;  // largest id with that distance: the last unexpanded one of its run in either list
-        uint32_t idL = 0, idF = 0;
-        if (any) {
-            if (p1 >= 0 && h1 == hi_p) {
-                for (int b0 = p1; b0 < l; b0 += 64) {  // the run of equal distances starts at p1
-                    const int r = b0 + lane;
-                    const uint64_t kv = r < l ? base[r] : ~0ull;
-                    const bool same = (uint32_t)(kv >> 32) == hi_p;
-                    const uint64_t ms = __ballot(same && !((uint32_t)kv & 1u));
-                    if (ms) {
-                        const int q = 63 - __clzll((long long)ms);
-                        bestL = b0 + q;
-                        idL = readlane_u32((uint32_t)kv, q) >> 1;
-                    }
-                    if (!((__ballot(same) >> 63) & 1ull)) break;  // the run ends inside this chunk
-                }
-            }
-            const uint64_t msf = __ballot(!(F.lo[0] & 1u) && F.hi[0] == hi_p);
-            if (msf) {
-                bestF = 63 - __clzll((long long)msf);
-                idF = readlane_u32(F.lo[0], bestF) >> 1;
-            }
-        }
-        const bool pickL = bestL >= 0 && (bestF < 0 || idL > idF);
-        const bool have = bestL >= 0 || bestF >= 0;
-        const uint32_t lid = pickL ? idL : idF;
-        if (tsize > 0 && (!have || hi_p == worst)) {
-            // tie entries all sit at the worst distance: the largest id among them competes
-            uint32_t v = (lane < tsize) ? key_id(tie[lane]) + 1u : 0u;
-            int w = lane;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t ov = (uint32_t)__shfl_xor((int)v, off);
-                const int ow = __shfl_xor(w, off);
-                if (ov > v) { v = ov; w = ow; }
-            }
-            v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-            w = __builtin_amdgcn_readfirstlane(w);
-            if (!have || v - 1u > lid) {
-                node = v - 1u;
-                if (lane == 0) tie[w] = tie[tsize - 1];
-                tsize -= 1;
-                wave_sync();
-                return true;
-            }
-        }
-        if (!have) return false;
-        node = lid;
-        if (pickL) expand_base(bestL, lane);
-        else if (lane == bestF) F.lo[0] |= 1u;
-        return true;
-    }
-};
-
 __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, unsigned char* smem) {
     const int lane = lane_id();
     const uint32_t slot = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;  // lane = 2 * adjacency slot + row half
     const int ef = p.ef;
-    const int ef_pad = (ef + 63) & ~63;
     BigList B;
-    B.tie = reinterpret_cast<uint64_t*>(smem);
-    B.stage = B.tie + kRegTieCap;
-    B.base = B.stage + kRegStageSlots;
-    B.flags = reinterpret_cast<unsigned char*>(B.base + ef_pad);
+    B.init(smem, ef);
     float* qf = reinterpret_cast<float*>(B.stage);  // the query is staged here until it sits in registers
     unsigned char* hash_bytes = smem + big_list_fixed_bytes(ef);
     uint32_t* hash = reinterpret_cast<uint32_t*>(hash_bytes);
@@ -2579,16 +2820,15 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
 #pragma unroll
     for (int t = 0; t < 4; ++t) qreg.v[t] = qs[4 * half + t];
 
-    B.F.clear();
-    B.ef = ef; B.l = 0; B.f = 1; B.tsize = 0;
-    B.mu_lo = B.mu_hi = 0u;
-    B.c_valid = false; B.p1 = B.p2 = -1; B.h1 = B.h2 = 0xFFFFFFFFu; B.n1 = B.n2 = 0u;
     int hops = 0, dist_calc = 1, edges = 0;
-    const uint32_t entry = p.entries ? p.entries[qi] : 0u;
+    // (every lane computes the same entry id and distance; readfirstlane tells the compiler they are wave-uniform --
+    // otherwise every piece of list state that is ever merged with them is kept in vector registers and the scalar
+    // control flow of the list turns into exec-masked regions)
+    const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p.entries ? p.entries[qi] : 0u));
     if (entry >= p.n) { write_bad_entry(p, qi, lane); return; }
     {
         const float d0 = walk_dist<0, 8>(qs, row_ptr<true>(p.db, entry, 32u), 32u);
-        B.worst = B.fworst = fkey(d0);
+        B.worst = B.fworst = (uint32_t)__builtin_amdgcn_readfirstlane((int)fkey(d0));
         if (lane == 0) {
             B.F.hi[0] = B.worst;
             B.F.lo[0] = entry << 1;
@@ -2659,36 +2899,15 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
         }
         return;
     }
-    B.flush(lane);  // one sorted list of l entries in LDS
-    const int size = B.l;
-    const int kept = size < p.k ? size : p.k;
-    for (int rank = lane; rank < (int)p.cand_stride; rank += 64) {  // POP order: rank i goes to position kept - 1 - i
-        if (rank < kept) {
-            const uint64_t kv = B.base[rank];
-            p.cand[(size_t)qi * p.cand_stride + (kept - 1 - rank)] = key_id(kv);
-            if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + (kept - 1 - rank)] = fkey_inv_out(key_hi(kv), p.zero_dist_bits);
-        } else {
-            p.cand[(size_t)qi * p.cand_stride + rank] = kInvalidId;
-            if (p.cand_dist) p.cand_dist[(size_t)qi * p.cand_stride + rank] = __builtin_inff();
-        }
-    }
-    if (lane == 0) {
-        p.count[qi] = kept;
-        p.hops[qi] = hops;
-        p.dist_calc[qi] = dist_calc;
-        atomicMax(p.max_dc, (uint32_t)dist_calc);
-        if (p.edges) p.edges[qi] = edges;
-        // PLAIN answer = topk.top() after trimming the heap to k (search_function.h:174-181): the k-th best
-        if (p.best) p.best[qi] = kept > 0 ? key_id(B.base[kept - 1]) : kInvalidId;
-    }
-    if (p.rr_db) {
-        // the original-space query is staged in the (dead) visited-set area: the base list stays readable
-        const uint64_t* base = B.base;
-        fused_rerank(p, qi, kept, hash_bytes, lane, [&](int rank) { return key_id(base[rank]); });
-    }
+    B.finish(p, qi, hops, dist_calc, edges, hash_bytes, lane);  // (re-rank query staged in the dead visited-set area)
 }
 
-__global__ __launch_bounds__(64) void walk_hot_big_kernel(WalkParams p) {  // 64 < ef <= 512
+__global__ __launch_bounds__(64) void walk_hot2_kernel(WalkParams p) {  // 64 < ef <= 128: two list registers per lane
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_hot_one<2>(p, blockIdx.x, smem);
+}
+
+__global__ __launch_bounds__(64) void walk_hot_big_kernel(WalkParams p) {  // 128 < ef <= 512
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_big(p, blockIdx.x, smem);
 }
@@ -3594,8 +3813,9 @@ bool walk_uses_hot(const WalkParams& p, int metric) {
 // LDS of one wavefront without the visited set.  Register kernels: tie list + merge buffer + query; the
 // hot kernel stages the query inside the merge buffer (it lives in registers once the walk starts).
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list) {
-    if (hot)  // tie list + merge buffer; ef > 64: + the base list and the flush's flag bytes (walk_hot_big)
-        return ef <= 64 ? (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 : big_list_fixed_bytes(ef);
+    if (hot)  // tie list + merge buffer of 1 / 2 list registers; ef > 128: + the base list and the flush's flag bytes (walk_hot_big)
+        return ef <= 64 ? (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8
+                        : (ef <= kHot2MaxEf ? (size_t)kRegTieCap * 8 + (size_t)(64 * 2 + 2) * 8 : big_list_fixed_bytes(ef));
     if (ef <= kRegListMaxEf && !lds_list) {  // tie list + merge buffer (ranks 0..ef of the 1 / 2 / 4-register list) + query
         const int regs = ef <= 64 ? 1 : (ef <= 128 ? 2 : (ef <= 256 ? 4 : 8));
         return (size_t)kRegTieCap * 8 + (size_t)(64 * regs + 2) * 8 + (size_t)dstride * 4;
@@ -3654,9 +3874,10 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
     }
     if constexpr (R >= 2 && METRIC == 0 && STEPS == 8) {
-        // 64 < ef <= 512 on the hot shape: base list in LDS + front list in a register, one kernel for every ef
+        // the hot shape beyond ef = 64: two list registers up to 128 (measured: 0.85 vs 0.93 ms at ef = 128), then the
+        // base list in LDS + front list in a register, one kernel for every ef up to 512
         if (!retry && walk_uses_hot(p, METRIC))
-            return launch_walk_k(walk_hot_big_kernel, p, false, walk_fast_lds_bytes(p, true), s);
+            return launch_walk_k(p.ef <= kHot2MaxEf ? walk_hot2_kernel : walk_hot_big_kernel, p, false, walk_fast_lds_bytes(p, true), s);
     }
     if constexpr ((R == 4 || R == 8) && STEPS == 8) {
         // 128-byte rows that the hot instances do not take (dot metric, adjacency rows of more than 32 slots): the

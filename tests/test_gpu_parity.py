@@ -933,7 +933,7 @@ def test_index_beyond_2pow24_nodes(g, orc):
         assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), ef
         assert np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]), ef
         assert np.array_equal(r["ids"], w["ids"][:, 0]), ef
-        assert r["cand"].max() >= (1 << 24) or ef < 64   # ids beyond 24 bits really occur in the results
+        assert r["cand"].max() >= (1 << 24) or k < 64   # ids beyond 24 bits really occur in the results
     # the general kernel on the large index (two entry points per query), and a forced hand-over chain
     ent2 = np.stack([ent, ent[::-1]], axis=1).copy()
     w = orc.walk(queries[:48], base, off, nbr.reshape(-1), 32, entries=ent2[:48], threads=8)

@@ -92,8 +92,8 @@ def test_projection_kernels_fma_only_in_div_sqrt_expansion(kernels):
 
 
 def test_hot_kernel_gather_does_not_wait_for_the_prefetch(kernels):
-    hot = {k: v for k, v in kernels.items() if re.search(r"walk_hot(_big)?_kernel", k)}
-    assert len({k.split("walk_hot")[1][:4] for k in hot}) == 2  # the ef <= 64 instance and the ef <= 512 one
+    hot = {k: v for k, v in kernels.items() if re.search(r"walk_hot(2|_big)?_kernel", k)}
+    assert len({k.split("walk_hot")[1][:4] for k in hot}) == 3  # the ef <= 64, ef <= 128 and ef <= 512 instances
     seen = set()
     for name, insts in hot.items():
         key = tuple(insts[:50])
