@@ -402,19 +402,6 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_name(ds, ef, max_degree, negdot, fused):
-    """The first-pass walk kernel api.cpp picks for this shape (launch_fast_t / launch_reg_t in kernels.hip)."""
-    regs = (ef + 63) // 64
-    hot_shape = ds.d_low == 32 and max_degree <= 32 and not negdot
-    if ef > 512:
-        name = "walk_bitmap_kernel / walk_fast_kernel (LDS result list)"
-    elif hot_shape:
-        name = "walk_hot_kernel" if regs == 1 else ("walk_hot2_kernel" if regs == 2 else "walk_hot_big_kernel")
-    else:
-        name = "walk_reg_kernel<R=%d>" % (regs if ds.d_low == 32 else (1 if regs == 1 else 2 if regs == 2 else 4 if regs <= 4 else 8))
-    return name + (" (walk + fused re-rank)" if fused else "")
-
-
 def counters_for(config, ef):
     """Committed PMC figures of this configuration's dominant kernel (profiles/counters_latest.json, written from
     the rocprofv3 --pmc passes by tools/digest_profile.py); bench.py cannot read hardware counters itself."""
@@ -450,7 +437,8 @@ def roofline_of(ds, res, prof, ef, nq, max_degree, cfg, rank):
         # the walked tables (db_low + adjacency) of the 10^6-node shapes fit the 256 MB Infinity Cache: the peak the
         # fraction is taken against is still the HBM spec figure (8 TB/s), i.e. a ceiling for any mix of the two
         "served_from": "HBM + Infinity Cache (MALL)",
-        "kernel": kernel_name(ds, ef, max_degree, bool(cfg.get("negdot")), fused),
+        # the first-pass kernel the library launched (gbnns_profile.walk_kernel), template arguments included
+        "kernel": prof["walk_kernel"] + (" (walk + fused re-rank)" if fused else ""),
         "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cxxabi.h>
 #include <map>
 #include <new>
 #include <string>
@@ -938,6 +939,8 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     // keeps its visited sets as bitmaps in HBM and runs as many persistent wavefronts as the LDS holds result
     // lists (LDS-list kernel); taken when that at least doubles the resident wavefronts.
     size_t bitmap_per_cu = 0;
+    const bool want_fuse = !plain && ix->d % 8 == 0 && !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
+    w.rr_reserve = want_fuse ? (uint32_t)ix->d_pad * 4u : 0u;
     {
         // measured crossover on the GloVe-like shape: ef = 300 is faster with the register list + LDS table
         // (4.3 vs 5.5 ms), ef = 400 with the bitmap pass (7.1 vs 9.4 ms); SIFT-like ef <= 180 clearly the former
@@ -958,10 +961,9 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         }
     }
     // (the ef > 128 hot instance keeps its result list in LDS and stages the re-rank query in the visited-set area)
-    const size_t rr_room = bitmap_per_cu ? walk_bitmap_lds_bytes(w, ix->metric)
-                           : (hot && ef > 128 ? walk_hash_bytes(w.hash_cap, packed) : walk_fast_lds_bytes(w, hot));
-    const bool fuse = !walk_uses_lds_list(w) && (!bitmap_per_cu || walk_bitmap_uses_reg(w, ix->metric)) && !plain && !w.all_general && ix->d % 8 == 0 &&
-                      (size_t)ix->d_pad * 4 <= rr_room && !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
+    const size_t rr_room = walk_rr_room(w, ix->metric, hot, bitmap_per_cu != 0);
+    const bool fuse = !walk_uses_lds_list(w) && (!bitmap_per_cu || walk_bitmap_uses_reg(w, ix->metric)) && want_fuse && !w.all_general &&
+                      (size_t)ix->d_pad * 4 <= rr_room;
     if (fuse) {
         w.rr_q = q_dev; w.rr_qstride = ix->d; w.rr_db = ix->db; w.rr_dstride = ix->d_pad; w.rr_dim = ix->d;
         w.rr_n = (uint32_t)ix->n; w.rr_out = out_dev; w.rr_metric = ix->metric;
@@ -999,7 +1001,23 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
             HIP_TRY(hipMemcpyAsync(w.ovf2_list, w.ovf_list, (size_t)nq * 4, hipMemcpyDeviceToDevice, s));
         }
     }
-    if (prof) HIP_TRY(hipEventRecord(pc.ev[2], s));
+    if (prof) {
+        HIP_TRY(hipEventRecord(pc.ev[2], s));
+        // name of the first-pass kernel of this call, template arguments included ("walk_general_kernel" when there was none)
+        const char* mangled = w.all_general ? nullptr : walk_first_pass_name(s);
+        std::string name = "walk_general_kernel";
+        if (mangled) {
+            int st = 0;
+            char* dm = abi::__cxa_demangle(mangled, nullptr, nullptr, &st);
+            name = (st == 0 && dm) ? dm : mangled;
+            std::free(dm);
+            size_t pos = name.find("walk_");  // drop "void gbnns::(anonymous namespace)::" and the parameter list
+            if (pos != std::string::npos) name = name.substr(pos);
+            pos = name.rfind("(gbnns::WalkParams)");
+            if (pos != std::string::npos) name = name.substr(0, pos);
+        }
+        std::snprintf(ix->acc.walk_kernel, sizeof(ix->acc.walk_kernel), "%s", name.c_str());
+    }
     HIP_TRY(launch_walk_general(w, ix->metric, s));
     ix->ctrl_clean[cur ^ 1] = true;  // cleared by that launch
     if (prof) HIP_TRY(hipEventRecord(pc.ev[3], s));

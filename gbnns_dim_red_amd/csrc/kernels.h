@@ -51,6 +51,7 @@ struct WalkParams {
     // first pass with the visited set in HBM (large ef): per-slot bitmaps and the work-queue head
     uint32_t* fp_bitmap;     // [slots x bitmap_words]
     uint32_t* fp_cursor;     // [1]
+    uint32_t rr_reserve;     // bytes the bitmap first pass of the two-list kernel sets aside for the re-rank query (0: none)
     uint32_t* g_cursor;      // [1] work-queue head
     uint32_t* g_total;       // [1] running count of queries the general kernel processed
     uint32_t* max_dc;        // [1] max dist_calc over the batch (feeds the host's visited-set sizing)
@@ -91,6 +92,8 @@ hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_general(const WalkParams& p, int metric, hipStream_t s);
 bool walk_bitmap_uses_reg(const WalkParams& p, int metric);
 size_t walk_bitmap_lds_bytes(const WalkParams& p, int metric);
+const char* walk_first_pass_name(hipStream_t s);  // (mangled) name of the first-pass kernel this thread launched last
+size_t walk_rr_room(const WalkParams& p, int metric, bool hot, bool bitmap_pass);  // LDS the fused re-rank may stage its query in
 hipError_t launch_walk_bitmap(const WalkParams& p, int metric, unsigned slots, hipStream_t s);  // persistent first pass, HBM bitmaps
 
 // Re-rank (search_function.h:105-125).  One query per wavefront, one candidate per lane.

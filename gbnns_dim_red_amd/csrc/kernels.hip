@@ -1692,6 +1692,9 @@ struct BigList {
         //   pred = runner-up id, -1 when there is none or the two runner-up candidates have equal distances
         uint32_t ok, fb, q1, q2, hf1, hf2, nf1, nf2, hw, ha, na, hb, nb2, hr, t0;
         uint64_t fm;
+        // (rfl: a no-op where the compiler already keeps the cache in scalar registers; where it chose vector registers for
+        // it -- it may, the values come out of LDS -- the asm below still gets scalars)
+        auto rfl = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
         asm volatile(
             "v_and_b32 %[t0], 1, %[flo]\n\t"
             "v_cmp_eq_u32 vcc, 0, %[t0]\n\t"
@@ -1734,7 +1737,7 @@ struct BigList {
             : [ok] "=&s"(ok), [fb] "=&s"(fb), [q1] "=&s"(q1), [q2] "=&s"(q2), [hf1] "=&s"(hf1), [hf2] "=&s"(hf2),
               [nf1] "=&s"(nf1), [nf2] "=&s"(nf2), [hw] "=&s"(hw), [ha] "=&s"(ha), [na] "=&s"(na), [hb] "=&s"(hb),
               [nb2] "=&s"(nb2), [hr] "=&s"(hr), [t0] "=&v"(t0), [fm] "=&s"(fm), [node] "=&s"(node), [pred] "=&s"(pred)
-            : [flo] "v"(F.lo[0]), [fhi] "v"(F.hi[0]), [h1] "s"(h1), [n1] "s"(n1), [h2] "s"(h2), [n2] "s"(n2), [ts] "s"(tsize)
+            : [flo] "v"(F.lo[0]), [fhi] "v"(F.hi[0]), [h1] "s"(rfl(h1)), [n1] "s"(rfl(n1)), [h2] "s"(rfl(h2)), [n2] "s"(rfl(n2)), [ts] "s"(rfl((uint32_t)tsize))
             : "vcc", "scc");
         h2k = hr;
         if (__builtin_expect(ok != 0, 1)) {
@@ -2343,7 +2346,10 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                 // sequential offers either way)
                 const uint64_t ma = kPair ? m : (m & 0xFFFFFFFFull), mb = kPair ? 0ull : (m & 0xFFFFFFFF00000000ull);
                 if (ma && !B.insert(ma, dk, nb, lane)) { status = 2; break; }
-                if (mb && !B.insert(mb, dk, nb, lane)) { status = 2; break; }
+                if (!kPair && mb) {
+                    const uint64_t mb2 = (B.l + B.f < ef) ? mb : (mb & __ballot(dk < B.worst));  // the first half may have lowered the bar
+                    if (mb2 && !B.insert(mb2, dk, nb, lane)) { status = 2; break; }
+                }
             }
         }
         if (status) break;
@@ -2938,6 +2944,20 @@ __global__ __launch_bounds__(64) void walk_bitmap_reg_kernel(WalkParams p) {
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
         if (w >= p.nq) break;
         walk_reg_one<METRIC, 8, true, R, false, false, true>(p, w, smem, p.ovf_count, p.ovf_list, bitmap);
+        wave_sync();
+    }
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(64) void walk_bitmap_big_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* bitmap = p.fp_bitmap + (size_t)blockIdx.x * p.bitmap_words;
+    while (true) {
+        uint32_t w = 0;
+        if (lane_id() == 0) w = atomicAdd(p.fp_cursor, 1u);
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
+        if (w >= p.nq) break;
+        walk_reg_big_one<METRIC, 8, true, false, true>(p, w, smem, p.ovf_count, p.ovf_list, bitmap);
         wave_sync();
     }
 }
@@ -3817,7 +3837,8 @@ size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_li
         return ef <= 64 ? (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8
                         : (ef <= kHot2MaxEf ? (size_t)kRegTieCap * 8 + (size_t)(64 * 2 + 2) * 8 : big_list_fixed_bytes(ef));
     if (ef <= kRegListMaxEf && !lds_list) {  // tie list + merge buffer (ranks 0..ef of the 1 / 2 / 4-register list) + query
-        const int regs = ef <= 64 ? 1 : (ef <= 128 ? 2 : (ef <= 256 ? 4 : 8));
+        if (ef > kHot2MaxEf) return big_list_fixed_bytes(ef) + (size_t)dstride * 4;  // walk_reg_big_one
+        const int regs = ef <= 64 ? 1 : 2;
         return (size_t)kRegTieCap * 8 + (size_t)(64 * regs + 2) * 8 + (size_t)dstride * 4;
     }
     const size_t ef_pad = ((size_t)ef + 63) & ~(size_t)63;
@@ -3847,10 +3868,20 @@ static hipError_t set_lds(K kernel, size_t bytes) {
     return hipSuccess;
 }
 
+// Host function of the last first-pass walk kernel this thread launched (profiling: gbnns_profile.walk_kernel).
+extern thread_local const void* g_walk_first_fn;
+#if GBNNS_TU == 0
+thread_local const void* g_walk_first_fn = nullptr;
+const char* walk_first_pass_name(hipStream_t s) {
+    return g_walk_first_fn ? hipKernelNameRefByPtr(g_walk_first_fn, s) : nullptr;
+}
+#endif
+
 template <typename K>
 static hipError_t launch_walk_k(K kernel, const WalkParams& p, bool retry, size_t lds, hipStream_t s) {
     hipError_t e = set_lds(kernel, lds);
     if (e != hipSuccess) return e;
+    if (!retry) g_walk_first_fn = reinterpret_cast<const void*>(kernel);
     const unsigned grid = retry ? (unsigned)kRetrySlots : p.nq;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), lds, s, p);
     return hipGetLastError();
@@ -3860,6 +3891,21 @@ template <int METRIC, int STEPS, int R>
 static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipStream_t s) {
     // 32-bit byte offsets when both tables are < 4 GiB
     const bool off32 = walk_off32(p);
+    if constexpr (R >= 4) {
+        // ef > 128: base list in LDS + front list in one register (walk_reg_big_one), whatever the shape
+        if constexpr (METRIC == 0 && STEPS == 8) {
+            if (!retry && walk_uses_hot(p, METRIC))
+                return launch_walk_k(walk_hot_big_kernel, p, false, walk_fast_lds_bytes(p, true), s);
+        }
+        if (p.aux_ell)
+            return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, true, true>, p, true, lds, s)
+                         : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, true>, p, false, lds, s);
+        if (off32)
+            return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, true>, p, true, lds, s)
+                         : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false>, p, false, lds, s);
+        return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, false, true>, p, true, lds, s)
+                     : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, false, false>, p, false, lds, s);
+    } else {
     if (p.aux_ell)  // auxiliary-graph walk (32-bit offsets only; otherwise launch_fast_t took the LDS-list kernel)
         return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, true, R, false, true>, p, true, lds, s)
                      : launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, R, false, true>, p, false, lds, s);
@@ -3873,30 +3919,17 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
         if (off32 && !retry && p.ell_stride <= (STEPS == 8 ? 32u : 64u))
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
     }
-    if constexpr (R >= 2 && METRIC == 0 && STEPS == 8) {
-        // the hot shape beyond ef = 64: two list registers up to 128 (measured: 0.85 vs 0.93 ms at ef = 128), then the
-        // base list in LDS + front list in a register, one kernel for every ef up to 512
+    if constexpr (R == 2 && METRIC == 0 && STEPS == 8) {
+        // the hot shape, 64 < ef <= 128: two list registers (measured: 0.85 ms against 0.93 ms with the two-list structure)
         if (!retry && walk_uses_hot(p, METRIC))
-            return launch_walk_k(p.ef <= kHot2MaxEf ? walk_hot2_kernel : walk_hot_big_kernel, p, false, walk_fast_lds_bytes(p, true), s);
-    }
-    if constexpr ((R == 4 || R == 8) && STEPS == 8) {
-        // 128-byte rows that the hot instances do not take (dot metric, adjacency rows of more than 32 slots): the
-        // first pass still gets the fewest registers that hold ef entries -- a merge costs per register
-        if (!retry && off32 && !walk_uses_hot(p, METRIC)) {
-            switch ((p.ef + 63) / 64) {
-                case 3: return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 3>, p, false, lds, s);
-                case 5: return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 5>, p, false, lds, s);
-                case 6: return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 6>, p, false, lds, s);
-                case 7: return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 7>, p, false, lds, s);
-                default: break;
-            }
-        }
+            return launch_walk_k(walk_hot2_kernel, p, false, walk_fast_lds_bytes(p, true), s);
     }
     if (off32)
         return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, true, R>, p, true, lds, s)
                      : launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, R>, p, false, lds, s);
     return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, false, true, R>, p, true, lds, s)
                  : launch_walk_k(walk_reg_kernel<METRIC, STEPS, false, false, R>, p, false, lds, s);
+    }
 }
 
 // ef <= 64: one list register per lane (all row-length specialisations); ef <= 128 / 256: two / four
@@ -3964,13 +3997,23 @@ bool walk_bitmap_uses_reg(const WalkParams& p, int metric) {
 
 // LDS of the bitmap first pass: result list (or merge buffer) + tie list + query (no visited table)
 size_t walk_bitmap_lds_bytes(const WalkParams& p, int metric) {
-    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, false, !walk_bitmap_uses_reg(p, metric));
+    const bool reg = walk_bitmap_uses_reg(p, metric);
+    // (two-list kernel: the re-rank query cannot overlay the base list it reads its candidates from)
+    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, false, !reg) + (reg && p.ef > kHot2MaxEf ? p.rr_reserve : 0u);
+}
+
+// Room the fused re-rank has for the original-space query (it is staged once the walk is over).
+size_t walk_rr_room(const WalkParams& p, int metric, bool hot, bool bitmap_pass) {
+    if (bitmap_pass) return walk_bitmap_uses_reg(p, metric) && p.ef > kHot2MaxEf ? (size_t)p.rr_reserve : walk_bitmap_lds_bytes(p, metric);
+    if (p.ef > kHot2MaxEf && !walk_uses_lds_list(p)) return walk_hash_bytes(p.hash_cap, walk_uses_packed(p));  // two-list kernels: the visited-set area
+    return walk_fast_lds_bytes(p, hot);
 }
 
 template <int R>
 static hipError_t launch_bitmap_reg(const WalkParams& p, unsigned slots, size_t lds, hipStream_t s) {
     hipError_t e = set_lds(walk_bitmap_reg_kernel<0, R>, lds);
     if (e != hipSuccess) return e;
+    g_walk_first_fn = reinterpret_cast<const void*>(walk_bitmap_reg_kernel<0, R>);
     hipLaunchKernelGGL((walk_bitmap_reg_kernel<0, R>), dim3(slots), dim3(64), lds, s, p);
     return hipGetLastError();
 }
@@ -3979,28 +4022,28 @@ hipError_t launch_walk_bitmap(const WalkParams& p, int metric, unsigned slots, h
     if (p.nq == 0) return hipSuccess;
     const size_t lds = walk_bitmap_lds_bytes(p, metric);
     if (walk_bitmap_uses_reg(p, metric)) {
-        switch ((p.ef + 63) / 64) {
-            case 1: return launch_bitmap_reg<1>(p, slots, lds, s);
-            case 2: return launch_bitmap_reg<2>(p, slots, lds, s);
-            case 3: return launch_bitmap_reg<3>(p, slots, lds, s);
-            case 4: return launch_bitmap_reg<4>(p, slots, lds, s);
-            case 5: return launch_bitmap_reg<5>(p, slots, lds, s);
-            case 6: return launch_bitmap_reg<6>(p, slots, lds, s);
-            case 7: return launch_bitmap_reg<7>(p, slots, lds, s);
-            default: return launch_bitmap_reg<8>(p, slots, lds, s);
-        }
+        if (p.ef <= 64) return launch_bitmap_reg<1>(p, slots, lds, s);
+        if (p.ef <= kHot2MaxEf) return launch_bitmap_reg<2>(p, slots, lds, s);
+        hipError_t e = set_lds(walk_bitmap_big_kernel<0>, lds);
+        if (e != hipSuccess) return e;
+        g_walk_first_fn = reinterpret_cast<const void*>(walk_bitmap_big_kernel<0>);
+        hipLaunchKernelGGL((walk_bitmap_big_kernel<0>), dim3(slots), dim3(64), lds, s, p);
+        return hipGetLastError();
     }
     if (metric == 1) {
         hipError_t e = set_lds(walk_bitmap_kernel<1, 0>, lds);
         if (e != hipSuccess) return e;
+        g_walk_first_fn = reinterpret_cast<const void*>(walk_bitmap_kernel<1, 0>);
         hipLaunchKernelGGL((walk_bitmap_kernel<1, 0>), dim3(slots), dim3(64), lds, s, p);
     } else if (p.dstride == p.dim && p.dim == 32) {
         hipError_t e = set_lds(walk_bitmap_kernel<0, 8>, lds);
         if (e != hipSuccess) return e;
+        g_walk_first_fn = reinterpret_cast<const void*>(walk_bitmap_kernel<0, 8>);
         hipLaunchKernelGGL((walk_bitmap_kernel<0, 8>), dim3(slots), dim3(64), lds, s, p);
     } else {
         hipError_t e = set_lds(walk_bitmap_kernel<0, 0>, lds);
         if (e != hipSuccess) return e;
+        g_walk_first_fn = reinterpret_cast<const void*>(walk_bitmap_kernel<0, 0>);
         hipLaunchKernelGGL((walk_bitmap_kernel<0, 0>), dim3(slots), dim3(64), lds, s, p);
     }
     return hipGetLastError();

@@ -202,6 +202,7 @@ typedef struct {
     double total_ms;              /* first launch .. last launch of each call */
     uint64_t queries;             /* queries processed */
     uint64_t general_queries;     /* of which were (re)run by the general kernel */
+    char walk_kernel[96];         /* first-pass walk kernel of the last profiled call, template arguments included */
 } gbnns_profile;
 
 int gbnns_profile_enable(gbnns_index* index, int on);

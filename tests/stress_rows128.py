@@ -2,7 +2,9 @@
 """Stress (GPU box; lives under tests/ because it uses the oracle as the checker, but it is not collected by
 pytest): many seeded random configurations with 128-byte walked rows against the oracle -- two-stage NET mode
 (fused re-rank) and PLAIN walks, both metrics, auxiliary graphs.
-usage: python tests/stress_rows128.py [seed] [cases] [only_case]"""
+usage: python tests/stress_rows128.py [seed] [cases] [only_case] [any]
+With a fourth argument "any" the walked rows take other lengths too (64 .. 400 bytes: the 12- / 16-step and generic
+distance instantiations)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +15,7 @@ orc = oracle.Oracle()
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 only = int(sys.argv[3]) if len(sys.argv) > 3 else -1  # replay the generator, run just this case, print details
+any_rows = len(sys.argv) > 4 and sys.argv[4] == "any"
 rng = np.random.Generator(np.random.PCG64(seed))
 bad = 0
 for case in range(cases):
@@ -21,7 +24,14 @@ for case in range(cases):
     metric = int(rng.integers(0, 2))
     net_mode = bool(rng.integers(0, 2))
     d = int(rng.choice([32, 64, 96, 128])) if net_mode else 32
-    c = datagen.Case("s", 9000 + seed * 1000 + case, n, nq, d, 32 if net_mode else 4, int(rng.choice([16, 40])), kind=kind)
+    d_low = 32
+    if any_rows:
+        walked = int(rng.choice([16, 48, 64, 100, 32]))
+        if net_mode:
+            d, d_low = max(d, walked), walked
+        else:
+            d = walked
+    c = datagen.Case("s", 9000 + seed * 1000 + case, n, nq, d, d_low if net_mode else 4, int(rng.choice([16, 40])), kind=kind)
     deg_hi = int(rng.choice([5, 17, 32, 33, 64, 70]))
     off, nbr = datagen.random_graph(rng, n, 0, min(deg_hi, n - 1))
     ent = rng.integers(0, n, size=nq).astype(np.uint32)

@@ -22,7 +22,10 @@ def short(name):
             retry = len(args) > idx and args[idx] in ("true", "1")
             regs = "/R%s" % args[4] if key == "walk_reg_kernel" and len(args) > 4 and args[4] != "1" else ""
             return key + regs + ("/retry" if retry else "")
-    for key in ("walk_hot_big_kernel", "walk_hot2_kernel", "mlp_fused_kernel", "walk_bitmap_reg_kernel", "walk_bitmap_kernel",
+    if "walk_reg_big_kernel" in name:  # walk_reg_big_kernel<METRIC, STEPS, OFF32, RETRY, AUX>
+        args = name[name.find("<") + 1:name.rfind(">")].replace(" ", "").split(",")
+        return "walk_reg_big_kernel" + ("/retry" if len(args) > 3 and args[3] in ("true", "1") else "")
+    for key in ("walk_bitmap_big_kernel", "walk_hot_big_kernel", "walk_hot2_kernel", "mlp_fused_kernel", "walk_bitmap_reg_kernel", "walk_bitmap_kernel",
                 "mlp_narrow_kernel", "gd_prune_kernel", "knn_scan_kernel"):
         if key in name:
             return key
