@@ -35,7 +35,7 @@ def test_struct_sizes_match_header(lib):
     # 8-byte aligned C layouts as declared in include/gbnns.h
     assert ctypes.sizeof(binding._IndexDesc) == 96
     assert ctypes.sizeof(binding._SearchArgs) == 136  # + n_entries, reserved2
-    assert ctypes.sizeof(binding.Profile) == 64
+    assert ctypes.sizeof(binding.Profile) == 160  # + walk_kernel[96]
 
 
 def test_shard_bounds_arithmetic(lib):
