@@ -1435,6 +1435,10 @@ struct BigList {
     bool c_valid;
     int p1, p2;             // ranks, -1 = none
     uint32_t h1, n1, h2, n2;
+#ifdef GBNNS_STAMPS
+    unsigned long long st_flush = 0, st_refresh = 0, st_evict = 0;  // cycles inside flush / refresh_cache / the eviction step
+    unsigned st_nflush = 0, st_nrefresh = 0, st_nbase = 0, st_nseq = 0, st_ninsert = 0, st_slow = 0;
+#endif
 
     // NOTE on lane-dependent updates: they are written as selects / unconditional same-value stores, never as
     // `if (lane == x) ...`.  A lane-dependent branch inside these functions lets the optimiser thread scalar list
@@ -1467,6 +1471,10 @@ struct BigList {
     }
     // the two lowest set bits of the masks -> (p1, h1, n1), (p2, h2, n2)
     __device__ __forceinline__ void refresh_cache(int lane) {
+        STAMP(tr0)
+#ifdef GBNNS_STAMPS
+        st_nrefresh += 1;
+#endif
         p1 = p2 = -1;
         h1 = h2 = 0xFFFFFFFFu;
         n1 = n2 = 0u;
@@ -1495,10 +1503,17 @@ struct BigList {
             }
         }
         c_valid = true;
+        STAMP(tr1)
+#ifdef GBNNS_STAMPS
+        st_refresh += tr1 - tr0;
+#endif
     }
     // marks base rank `p` expanded: the key's flag bit in LDS and the mask bit
     __device__ __forceinline__ void expand_base(int p, int lane) {
         p = __builtin_amdgcn_readfirstlane(p);  // wave-uniform by construction; tell the compiler
+#ifdef GBNNS_STAMPS
+        st_nbase += 1;
+#endif
         reinterpret_cast<uint32_t*>(base)[2 * p] |= 1u;  // (every lane: same address, same value)
         const int c = p >> 6;
         uint64_t m = ((uint64_t)readlane_u32(mu_hi, c) << 32) | readlane_u32(mu_lo, c);
@@ -1512,6 +1527,7 @@ struct BigList {
     // the front register holds all-ones, the masks and the cache are rebuilt lazily.
     __device__ __forceinline__ void flush(int lane) {
         if (f == 0) return;
+        STAMP(tf0)
         l = __builtin_amdgcn_readfirstlane(l);  // wave-uniform by construction; tell the compiler (loop counters
         f = __builtin_amdgcn_readfirstlane(f);  // below index lanes through scalar registers)
         const int total = l + f;
@@ -1571,6 +1587,11 @@ struct BigList {
         f = 0;
         F.clear();
         c_valid = false;
+        STAMP(tf1)
+#ifdef GBNNS_STAMPS
+        st_flush += tf1 - tf0;
+        st_nflush += 1;
+#endif
     }
 
     // One offer with the reference's rule (search_function.h:31-37): the sequential path (single survivors into a full
@@ -1628,6 +1649,7 @@ struct BigList {
                 reg_offer<1>(readlane_u32(dk, sl), readlane_u32(nb, sl) << 1, F, f, fworst, ts_unused, tie, 64, lane);
             }
             const int E = l + f - ef;
+            STAMP(te0)
             if (E > 0) {
                 // lane j: "the base list drops its top j entries, the front list its top E - j" (0 <= j <= E <= 32)
                 const int j = lane;
@@ -1667,10 +1689,18 @@ struct BigList {
             } else if (E == 0) {
                 worst = union_worst();  // the union just became full
             }
+            STAMP(te1)
+#ifdef GBNNS_STAMPS
+            st_evict += te1 - te0;
+            st_ninsert += 1;
+#endif
         } else {
             sequential = true;  // a single survivor into a full union: one offer
         }
         if (sequential) {
+#ifdef GBNNS_STAMPS
+            st_nseq += 1;
+#endif
             do {
                 const int sl = __ffsll((unsigned long long)m) - 1;
                 m &= m - 1;
@@ -1749,6 +1779,9 @@ struct BigList {
         h2k = 0xFFFFFFFFu;
         const int pF = (int)q1;
         const uint32_t hF1 = hf1;
+#ifdef GBNNS_STAMPS
+        st_slow += 1;
+#endif
         // rare: equal distances among the closest unexpanded entries, a non-empty tie list, or the end
         const bool any = p1 >= 0 || pF >= 0;
         const uint32_t hi_p = h1 < hF1 ? h1 : hF1;
@@ -2216,6 +2249,11 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
     constexpr uint32_t kChunk = kPair ? 32u : 64u;
     constexpr uint64_t kSlotLanes = kPair ? 0x5555555555555555ull : ~0ull;
     const int lane = lane_id();
+#ifdef GBNNS_STAMPS  // diagnostic build: cycles per segment of the hop (tools/stamps.py)
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    STAMP(t_begin)
+    unsigned long long t_prev = t_begin;
+#endif
     const uint32_t slot = kPair ? (uint32_t)lane >> 1 : (uint32_t)lane;
     const uint32_t half = kPair ? (uint32_t)lane & 1u : 0u;
     const int ef = p.ef;
@@ -2262,7 +2300,11 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
     uint32_t pf_node = kInvalidId, pf_val = kInvalidId;
     while (true) {
         uint32_t node, pred, h2;
+        STAMP(t0)
+        STAMP_ADD(7, t_prev, t0)
         if (!B.select(node, pred, h2, lane)) { status = 1; break; }
+        STAMP(t1)
+        STAMP_ADD(0, t0, t1)
         // ---- adjacency row of `node` (prefetched or loaded now), then the prefetch for the next hop
         const uint32_t* row = reinterpret_cast<const uint32_t*>(
             row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), node, p.ell_stride));
@@ -2270,6 +2312,8 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
         if (node == pf_node) nb0 = pf_val;
         else nb0 = (slot < p.ell_stride) ? row[slot] : kInvalidId;
         const uint64_t mv0 = __ballot(nb0 != kInvalidId);  // consumed BEFORE the prefetch is issued
+        STAMP(t2)
+        STAMP_ADD(1, t1, t2)
         pf_node = pred;
         if (pred != kInvalidId)
             pf_val = (slot < p.ell_stride) ? reinterpret_cast<const uint32_t*>(row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), pred, p.ell_stride))[slot] : kInvalidId;
@@ -2295,6 +2339,8 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
             if constexpr (!BITMAP)
                 if ((uint32_t)dist_calc + 64u > p.hash_limit) { status = 2; break; }
             const bool valid = nb != kInvalidId;
+            STAMP(t3)
+            if (c == 0 && !is_aux) { STAMP_ADD(2, t2, t3) }
             edges += __popcll(mv & kSlotLanes);
             RowRegs<kQSteps> rr;
             uint32_t roff = 0;
@@ -2321,6 +2367,8 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
             } else if constexpr (packed) mclaimed = visited_claim_mask_packed(hash_lds, nbuckets, nb, mv & kSlotLanes);
             else mclaimed = visited_claim_mask(hash_lds, nbuckets, nb, mv & kSlotLanes);
             const uint64_t mfresh = kPair ? (mclaimed << 1) : mclaimed;
+            STAMP(t4)
+            STAMP_ADD(3, t3, t4)
             const bool fresh = __builtin_amdgcn_inverse_ballot_w64(mfresh);
             uint32_t dk = 0xFFFFFFFFu;
             if constexpr (kEarlyLoad) {
@@ -2339,6 +2387,8 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
             }
             dist_calc += __popcll(mfresh);
             const uint64_t m = (B.l + B.f < ef) ? mfresh : __ballot(fresh && dk < B.worst);
+            STAMP(t5)
+            STAMP_ADD(4, t4, t5)
             if (m) {
                 if (AUX) found = true;  // the first of them is inserted whatever happens to the others
                 // BigList::insert takes up to 32 survivors (its eviction step is one lane per split): the two halves of
@@ -2351,6 +2401,11 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                     if (mb2 && !B.insert(mb2, dk, nb, lane)) { status = 2; break; }
                 }
             }
+            STAMP(t6)
+            STAMP_ADD(5, t5, t6)
+#ifdef GBNNS_STAMPS
+            t_prev = t6;
+#endif
         }
         if (status) break;
         }
@@ -2358,6 +2413,20 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
         hops += 1;
     }
 
+#ifdef GBNNS_STAMPS
+    {
+        STAMP(t_end)
+        seg[6] = t_end - t_begin;
+        if (lane == 0 && p.stamps) {
+            for (int i = 0; i < 7; ++i) atomicAdd(p.stamps + i, seg[i]);
+            atomicAdd(p.stamps + 30, seg[7]);
+            atomicAdd(p.stamps + 21, B.st_flush); atomicAdd(p.stamps + 22, B.st_refresh); atomicAdd(p.stamps + 23, B.st_evict);
+            atomicAdd(p.stamps + 24, (unsigned long long)B.st_nflush); atomicAdd(p.stamps + 25, (unsigned long long)B.st_nrefresh);
+            atomicAdd(p.stamps + 26, (unsigned long long)B.st_nbase); atomicAdd(p.stamps + 27, (unsigned long long)B.st_nseq);
+            atomicAdd(p.stamps + 28, (unsigned long long)B.st_ninsert); atomicAdd(p.stamps + 29, (unsigned long long)B.st_slow);
+        }
+    }
+#endif
     if (status == 2) {
         if (lane == 0) {
             const uint32_t s = atomicAdd(ovf_count, 1u);

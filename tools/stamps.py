@@ -30,5 +30,11 @@ for ef in (int(a) for a in (sys.argv[1:] or ["64"])):
     h = [buf[8 + i] for i in range(13)]
     lab = ["0", "1", "2", "3", "4", "5-8", "9-16", "17+"]
     print("   survivors/hop histogram: " + "  ".join(f"{lab[i]}:{100.0*h[i]/max(sum(h[:8]),1):.1f}%" for i in range(8)))
+    if buf[30]:
+        print(f"   loop latch (insert end -> next select) {buf[30]/hops:.0f} cycles/hop")
+    if any(buf[21:30]):
+        print(f"   two-list structure: flush {buf[21]/hops:.0f} cycles/hop ({buf[24]/hops:.3f} flushes/hop, {buf[21]/max(buf[24],1):.0f} cycles each), "
+              f"refresh_cache {buf[22]/hops:.0f} cycles/hop ({buf[25]/hops:.3f}/hop, {buf[22]/max(buf[25],1):.0f} each), eviction step {buf[23]/hops:.0f} cycles/hop "
+              f"({buf[28]/hops:.3f} batch inserts/hop); base expansions {buf[26]/hops:.3f}/hop, sequential fallbacks {buf[27]/hops:.4f}/hop, slow selects {buf[29]/hops:.4f}/hop")
     print(f"   merges {h[8]/hops:.3f}/hop  merge fallbacks {h[9]/hops:.4f}/hop  sequential offers {h[10]/hops:.3f}/hop  "
           f"fast selects {h[11]/hops:.3f}/hop  probe iterations {h[12]/hops:.3f}/hop")
