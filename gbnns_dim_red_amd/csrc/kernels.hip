@@ -2877,6 +2877,11 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
 
 __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, unsigned char* smem) {
     const int lane = lane_id();
+#ifdef GBNNS_STAMPS  // diagnostic build: cycles per segment of the hop (tools/stamps.py)
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    STAMP(t_begin)
+    unsigned long long t_prev = t_begin;
+#endif
     const uint32_t slot = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;  // lane = 2 * adjacency slot + row half
     const int ef = p.ef;
     BigList B;
@@ -2923,7 +2928,11 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
 
     while (true) {
         uint32_t node, pred, h2;
+        STAMP(t0)
+        STAMP_ADD(7, t_prev, t0)
         if (!B.select(node, pred, h2, lane)) break;
+        STAMP(t1)
+        STAMP_ADD(0, t0, t1)
 
         // ---- adjacency row of `node` (prefetched, or loaded now), then the prefetch for the next hop
         uint32_t nb;
@@ -2933,17 +2942,23 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
         nb = slot_ok ? nb : kInvalidId;
         pf2_node = kInvalidId;
         const uint64_t mv = __ballot(nb != kInvalidId);
+        STAMP(t2)
+        STAMP_ADD(1, t1, t2)
         pf_node = pred;
         if (pred != kInvalidId) pf_val = *reinterpret_cast<const uint32_t*>(ell_base + pred * ell_row_bytes + slot_off);
         if (__builtin_expect(mv != 0, 1)) {
             if (__builtin_expect((uint32_t)dist_calc > dc_limit, 0)) { handed_over = true; break; }
             edges += __popcll(mv & 0x5555555555555555ull);
+            STAMP(t3)
+            STAMP_ADD(2, t2, t3)
             uint64_t mclaimed;
             const uint32_t kd = hot_expand(db_base, (nb << 7) + half * 64u, nb, mv, hash_lds, nbuckets, qreg.v, mclaimed);
             const uint64_t mfresh = mclaimed << 1;  // odd lanes hold the distances
             const uint32_t dk = __builtin_amdgcn_inverse_ballot_w64(mfresh) ? kd : 0xFFFFFFFFu;
             dist_calc += __popcll(mfresh);
             const uint64_t m = (B.l + B.f < ef) ? mfresh : __ballot(dk < B.worst);
+            STAMP(t5)
+            STAMP_ADD(4, t3, t5)
             if (m != 0) {
                 // prefetch 2: a unique survivor closer than the runner-up is the next node
                 {
@@ -2963,10 +2978,29 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
                 }
                 if (!B.insert(m, dk, nb, lane)) { handed_over = true; break; }
             }
+            STAMP(t6)
+            STAMP_ADD(5, t5, t6)
+#ifdef GBNNS_STAMPS
+            t_prev = t6;
+#endif
         }
         hops += 1;
     }
 
+#ifdef GBNNS_STAMPS
+    {
+        STAMP(t_end)
+        seg[6] = t_end - t_begin;
+        if (lane == 0 && p.stamps) {
+            for (int i = 0; i < 7; ++i) atomicAdd(p.stamps + i, seg[i]);
+            atomicAdd(p.stamps + 30, seg[7]);
+            atomicAdd(p.stamps + 21, B.st_flush); atomicAdd(p.stamps + 22, B.st_refresh); atomicAdd(p.stamps + 23, B.st_evict);
+            atomicAdd(p.stamps + 24, (unsigned long long)B.st_nflush); atomicAdd(p.stamps + 25, (unsigned long long)B.st_nrefresh);
+            atomicAdd(p.stamps + 26, (unsigned long long)B.st_nbase); atomicAdd(p.stamps + 27, (unsigned long long)B.st_nseq);
+            atomicAdd(p.stamps + 28, (unsigned long long)B.st_ninsert); atomicAdd(p.stamps + 29, (unsigned long long)B.st_slow);
+        }
+    }
+#endif
     if (handed_over) {
         if (lane == 0) {
             const uint32_t s = atomicAdd(p.ovf_count, 1u);
@@ -3895,7 +3929,7 @@ bool walk_uses_lds_list(const WalkParams& p) { return p.ef > kRegListMaxEf || (p
 
 bool walk_uses_hot(const WalkParams& p, int metric) {
     const bool off32 = walk_off32(p);
-    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 512 && p.ell_stride <= 32u && off32 && !p.stamps_on &&
+    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 512 && p.ell_stride <= 32u && off32 && (!p.stamps_on || (p.ef > kHot2MaxEf && !getenv("GBNNS_STAMPS_GENERIC"))) &&
            !p.aux_ell;  // (off32 includes n < 2^24: its visited set stores 24-bit ids)
 }
 

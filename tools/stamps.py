@@ -10,7 +10,7 @@ ds = synth.make_dataset(device="cuda:0", cache_dir=os.environ.get("GBNNS_CACHE",
 ix = ds.index()
 lib = g.load_library()
 lib.gbnns_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
-names = ["select", "row wait", "prefetch issue", "visited (hash)", "gather+dist", "inserts", "TOTAL wave life"]
+names = ["select", "row wait", "prefetch issue", "visited (hash)", "gather+dist (hot instance: + visited)", "inserts", "TOTAL wave life"]
 NQ = int(os.environ.get("NQ", len(ds.queries)))
 qsub = ds.queries[:NQ].contiguous()
 for ef in (int(a) for a in (sys.argv[1:] or ["64"])):
