@@ -2345,15 +2345,22 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
             RowRegs<kQSteps> rr;
             uint32_t roff = 0;
             if constexpr (kEarlyLoad) {
+                // Rows of 12 / 16 steps (48 / 64 registers per lane): EVERY lane loads -- empty slots read row 0, all of them
+                // the same lines -- so that the row registers are defined by this pass alone.  Loaded under `if (valid)`
+                // the other lanes keep "the previous value", the compiler carries 64 registers around the hop loop and
+                // copies them twice per hop (measured in the code object: 2 x 32 v_mov_b64 per hop on 256-byte rows).
+                constexpr bool kAllLanes = !kPair && kQSteps >= 12;
+                const uint32_t nbl = kAllLanes ? (valid ? nb : 0u) : nb;
+                const bool ld = kAllLanes || valid;
                 if constexpr (OFF32) {
-                    roff = kPair ? (nb << 7) + half * (kAlt ? 16u : 64u) : nb * (p.dstride * 4u);
+                    roff = kPair ? (nbl << 7) + half * (kAlt ? 16u : 64u) : nbl * (p.dstride * 4u);
                     const float* rp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff);
-                    if constexpr (kAlt) { if (valid) load_row_alt(rr, rp); }
-                    else { if (valid) load_row<kQSteps>(rr, rp); }
+                    if constexpr (kAlt) { if (ld) load_row_alt(rr, rp); }
+                    else { if (ld) load_row<kQSteps>(rr, rp); }
                 } else {
-                    const float* rp = row_ptr<OFF32>(p.db, nb, p.dstride) + half * (kAlt ? 4u : 16u);
-                    if constexpr (kAlt) { if (valid) load_row_alt(rr, rp); }
-                    else { if (valid) load_row<kQSteps>(rr, rp); }
+                    const float* rp = row_ptr<OFF32>(p.db, nbl, p.dstride) + half * (kAlt ? 4u : 16u);
+                    if constexpr (kAlt) { if (ld) load_row_alt(rr, rp); }
+                    else { if (ld) load_row<kQSteps>(rr, rp); }
                 }
             }
             uint64_t mclaimed;

@@ -6,8 +6,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import gbnns_dim_red_amd as g
 from gbnns_dim_red_amd import synth
-ds = synth.make_dataset(device="cuda:0", cache_dir=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"))
-ix = ds.index()
+# CONFIG=<bench.py configuration> (default sift): same synthetic recipe as the bench
+import bench
+cfg = bench.CONFIGS[os.environ.get("CONFIG", "sift")]
+kw = dict(n=cfg["n"], nq=cfg["nq"], d=cfg["d"], d_low=cfg["d_low"], d_hidden=cfg["d_hidden"], seed=1234)
+if cfg.get("unit_norm"):
+    kw["unit_norm"] = True
+ds = synth.make_dataset(device="cuda:0", cache_dir=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"), **kw)
+ix = ds.index(metric=g.METRIC_NEG_DOT if cfg.get("negdot") else g.METRIC_L2)
 lib = g.load_library()
 lib.gbnns_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 names = ["select", "row wait", "prefetch issue", "visited (hash)", "gather+dist (hot instance: + visited)", "inserts", "TOTAL wave life"]
