@@ -2239,7 +2239,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
 // the base list in LDS + the front list in one register, so that selection and insertion cost what they cost at
 // ef <= 64 whatever ef is (the R-register lists spent 28 % of a hop selecting and 30 % inserting at ef = 300).
 // LDS: [BigList: big_list_fixed_bytes(ef)][query: dstride floats][visited set | (BITMAP) re-rank scratch].
-template <int METRIC, int STEPS, bool OFF32, bool AUX = false, bool BITMAP = false>
+// ONE_PASS: adjacency rows of one pass (the host checks ell_stride), no auxiliary graph -- the hop is straight-line code.
+template <int METRIC, int STEPS, bool OFF32, bool AUX = false, bool BITMAP = false, bool ONE_PASS = false>
 __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                                  uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
     constexpr bool kEarlyLoad = (STEPS > 0);
@@ -2328,7 +2329,7 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
             grow = reinterpret_cast<const uint32_t*>(row_ptr<OFF32>(reinterpret_cast<const float*>(p.aux_ell), node, p.aux_stride));
             gstride = p.aux_stride;
         }
-        for (uint32_t c = 0; c < gstride; c += kChunk) {
+        for (uint32_t c = 0; c < (ONE_PASS ? 1u : gstride); c += kChunk) {
             uint32_t nb = nb0;
             uint64_t mv = mv0;
             if (c || is_aux) {
@@ -2349,7 +2350,7 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                 // the same lines -- so that the row registers are defined by this pass alone.  Loaded under `if (valid)`
                 // the other lanes keep "the previous value", the compiler carries 64 registers around the hop loop and
                 // copies them twice per hop (measured in the code object: 2 x 32 v_mov_b64 per hop on 256-byte rows).
-                constexpr bool kAllLanes = !kPair && kQSteps >= 12;
+                constexpr bool kAllLanes = kPair || kQSteps >= 12;
                 const uint32_t nbl = kAllLanes ? (valid ? nb : 0u) : nb;
                 const bool ld = kAllLanes || valid;
                 if constexpr (OFF32) {
@@ -2444,13 +2445,13 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
     B.finish(p, qi, hops, dist_calc, edges, after_q, lane);
 }
 
-template <int METRIC, int STEPS, bool OFF32, bool RETRY, bool AUX = false>
+template <int METRIC, int STEPS, bool OFF32, bool RETRY, bool AUX = false, bool ONE_PASS = false>
 __global__ __launch_bounds__(64) void walk_reg_big_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if constexpr (RETRY) {
         retry_loop(p, [&](uint32_t qi) { walk_reg_big_one<METRIC, STEPS, OFF32, AUX>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
     } else {
-        walk_reg_big_one<METRIC, STEPS, OFF32, AUX>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
+        walk_reg_big_one<METRIC, STEPS, OFF32, AUX, false, ONE_PASS>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
     }
 }
 
@@ -4010,9 +4011,13 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
         if (p.aux_ell)
             return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, true, true>, p, true, lds, s)
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, true>, p, false, lds, s);
-        if (off32)
+        if (off32) {
+            // the common shape (compact index, adjacency rows of one pass) gets the hop without the pass loop
+            if (!retry && p.ell_stride <= (STEPS == 8 ? 32u : 64u))
+                return launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, false, true>, p, false, lds, s);
             return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, true>, p, true, lds, s)
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false>, p, false, lds, s);
+        }
         return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, false, true>, p, true, lds, s)
                      : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, false, false>, p, false, lds, s);
     } else {
