@@ -1407,7 +1407,10 @@ __device__ __forceinline__ uint32_t reg_id_at_rank(const RegList<R>& L, int rank
 // sequential fallback on a boundary tie and the tie list work as before.  Nothing depends on R any more: one kernel.
 
 constexpr int kBigMaxEf = 512;
-constexpr int kHot2MaxEf = 128;  // up to here the two-register list of walk_hot_one<2> is the faster one
+#ifndef GBNNS_HOT2_MAX
+#define GBNNS_HOT2_MAX 128  // (64: experiments with the two-list kernels from ef = 65 on)
+#endif
+constexpr int kHot2MaxEf = GBNNS_HOT2_MAX;  // up to here the two-register lists (walk_hot_one<2>, walk_reg_one<2>) are the faster ones
 
 __device__ __forceinline__ uint64_t dpp_wave_shl1_u64(uint64_t v) {  // lane j <- lane j + 1
     const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x130, 0xf, 0xf, false);
@@ -4055,7 +4058,7 @@ static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) 
     constexpr int kWideSteps = (STEPS == 8) ? 8 : 0;
     // 256-byte rows (d_low = 64, the GIST shape, whose efs start at 200): the 4- and 8-register lists keep the
     // unrolled distance with early row loads as well
-    constexpr int kWideSteps48 = (STEPS == 8 || STEPS == 16) ? STEPS : 0;
+    constexpr int kWideSteps48 = (STEPS == 8 || STEPS == 12 || STEPS == 16) ? STEPS : 0;
     if (walk_uses_lds_list(p)) {
         if (walk_uses_packed(p))
             return retry ? launch_walk_k(walk_fast_kernel<METRIC, STEPS, true, true>, p, true, lds, s)
@@ -4064,9 +4067,8 @@ static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) 
                      : launch_walk_k(walk_fast_kernel<METRIC, STEPS, false, false>, p, false, lds, s);
     }
     if (p.ef <= 64) return launch_reg_t<METRIC, STEPS, 1>(p, retry, lds, s);
-    if (p.ef <= 128) return launch_reg_t<METRIC, kWideSteps, 2>(p, retry, lds, s);
-    if (p.ef <= 256) return launch_reg_t<METRIC, kWideSteps48, 4>(p, retry, lds, s);
-    return launch_reg_t<METRIC, kWideSteps48, 8>(p, retry, lds, s);
+    if (p.ef <= kHot2MaxEf) return launch_reg_t<METRIC, kWideSteps, 2>(p, retry, lds, s);
+    return launch_reg_t<METRIC, kWideSteps48, 4>(p, retry, lds, s);  // (R >= 4: the two-list kernels, one instance for every ef up to 512)
 }
 
 // the walk launchers of the other two compilation units of this file
