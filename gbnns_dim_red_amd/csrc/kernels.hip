@@ -1078,6 +1078,32 @@ __device__ __forceinline__ float l2_pair_from_regs(const RowRegs<4>& r, QP qh) {
 __device__ __forceinline__ float dpp_from_even(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xA0, 0xf, 0xf, false));
 }
+// Pair form of L2Metric::Dist for rows of 2 H steps (256-byte rows: H = 8), plain C++: the even lane of a pair holds steps
+// 0 .. H-1, the odd lane steps H .. 2H-1.  Every lane squares its H steps; chain A adds them in order onto the four
+// running sums (meaningful in the even lane: the reference's sums after step H-1; 0 + e*e == e*e), a quad-permute DPP
+// hands the even lane's sums to the odd lane, chain B continues there over steps H .. 2H-1; ((s0 + s1) + s2) + s3 as
+// the reference.  Same operations in the same order as one lane walking the whole row (support_func.h:107-128).
+template <int H, typename QP>
+__device__ __forceinline__ float l2_pair_from_regs_wide(const RowRegs<H>& r, QP qh) {
+    float4 e[H];
+#pragma unroll
+    for (int t = 0; t < H; ++t) {
+        const float4 a = r.v[t], b = qh[t];
+        const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
+        e[t] = make_float4(dx * dx, dy * dy, dz * dz, dw * dw);
+    }
+    float4 sa = e[0];
+#pragma unroll
+    for (int t = 1; t < H; ++t) sa = make_float4(sa.x + e[t].x, sa.y + e[t].y, sa.z + e[t].z, sa.w + e[t].w);
+    auto from_even = [](float v) {  // lanes 2i and 2i + 1 <- lane 2i   (quad_perm [0, 0, 2, 2])
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xA0, 0xf, 0xf, false));
+    };
+    float4 sb = make_float4(from_even(sa.x), from_even(sa.y), from_even(sa.z), from_even(sa.w));
+#pragma unroll
+    for (int t = 0; t < H; ++t) sb = make_float4(sb.x + e[t].x, sb.y + e[t].y, sb.z + e[t].z, sb.w + e[t].w);
+    return ((sb.x + sb.y) + sb.z) + sb.w;
+}
+
 template <typename QP>
 __device__ __forceinline__ float dot_pair_from_regs(const RowRegs<4>& r, QP qh) {
     float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
@@ -2247,9 +2273,10 @@ template <int METRIC, int STEPS, bool OFF32, bool AUX = false, bool BITMAP = fal
 __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                                  uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
     constexpr bool kEarlyLoad = (STEPS > 0);
-    constexpr bool kPair = (STEPS == 8);                      // 128-byte rows: two lanes per neighbour
-    constexpr bool kAlt = (kPair && METRIC == 1);
-    constexpr int kQSteps = kPair ? 4 : STEPS;
+    constexpr bool kPair = (STEPS == 8) || (STEPS == 16 && METRIC == 0);  // 128-byte rows, and 256-byte rows with L2: two lanes per neighbour
+    constexpr bool kAlt = (STEPS == 8 && METRIC == 1);
+    constexpr int kQSteps = kPair ? STEPS / 2 : STEPS;        // row steps (16 bytes) per lane
+    constexpr uint32_t kRowBytes = (uint32_t)STEPS * 16u;
     constexpr uint32_t kChunk = kPair ? 32u : 64u;
     constexpr uint64_t kSlotLanes = kPair ? 0x5555555555555555ull : ~0ull;
     const int lane = lane_id();
@@ -2357,12 +2384,12 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                 const uint32_t nbl = kAllLanes ? (valid ? nb : 0u) : nb;
                 const bool ld = kAllLanes || valid;
                 if constexpr (OFF32) {
-                    roff = kPair ? (nbl << 7) + half * (kAlt ? 16u : 64u) : nbl * (p.dstride * 4u);
+                    roff = kPair ? nbl * kRowBytes + half * (kAlt ? 16u : kRowBytes / 2u) : nbl * (p.dstride * 4u);
                     const float* rp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff);
                     if constexpr (kAlt) { if (ld) load_row_alt(rr, rp); }
                     else { if (ld) load_row<kQSteps>(rr, rp); }
                 } else {
-                    const float* rp = row_ptr<OFF32>(p.db, nbl, p.dstride) + half * (kAlt ? 4u : 16u);
+                    const float* rp = row_ptr<OFF32>(p.db, nbl, p.dstride) + half * (kAlt ? 4u : kRowBytes / 8u);
                     if constexpr (kAlt) { if (ld) load_row_alt(rr, rp); }
                     else { if (ld) load_row<kQSteps>(rr, rp); }
                 }
@@ -2386,8 +2413,11 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                 if constexpr (kAlt) {
                     const uint32_t kd = fkey(dot_pair_from_regs(rr, qreg.v));
                     dk = fresh ? kd : 0xFFFFFFFFu;
-                } else if constexpr (kPair) {
+                } else if constexpr (kPair && STEPS == 8) {
                     const uint32_t kd = fkey_sumsq(l2_pair_from_regs(rr, qreg.v));
+                    dk = fresh ? kd : 0xFFFFFFFFu;
+                } else if constexpr (kPair) {
+                    const uint32_t kd = fkey_sumsq(l2_pair_from_regs_wide<kQSteps>(rr, qreg.v));
                     dk = fresh ? kd : 0xFFFFFFFFu;
                 } else {
                     if (fresh) dk = fkey(l2_from_regs<STEPS>(rr, qreg.v));
@@ -4016,7 +4046,7 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, true>, p, false, lds, s);
         if (off32) {
             // the common shape (compact index, adjacency rows of one pass) gets the hop without the pass loop
-            if (!retry && p.ell_stride <= (STEPS == 8 ? 32u : 64u))
+            if (!retry && p.ell_stride <= ((STEPS == 8 || (STEPS == 16 && METRIC == 0)) ? 32u : 64u))  // pair form: 32 slots per pass
                 return launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, false, true>, p, false, lds, s);
             return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, true>, p, true, lds, s)
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false>, p, false, lds, s);
