@@ -428,7 +428,9 @@ def roofline_of(ds, res, prof, ef, nq, max_degree, cfg, rank):
     rerank_ms = prof["rerank_ms"] / calls
     project_ms = prof["project_ms"] / calls
     general_ms = prof["walk_general_ms"] / calls
-    fused = ef <= 512 and ds.d % 8 == 0   # every register-list first pass re-ranks at the end of the walk
+    # the register-list / two-list first passes (ef <= 1024) re-rank at the end of the walk: then no re-rank kernel is
+    # launched and the library's re-rank interval is an empty pair of events (~0.006 ms)
+    fused = ds.d % 8 == 0 and rerank_ms < 0.02
     kernel_bytes = walk_bytes + (rerank_bytes if fused else 0.0)
     achieved = kernel_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
     pmc = counters_for(cfg["name"], ef)

@@ -932,7 +932,7 @@ __device__ __forceinline__ uint64_t clear_bit64(uint64_t m, int bit) {  // wave-
 }
 
 constexpr int kRegTieCap = 16;       // tie list of the register kernel (LDS, 128 B)
-constexpr int kRegListMaxEf = 512;   // largest ef served by the register-list kernels (8 registers per lane)
+constexpr int kRegListMaxEf = 1024;  // largest ef served by the register-list / two-list kernels (beyond: result list as one sorted LDS array)
 
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
@@ -1412,7 +1412,7 @@ __device__ __forceinline__ uint32_t reg_id_at_rank(const RegList<R>& L, int rank
     return v;
 }
 
-// ---- hot instance for 64 < ef <= 512: the result list as a sorted BASE list in LDS + a sorted FRONT list in a register
+// ---- hot instance for 128 < ef <= 1024: the result list as a sorted BASE list in LDS + a sorted FRONT list in a register
 //
 // With the whole list in R = ceil(ef / 64) registers per lane (walk_hot_one<R>, reg_merge_multi), finding the next node
 // costs ~16 R instructions EVERY hop and a merge rewrites all R registers; the walk is instruction-issue bound, so ef =
@@ -1432,7 +1432,7 @@ __device__ __forceinline__ uint32_t reg_id_at_rank(const RegList<R>& L, int rank
 // the union holds the same keys as the single list did, selection and eviction see the same total order; the
 // sequential fallback on a boundary tie and the tie list work as before.  Nothing depends on R any more: one kernel.
 
-constexpr int kBigMaxEf = 512;
+constexpr int kBigMaxEf = kRegListMaxEf;  // (the structure itself reaches 64 chunks = 4 096 entries: one mask lane per chunk)
 #ifndef GBNNS_HOT2_MAX
 #define GBNNS_HOT2_MAX 128  // (64: experiments with the two-list kernels from ef = 65 on)
 #endif
@@ -1561,10 +1561,10 @@ struct BigList {
         f = __builtin_amdgcn_readfirstlane(f);  // below index lanes through scalar registers)
         const int total = l + f;
         const int chunks = (total + 63) >> 6;
-        {   // zero the flag bytes of ranks 0 .. 64 chunks + 63 (<= 72 words): two unconditional stores per lane
+        {   // zero the flag bytes of ranks 0 .. 64 chunks + 63: unconditional (clamped) stores, 64 words per round
             const int words = chunks * 8 + 8;
-            reinterpret_cast<uint64_t*>(flags)[lane < words ? lane : 0] = 0ull;
-            reinterpret_cast<uint64_t*>(flags)[64 + lane < words ? 64 + lane : 0] = 0ull;
+            for (int w0 = 0; w0 < words; w0 += 64)
+                reinterpret_cast<uint64_t*>(flags)[w0 + lane < words ? w0 + lane : 0] = 0ull;
         }
         wave_sync();
         // every front entry: number of base entries below it (lower bound by bisection)
@@ -2261,7 +2261,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     }
 }
 
-// ---- generic walk for 64 < ef <= 512: walk_reg_one's hop around the two-list result structure (BigList) ---------------
+// ---- generic walk for 128 < ef <= 1024: walk_reg_one's hop around the two-list result structure (BigList) ---------------
 //
 // Every shape the hot instances do not take (256-byte rows, the dot metric, adjacency rows of more than one pass,
 // auxiliary graphs, large indexes, the HBM-bitmap first pass): same expansion as walk_reg_one, but the result list is
@@ -3057,7 +3057,7 @@ __global__ __launch_bounds__(64) void walk_hot2_kernel(WalkParams p) {  // 64 < 
     walk_hot_one<2>(p, blockIdx.x, smem);
 }
 
-__global__ __launch_bounds__(64) void walk_hot_big_kernel(WalkParams p) {  // 128 < ef <= 512
+__global__ __launch_bounds__(64) void walk_hot_big_kernel(WalkParams p) {  // 128 < ef <= 1024
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_big(p, blockIdx.x, smem);
 }
@@ -3970,7 +3970,7 @@ bool walk_uses_lds_list(const WalkParams& p) { return p.ef > kRegListMaxEf || (p
 
 bool walk_uses_hot(const WalkParams& p, int metric) {
     const bool off32 = walk_off32(p);
-    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= 512 && p.ell_stride <= 32u && off32 && (!p.stamps_on || (p.ef > kHot2MaxEf && !getenv("GBNNS_STAMPS_GENERIC"))) &&
+    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= kBigMaxEf && p.ell_stride <= 32u && off32 && (!p.stamps_on || (p.ef > kHot2MaxEf && !getenv("GBNNS_STAMPS_GENERIC"))) &&
            !p.aux_ell;  // (off32 includes n < 2^24: its visited set stores 24-bit ids)
 }
 
@@ -4136,10 +4136,10 @@ static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, h
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s) { return launch_walk_any(p, metric, false, s); }
 hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s) { return launch_walk_any(p, metric, true, s); }
 
-// The bitmap first pass keeps the result list in registers for 128-byte rows of a compact index up to 512 entries
-// (L2 only for now), else in LDS.
+// The bitmap first pass runs the register-list (ef <= 128, L2) / two-list (128 < ef <= 1 024, both metrics) walk for
+// 128-byte rows of a compact index, else the LDS-list walk.
 bool walk_bitmap_uses_reg(const WalkParams& p, int metric) {
-    return metric == 0 && p.ef <= kRegListMaxEf && p.dim == 32u && p.dstride == 32u && walk_off32(p) && !p.aux_ell;
+    return (metric == 0 || p.ef > kHot2MaxEf) && p.ef <= kRegListMaxEf && p.dim == 32u && p.dstride == 32u && walk_off32(p) && !p.aux_ell;
 }
 
 // LDS of the bitmap first pass: result list (or merge buffer) + tie list + query (no visited table)
@@ -4171,6 +4171,13 @@ hipError_t launch_walk_bitmap(const WalkParams& p, int metric, unsigned slots, h
     if (walk_bitmap_uses_reg(p, metric)) {
         if (p.ef <= 64) return launch_bitmap_reg<1>(p, slots, lds, s);
         if (p.ef <= kHot2MaxEf) return launch_bitmap_reg<2>(p, slots, lds, s);
+        if (metric == 1) {
+            hipError_t e = set_lds(walk_bitmap_big_kernel<1>, lds);
+            if (e != hipSuccess) return e;
+            g_walk_first_fn = reinterpret_cast<const void*>(walk_bitmap_big_kernel<1>);
+            hipLaunchKernelGGL((walk_bitmap_big_kernel<1>), dim3(slots), dim3(64), lds, s, p);
+            return hipGetLastError();
+        }
         hipError_t e = set_lds(walk_bitmap_big_kernel<0>, lds);
         if (e != hipSuccess) return e;
         g_walk_first_fn = reinterpret_cast<const void*>(walk_bitmap_big_kernel<0>);

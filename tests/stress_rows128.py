@@ -35,7 +35,7 @@ for case in range(cases):
     deg_hi = int(rng.choice([5, 17, 32, 33, 64, 70]))
     off, nbr = datagen.random_graph(rng, n, 0, min(deg_hi, n - 1))
     ent = rng.integers(0, n, size=nq).astype(np.uint32)
-    ef = int(rng.choice([1, 3, 16, 40, 64, 65, 90, 128, 130, 256, 257, 400]))
+    ef = int(rng.choice([1, 3, 16, 40, 64, 65, 90, 128, 130, 256, 257, 400, 513, 700, 1024, 1100]))
     cap = int(rng.choice([0, 0, 0, 128, 512]))
     # a third of the cases walk with an auxiliary graph (use_second_graph), random llf / hops_bound
     use_aux = rng.integers(0, 3) == 0
