@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the diagnostic sections (separate stages, MFMA option, host buffers, ef sweep): profiling runs")
     ap.add_argument("--hash-capacity", type=int, default=0, help="0 = library default (tuning knob)")
+    ap.add_argument("--bitmap-pass", action="store_true", help="force the HBM-bitmap first pass (tuning knob: GBNNS_FLAG_BITMAP_PASS)")
     ap.add_argument("--sweep", action="store_true", help="also time every reference ef (stderr)")
     ap.add_argument("--cache-dir", default=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"))
     args = ap.parse_args()
@@ -183,6 +184,8 @@ def main():
     nstep = 0
     pad = sharding.shard_pad(nq_total, world) if strong else nq_rank  # equal-sized pieces for the all-gather
 
+    tune_flags = g.FLAG_BITMAP_PASS if args.bitmap_pass else 0
+
     def step():
         nonlocal nstep
         b = nstep & 1
@@ -190,7 +193,7 @@ def main():
         if pending[b] is not None:
             pending[b].wait()
             pending[b] = None
-        r = ix.search(q, ef, want=want, out=outs[b], hash_capacity=args.hash_capacity)
+        r = ix.search(q, ef, want=want, out=outs[b], hash_capacity=args.hash_capacity, flags=tune_flags)
         if world > 1:
             # the path's only exchange step: all-gather of the int32 answer ids over RCCL/xGMI
             if gathered[b] is None:
@@ -213,7 +216,7 @@ def main():
     # The library sizes its visited sets from the walks it has seen and drops the retry launch once a few batches
     # of a configuration were quiet: let that settle before the W warm-up steps, whatever W is.
     for _ in range(8 if nq_rank <= 20_000 else 3):
-        ix.search(q, ef, want=(), hash_capacity=args.hash_capacity)
+        ix.search(q, ef, want=(), hash_capacity=args.hash_capacity, flags=tune_flags)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
