@@ -955,7 +955,9 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
             const size_t table_waves = std::min<size_t>(32, kMaxLds / ((walk_fast_lds_bytes(w, hot) + gran - 1) / gran * gran));
             // ... and only when the batch is deeper than 1.5 rounds of the wavefronts the table would allow (a
             // 1 000-query batch is resident at once either way, and the register list is faster per hop)
-            if (((per_cu >= 2 * std::max<size_t>(table_waves, 1) && 2 * (size_t)nq > 3 * table_waves * 256) || forced) &&
+            // ... or, short of that, when the table needs a second round and the bitmap pass holds the whole batch at once
+            const bool one_round = (size_t)nq > table_waves * 256 && (size_t)nq <= per_cu * 256;
+            if (((per_cu >= 2 * std::max<size_t>(table_waves, 1) && (2 * (size_t)nq > 3 * table_waves * 256 || one_round)) || forced) &&
                 per_cu >= 1 && per_cu * 256 * (size_t)bitmap_words * 4 <= (8ull << 30))
                 bitmap_per_cu = per_cu;
         }

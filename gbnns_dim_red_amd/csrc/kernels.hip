@@ -3092,7 +3092,7 @@ __global__ __launch_bounds__(64) void walk_bitmap_reg_kernel(WalkParams p) {
     }
 }
 
-template <int METRIC>
+template <int METRIC, int STEPS = 8>
 __global__ __launch_bounds__(64) void walk_bitmap_big_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* bitmap = p.fp_bitmap + (size_t)blockIdx.x * p.bitmap_words;
@@ -3101,7 +3101,7 @@ __global__ __launch_bounds__(64) void walk_bitmap_big_kernel(WalkParams p) {
         if (lane_id() == 0) w = atomicAdd(p.fp_cursor, 1u);
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
         if (w >= p.nq) break;
-        walk_reg_big_one<METRIC, 8, true, false, true>(p, w, smem, p.ovf_count, p.ovf_list, bitmap);
+        walk_reg_big_one<METRIC, STEPS, true, false, true>(p, w, smem, p.ovf_count, p.ovf_list, bitmap);
         wave_sync();
     }
 }
@@ -4137,9 +4137,10 @@ hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s) { re
 hipError_t launch_walk_retry(const WalkParams& p, int metric, hipStream_t s) { return launch_walk_any(p, metric, true, s); }
 
 // The bitmap first pass runs the register-list (ef <= 128, L2) / two-list (128 < ef <= 1 024, both metrics) walk for
-// 128-byte rows of a compact index, else the LDS-list walk.
+// 128-byte rows of a compact index, the two-list walk for 256-byte rows with L2, else the LDS-list walk.
 bool walk_bitmap_uses_reg(const WalkParams& p, int metric) {
-    return (metric == 0 || p.ef > kHot2MaxEf) && p.ef <= kRegListMaxEf && p.dim == 32u && p.dstride == 32u && walk_off32(p) && !p.aux_ell;
+    const bool rows128 = p.dim == 32u && p.dstride == 32u, rows256 = p.dim == 64u && p.dstride == 64u && metric == 0 && p.ef > kHot2MaxEf;
+    return (metric == 0 || p.ef > kHot2MaxEf) && p.ef <= kRegListMaxEf && (rows128 || rows256) && walk_off32(p) && !p.aux_ell;
 }
 
 // LDS of the bitmap first pass: result list (or merge buffer) + tie list + query (no visited table)
@@ -4171,6 +4172,13 @@ hipError_t launch_walk_bitmap(const WalkParams& p, int metric, unsigned slots, h
     if (walk_bitmap_uses_reg(p, metric)) {
         if (p.ef <= 64) return launch_bitmap_reg<1>(p, slots, lds, s);
         if (p.ef <= kHot2MaxEf) return launch_bitmap_reg<2>(p, slots, lds, s);
+        if (p.dim == 64u) {  // 256-byte rows, L2 (pair form)
+            hipError_t e = set_lds(walk_bitmap_big_kernel<0, 16>, lds);
+            if (e != hipSuccess) return e;
+            g_walk_first_fn = reinterpret_cast<const void*>(walk_bitmap_big_kernel<0, 16>);
+            hipLaunchKernelGGL((walk_bitmap_big_kernel<0, 16>), dim3(slots), dim3(64), lds, s, p);
+            return hipGetLastError();
+        }
         if (metric == 1) {
             hipError_t e = set_lds(walk_bitmap_big_kernel<1>, lds);
             if (e != hipSuccess) return e;
