@@ -2139,15 +2139,18 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             RowRegs<kQSteps> rr;
             uint32_t roff = 0;  // row byte offset, kept live past the loads (see below)
             if constexpr (kEarlyLoad) {
+                constexpr bool kAllLanes = kPair && ONE_CHUNK;  // (see walk_reg_big_one: every lane loads, empty slots read row 0; measured: pays in the one-pass hop only)
+                const uint32_t nbl = kAllLanes ? (valid ? nb : 0u) : nb;
+                const bool ld = kAllLanes || valid;
                 if constexpr (OFF32) {
-                    roff = kPair ? (nb << 7) + half * (kAlt ? 16u : 64u) : nb * (p.dstride * 4u);  // kPair: rows are 128 B
+                    roff = kPair ? (nbl << 7) + half * (kAlt ? 16u : 64u) : nbl * (p.dstride * 4u);  // kPair: rows are 128 B
                     const float* rp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff);
-                    if constexpr (kAlt) { if (valid) load_row_alt(rr, rp); }
-                    else { if (valid) load_row<kQSteps>(rr, rp); }
+                    if constexpr (kAlt) { if (ld) load_row_alt(rr, rp); }
+                    else { if (ld) load_row<kQSteps>(rr, rp); }
                 } else {
-                    const float* rp = row_ptr<OFF32>(p.db, nb, p.dstride) + half * (kAlt ? 4u : 16u);
-                    if constexpr (kAlt) { if (valid) load_row_alt(rr, rp); }
-                    else { if (valid) load_row<kQSteps>(rr, rp); }
+                    const float* rp = row_ptr<OFF32>(p.db, nbl, p.dstride) + half * (kAlt ? 4u : 16u);
+                    if constexpr (kAlt) { if (ld) load_row_alt(rr, rp); }
+                    else { if (ld) load_row<kQSteps>(rr, rp); }
                 }
             }
             // pair form: the even lane of a pair tests / claims the id, the odd lane ends up with the distance
