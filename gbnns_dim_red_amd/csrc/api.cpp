@@ -119,6 +119,7 @@ struct gbnns_index {
     int stats_ef = 0;
     uint32_t stats_cap = 0;
     std::map<int, uint32_t> cap_for_ef;
+    std::map<int, uint32_t> maxdc_for_ef;  // largest dist_calc seen per (ef, mode, aux, wide): the raw figure behind cap_for_ef
     std::map<int, int> calm_streak;   // per (ef, mode): consecutive observed batches without hand-over / resize
     uint32_t stats_tick = 0;
     // which of the two control-word blocks the next call uses, and whether each is known to be zero
@@ -883,6 +884,8 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         // 15/16 fill limit
         uint32_t need = (maxdc + maxdc / 16 + 64) / 15 * 16 + 16;
         // max_dc covers the retry / general passes too, so a hand-over needs no extra sizing rule
+        uint32_t& seen = ix->maxdc_for_ef[ix->stats_ef];
+        seen = std::max(seen, maxdc);
         uint32_t& slot = ix->cap_for_ef[ix->stats_ef];  // stats_ef = skey of that call
         const bool grew = need > slot;
         slot = std::max(slot, need);  // never shrinks: batches with one long walk do not make it oscillate
@@ -924,8 +927,21 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         if (slots == 0) {
             cap = need;  // does not fit LDS at all: the general kernel takes the batch
         } else {
+            // One more wavefront per CU when it costs only part of the margin: `need` keeps 1/16 of headroom over the
+            // largest walk seen; a share that still leaves 1/32 is taken (a later, longer walk is handed over once and
+            // raises the requirement for good -- it never shrinks).
+            if (slots < 32 && ix->maxdc_for_ef.count(skey)) {
+                const uint32_t m = ix->maxdc_for_ef[skey];
+                const uint32_t need_min = (m + m / 32 + 64) / 15 * 16 + 16;
+                const size_t share1 = kMaxLds / (slots + 1) / gran * gran;
+                if (share1 > lds_fixed && walk_hash_entries(share1 - lds_fixed, packed) >= need_min + 4) slots += 1;
+            }
             const size_t share = kMaxLds / slots / gran * gran;
             cap = walk_hash_entries(share - lds_fixed, packed);
+            static const bool dbg = getenv("GBNNS_DEBUG_SIZING") != nullptr;  // diagnostic: the sizing decision of every call
+            if (dbg)
+                std::fprintf(stderr, "[gbnns sizing] ef %d need %u maxdc %u fixed %zu want %zu slots %zu share %zu cap %u\n", ef, need,
+                             ix->maxdc_for_ef.count(skey) ? ix->maxdc_for_ef[skey] : 0u, lds_fixed, want, slots, share, cap);
         }
     }
     cap = walk_hash_entries(walk_hash_bytes(cap, packed), packed);  // whole buckets

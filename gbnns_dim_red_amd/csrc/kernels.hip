@@ -1445,9 +1445,15 @@ __device__ __forceinline__ uint64_t dpp_wave_shl1_u64(uint64_t v) {  // lane j <
 }
 
 // LDS of the instance besides the visited set: [tie list][front-merge buffer: 66 keys][base list: ef_pad keys]
-// [flush flags: ef_pad + 64 bytes], ef_pad = ef rounded up to 64
+// [flush flags: ef_pad + 64 bytes], ef_pad = ef rounded up to 64.  The flush flags live inside the front-merge buffer
+// when they fit (ef <= 448: the two are never in use at the same time) -- at ef = 140 .. 180 those 256 bytes are what
+// separates 14 / 13 / 12 resident wavefronts per CU from 15 / 14 / 13.
+__host__ __device__ __forceinline__ constexpr bool big_list_flags_in_stage(int ef) {
+    return (size_t)((ef + 63) / 64 * 64) + 64 <= (size_t)kRegStageSlots * 8;
+}
 __host__ __device__ __forceinline__ constexpr size_t big_list_fixed_bytes(int ef) {
-    return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (size_t)((ef + 63) / 64 * 64) * 9 + 64;
+    return (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (size_t)((ef + 63) / 64 * 64) * 8 +
+           (big_list_flags_in_stage(ef) ? 0 : (size_t)((ef + 63) / 64 * 64) + 64);
 }
 
 struct BigList {
@@ -1901,7 +1907,7 @@ struct BigList {
         tie = reinterpret_cast<uint64_t*>(smem);
         stage = tie + kRegTieCap;
         base = stage + kRegStageSlots;
-        flags = reinterpret_cast<unsigned char*>(base + ef_pad);
+        flags = big_list_flags_in_stage(ef_) ? reinterpret_cast<unsigned char*>(stage) : reinterpret_cast<unsigned char*>(base + ef_pad);
         F.clear();
         ef = ef_; l = 0; f = 1; tsize = 0;
         mu_lo = mu_hi = 0u;
