@@ -1,3 +1,4 @@
+# (experiment script of round 2: expects the variant library built beside the shipped one; restores nothing -- run on a throw-away GPU box copy only)
 mkdir -p gpurun_out/r03a && export GBNNS_CACHE=/tmp/gbnns_cache
 for lib in old new; do
   if [ $lib == new ]; then cp gbnns_dim_red_amd/lib/libgbnns_hip_new.so gbnns_dim_red_amd/lib/libgbnns_hip.so; fi

@@ -1,3 +1,4 @@
+# (experiment script of round 2: expects the variant library built beside the shipped one; restores nothing -- run on a throw-away GPU box copy only)
 mkdir -p gpurun_out/r02y && export GBNNS_CACHE=/tmp/gbnns_cache
 for lib in base h64; do
   if [ $lib == h64 ]; then cp gbnns_dim_red_amd/lib/libgbnns_hip_h64.so gbnns_dim_red_amd/lib/libgbnns_hip.so; fi
