@@ -167,7 +167,20 @@ def main():
                 torch.cuda.synchronize()
                 sweep[e] = recall_of(r["ids"])
             if sweep[e] >= 0.95:
-                ef = e
+                # the reference's ef grid is coarse (40 -> 60 here): bisect down to a grid of 4 for the smallest beam
+                # that still meets the metric's recall gate; the reference-grid point stays in `recall_sweep` / `ef_sweep`
+                lo, hi = max(x for x in sweep if x < e and sweep[x] < 0.95), e
+                while hi - lo > 4:
+                    mid = (lo + hi) // 2
+                    if mid not in sweep:
+                        r = ix.search(q, mid, want=())
+                        torch.cuda.synchronize()
+                        sweep[mid] = recall_of(r["ids"])
+                    if sweep[mid] >= 0.95:
+                        hi = mid
+                    else:
+                        lo = mid
+                ef = hi
                 break
         else:
             gate_failed = True  # no ef up to 1000 reaches the metric's recall threshold on this data
