@@ -1080,3 +1080,43 @@ def test_bitmap_first_pass(g, orc):
         assert np.array_equal(r["dist_calc"], w["dist_calc"]), ef
     ix.profile_read()
     ix.close()
+
+
+@pytest.mark.gpu
+def test_two_list_kernels_by_name(g, orc):
+    """128 < ef <= 1024 runs on the two-list kernels (sorted base list in LDS + front list in a register) whatever the
+    row length and metric; the library reports the first-pass kernel it launched (gbnns_profile.walk_kernel), so the
+    test checks WHICH kernel produced the bit-exact answer: hot instance (L2, 128-byte rows), generic pair form for the
+    dot metric, pair form for 256-byte rows, one lane per row for 192-byte rows, the HBM-bitmap variants, and the
+    two-register kernels below the crossover."""
+    shapes = [  # d, d_low, d_hidden, metric, max degree, [(ef, flags, expected kernel-name prefix)]
+        (64, 32, 64, 0, 30, [(100, 0, "walk_hot2_kernel"), (200, 0, "walk_hot_big_kernel"), (1024, 0, "walk_hot_big_kernel"),
+                             (300, "bitmap", "walk_bitmap_big_kernel<0, 8>")]),
+        (64, 32, 64, 1, 30, [(100, 0, "walk_reg_kernel<1, 8,"), (200, 0, "walk_reg_big_kernel<1, 8,"),
+                             (700, "bitmap", "walk_bitmap_big_kernel<1, 8>")]),
+        (128, 64, 128, 0, 30, [(64, 0, "walk_reg_kernel<0, 16,"), (200, 0, "walk_reg_big_kernel<0, 16,"),
+                               (1000, 0, "walk_reg_big_kernel<0, 16,"), (600, "bitmap", "walk_bitmap_big_kernel<0, 16>")]),
+        (96, 48, 64, 0, 30, [(200, 0, "walk_reg_big_kernel<0, 12,")]),
+        (64, 32, 64, 0, 70, [(300, 0, "walk_reg_big_kernel<0, 8,")]),  # adjacency rows of several passes: generic kernel
+    ]
+    for si, (d, dlow, dh, metric, deg, cases) in enumerate(shapes):
+        c, off, nbr, db_low, ent = _oracle_case(orc, 2300 + si, 6000, 120, d, dlow, dh, deg=(2, deg))
+        q_low = orc.project(c.net, c.queries)
+        ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net, metric=metric)
+        ix.profile_enable(True)
+        for ef, fl, kname in cases:
+            flags = g.FLAG_BITMAP_PASS if fl == "bitmap" else 0
+            w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, metric=metric, threads=8)
+            s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net,
+                                 entries=ent, metric=metric, threads=8)
+            ix.profile_read(reset=True)
+            r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), flags=flags)
+            key = (d, dlow, metric, deg, ef, fl)
+            assert np.array_equal(r["cand"], w["ids"]), key
+            assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
+            assert np.array_equal(r["hops"], w["hops"]), key
+            assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
+            assert np.array_equal(r["ids"], s["ids"]), key
+            launched = ix.profile_read(reset=True)["walk_kernel"]
+            assert launched.startswith(kname), (key, launched)
+        ix.close()
