@@ -39,7 +39,7 @@ REF_EFS = [1, 3, 8, 15, 20, 25, 40, 60, 80, 100, 120, 140, 160, 180]  # paramete
 
 CONFIGS = {
     # name: dataset shape, timed ef, further efs reported in `ef_sweep`, metric, batch policy
-    "sift": dict(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, ef=64, efs=[40, 128, 140, 160, 180],
+    "sift": dict(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, ef=64, efs=[36, 40, 128, 140, 160, 180],
                  label="SIFT1M 128->32", shape="SIFT1M-shaped"),
     "gist": dict(n=1_000_000, nq=1_000, d=960, d_low=64, d_hidden=1024, ef=200, efs=[400],
                  label="GIST1M 960->64", shape="GIST1M-shaped"),
