@@ -20,6 +20,7 @@ timed search path.
 """
 import hashlib
 import os
+import sys
 import time
 
 import numpy as np
@@ -171,7 +172,7 @@ def make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=123
         for s0 in range(0, n, step):
             parts.append(binding.exact_knn(db_low, db_low[s0:s0 + step], knn_k, self_offset=s0))
             if verbose:
-                print("synth: kNN rows", min(n, s0 + step), "of", n, "at %.1fs" % (time.time() - t1), flush=True)
+                print("synth: kNN rows", min(n, s0 + step), "of", n, "at %.1fs" % (time.time() - t1), file=sys.stderr, flush=True)
         knn = torch.cat(parts)
         del parts
     else:
@@ -195,7 +196,7 @@ def make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=123
     timings["gt_s"] = time.time() - t1
     timings["total_s"] = time.time() - t0
     if verbose:
-        print("synth:", {k: round(v, 2) for k, v in timings.items()}, flush=True)
+        print("synth:", {k: round(v, 2) for k, v in timings.items()}, file=sys.stderr, flush=True)
 
     ds = Dataset(recipe=recipe, n=n, nq=nq, d=d, d_low=d_low, d_hidden=d_hidden, base=base,
                  queries=queries, net=net, db_low=db_low, graph_off=goff, graph_nbr=gnbr,

@@ -100,7 +100,8 @@ def main():
     walks = [k for k in res if k.startswith("walk_") and "general" not in k and "timed_total_us" in res[k]]
     dom = max(walks, key=lambda k: res[k]["timed_total_us"]) if walks else "walk_fast_kernel"
     try:  # the kernel bench.py's own line names (gbnns_profile.walk_kernel): other efs' walks of the recall sweep may be longer
-        named = json.load(open(os.path.join(out, "bench_plain.json")))["roofline"]["kernel"].split(" (")[0]
+        line = [l for l in open(os.path.join(out, "bench_plain.json")) if l.startswith("{")][-1]
+        named = json.loads(line)["roofline"]["kernel"].split(" (")[0]
         if short(named) in res:
             dom = short(named)
     except Exception:
@@ -131,7 +132,7 @@ def main():
     if a.config:
         ef = None
         try:
-            ef = json.load(open(os.path.join(out, "bench_plain.json")))["config"]["ef"]
+            ef = json.loads([l for l in open(os.path.join(out, "bench_plain.json")) if l.startswith("{")][-1])["config"]["ef"]
         except Exception:
             pass
         if ef is not None and "FETCH_SIZE" in w:
