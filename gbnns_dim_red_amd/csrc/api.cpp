@@ -995,10 +995,6 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         w.ovf_count = w.ovf2_count;
         w.ovf_list = w.ovf2_list;
     }
-    {
-        static const int touch_env = getenv("GBNNS_TOUCH_AHEAD") ? atoi(getenv("GBNNS_TOUCH_AHEAD")) : 1;
-        w.touch_ahead = (uint32_t)touch_env;
-    }
     bool bitmap_pass = false;
     if (bitmap_per_cu) {
         if ((rc = ix->fp_bitmap.ensure(bitmap_per_cu * 256 * (size_t)bitmap_words * 4))) return rc;

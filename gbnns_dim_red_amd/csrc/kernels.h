@@ -51,7 +51,6 @@ struct WalkParams {
     // first pass with the visited set in HBM (large ef): per-slot bitmaps and the work-queue head
     uint32_t* fp_bitmap;     // [slots x bitmap_words]
     uint32_t* fp_cursor;     // [1]
-    uint32_t touch_ahead;    // HBM-bitmap two-list pass: touch the predicted next hop's rows / bitmap words
     uint32_t rr_reserve;     // bytes the bitmap first pass of the two-list kernel sets aside for the re-rank query (0: none)
     uint32_t* g_cursor;      // [1] work-queue head
     uint32_t* g_total;       // [1] running count of queries the general kernel processed

@@ -2338,12 +2338,6 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
 
     int status = 0;  // 0 = walking, 1 = finished, 2 = handed over
     uint32_t pf_node = kInvalidId, pf_val = kInvalidId;
-    // HBM-bitmap pass: a hop there is two dependent trips to HBM (adjacency row, then rows + the bitmap's read-modify-
-    // write) and the wavefronts wait 63 % of their life.  Once a hop's distances are done, the predicted next node's
-    // adjacency row has arrived: its neighbours' rows and bitmap words are touched (plain loads whose values are only
-    // "used" by an empty asm one hop later) so that the next hop finds them in the L2.
-    constexpr bool kTouch = BITMAP && OFF32 && kEarlyLoad;
-    uint32_t touch_a = 0, touch_b = 0;
     while (true) {
         uint32_t node, pred, h2;
         STAMP(t0)
@@ -2442,17 +2436,6 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                 if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, nb, p.dstride), p.dim));
             }
             dist_calc += __popcll(mfresh);
-            if constexpr (kTouch) {
-                asm volatile("" ::"v"(touch_a), "v"(touch_b));  // last hop's touches: long done by now
-                if (c == 0 && !is_aux && pred != kInvalidId && p.touch_ahead) {
-                    const uint32_t pn = pf_val;
-                    if (pn != kInvalidId) {
-                        const uint32_t toff = kPair ? pn * kRowBytes + half * (kRowBytes / 2u) : pn * (p.dstride * 4u);
-                        touch_a = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.db) + toff);
-                        touch_b = bitmap[pn >> 5];
-                    }
-                }
-            }
             const uint64_t m = (B.l + B.f < ef) ? mfresh : __ballot(fresh && dk < B.worst);
             STAMP(t5)
             STAMP_ADD(4, t4, t5)
