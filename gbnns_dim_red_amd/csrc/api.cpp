@@ -778,7 +778,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         if ((rc = ix->edges.ensure((size_t)nq * 4))) return rc;
     // general-kernel slots: visited bits + tie bits (n / 4 bytes per slot) and the result list -- 16 n bytes + 512 ef
     // per handle in all (see gbnns.h, "Device memory")
-    const uint32_t bitmap_words = (uint32_t)((ix->n + 31) / 32);
+    const uint32_t bitmap_words = ((uint32_t)((ix->n + 31) / 32) + 3u) & ~3u;  // per slot; a multiple of 4 words: slots stay 16-B aligned (the bitmap pass clears with 16-B stores)
     {
         const size_t before = ix->g_bitmap.bytes;  // (re)allocation always changes the size
         if ((rc = ix->g_bitmap.ensure((size_t)kGeneralSlots * 2 * bitmap_words * 4))) return rc;

@@ -2307,7 +2307,15 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
     const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
     constexpr bool packed = OFF32;
     const uint32_t nbuckets = packed ? cap / 5u : cap >> 2;
-    if constexpr (BITMAP) { for (uint32_t i = lane; i < p.bitmap_words; i += 64) bitmap[i] = 0u; }
+    if constexpr (BITMAP) {
+        // 16 bytes per lane and store (n / 8 bytes per query: 150 KB at n = 1.2 M); not unrolled: the unrolled form's address
+        // registers were the kernel's register peak
+        uint4* b4 = reinterpret_cast<uint4*>(bitmap);
+        const uint32_t n4 = p.bitmap_words >> 2;
+#pragma clang loop unroll(disable)
+        for (uint32_t i = lane; i < n4; i += 64) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t i = (n4 << 2) + lane; i < p.bitmap_words; i += 64) bitmap[i] = 0u;
+    }
     else if constexpr (packed) packed_table_init(hash, nbuckets, 0u, lane);
     else for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
     for (uint32_t i = lane; i < p.dstride; i += 64)
@@ -3101,7 +3109,7 @@ __global__ __launch_bounds__(64) void walk_bitmap_reg_kernel(WalkParams p) {
     }
 }
 
-template <int METRIC, int STEPS = 8>
+template <int METRIC, int STEPS = 8, bool ONE_PASS = false>
 __global__ __launch_bounds__(64) void walk_bitmap_big_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* bitmap = p.fp_bitmap + (size_t)blockIdx.x * p.bitmap_words;
@@ -3110,7 +3118,7 @@ __global__ __launch_bounds__(64) void walk_bitmap_big_kernel(WalkParams p) {
         if (lane_id() == 0) w = atomicAdd(p.fp_cursor, 1u);
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
         if (w >= p.nq) break;
-        walk_reg_big_one<METRIC, STEPS, true, false, true>(p, w, smem, p.ovf_count, p.ovf_list, bitmap);
+        walk_reg_big_one<METRIC, STEPS, true, false, true, ONE_PASS>(p, w, smem, p.ovf_count, p.ovf_list, bitmap);
         wave_sync();
     }
 }
@@ -4181,25 +4189,18 @@ hipError_t launch_walk_bitmap(const WalkParams& p, int metric, unsigned slots, h
     if (walk_bitmap_uses_reg(p, metric)) {
         if (p.ef <= 64) return launch_bitmap_reg<1>(p, slots, lds, s);
         if (p.ef <= kHot2MaxEf) return launch_bitmap_reg<2>(p, slots, lds, s);
-        if (p.dim == 64u) {  // 256-byte rows, L2 (pair form)
-            hipError_t e = set_lds(walk_bitmap_big_kernel<0, 16>, lds);
+        // (adjacency rows of one 32-slot pass -- the common case -- take the instance without the pass loop)
+        auto go = [&](auto kernel) -> hipError_t {
+            hipError_t e = set_lds(kernel, lds);
             if (e != hipSuccess) return e;
-            g_walk_first_fn = reinterpret_cast<const void*>(walk_bitmap_big_kernel<0, 16>);
-            hipLaunchKernelGGL((walk_bitmap_big_kernel<0, 16>), dim3(slots), dim3(64), lds, s, p);
+            g_walk_first_fn = reinterpret_cast<const void*>(kernel);
+            hipLaunchKernelGGL(kernel, dim3(slots), dim3(64), lds, s, p);
             return hipGetLastError();
-        }
-        if (metric == 1) {
-            hipError_t e = set_lds(walk_bitmap_big_kernel<1>, lds);
-            if (e != hipSuccess) return e;
-            g_walk_first_fn = reinterpret_cast<const void*>(walk_bitmap_big_kernel<1>);
-            hipLaunchKernelGGL((walk_bitmap_big_kernel<1>), dim3(slots), dim3(64), lds, s, p);
-            return hipGetLastError();
-        }
-        hipError_t e = set_lds(walk_bitmap_big_kernel<0>, lds);
-        if (e != hipSuccess) return e;
-        g_walk_first_fn = reinterpret_cast<const void*>(walk_bitmap_big_kernel<0>);
-        hipLaunchKernelGGL((walk_bitmap_big_kernel<0>), dim3(slots), dim3(64), lds, s, p);
-        return hipGetLastError();
+        };
+        const bool one = p.ell_stride <= 32u;
+        if (p.dim == 64u) return one ? go(walk_bitmap_big_kernel<0, 16, true>) : go(walk_bitmap_big_kernel<0, 16, false>);  // 256-byte rows, L2 (pair form)
+        if (metric == 1) return one ? go(walk_bitmap_big_kernel<1, 8, true>) : go(walk_bitmap_big_kernel<1, 8, false>);
+        return one ? go(walk_bitmap_big_kernel<0, 8, true>) : go(walk_bitmap_big_kernel<0, 8, false>);
     }
     if (metric == 1) {
         hipError_t e = set_lds(walk_bitmap_kernel<1, 0>, lds);

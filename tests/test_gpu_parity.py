@@ -1091,11 +1091,11 @@ def test_two_list_kernels_by_name(g, orc):
     two-register kernels below the crossover."""
     shapes = [  # d, d_low, d_hidden, metric, max degree, [(ef, flags, expected kernel-name prefix)]
         (64, 32, 64, 0, 30, [(100, 0, "walk_hot2_kernel"), (200, 0, "walk_hot_big_kernel"), (1024, 0, "walk_hot_big_kernel"),
-                             (300, "bitmap", "walk_bitmap_big_kernel<0, 8>")]),
+                             (300, "bitmap", "walk_bitmap_big_kernel<0, 8,")]),
         (64, 32, 64, 1, 30, [(100, 0, "walk_reg_kernel<1, 8,"), (200, 0, "walk_reg_big_kernel<1, 8,"),
-                             (700, "bitmap", "walk_bitmap_big_kernel<1, 8>")]),
+                             (700, "bitmap", "walk_bitmap_big_kernel<1, 8,")]),
         (128, 64, 128, 0, 30, [(64, 0, "walk_reg_kernel<0, 16,"), (200, 0, "walk_reg_big_kernel<0, 16,"),
-                               (1000, 0, "walk_reg_big_kernel<0, 16,"), (600, "bitmap", "walk_bitmap_big_kernel<0, 16>")]),
+                               (1000, 0, "walk_reg_big_kernel<0, 16,"), (600, "bitmap", "walk_bitmap_big_kernel<0, 16,")]),
         (96, 48, 64, 0, 30, [(200, 0, "walk_reg_big_kernel<0, 12,")]),
         (64, 32, 64, 0, 70, [(300, 0, "walk_reg_big_kernel<0, 8,")]),  # adjacency rows of several passes: generic kernel
     ]
