@@ -2332,8 +2332,23 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
     const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p.entries ? p.entries[qi] : 0u));
     if (entry >= p.n) { write_bad_entry(p, qi, lane); return; }
     {
-        const float d0 = walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, entry, p.dstride), p.dim);
-        B.worst = B.fworst = (uint32_t)__builtin_amdgcn_readfirstlane((int)fkey(d0));
+        uint32_t k0;
+        if constexpr (kPair) {
+            // the entry's distance in the pair form, on the query registers (lanes 0 / 1 would do; every pair computes it):
+            // the one-lane form reads the whole row and the whole query into registers and was the kernel's register peak
+            RowRegs<kQSteps> er;
+            const float* rp = row_ptr<OFF32>(p.db, entry, p.dstride) + half * (kAlt ? 4u : kRowBytes / 8u);
+            if constexpr (kAlt) load_row_alt(er, rp);
+            else load_row<kQSteps>(er, rp);
+            uint32_t kd;
+            if constexpr (kAlt) kd = fkey(dot_pair_from_regs(er, qreg.v));
+            else if constexpr (STEPS == 8) kd = fkey_sumsq(l2_pair_from_regs(er, qreg.v));
+            else kd = fkey_sumsq(l2_pair_from_regs_wide<kQSteps>(er, qreg.v));
+            k0 = readlane_u32(kd, 1);  // odd lanes hold the distance
+        } else {
+            k0 = fkey(walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, entry, p.dstride), p.dim));
+        }
+        B.worst = B.fworst = (uint32_t)__builtin_amdgcn_readfirstlane((int)k0);
         B.F.hi[0] = lane == 0 ? B.worst : B.F.hi[0];
         B.F.lo[0] = lane == 0 ? entry << 1 : B.F.lo[0];
         if (lane == 0) {
