@@ -47,6 +47,9 @@ CONFIGS = {
                   label="GloVe-1.2M 200->32 (L2 on normalised data)", shape="GloVe-1.2M-shaped"),
     "glove-dot": dict(n=1_200_000, nq=10_000, d=200, d_low=32, d_hidden=256, ef=64, efs=[300], negdot=True, unit_norm=True,
                       label="GloVe-1.2M 200->32 (negative-dot metric)", shape="GloVe-1.2M-shaped"),
+    # the reference's own DEEP row (parameters_of_databases.txt:23-33): 10^6 base vectors, 96 -> 48 (192-byte walked rows)
+    "deep1m": dict(n=1_000_000, nq=10_000, d=96, d_low=48, d_hidden=128, ef=40, efs=[80, 120, 160, 200],
+                   label="DEEP1M 96->48 (the reference's parameter file)", shape="DEEP1M-shaped"),
     "deep": dict(n=10_000_000, nq=1_000_000, d=96, d_low=32, d_hidden=128, ef=40, efs=[60, 120], strong=True,
                  native_knn=True, label="DEEP10M 96->32, 1M-query batch", shape="DEEP10M-shaped"),
 }

@@ -1931,9 +1931,10 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
 #endif
     constexpr bool kEarlyLoad = (STEPS > 0);  // speculative row loads (METRIC 1 is instantiated with STEPS 0 or 8 only)
     // 128-byte rows: two lanes per neighbour (lane = 2 * slot + half), 32 adjacency slots per pass
-    constexpr bool kPair = (STEPS == 8);
-    constexpr bool kAlt = (kPair && METRIC == 1);            // dot metric: even / odd 16-B pieces instead of halves
-    constexpr int kQSteps = kPair ? 4 : STEPS;               // 16-B steps of the row one lane holds
+    constexpr bool kPair = (STEPS == 8) || ((STEPS == 12 || STEPS == 16) && METRIC == 0);  // 128-byte rows; 192- / 256-byte rows with L2
+    constexpr bool kAlt = (STEPS == 8 && METRIC == 1);        // dot metric: even / odd 16-B pieces instead of halves
+    constexpr int kQSteps = kPair ? STEPS / 2 : STEPS;        // 16-B steps of the row one lane holds
+    constexpr uint32_t kRowBytes = (uint32_t)STEPS * 16u;
     constexpr uint32_t kChunk = kPair ? 32u : 64u;           // adjacency slots per pass
     constexpr uint64_t kSlotLanes = kPair ? 0x5555555555555555ull : ~0ull;  // lanes that own a slot
     const int lane = lane_id();
@@ -2145,16 +2146,18 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             RowRegs<kQSteps> rr;
             uint32_t roff = 0;  // row byte offset, kept live past the loads (see below)
             if constexpr (kEarlyLoad) {
-                constexpr bool kAllLanes = kPair && ONE_CHUNK;  // (see walk_reg_big_one: every lane loads, empty slots read row 0; measured: pays in the one-pass hop only)
+                // (see walk_reg_big_one: every lane loads, empty slots read row 0; measured: the pair form gains in the one-pass
+                // hop only, 12- / 16-step rows one lane each wherever their 48 / 64 row registers would be carried around the loop)
+                constexpr bool kAllLanes = (kPair && ONE_CHUNK) || (!kPair && kQSteps >= 12);
                 const uint32_t nbl = kAllLanes ? (valid ? nb : 0u) : nb;
                 const bool ld = kAllLanes || valid;
                 if constexpr (OFF32) {
-                    roff = kPair ? (nbl << 7) + half * (kAlt ? 16u : 64u) : nbl * (p.dstride * 4u);  // kPair: rows are 128 B
+                    roff = kPair ? nbl * kRowBytes + half * (kAlt ? 16u : kRowBytes / 2u) : nbl * (p.dstride * 4u);
                     const float* rp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff);
                     if constexpr (kAlt) { if (ld) load_row_alt(rr, rp); }
                     else { if (ld) load_row<kQSteps>(rr, rp); }
                 } else {
-                    const float* rp = row_ptr<OFF32>(p.db, nbl, p.dstride) + half * (kAlt ? 4u : 16u);
+                    const float* rp = row_ptr<OFF32>(p.db, nbl, p.dstride) + half * (kAlt ? 4u : kRowBytes / 8u);
                     if constexpr (kAlt) { if (ld) load_row_alt(rr, rp); }
                     else { if (ld) load_row<kQSteps>(rr, rp); }
                 }
@@ -2179,8 +2182,11 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                 if constexpr (kAlt) {
                     const uint32_t kd = fkey(dot_pair_from_regs(rr, qreg.v));  // all lanes; odd lanes hold distances
                     dk = fresh ? kd : 0xFFFFFFFFu;
-                } else if constexpr (kPair) {
+                } else if constexpr (kPair && STEPS == 8) {
                     const uint32_t kd = fkey_sumsq(l2_pair_from_regs(rr, qreg.v));  // all lanes; odd lanes hold distances
+                    dk = fresh ? kd : 0xFFFFFFFFu;
+                } else if constexpr (kPair) {
+                    const uint32_t kd = fkey_sumsq(l2_pair_from_regs_wide<kQSteps>(rr, qreg.v));
                     dk = fresh ? kd : 0xFFFFFFFFu;
                 } else if constexpr (STEPS == 8) {
                     if (fresh) dk = fkey_sumsq(l2_from_regs8(rr, qreg.v));
@@ -2282,7 +2288,7 @@ template <int METRIC, int STEPS, bool OFF32, bool AUX = false, bool BITMAP = fal
 __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                                  uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
     constexpr bool kEarlyLoad = (STEPS > 0);
-    constexpr bool kPair = (STEPS == 8) || (STEPS == 16 && METRIC == 0);  // 128-byte rows, and 256-byte rows with L2: two lanes per neighbour
+    constexpr bool kPair = (STEPS == 8) || ((STEPS == 12 || STEPS == 16) && METRIC == 0);  // 128-byte rows, and 192- / 256-byte rows with L2: two lanes per neighbour
     constexpr bool kAlt = (STEPS == 8 && METRIC == 1);
     constexpr int kQSteps = kPair ? STEPS / 2 : STEPS;        // row steps (16 bytes) per lane
     constexpr uint32_t kRowBytes = (uint32_t)STEPS * 16u;
@@ -4078,7 +4084,7 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, true>, p, false, lds, s);
         if (off32) {
             // the common shape (compact index, adjacency rows of one pass) gets the hop without the pass loop
-            if (!retry && p.ell_stride <= ((STEPS == 8 || (STEPS == 16 && METRIC == 0)) ? 32u : 64u))  // pair form: 32 slots per pass
+            if (!retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16) && METRIC == 0)) ? 32u : 64u))  // pair form: 32 slots per pass
                 return launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, false, true>, p, false, lds, s);
             return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, true>, p, true, lds, s)
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false>, p, false, lds, s);
@@ -4096,7 +4102,7 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
             if (!retry && walk_uses_hot(p, METRIC))
                 return launch_walk_k(walk_hot_kernel, p, false, walk_fast_lds_bytes(p, true), s);
         }
-        if (off32 && !retry && p.ell_stride <= (STEPS == 8 ? 32u : 64u))
+        if (off32 && !retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16) && METRIC == 0)) ? 32u : 64u))  // pair form: 32 slots per pass
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
     }
     if constexpr (R == 2 && METRIC == 0 && STEPS == 8) {
@@ -4129,7 +4135,7 @@ static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) 
                      : launch_walk_k(walk_fast_kernel<METRIC, STEPS, false, false>, p, false, lds, s);
     }
     if (p.ef <= 64) return launch_reg_t<METRIC, STEPS, 1>(p, retry, lds, s);
-    if (p.ef <= kHot2MaxEf) return launch_reg_t<METRIC, kWideSteps, 2>(p, retry, lds, s);
+    if (p.ef <= kHot2MaxEf) return launch_reg_t<METRIC, kWideSteps48, 2>(p, retry, lds, s);  // (12- / 16-step rows keep the unrolled distance)
     return launch_reg_t<METRIC, kWideSteps48, 4>(p, retry, lds, s);  // (R >= 4: the two-list kernels, one instance for every ef up to 512)
 }
 
