@@ -37,7 +37,14 @@ int main(int argc, char** argv) {
     const size_t n_tr = atoi(params["n_tr"].c_str());
     const size_t d = atoi(params["d"].c_str());
     const size_t d_low = atoi(params["d_low"].c_str());
-    const size_t d_hidden = atoi(params["d_hidden"].c_str());
+    size_t d_hidden = atoi(params["d_hidden"].c_str());
+    if (d_hidden == 0) {
+        // parameters_of_databases.txt has no d_hidden row for gist and deep (the reference reads 0 there and cannot load
+        // their nets): take the width from the `second_part` tag, "..._w_<width>_e_..." (:20, :31)
+        const string& tag = params["second_part"];
+        const size_t at = tag.find("_w_");
+        if (at != string::npos) d_hidden = atoi(tag.c_str() + at + 3);
+    }
     cout << n << " " << n_q << " " << n_tr << " " << d << " " << d_low << endl;
     if (n == 0 || n_q == 0 || d == 0) {
         cout << "dataset '" << datasetName << "' not found in " << paramsPath << endl;

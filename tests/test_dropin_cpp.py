@@ -60,7 +60,9 @@ def test_final_test_result_lines(tmp_path, orc, name, devices):
     params = tmp_path / "params.txt"
     params.write_text("\n".join([
         f"{ds} n {c.n}", f"{ds} n_q {c.nq}", f"{ds} n_tr {gd['truth'].shape[1]}", f"{ds} d {c.d}",
-        f"{ds} d_low {c.dlow}", f"{ds} d_hidden {c.dh}", f"{ds} efs {efs}", f"{ds} efs_hnsw {efs}",
+        # (the tail_toy case has no d_hidden row, as gist / deep in the reference's file: the width comes from second_part)
+        f"{ds} d_low {c.dlow}", (f"{ds} second_part _{c.dlow}_l_2_1m_5_40_w_{c.dh}_e_40" if name == "tail_toy" else f"{ds} d_hidden {c.dh}"),
+        f"{ds} efs {efs}", f"{ds} efs_hnsw {efs}",
         f"{ds} hnsw_name toygraph", "other n 5", "# comment line with three tokens"]) + "\n")
     env = dict(os.environ, GBNNS_NUM_EXPER="2")
     if devices:
