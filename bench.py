@@ -20,10 +20,16 @@ quoted on; the others are the survey's configurations 3-5 as bench lines of thei
                over the ranks (125 000 per GPU at N = 8), ef 40                        strong scaling
 
 Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement" for how every field is derived.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts N workers itself
+(python -m torch.distributed.run, rendezvous on 127.0.0.1) BEFORE anything touches the GPU, lets rank 0's
+line through and exits with their status.  Under an external launcher (WORLD_SIZE set) it is a worker.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -64,9 +70,47 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def launcher_command(gpus, argv, environ):
+    """The worker launch for `--gpus N` when this process is not already a worker (WORLD_SIZE unset), else None.
+    The workers get this process's arguments through GBNNS_BENCH_ARGV (torch.distributed.run's own parser would
+    take a script option such as --n for an abbreviation of one of its own)."""
+    if gpus <= 1 or "WORLD_SIZE" in environ:
+        return None
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+
+
+def launch_probe():
+    """`--launch-probe`: what a worker does to prove the launch path without a GPU -- gloo rendezvous, one all-reduce,
+    rank 0 prints the number of ranks it saw."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("GBNNS_PROBE_FAIL_RANK") == os.environ.get("RANK", "0"):
+        sys.exit(3)  # test hook: a worker that dies must make the launcher's exit status non-zero
+    seen = 1
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        assert dist.get_world_size() == world
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(json.dumps({"launch_probe": True, "ranks_seen": seen, "world_size": world}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--launch-probe", action="store_true", help="test hook: exercise the N-worker launch only (no GPU)")
+    ap.add_argument("--graph-M", type=int, default=None,
+                    help="GD pruning parameter of the synthetic graph (default 16: max degree <= 32, 32-slot adjacency rows; "
+                         "18 gives the 48-slot rows of the reference's own gist / deep graphs)")
+    ap.add_argument("--batches", type=int, default=4, help="distinct query batches rotated through the timed loop")
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 20 for gist / glove*, 3 for deep)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="sift")
@@ -79,8 +123,23 @@ def main():
     ap.add_argument("--hash-capacity", type=int, default=0, help="0 = library default (tuning knob)")
     ap.add_argument("--bitmap-pass", action="store_true", help="force the HBM-bitmap first pass (tuning knob: GBNNS_FLAG_BITMAP_PASS)")
     ap.add_argument("--sweep", action="store_true", help="also time every reference ef (stderr)")
+    ap.add_argument("--serial", action="store_true",
+                    help="timed steps one batch at a time on one stream (no GBNNS_FLAG_DEFER_JOIN pipelining)")
     ap.add_argument("--cache-dir", default=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"))
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    if not argv and os.environ.get("GBNNS_BENCH_ARGV") and "WORLD_SIZE" in os.environ:
+        argv = json.loads(os.environ["GBNNS_BENCH_ARGV"])  # a worker started by the branch below
+    args = ap.parse_args(argv)
+    cmd = launcher_command(args.gpus, argv, os.environ)
+    if cmd is not None:
+        # nothing above has touched the GPU (importing torch does not): the workers are fresh processes
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env["GBNNS_BENCH_ARGV"] = json.dumps(argv)
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+    if args.launch_probe:
+        launch_probe()
+        return
     cfg = dict(CONFIGS[args.config])
     cfg["name"] = args.config
     if args.steps is None:
@@ -121,6 +180,8 @@ def main():
               cache_dir=args.cache_dir, native_knn=bool(cfg.get("native_knn")) and cfg["n"] > 2_000_000)
     if cfg.get("unit_norm"):
         kw["unit_norm"] = True  # GloVe vectors are normalised before anything else (train_naive_triplet.py:233-237)
+    if args.graph_M:
+        kw["M"] = args.graph_M
     if cfg.get("strong"):
         kw["gt_queries"] = 20_000  # exact ground truth for the first 20 000 queries of the 1M batch (recall sample)
     if rank == 0:
@@ -196,9 +257,16 @@ def main():
 
     # ---- timed region -----------------------------------------------------------------------
     want = ("hops", "dist_calc", "edges")
-    # Two sets of output buffers used alternately: the all-gather of step i (RCCL's own stream) runs
-    # beside the kernels of step i+1; step i+2 reuses step i's buffers and therefore waits for that
-    # gather first (a stream-level wait, the host never blocks).
+    # Distinct query batches rotated through the loop (the recall-scored batch first): replaying one batch would touch
+    # the same rows every step, the friendliest case for L2 / Infinity Cache.
+    nb = max(1, min(args.batches, args.steps))
+    batches = [q] + [synth.more_queries(ds, nq_rank, batch=rank * 64 + j) for j in range(1, nb)]
+    # Steps are pipelined two deep inside the library (GBNNS_FLAG_DEFER_JOIN, include/gbnns.h): batch i runs on one
+    # of the handle's two internal streams and the caller's stream is made to wait for it by call i+1, after batch
+    # i+1 has been released -- the projection of batch i+1 runs in the half-empty tail of batch i's walk kernel.
+    # Two sets of output buffers used alternately; the all-gather of step i (RCCL's own stream) is issued once the
+    # stream has joined batch i and runs beside the kernels of step i+1; step i+2 reuses step i's buffers and
+    # therefore waits for that gather first (a stream-level wait, the host never blocks).
     outs = [{}, {}]
     gathered = [None, None]
     pending = [None, None]
@@ -206,29 +274,41 @@ def main():
     pad = sharding.shard_pad(nq_total, world) if strong else nq_rank  # equal-sized pieces for the all-gather
 
     tune_flags = g.FLAG_BITMAP_PASS if args.bitmap_pass else 0
+    pipelined = args.hash_capacity == 0 and not args.bitmap_pass and not args.serial
+    step_flags = tune_flags | (g.FLAG_DEFER_JOIN if pipelined else 0)
+
+    def gather(b):
+        # the path's only exchange step: all-gather of the int32 answer ids over RCCL/xGMI
+        if gathered[b] is None:
+            gathered[b] = torch.empty(world * pad, dtype=outs[b]["ids"].dtype, device=dev)
+        piece = outs[b]["ids"]
+        if pad != nq_rank:
+            if "ids_pad" not in outs[b]:
+                outs[b]["ids_pad"] = torch.full((pad,), -1, dtype=piece.dtype, device=dev)
+            outs[b]["ids_pad"][:nq_rank] = piece
+            piece = outs[b]["ids_pad"]
+        pending[b] = dist.all_gather_into_tensor(gathered[b], piece, async_op=True)
 
     def step():
         nonlocal nstep
-        b = nstep & 1
+        i = nstep
+        b = i & 1
         nstep += 1
         if pending[b] is not None:
             pending[b].wait()
             pending[b] = None
-        r = ix.search(q, ef, want=want, out=outs[b], hash_capacity=args.hash_capacity, flags=tune_flags)
+        r = ix.search(batches[i % nb], ef, want=want, out=outs[b], hash_capacity=args.hash_capacity, flags=step_flags)
         if world > 1:
-            # the path's only exchange step: all-gather of the int32 answer ids over RCCL/xGMI
-            if gathered[b] is None:
-                gathered[b] = torch.empty(world * pad, dtype=r["ids"].dtype, device=dev)
-            piece = r["ids"]
-            if pad != nq_rank:
-                if "ids_pad" not in outs[b]:
-                    outs[b]["ids_pad"] = torch.full((pad,), -1, dtype=piece.dtype, device=dev)
-                outs[b]["ids_pad"][:nq_rank] = piece
-                piece = outs[b]["ids_pad"]
-            pending[b] = dist.all_gather_into_tensor(gathered[b], piece, async_op=True)
+            if not pipelined:
+                gather(b)
+            elif i > 0:
+                gather(b ^ 1)  # that call made the stream wait for batch i-1: its answers are complete in stream order
         return r
 
     def drain():
+        ix.join()  # the stream waits for the last batch
+        if world > 1 and pipelined and nstep > 0 and pending[(nstep - 1) & 1] is None:
+            gather((nstep - 1) & 1)
         for b in (0, 1):
             if pending[b] is not None:
                 pending[b].wait()
@@ -236,22 +316,22 @@ def main():
 
     # The library sizes its visited sets from the walks it has seen and drops the retry launch once a few batches
     # of a configuration were quiet: let that settle before the W warm-up steps, whatever W is.
-    for _ in range(8 if nq_rank <= 20_000 else 3):
-        ix.search(q, ef, want=(), hash_capacity=args.hash_capacity, flags=tune_flags)
+    for j in range(8 if nq_rank <= 20_000 else 3):
+        ix.search(batches[j % nb], ef, want=(), hash_capacity=args.hash_capacity, flags=step_flags)
+        ix.join()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     drain()
     torch.cuda.synchronize()
-    ix.profile_read(reset=True)
-    ix.profile_enable(True)
+    nstep = 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
-    drain()  # every step's gather is inside the timed region
+        step()
+    drain()  # every step's join and gather is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -261,15 +341,36 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    prof = ix.profile_read(reset=True)
-    ix.profile_enable(False)
 
     ms_per_step = elapsed * 1e3 / args.steps
     qps = nq_total * args.steps / elapsed
 
+    # ---- the same K steps serialised (GBNNS_FLAG_SERIAL semantics: profiling implies it): one batch at a time on one
+    # stream, kernels back to back, with the library's hipEvent pairs around every stage on the launch stream.  This is
+    # where roofline.kernel_ms comes from -- overlapped kernels cannot be timed individually.
+    ix.profile_read(reset=True)
+    ix.profile_enable(True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        ix.search(batches[i % nb], ef, want=want, out=outs[i & 1], hash_capacity=args.hash_capacity, flags=tune_flags)
+    torch.cuda.synchronize()
+    elapsed_serial = time.perf_counter() - t1
+    prof = ix.profile_read(reset=True)
+    ix.profile_enable(False)
+    # walk statistics of every rotated batch (algorithmic bytes are averaged over them)
+    stats = {k: [] for k in want}
+    for j in range(nb):
+        r = ix.search(batches[j], ef, want=want, flags=tune_flags | g.FLAG_SERIAL)
+        for k in want:
+            stats[k].append(r[k].clone())
+    res = {k: torch.cat(v) for k, v in stats.items()}
+    res["ids"] = ix.search(q, ef, want=(), flags=tune_flags | g.FLAG_SERIAL)["ids"].clone()
+    torch.cuda.synchronize()
+
     # ---- algorithmic bytes of the dominant kernel (the beam walk), SURVEY.md section 8d ------
     max_degree = int(np.diff(np.asarray(ds.graph_off).astype(np.int64)).max())
-    rl = roofline_of(ds, res, prof, ef, nq_rank, max_degree, cfg, rank)
+    rl = roofline_of(ds, res, prof, ef, nq_rank, max_degree, cfg, rank, launches=nb)
     hops = res["hops"].double()
     dc = res["dist_calc"].double()
 
@@ -305,12 +406,22 @@ def main():
             "parallelism": "query-sharded replicas x%d" % world,
             "recipe": ds.recipe,
         },
+        "ranks_seen": dist.get_world_size() if world > 1 else 1,
         "roofline": rl["roofline"],
         "kernels_ms": rl["kernels_ms"],
+        "batches_rotated": nb,
+        "pipelined": bool(pipelined),
+        # the same K steps one batch at a time on one stream, kernels back to back (what round 1 / 2 reported as `value`)
+        "serial": {"ms_per_step": round(elapsed_serial * 1e3 / args.steps, 4),
+                   "queries_per_s": round(nq_rank * args.steps / elapsed_serial, 1),
+                   "note": "per rank, GBNNS_FLAG_SERIAL semantics, hipEvent profiling on: roofline.kernel_ms is measured here"},
         # what `value` leaves out, per SURVEY 8d's definition (one gbnns_search_batch incl. H2D / D2H): see
-        # host_buffers_qps below (filled at N = 1 unless --no-extras)
-        "value_definition": "queries of all ranks / wall time of K steps, inputs and outputs resident in HBM "
-                            "(device buffers); the PCIe-inclusive rate of the host-buffer call is host_buffers_qps",
+        # survey_8d_value below (filled at N = 1 unless --no-extras)
+        "value_definition": "queries of all ranks / wall time of K steps, inputs and outputs resident in HBM (device "
+                            "buffers), %s; the PCIe-inclusive rate of the host-buffer call is survey_8d_value" % (
+                                "steps pipelined two deep inside the library (GBNNS_FLAG_DEFER_JOIN: batch i+1 is released "
+                                "before the stream waits for batch i), %d distinct batches rotating" % nb if pipelined
+                                else "one batch at a time"),
     }
     if gate_failed:
         result["recall_gate_failed"] = True  # `value` is NOT a figure at recall >= 0.95
@@ -367,33 +478,6 @@ def main():
             "note": "f32 MFMA fma-chain rounding; off by default, default path is bit-exact",
         }
 
-    # ---- two batches in flight: two handles over the same resident index, one HIP stream each, used
-    # alternately, so the tail of batch i (a 10 k batch is < 2 "rounds" of resident wavefronts) runs
-    # beside the projection and the first round of batch i+1.  A serving-throughput figure; never `value`
-    # (which keeps one batch at a time on one stream).
-    if extras and small:
-        ix2 = ds.index(device_index=local, metric=metric_id)
-        handles = (ix, ix2)
-        streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-        outs2 = ({}, {})
-        torch.cuda.synchronize()
-        for i in range(12):  # both handles reach their settled sizing
-            handles[i & 1].search(q, ef, want=(), stream=streams[i & 1], out=outs2[i & 1])
-        torch.cuda.synchronize()
-        nrep = 40
-        t1 = time.perf_counter()
-        for i in range(nrep):
-            handles[i & 1].search(q, ef, want=(), stream=streams[i & 1], out=outs2[i & 1])
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
-        result["two_batches_in_flight"] = {
-            "queries_per_s": round(nrep * nq_rank / dt2, 1),
-            "ms_per_batch": round(dt2 * 1e3 / nrep, 4),
-            "answers_identical": bool(((outs2[0]["ids"] == res["ids"]) & (outs2[1]["ids"] == res["ids"])).all().item()),
-            "note": "two index handles (shared resident tensors) on two HIP streams, batches alternate",
-        }
-        ix2.close()
-
     # ---- PCIe-inclusive rate (host buffers in, ids out: what the C++ drop-in times, and SURVEY 8d's
     # "one gbnns_search_batch incl. H2D of queries and D2H of ids"); never `value`
     if extras and small:
@@ -403,6 +487,8 @@ def main():
         for _ in range(5):
             ix.search(qh, ef, want=())
         result["host_buffers_qps"] = round(5 * nq_rank / (time.perf_counter() - t1), 1)
+        # SURVEY 8d defines the metric's rate over one batch call INCLUDING H2D of the queries and D2H of the ids
+        result["survey_8d_value"] = result["host_buffers_qps"]
 
     # ---- CPU baseline (rank 0, N = 1 only): the compiled reference if present, else the port ----
     if world == 1 and not args.no_cpu_baseline:
@@ -436,7 +522,8 @@ def counters_for(config, ef):
         return None
 
 
-def roofline_of(ds, res, prof, ef, nq, max_degree, cfg, rank):
+def roofline_of(ds, res, prof, ef, nq, max_degree, cfg, rank, launches=1):
+    """`res` holds the walk counters of `launches` batches of nq queries each (concatenated)."""
     dc = res["dist_calc"].double()
     hops = res["hops"].double()
     edges = res["edges"].double()
@@ -446,7 +533,7 @@ def roofline_of(ds, res, prof, ef, nq, max_degree, cfg, rank):
             "hops max", int(hops.max().item()))
     d_low, d = ds.d_low, ds.d
     calls = max(prof["calls"], 1)
-    walk_bytes = (dc * 4 * d_low + edges * 4 + hops * 8 + 4 * d_low + 4 * ef).sum().item()
+    walk_bytes = (dc * 4 * d_low + edges * 4 + hops * 8 + 4 * d_low + 4 * ef).sum().item() / launches
     rerank_bytes = nq * (ef * 4.0 * d + 4 * d + 4 + 4 * ef)
     walk_ms = prof["walk_ms"] / calls
     rerank_ms = prof["rerank_ms"] / calls
@@ -478,6 +565,7 @@ def roofline_of(ds, res, prof, ef, nq, max_degree, cfg, rank):
         "algorithmic_bytes_walk_part": round(walk_bytes),
         "algorithmic_bytes_rerank_part": round(rerank_bytes if fused else 0),
         "kernel_ms": round(walk_ms, 4),
+        "kernel_ms_mode": "serialised steps (one stream, kernels back to back), hipEvent pairs on the launch stream",
     }
     if pmc and pmc.get("valu_insts"):
         # second roofline: vector-instruction issue.  One VALU instruction occupies its SIMD's issue port for 4
@@ -594,7 +682,34 @@ def cpu_baseline(ds, q, ef, gpu_ids, metric_id):
     tn, r = run(nfull, avail)
     scaling[str(avail)] = round(nfull / tn, 1)
     same = int((r["ids"].astype(np.int64) == gpu_ids[:nfull].cpu().numpy().astype(np.int64)).sum())
+    # the same sample on the reference built with the README's own flags (README.md:33: -Ofast -march=native; built in the
+    # build container, so first probed in a child process: an instruction this host lacks must not take the bench down)
+    readme = {"value_readme_flags": None}
+    if kind == "reference" and oracle.have_ref_fast():
+        probe_rc = subprocess.run([sys.executable, "-c",
+                                   "import sys; sys.path.insert(0, %r); import oracle, numpy as np; "
+                                   "r = oracle.Ref(oracle.REF_FAST_SO); "
+                                   "a = np.arange(64, dtype=np.float32); print(float(r.l2(a, a[::-1].copy())))" % ROOT],
+                                  capture_output=True).returncode
+        if probe_rc == 0:
+            fast = oracle.Ref(oracle.REF_FAST_SO)
+            fast.prepare(base)
+            fast.search_batch(oracle.MODE_NET, qh[:8], base, off, nbr, ef, db_low=dbl, net=net, metric=metric_id)
+            t0 = time.perf_counter()
+            rf = fast.search_batch(oracle.MODE_NET, qh[:nfull], base, off, nbr, ef, db_low=dbl, net=net, threads=avail,
+                                   metric=metric_id)
+            tf = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            fast.search_batch(oracle.MODE_NET, qh[:ns], base, off, nbr, ef, db_low=dbl, net=net, threads=1, metric=metric_id)
+            tf1 = time.perf_counter() - t0
+            readme = {"value_readme_flags": round(nfull / tf, 1), "value_readme_flags_1thread": round(ns / tf1, 1),
+                      "readme_flags": "g++ -Ofast -std=c++11 -fopenmp -march=native -ftree-vectorize (README.md:33), built on "
+                                      "the build container's CPU; host-dependent arithmetic (SURVEY F5), timing only",
+                      "readme_flags_ids_identical_to_strict": bool((rf["ids"] == r["ids"]).all())}
+        else:
+            readme["readme_flags"] = "the -march=native build of the build container does not run on this host (probe rc %d)" % probe_rc
     return {
+        **readme,
         "value": round(nfull / tn, 1),
         "unit": "queries/s",
         "cores": avail,

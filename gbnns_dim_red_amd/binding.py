@@ -20,10 +20,12 @@ FLAG_AUX_GRAPH = 4
 FLAG_LLF = 8
 FLAG_WIDE_INDEX = 16
 FLAG_BITMAP_PASS = 32
+FLAG_SERIAL = 64
+FLAG_DEFER_JOIN = 128
 
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "gbnns_index_create", "gbnns_index_destroy", "gbnns_index_set_aux_graph", "gbnns_search_ex", "gbnns_search_batch",
+    "gbnns_index_create", "gbnns_index_destroy", "gbnns_index_set_aux_graph", "gbnns_search_ex", "gbnns_search_batch", "gbnns_index_join",
     "gbnns_project", "gbnns_rerank", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd", "gbnns_build_graph_gd_device",
     "gbnns_free", "gbnns_exact_knn", "gbnns_device_count", "gbnns_version", "gbnns_last_error",
     "gbnns_index_n", "gbnns_index_d", "gbnns_index_d_low", "gbnns_index_device",
@@ -97,6 +99,7 @@ def load_library():
     lib.gbnns_index_destroy.argtypes = [C.c_void_p]
     lib.gbnns_index_set_aux_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gbnns_search_ex.argtypes = [C.c_void_p, C.POINTER(_SearchArgs)]
+    lib.gbnns_index_join.argtypes = [C.c_void_p]
     lib.gbnns_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gbnns_project.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int,
@@ -473,6 +476,10 @@ class Index:
         _check(self._lib.gbnns_search_ex(self._h, C.byref(a)))
         self._last = (queries, queries_low, entry_ids)  # keep device inputs alive until next call
         return res
+
+    def join(self):
+        """gbnns_index_join: the stream of the last FLAG_DEFER_JOIN call waits for that call's pieces."""
+        _check(self._lib.gbnns_index_join(self._h))
 
     def search_batch(self, queries, ef, entry_ids=None, want_cand=False):
         """The plain 9-argument C entry point (NET mode, host buffers)."""

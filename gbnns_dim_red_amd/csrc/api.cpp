@@ -87,6 +87,34 @@ struct ProfCall {
     bool has_project, has_rerank;
 };
 
+constexpr int kMaxLanes = 2;
+
+// One workspace of per-batch buffers + control words.  A handle has several so that the sub-batches of one call can be
+// in flight side by side on internal streams (the tail of one sub-batch's walk -- a 10 k batch is < 2 "rounds" of
+// resident wavefronts -- then runs beside the projection and the first round of the next one).
+struct Lane {
+    hipStream_t stream = nullptr;      // internal stream (created on first split call)
+    hipEvent_t done_ev = nullptr;      // recorded after the lane's last sub-batch of a call
+    DevBuf q_in, q_low, h1, h2, cand, cand_dist, cnt, hops, dc, edges, out, entries, ovf_list, ovf2_list, ctrl;
+    DevBuf g_bitmap, g_keys, fp_bitmap;
+    // visited-set sizing feedback: stats of an earlier call arrive asynchronously in pinned memory
+    uint32_t* h_stats = nullptr;       // [4] copy of ctrl after the walk kernels
+    hipEvent_t stats_ev = nullptr;
+    bool stats_pending = false;
+    int stats_ef = 0;
+    uint32_t stats_cap = 0;
+    // which of the two control-word blocks the next call uses, and whether each is known to be zero
+    int ctrl_phase = 0;
+    bool ctrl_clean[2] = {true, true};
+    bool ctrl_ready = false;
+    uint32_t last_general = 0;
+    DevBuf* bufs(int i) {
+        DevBuf* b[] = {&q_in, &q_low, &h1, &h2, &cand, &cand_dist, &cnt, &hops, &dc, &edges, &out, &entries,
+                       &ovf_list, &ovf2_list, &ctrl, &g_bitmap, &g_keys, &fp_bitmap};
+        return i < (int)(sizeof b / sizeof b[0]) ? b[i] : nullptr;
+    }
+};
+
 }  // namespace
 
 struct gbnns_index {
@@ -103,28 +131,25 @@ struct gbnns_index {
     bool has_net = false;
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     uint32_t ws1 = 0, ws2 = 0, ws3 = 0;
-    // workspace
-    DevBuf q_in, q_low, h1, h2, cand, cand_dist, cnt, hops, dc, edges, out, entries, ovf_list, ovf2_list, ctrl;
-    DevBuf g_bitmap, g_keys, fp_bitmap;
+    // workspaces: lane 0 serves serialised calls on the caller's stream; sub-batches of a split call run on
+    // lanes 0 .. n_lanes-1, each on its own internal stream (see gbnns_search_ex)
+    Lane lanes[kMaxLanes];
+    hipEvent_t fork_ev = nullptr;      // caller's stream -> lanes
     // profiling
     bool profiling = false;
     std::vector<ProfCall> pending;
     gbnns_profile acc{};
-    // last-call statistics (host mode only)
-    uint32_t last_general = 0;
-    // visited-set sizing feedback: stats of the previous call arrive asynchronously in pinned memory
-    uint32_t* h_stats = nullptr;       // [4] copy of ctrl after the walk kernels
-    hipEvent_t stats_ev = nullptr;
-    bool stats_pending = false;
-    int stats_ef = 0;
-    uint32_t stats_cap = 0;
+    // visited-set sizing feedback, shared by the lanes (host-side bookkeeping; the statistics of a call arrive
+    // asynchronously in the lane's pinned block)
     std::map<int, uint32_t> cap_for_ef;
     std::map<int, uint32_t> maxdc_for_ef;  // largest dist_calc seen per (ef, mode, aux, wide): the raw figure behind cap_for_ef
     std::map<int, int> calm_streak;   // per (ef, mode): consecutive observed batches without hand-over / resize
     uint32_t stats_tick = 0;
-    // which of the two control-word blocks the next call uses, and whether each is known to be zero
-    int ctrl_phase = 0;
-    bool ctrl_clean[2] = {true, true};
+    // a split call whose join (caller's stream waits for the lanes) has been deferred to the next call / gbnns_index_join
+    bool join_pending = false;
+    hipStream_t join_stream = nullptr;
+    int join_lanes = 0;                // bit mask
+    int next_lane = 0;
     // stream of the last call that left work in flight (the workspace and the control words are ordered by
     // stream order only: a call on another stream first waits for that work, see enter_stream)
     hipStream_t last_stream = nullptr;
@@ -216,7 +241,11 @@ constexpr size_t kMaxLds = 160 * 1024;
 // calls and ordered by stream order.  When a call names another stream than the last one that left work in
 // flight, the new stream first waits for that work (an event recorded on the old stream now covers everything
 // enqueued there so far).  Should the old stream be gone, the device is synchronised instead.
+int flush_join(gbnns_index* ix);
+
 int enter_stream(gbnns_index* ix, hipStream_t s) {
+    int rc = flush_join(ix);  // a split call's deferred join: its stream first waits for its lanes
+    if (rc) return rc;
     if (ix->in_flight && ix->last_stream != s) {
         hipError_t e = hipSuccess;
         if (!ix->order_ev) e = hipEventCreateWithFlags(&ix->order_ev, hipEventDisableTiming);
@@ -467,10 +496,14 @@ int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out) {
             ix->has_net = true;
         }
     }
-    if (!rc) rc = ix->ctrl.ensure(512);
+    if (!rc) rc = ix->lanes[0].ctrl.ensure(512);
     if (!rc) {
-        hipError_t e = hipMemset(ix->ctrl.p, 0, 512);
+        // (hipMemset on device memory may return before the fill has run: callers' streams may be non-blocking
+        // ones that do not order themselves after the null stream, so wait for it here)
+        hipError_t e = hipMemset(ix->lanes[0].ctrl.p, 0, 512);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess) rc = fail(GBNNS_ERR_HIP, "ctrl init: %s", hipGetErrorString(e));
+        ix->lanes[0].ctrl_ready = true;
     }
     if (rc) {
         gbnns_index_destroy(ix);
@@ -506,12 +539,17 @@ int gbnns_index_destroy(gbnns_index* ix) {
     (void)hipSetDevice(ix->device);
     for (auto& pc : ix->pending)
         for (auto& e : pc.ev) (void)hipEventDestroy(e);
-    if (ix->stats_ev) (void)hipEventDestroy(ix->stats_ev);
+    (void)hipDeviceSynchronize();  // lanes may still be running a call whose join was deferred
     if (ix->order_ev) (void)hipEventDestroy(ix->order_ev);
-    if (ix->h_stats) (void)hipHostFree(ix->h_stats);
-    DevBuf* bufs[] = {&ix->db_own, &ix->db_low_own, &ix->ell, &ix->aux_ell, &ix->net, &ix->q_in, &ix->q_low,
-                      &ix->h1, &ix->h2, &ix->cand, &ix->cand_dist, &ix->cnt, &ix->hops, &ix->dc, &ix->edges,
-                      &ix->out, &ix->entries, &ix->ovf_list, &ix->ovf2_list, &ix->ctrl, &ix->g_bitmap, &ix->fp_bitmap, &ix->g_keys};
+    if (ix->fork_ev) (void)hipEventDestroy(ix->fork_ev);
+    for (Lane& L : ix->lanes) {
+        if (L.stats_ev) (void)hipEventDestroy(L.stats_ev);
+        if (L.done_ev) (void)hipEventDestroy(L.done_ev);
+        if (L.h_stats) (void)hipHostFree(L.h_stats);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+        for (int i = 0; DevBuf* b = L.bufs(i); ++i) b->release();
+    }
+    DevBuf* bufs[] = {&ix->db_own, &ix->db_low_own, &ix->ell, &ix->aux_ell, &ix->net};
     for (DevBuf* b : bufs) b->release();
     delete ix;
     return GBNNS_OK;
@@ -522,7 +560,7 @@ int gbnns_index_destroy(gbnns_index* ix) {
 namespace {
 
 // MLP over rows x [nx x xstride] (device) -> out [nx x dl_pad] (device); h1/h2 are scratch.
-int run_project(gbnns_index* ix, const float* x, uint32_t xstride, uint32_t nx, float* out,
+int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint32_t nx, float* out,
                 hipStream_t s, bool mfma = false) {
     // GBNNS_FUSED_MLP=1: one launch for the whole net when its activations fit the LDS (project.hip; identical
     // outputs).  Off by default: measured 0.084 ms against 0.071 ms for the three per-layer launches on the SIFT
@@ -542,18 +580,18 @@ int run_project(gbnns_index* ix, const float* x, uint32_t xstride, uint32_t nx, 
             return GBNNS_OK;
         }
     }
-    int rc = ix->h1.ensure((size_t)nx * ix->d_hidden * 4);
-    if (!rc) rc = ix->h2.ensure((size_t)nx * ix->d_hidden * 4);
+    int rc = L.h1.ensure((size_t)nx * ix->d_hidden * 4);
+    if (!rc) rc = L.h2.ensure((size_t)nx * ix->d_hidden * 4);
     if (rc) return rc;
     LayerParams p{};
     p.x = x; p.xstride = xstride; p.w = ix->w1; p.wstride = ix->ws1; p.bias = ix->b1;
-    p.out = ix->h1.as<float>(); p.ostride = ix->d_hidden; p.nq = nx; p.din = ix->d;
+    p.out = L.h1.as<float>(); p.ostride = ix->d_hidden; p.nq = nx; p.din = ix->d;
     p.dout = ix->d_hidden; p.relu = 1; p.mfma = mfma ? 1 : 0;
     HIP_TRY(launch_mlp_layer(p, s));
-    p.x = ix->h1.as<float>(); p.xstride = ix->d_hidden; p.w = ix->w2; p.wstride = ix->ws2;
-    p.bias = ix->b2; p.out = ix->h2.as<float>(); p.din = ix->d_hidden;
+    p.x = L.h1.as<float>(); p.xstride = ix->d_hidden; p.w = ix->w2; p.wstride = ix->ws2;
+    p.bias = ix->b2; p.out = L.h2.as<float>(); p.din = ix->d_hidden;
     HIP_TRY(launch_mlp_layer(p, s));
-    p.x = ix->h2.as<float>(); p.w = ix->w3; p.wstride = ix->ws3; p.bias = ix->b3; p.out = out;
+    p.x = L.h2.as<float>(); p.w = ix->w3; p.wstride = ix->ws3; p.bias = ix->b3; p.out = out;
     p.ostride = ix->dl_pad; p.dout = ix->d_low; p.relu = 0; p.normalize = 1;
     HIP_TRY(launch_mlp_layer(p, s));
     return GBNNS_OK;
@@ -590,8 +628,9 @@ int gbnns_debug_read_stamps(gbnns_index* ix, unsigned long long* out32) {
     if (!ix || !out32) return fail(GBNNS_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(ix->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out32, ix->ctrl.as<uint32_t>() + 8, 256, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(ix->ctrl.as<uint32_t>() + 8, 0, 256));
+    HIP_TRY(hipMemcpy(out32, ix->lanes[0].ctrl.as<uint32_t>() + 8, 256, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ix->lanes[0].ctrl.as<uint32_t>() + 8, 0, 256));
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return GBNNS_OK;
 }
 
@@ -632,13 +671,14 @@ int gbnns_profile_read(gbnns_index* ix, gbnns_profile* out, int reset) {
     if (rc) return rc;
     uint32_t total = 0;  // ctrl[5]: queries the general kernel has processed since the last reset
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&total, ix->ctrl.as<uint32_t>() + 5, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&total, ix->lanes[0].ctrl.as<uint32_t>() + 5, 4, hipMemcpyDeviceToHost));
     ix->acc.general_queries = total;
     ix->acc.struct_size = sizeof(gbnns_profile);
     *out = ix->acc;
     if (reset) {
         ix->acc = gbnns_profile{};
-        HIP_TRY(hipMemset(ix->ctrl.as<uint32_t>() + 5, 0, 4));
+        HIP_TRY(hipMemset(ix->lanes[0].ctrl.as<uint32_t>() + 5, 0, 4));
+        HIP_TRY(hipStreamSynchronize(nullptr));  // callers' streams need not order themselves after the null stream
     }
     return GBNNS_OK;
 }
@@ -652,23 +692,24 @@ int gbnns_project(gbnns_index* ix, const float* x, uint64_t n_x, float* out, int
     const uint64_t chunk = 1u << 16;
     int rc = enter_stream(ix, s);
     if (rc) return rc;
-    rc = ix->q_low.ensure((size_t)std::min<uint64_t>(chunk, n_x) * ix->dl_pad * 4);
+    Lane& L = ix->lanes[0];
+    rc = L.q_low.ensure((size_t)std::min<uint64_t>(chunk, n_x) * ix->dl_pad * 4);
     if (rc) return rc;
     if (mem_kind == GBNNS_MEM_HOST) {
-        rc = ix->q_in.ensure((size_t)std::min<uint64_t>(chunk, n_x) * ix->d * 4);
+        rc = L.q_in.ensure((size_t)std::min<uint64_t>(chunk, n_x) * ix->d * 4);
         if (rc) return rc;
     }
     for (uint64_t b = 0; b < n_x; b += chunk) {
         const uint32_t m = (uint32_t)std::min<uint64_t>(chunk, n_x - b);
         const float* xin = x + b * ix->d;
         if (mem_kind == GBNNS_MEM_HOST) {
-            HIP_TRY(hipMemcpyAsync(ix->q_in.p, xin, (size_t)m * ix->d * 4, hipMemcpyHostToDevice, s));
-            xin = ix->q_in.as<float>();
+            HIP_TRY(hipMemcpyAsync(L.q_in.p, xin, (size_t)m * ix->d * 4, hipMemcpyHostToDevice, s));
+            xin = L.q_in.as<float>();
         }
-        float* dst = ix->q_low.as<float>();
+        float* dst = L.q_low.as<float>();
         const bool direct = mem_kind == GBNNS_MEM_DEVICE && ix->dl_pad == ix->d_low;
         if (direct) dst = out + b * ix->d_low;
-        rc = run_project(ix, xin, ix->d, m, dst, s);
+        rc = run_project(ix, L, xin, ix->d, m, dst, s);
         if (rc) return rc;
         if (!direct) {
             const hipMemcpyKind kind = mem_kind == GBNNS_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
@@ -692,15 +733,16 @@ int gbnns_rerank(gbnns_index* ix, const float* queries, uint64_t n_q, const uint
     const bool host = mem_kind == GBNNS_MEM_HOST;
     int rc;
     if ((rc = enter_stream(ix, s))) return rc;
+    Lane& L = ix->lanes[0];
     RerankParams r{};
     r.db = ix->db; r.dstride = ix->d_pad; r.dim = ix->d; r.qstride = ix->d; r.cand_stride = cand_stride;
     r.nq = nq; r.n = (uint32_t)ix->n;
-    if ((rc = ix->cnt.ensure((size_t)nq * 4))) return rc;
-    int32_t* cnt_dev = ix->cnt.as<int32_t>();
+    if ((rc = L.cnt.ensure((size_t)nq * 4))) return rc;
+    int32_t* cnt_dev = L.cnt.as<int32_t>();
     if (host) {
-        if ((rc = ix->q_in.ensure((size_t)nq * ix->d * 4))) return rc;
-        if ((rc = ix->cand.ensure((size_t)nq * cand_stride * 4))) return rc;
-        if ((rc = ix->out.ensure((size_t)nq * 4))) return rc;
+        if ((rc = L.q_in.ensure((size_t)nq * ix->d * 4))) return rc;
+        if ((rc = L.cand.ensure((size_t)nq * cand_stride * 4))) return rc;
+        if ((rc = L.out.ensure((size_t)nq * 4))) return rc;
         for (uint64_t i = 0; i < n_q; ++i) {
             const uint32_t c = count ? (uint32_t)std::max(count[i], 0) : cand_stride;
             if (c > cand_stride) return fail(GBNNS_ERR_INVALID, "count[%llu] > stride", (unsigned long long)i);
@@ -708,10 +750,10 @@ int gbnns_rerank(gbnns_index* ix, const float* queries, uint64_t n_q, const uint
                 if (cand[i * cand_stride + j] >= ix->n)
                     return fail(GBNNS_ERR_INVALID, "candidate id %u >= n", cand[i * cand_stride + j]);
         }
-        HIP_TRY(hipMemcpyAsync(ix->q_in.p, queries, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(ix->cand.p, cand, (size_t)nq * cand_stride * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(L.q_in.p, queries, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(L.cand.p, cand, (size_t)nq * cand_stride * 4, hipMemcpyHostToDevice, s));
         if (count) HIP_TRY(hipMemcpyAsync(cnt_dev, count, (size_t)nq * 4, hipMemcpyHostToDevice, s));
-        r.q = ix->q_in.as<float>(); r.cand = ix->cand.as<uint32_t>(); r.out = ix->out.as<uint32_t>();
+        r.q = L.q_in.as<float>(); r.cand = L.cand.as<uint32_t>(); r.out = L.out.as<uint32_t>();
     } else {
         r.q = queries; r.cand = cand; r.out = out_ids;
         if (count) cnt_dev = const_cast<int32_t*>(count);
@@ -727,34 +769,61 @@ int gbnns_rerank(gbnns_index* ix, const float* queries, uint64_t n_q, const uint
     return GBNNS_OK;
 }
 
-int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
-    if (!ix || !a) return fail(GBNNS_ERR_INVALID, "null argument");
-    if (a->struct_size != sizeof(gbnns_search_args))
-        return fail(GBNNS_ERR_INVALID, "gbnns_search_args.struct_size mismatch (%u != %zu)",
-                    a->struct_size, sizeof(gbnns_search_args));
-    if (a->mode < GBNNS_MODE_NET || a->mode > GBNNS_MODE_PLAIN) return fail(GBNNS_ERR_INVALID, "bad mode");
-    if (a->ef <= 0) return fail(GBNNS_ERR_INVALID, "ef must be >= 1");
-    if (a->mem_kind != GBNNS_MEM_HOST && a->mem_kind != GBNNS_MEM_DEVICE)
-        return fail(GBNNS_ERR_INVALID, "unknown mem_kind %d", a->mem_kind);
-    if (a->n_q == 0) return GBNNS_OK;
-    if (a->n_q >= (1ull << 31)) return fail(GBNNS_ERR_INVALID, "n_q too large");
-    if (!a->queries || !a->out_ids) return fail(GBNNS_ERR_INVALID, "queries / out_ids missing");
-    if (a->mode == GBNNS_MODE_NET && !ix->has_net) return fail(GBNNS_ERR_INVALID, "NET mode needs a net");
-    if (a->mode != GBNNS_MODE_PLAIN && !ix->db_low) return fail(GBNNS_ERR_INVALID, "mode needs db_low");
-    if (a->mode == GBNNS_MODE_LOWQ && !a->queries_low) return fail(GBNNS_ERR_INVALID, "queries_low missing");
-    if ((a->flags & GBNNS_FLAG_LLF) && !(a->flags & GBNNS_FLAG_AUX_GRAPH))
-        return fail(GBNNS_ERR_INVALID, "GBNNS_FLAG_LLF needs GBNNS_FLAG_AUX_GRAPH");
-    if ((a->flags & GBNNS_FLAG_AUX_GRAPH) && !ix->has_aux)
-        return fail(GBNNS_ERR_INVALID, "GBNNS_FLAG_AUX_GRAPH without gbnns_index_set_aux_graph");
-    if (a->hash_capacity != 0 && a->hash_capacity < 128)
-        return fail(GBNNS_ERR_INVALID, "hash_capacity must be 0 (auto) or >= 128");
-    const uint32_t n_ent = a->n_entries ? a->n_entries : 1u;
-    if (n_ent > 1 && !a->entry_ids) return fail(GBNNS_ERR_INVALID, "n_entries > 1 needs entry_ids");
-    if (n_ent > 4096) return fail(GBNNS_ERR_INVALID, "n_entries too large");
-    HIP_TRY(hipSetDevice(ix->device));
-    hipStream_t s = static_cast<hipStream_t>(a->stream);
+}  // extern "C"
+
+namespace {
+
+// Makes lane i usable for split calls: its internal stream, its "done" event and its zeroed control words.
+int ensure_lane(gbnns_index* ix, int i) {
+    Lane& L = ix->lanes[i];
+    if (!L.stream) HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    if (!L.done_ev) HIP_TRY(hipEventCreateWithFlags(&L.done_ev, hipEventDisableTiming));
+    if (!L.ctrl_ready) {
+        int rc = L.ctrl.ensure(512);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(L.ctrl.p, 0, 512, L.stream));  // in the lane's stream order: first use follows it
+        L.ctrl_ready = true;
+    }
+    return GBNNS_OK;
+}
+
+// How one call is laid out over the handle's lanes (workspace + internal stream each).
+//   * default: lane 0 in the caller's stream -- kernels back to back.
+//   * DEVICE buffers + GBNNS_FLAG_DEFER_JOIN: the whole batch on the next of two lanes, consecutive calls alternating,
+//     so that the projection of batch i+1 runs in the half-empty tail of batch i's walk kernel.
+// Measured and NOT done (profiles/r03_split_timelines.txt): cutting one batch into sub-batches on two streams.  A walk
+// kernel of 2 500 queries lasts 0.14 ms -- the latency chain of its longest walk -- where 10 000 queries take 0.33 ms,
+// and the projection blocks of the next piece (4 wavefronts, 14 KB of LDS) are not scheduled while a walk kernel still
+// has workgroups to dispatch (its single wavefronts take the LDS as it frees up), so the pieces queue behind one
+// another: 0.43 ms (halves) ... 0.52 ms (quarters) against 0.40 ms undivided.  The same holds with page-locked HOST
+// buffers, where the halves' copies do overlap: 0.55 against 0.52 ms.
+void plan_call(gbnns_index* ix, const gbnns_search_args* a, int& lanes, int& lane) {
+    lanes = 1;
+    lane = 0;
+#ifdef GBNNS_STAMPS
+    return;
+#endif
+    if ((a->flags & GBNNS_FLAG_SERIAL) || ix->profiling) return;
+    if (a->mem_kind != GBNNS_MEM_DEVICE || !(a->flags & GBNNS_FLAG_DEFER_JOIN)) return;
+    lanes = 2;
+    lane = ix->next_lane;
+    ix->next_lane ^= 1;
+}
+
+// The caller's stream waits for the lanes of a split call whose join was deferred.
+int flush_join(gbnns_index* ix) {
+    if (!ix->join_pending) return GBNNS_OK;
+    ix->join_pending = false;
+    for (int i = 0; i < kMaxLanes; ++i)
+        if (ix->join_lanes & (1 << i)) HIP_TRY(hipStreamWaitEvent(ix->join_stream, ix->lanes[i].done_ev, 0));
+    return GBNNS_OK;
+}
+
+// One (sub-)batch on one lane's workspace, enqueued on stream s; arguments validated by gbnns_search_ex.  With HOST
+// buffers the copies in and out are enqueued on s too and, when sync_host, waited for.
+int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_t s, bool sync_host) {
     int rc;
-    if ((rc = enter_stream(ix, s))) return rc;
+    const uint32_t n_ent = a->n_entries ? a->n_entries : 1u;
     const bool host = a->mem_kind == GBNNS_MEM_HOST;
     const uint32_t nq = (uint32_t)a->n_q;
     const int ef = a->ef;
@@ -763,42 +832,42 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     const uint32_t cstride = (uint32_t)k;
 
     // ---- workspace ----------------------------------------------------------------------
-    if ((rc = ix->cnt.ensure((size_t)nq * 4))) return rc;
-    if ((rc = ix->hops.ensure((size_t)nq * 4))) return rc;
-    if ((rc = ix->dc.ensure((size_t)nq * 4))) return rc;
-    if ((rc = ix->ovf_list.ensure((size_t)nq * 4))) return rc;
-    if ((rc = ix->ovf2_list.ensure((size_t)nq * 4))) return rc;
+    if ((rc = L.cnt.ensure((size_t)nq * 4))) return rc;
+    if ((rc = L.hops.ensure((size_t)nq * 4))) return rc;
+    if ((rc = L.dc.ensure((size_t)nq * 4))) return rc;
+    if ((rc = L.ovf_list.ensure((size_t)nq * 4))) return rc;
+    if ((rc = L.ovf2_list.ensure((size_t)nq * 4))) return rc;
     if (host || !a->out_cand)
-        if ((rc = ix->cand.ensure((size_t)nq * cstride * 4))) return rc;
+        if ((rc = L.cand.ensure((size_t)nq * cstride * 4))) return rc;
     if (a->out_cand_dist && host)
-        if ((rc = ix->cand_dist.ensure((size_t)nq * cstride * 4))) return rc;
+        if ((rc = L.cand_dist.ensure((size_t)nq * cstride * 4))) return rc;
     if (host)
-        if ((rc = ix->out.ensure((size_t)nq * 4))) return rc;
+        if ((rc = L.out.ensure((size_t)nq * 4))) return rc;
     if (host && a->out_edges)
-        if ((rc = ix->edges.ensure((size_t)nq * 4))) return rc;
+        if ((rc = L.edges.ensure((size_t)nq * 4))) return rc;
     // general-kernel slots: visited bits + tie bits (n / 4 bytes per slot) and the result list -- 16 n bytes + 512 ef
     // per handle in all (see gbnns.h, "Device memory")
     const uint32_t bitmap_words = ((uint32_t)((ix->n + 31) / 32) + 3u) & ~3u;  // per slot; a multiple of 4 words: slots stay 16-B aligned (the bitmap pass clears with 16-B stores)
     {
-        const size_t before = ix->g_bitmap.bytes;  // (re)allocation always changes the size
-        if ((rc = ix->g_bitmap.ensure((size_t)kGeneralSlots * 2 * bitmap_words * 4))) return rc;
+        const size_t before = L.g_bitmap.bytes;  // (re)allocation always changes the size
+        if ((rc = L.g_bitmap.ensure((size_t)kGeneralSlots * 2 * bitmap_words * 4))) return rc;
         // the tie bits must start out all zero (the kernel keeps them so); the visited bits are cleared per query
-        if (ix->g_bitmap.bytes != before) HIP_TRY(hipMemsetAsync(ix->g_bitmap.p, 0, ix->g_bitmap.bytes, s));
+        if (L.g_bitmap.bytes != before) HIP_TRY(hipMemsetAsync(L.g_bitmap.p, 0, L.g_bitmap.bytes, s));
     }
-    if ((rc = ix->g_keys.ensure((size_t)kGeneralSlots * ((size_t)ef + n_ent - 1) * 8))) return rc;
+    if ((rc = L.g_keys.ensure((size_t)kGeneralSlots * ((size_t)ef + n_ent - 1) * 8))) return rc;
 
     // ---- inputs -------------------------------------------------------------------------
     const float* q_dev = a->queries;
     if (host) {
-        if ((rc = ix->q_in.ensure((size_t)nq * ix->d * 4))) return rc;
-        HIP_TRY(hipMemcpyAsync(ix->q_in.p, a->queries, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice, s));
-        q_dev = ix->q_in.as<float>();
+        if ((rc = L.q_in.ensure((size_t)nq * ix->d * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(L.q_in.p, a->queries, (size_t)nq * ix->d * 4, hipMemcpyHostToDevice, s));
+        q_dev = L.q_in.as<float>();
     }
     const uint32_t* entries_dev = a->entry_ids;
     if (a->entry_ids && host) {
-        if ((rc = ix->entries.ensure((size_t)nq * n_ent * 4))) return rc;
-        HIP_TRY(hipMemcpyAsync(ix->entries.p, a->entry_ids, (size_t)nq * n_ent * 4, hipMemcpyHostToDevice, s));
-        entries_dev = ix->entries.as<uint32_t>();
+        if ((rc = L.entries.ensure((size_t)nq * n_ent * 4))) return rc;
+        HIP_TRY(hipMemcpyAsync(L.entries.p, a->entry_ids, (size_t)nq * n_ent * 4, hipMemcpyHostToDevice, s));
+        entries_dev = L.entries.as<uint32_t>();
     }
     if (a->entry_ids && host) {
         for (size_t i = 0; i < (size_t)nq * n_ent; ++i)
@@ -818,10 +887,10 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     if (plain) {
         w.q = q_dev; w.qstride = ix->d; w.db = ix->db; w.dstride = ix->d_pad; w.dim = ix->d;
     } else {
-        if ((rc = ix->q_low.ensure((size_t)nq * ix->dl_pad * 4))) return rc;
-        float* ql = ix->q_low.as<float>();
+        if ((rc = L.q_low.ensure((size_t)nq * ix->dl_pad * 4))) return rc;
+        float* ql = L.q_low.as<float>();
         if (a->mode == GBNNS_MODE_NET) {
-            if ((rc = run_project(ix, q_dev, ix->d, nq, ql, s, (a->flags & GBNNS_FLAG_MFMA_PROJECT) != 0))) return rc;
+            if ((rc = run_project(ix, L, q_dev, ix->d, nq, ql, s, (a->flags & GBNNS_FLAG_MFMA_PROJECT) != 0))) return rc;
             w.q = ql; w.qstride = ix->dl_pad;
         } else if (host) {
             HIP_TRY(hipMemcpyAsync(ql, a->queries_low, (size_t)nq * ix->d_low * 4, hipMemcpyHostToDevice, s));
@@ -841,34 +910,34 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     // ---- stage 2: beam walk -----------------------------------------------------------
     w.ell = ix->ell.as<uint32_t>(); w.ell_stride = ix->ell_stride; w.n = (uint32_t)ix->n; w.nq = nq;
     w.ef = ef; w.k = k; w.entries = entries_dev; w.n_entries = n_ent;
-    w.cand = (!host && a->out_cand) ? a->out_cand : ix->cand.as<uint32_t>();
-    w.cand_dist = a->out_cand_dist ? (host ? ix->cand_dist.as<float>() : a->out_cand_dist) : nullptr;
+    w.cand = (!host && a->out_cand) ? a->out_cand : L.cand.as<uint32_t>();
+    w.cand_dist = a->out_cand_dist ? (host ? L.cand_dist.as<float>() : a->out_cand_dist) : nullptr;
     w.cand_stride = cstride;
     w.zero_dist_bits = ix->metric == GBNNS_METRIC_NEG_DOT ? 0x80000000u : 0u;
-    w.count = ix->cnt.as<int32_t>();
-    w.hops = (!host && a->out_hops) ? a->out_hops : ix->hops.as<int32_t>();
-    w.dist_calc = (!host && a->out_dist_calc) ? a->out_dist_calc : ix->dc.as<int32_t>();
-    w.edges = a->out_edges ? (host ? ix->edges.as<int32_t>() : a->out_edges) : nullptr;
-    uint32_t* out_dev = host ? ix->out.as<uint32_t>() : a->out_ids;
+    w.count = L.cnt.as<int32_t>();
+    w.hops = (!host && a->out_hops) ? a->out_hops : L.hops.as<int32_t>();
+    w.dist_calc = (!host && a->out_dist_calc) ? a->out_dist_calc : L.dc.as<int32_t>();
+    w.edges = a->out_edges ? (host ? L.edges.as<int32_t>() : a->out_edges) : nullptr;
+    uint32_t* out_dev = host ? L.out.as<uint32_t>() : a->out_ids;
     w.best = plain ? out_dev : nullptr;
     // Control words, two per-call blocks used alternately: [0] list A count, [1] general cursor,
     // [2] max dist_calc, [3] list B count, [4] retry cursor, [6] bitmap-pass cursor.  A call works on one block while its
     // general kernel (the last walk launch) clears the other for the next call -- no per-call memset
     // launch.  Word 5 of block 0 = general-kernel query total (persistent); words 8..71 = diagnostics.
-    uint32_t* ctrl_base = ix->ctrl.as<uint32_t>();
-    const int cur = ix->ctrl_phase;
+    uint32_t* ctrl_base = L.ctrl.as<uint32_t>();
+    const int cur = L.ctrl_phase;
     uint32_t* ctrl = ctrl_base + (cur ? 72 : 0);
     uint32_t* ctrl_next = ctrl_base + (cur ? 0 : 72);
-    if (!ix->ctrl_clean[cur]) {  // after a failed call only (word 5 of block 0 is the persistent general-kernel total)
+    if (!L.ctrl_clean[cur]) {  // after a failed call only (word 5 of block 0 is the persistent general-kernel total)
         HIP_TRY(hipMemsetAsync(ctrl, 0, 20, s));
         HIP_TRY(hipMemsetAsync(ctrl + 6, 0, 4, s));
     }
-    ix->ctrl_clean[cur] = false;
-    ix->ctrl_phase = cur ^ 1;
+    L.ctrl_clean[cur] = false;
+    L.ctrl_phase = cur ^ 1;
     w.next_ctrl = ctrl_next;
     w.ovf_count = ctrl; w.g_cursor = ctrl + 1; w.max_dc = ctrl + 2; w.ovf2_count = ctrl + 3; w.r_cursor = ctrl + 4;
-    w.g_total = ctrl_base + 5; w.ovf_list = ix->ovf_list.as<uint32_t>(); w.ovf2_list = ix->ovf2_list.as<uint32_t>();
-    w.g_bitmap = ix->g_bitmap.as<uint32_t>(); w.g_keys = ix->g_keys.as<uint64_t>();
+    w.g_total = ix->lanes[0].ctrl.as<uint32_t>() + 5; w.ovf_list = L.ovf_list.as<uint32_t>(); w.ovf2_list = L.ovf2_list.as<uint32_t>();
+    w.g_bitmap = L.g_bitmap.as<uint32_t>(); w.g_keys = L.g_keys.as<uint64_t>();
     w.bitmap_words = bitmap_words;
 
     // Visited-set capacity.  The walk kernel's occupancy is LDS-bound, and a 10k-query batch is only
@@ -877,21 +946,21 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     // 17/15 x the largest dist_calc of earlier batches, doubled whenever a batch handed queries
     // over), find how many wavefronts per CU that allows, then give each wavefront the whole
     // 160 KB / wavefronts share (capacity need not be a power of two: slot = mulhi(hash, cap)).
-    if (ix->stats_pending && hipEventQuery(ix->stats_ev) == hipSuccess) {
-        ix->stats_pending = false;
-        const uint32_t ovf = ix->h_stats[0], maxdc = ix->h_stats[2];
+    if (L.stats_pending && hipEventQuery(L.stats_ev) == hipSuccess) {
+        L.stats_pending = false;
+        const uint32_t ovf = L.h_stats[0], maxdc = L.h_stats[2];
         // entries so that the largest walk seen (+ 1/16 margin + one pass of new ids) stays under the
         // 15/16 fill limit
         uint32_t need = (maxdc + maxdc / 16 + 64) / 15 * 16 + 16;
         // max_dc covers the retry / general passes too, so a hand-over needs no extra sizing rule
-        uint32_t& seen = ix->maxdc_for_ef[ix->stats_ef];
+        uint32_t& seen = ix->maxdc_for_ef[L.stats_ef];
         seen = std::max(seen, maxdc);
-        uint32_t& slot = ix->cap_for_ef[ix->stats_ef];  // stats_ef = skey of that call
+        uint32_t& slot = ix->cap_for_ef[L.stats_ef];  // stats_ef = skey of that call
         const bool grew = need > slot;
         slot = std::max(slot, need);  // never shrinks: batches with one long walk do not make it oscillate
         // calm = the last observed batch of this (ef, mode) handed nothing over and did not move the size
-        const bool quiet = ovf + ix->h_stats[3] == 0 && !grew;
-        int& streak = ix->calm_streak[ix->stats_ef];
+        const bool quiet = ovf + L.h_stats[3] == 0 && !grew;
+        int& streak = ix->calm_streak[L.stats_ef];
         streak = quiet ? std::min(streak + 1, 1 << 20) : 0;
     }
     w.force_wide = (a->flags & GBNNS_FLAG_WIDE_INDEX) ? 1 : 0;
@@ -997,8 +1066,8 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     }
     bool bitmap_pass = false;
     if (bitmap_per_cu) {
-        if ((rc = ix->fp_bitmap.ensure(bitmap_per_cu * 256 * (size_t)bitmap_words * 4))) return rc;
-        w.fp_bitmap = ix->fp_bitmap.as<uint32_t>();
+        if ((rc = L.fp_bitmap.ensure(bitmap_per_cu * 256 * (size_t)bitmap_words * 4))) return rc;
+        w.fp_bitmap = L.fp_bitmap.as<uint32_t>();
         w.fp_cursor = ctrl + 6;
         HIP_TRY(launch_walk_bitmap(w, ix->metric, (unsigned)(bitmap_per_cu * 256), s));
         bitmap_pass = true;
@@ -1037,21 +1106,21 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         std::snprintf(ix->acc.walk_kernel, sizeof(ix->acc.walk_kernel), "%s", name.c_str());
     }
     HIP_TRY(launch_walk_general(w, ix->metric, s));
-    ix->ctrl_clean[cur ^ 1] = true;  // cleared by that launch
+    L.ctrl_clean[cur ^ 1] = true;  // cleared by that launch
     if (prof) HIP_TRY(hipEventRecord(pc.ev[3], s));
     // statistics of this call (hand-over counts, largest walk), read back asynchronously: every call until
     // things are calm, every 16th afterwards (each read is a small copy on the stream)
     ix->stats_tick += 1;
-    if (auto_cap && !w.all_general && !ix->stats_pending && (calm < 4 || (ix->stats_tick & 15u) == 0)) {
-        if (!ix->h_stats) {
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ix->h_stats), 16, hipHostMallocDefault));
-            HIP_TRY(hipEventCreateWithFlags(&ix->stats_ev, hipEventDisableTiming));
+    if (auto_cap && !w.all_general && !L.stats_pending && (calm < 4 || (ix->stats_tick & 15u) == 0)) {
+        if (!L.h_stats) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&L.h_stats), 16, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&L.stats_ev, hipEventDisableTiming));
         }
-        HIP_TRY(hipMemcpyAsync(ix->h_stats, ctrl, 16, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(ix->stats_ev, s));
-        ix->stats_pending = true;
-        ix->stats_ef = skey;
-        ix->stats_cap = cap;
+        HIP_TRY(hipMemcpyAsync(L.h_stats, ctrl, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(L.stats_ev, s));
+        L.stats_pending = true;
+        L.stats_ef = skey;
+        L.stats_cap = cap;
     }
 
     // ---- stage 3: re-rank in the original space ------------------------------------------
@@ -1077,12 +1146,85 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
             HIP_TRY(hipMemcpyAsync(a->out_cand, w.cand, (size_t)nq * cstride * 4, hipMemcpyDeviceToHost, s));
         if (a->out_cand_dist)
             HIP_TRY(hipMemcpyAsync(a->out_cand_dist, w.cand_dist, (size_t)nq * cstride * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&ix->last_general, ctrl, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        ix->in_flight = false;
-        if (w.all_general) ix->last_general = nq;
+        if (sync_host) {
+            HIP_TRY(hipStreamSynchronize(s));
+            ix->in_flight = false;
+        }
     }
     return GBNNS_OK;
+}
+
+
+}  // namespace
+
+extern "C" {
+
+int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
+    if (!ix || !a) return fail(GBNNS_ERR_INVALID, "null argument");
+    if (a->struct_size != sizeof(gbnns_search_args))
+        return fail(GBNNS_ERR_INVALID, "gbnns_search_args.struct_size mismatch (%u != %zu)",
+                    a->struct_size, sizeof(gbnns_search_args));
+    if (a->mode < GBNNS_MODE_NET || a->mode > GBNNS_MODE_PLAIN) return fail(GBNNS_ERR_INVALID, "bad mode");
+    if (a->ef <= 0) return fail(GBNNS_ERR_INVALID, "ef must be >= 1");
+    if (a->mem_kind != GBNNS_MEM_HOST && a->mem_kind != GBNNS_MEM_DEVICE)
+        return fail(GBNNS_ERR_INVALID, "unknown mem_kind %d", a->mem_kind);
+    if (a->n_q == 0) return GBNNS_OK;
+    if (a->n_q >= (1ull << 31)) return fail(GBNNS_ERR_INVALID, "n_q too large");
+    if (!a->queries || !a->out_ids) return fail(GBNNS_ERR_INVALID, "queries / out_ids missing");
+    if (a->mode == GBNNS_MODE_NET && !ix->has_net) return fail(GBNNS_ERR_INVALID, "NET mode needs a net");
+    if (a->mode != GBNNS_MODE_PLAIN && !ix->db_low) return fail(GBNNS_ERR_INVALID, "mode needs db_low");
+    if (a->mode == GBNNS_MODE_LOWQ && !a->queries_low) return fail(GBNNS_ERR_INVALID, "queries_low missing");
+    if ((a->flags & GBNNS_FLAG_LLF) && !(a->flags & GBNNS_FLAG_AUX_GRAPH))
+        return fail(GBNNS_ERR_INVALID, "GBNNS_FLAG_LLF needs GBNNS_FLAG_AUX_GRAPH");
+    if ((a->flags & GBNNS_FLAG_AUX_GRAPH) && !ix->has_aux)
+        return fail(GBNNS_ERR_INVALID, "GBNNS_FLAG_AUX_GRAPH without gbnns_index_set_aux_graph");
+    if (a->hash_capacity != 0 && a->hash_capacity < 128)
+        return fail(GBNNS_ERR_INVALID, "hash_capacity must be 0 (auto) or >= 128");
+    const uint32_t n_ent = a->n_entries ? a->n_entries : 1u;
+    if (n_ent > 1 && !a->entry_ids) return fail(GBNNS_ERR_INVALID, "n_entries > 1 needs entry_ids");
+    if (n_ent > 4096) return fail(GBNNS_ERR_INVALID, "n_entries too large");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = static_cast<hipStream_t>(a->stream);
+    int rc;
+    int n_lanes = 1, lane = 0;
+    plan_call(ix, a, n_lanes, lane);
+    if (n_lanes <= 1) {
+        if ((rc = enter_stream(ix, s))) return rc;
+        return search_core(ix, ix->lanes[0], a, s, true);
+    }
+
+    // ---- deferred join: the batch runs on lane `lane`'s internal stream ---------------------------------------
+    if ((rc = ensure_lane(ix, lane))) return rc;
+    Lane& L = ix->lanes[lane];
+    if (!ix->fork_ev) HIP_TRY(hipEventCreateWithFlags(&ix->fork_ev, hipEventDisableTiming));
+    if (ix->join_pending && ix->join_stream == s && ix->last_stream == s) {
+        // the previous call's join is still owed to this very stream: fork first, so that this batch is released
+        // beside the previous one, then let the stream wait for the previous one
+        HIP_TRY(hipEventRecord(ix->fork_ev, s));
+        if ((rc = flush_join(ix))) return rc;
+    } else {
+        if ((rc = enter_stream(ix, s))) return rc;
+        HIP_TRY(hipEventRecord(ix->fork_ev, s));
+    }
+    ix->last_stream = s;
+    ix->in_flight = true;
+    HIP_TRY(hipStreamWaitEvent(L.stream, ix->fork_ev, 0));
+    if ((rc = search_core(ix, L, a, L.stream, false))) {
+        (void)hipDeviceSynchronize();  // leave nothing in flight behind an error
+        ix->in_flight = false;
+        return rc;
+    }
+    HIP_TRY(hipEventRecord(L.done_ev, L.stream));
+    ix->join_pending = true;
+    ix->join_stream = s;
+    ix->join_lanes = 1 << lane;
+    return GBNNS_OK;
+}
+
+int gbnns_index_join(gbnns_index* ix) {
+    if (!ix) return fail(GBNNS_ERR_INVALID, "null index");
+    HIP_TRY(hipSetDevice(ix->device));
+    return flush_join(ix);
 }
 
 int gbnns_search_batch(gbnns_index* index, const float* queries, size_t n_q, int ef,

@@ -111,6 +111,28 @@ def ground_truth(base, queries, k=2, chunk=2048):
     return out
 
 
+def more_queries(ds, count, batch=0):
+    """`count` further query vectors from the dataset's distribution (same clusters, same embedding, an
+    independent random stream per `batch`): distinct batches for a timed loop.  No ground truth."""
+    r = ds.recipe
+    dev = ds.base.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(r["seed"])
+    m = r["intrinsic"]
+    A = _orthonormal_rows(gen, r["d_low"], r["d"], dev)  # the first two draws of make_dataset, replayed
+    centers = torch.randn(r["n_clusters"], m, generator=gen, device=dev)
+    centers = centers / centers.norm(dim=1, keepdim=True)
+    g2 = torch.Generator(device=dev)
+    g2.manual_seed(r["seed"] + 7919 * (batch + 1))
+    j = torch.randint(0, r["n_clusters"], (count,), generator=g2, device=dev)
+    z = centers[j] + r["cluster_scale"] * torch.randn(count, m, generator=g2, device=dev)
+    z = z / z.norm(dim=1, keepdim=True)
+    x = z @ A[:m] + r["sigma"] * torch.randn(count, r["d"], generator=g2, device=dev)
+    if r.get("unit_norm"):
+        x = x / x.norm(dim=1, keepdim=True)
+    return x.contiguous()
+
+
 def make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=1234,
                  device="cuda:0", intrinsic=16, n_clusters=1000, cluster_scale=0.5, sigma=0.03,
                  knn_k=48, M=16, threads=0, cache_dir=None, projector=None, verbose=False, native_knn=False,

@@ -166,11 +166,30 @@ typedef struct {
  * table would allow.  Same results. */
 #define GBNNS_FLAG_BITMAP_PASS 32u
 
+/* Batches in flight.  A handle owns two workspaces with an internal HIP stream each ("lanes"); plain calls use the
+ * first one on the caller's stream.  Every query is independent (search_function.h:348), so the answers never
+ * depend on how a call is laid out.
+ *   GBNNS_FLAG_DEFER_JOIN  DEVICE buffers: the batch runs on the next lane (consecutive calls alternate) after what
+ *                          was enqueued on args->stream before the call, and the call returns WITHOUT making
+ *                          args->stream wait for it; that wait is enqueued by the next call on this handle -- after
+ *                          the new batch has been released, so the tail of batch i (a 10 k batch is < 2 "rounds" of
+ *                          resident wavefronts) runs beside the projection and the head of batch i+1 -- or by
+ *                          gbnns_index_join.  Until then the outputs of the call must not be read and its inputs /
+ *                          outputs must not be reused: a serving loop alternates two sets of buffers.
+ *   GBNNS_FLAG_SERIAL      the caller's stream, kernels back to back, whatever else is asked (what per-kernel timing
+ *                          needs; gbnns_profile_enable(..., 1) implies it).  HOST-buffer calls always run this way. */
+#define GBNNS_FLAG_SERIAL 64u
+#define GBNNS_FLAG_DEFER_JOIN 128u
+
 /* Replaces the timed query loop of performNetTest (search_function.h:346-387) / performTest
  * (:151-188): one call = the whole batch.  With HOST buffers the call copies in, runs and
  * copies out synchronously (what the drop-in harness times).  With DEVICE buffers everything is
  * enqueued on args->stream and the call returns without synchronising. */
 int gbnns_search_ex(gbnns_index* index, const gbnns_search_args* args);
+
+/* Enqueues, on the stream of the last GBNNS_FLAG_DEFER_JOIN call, the wait for that call's pieces (no-op when
+ * nothing is owed).  Everything enqueued on that stream afterwards sees the call's outputs. */
+int gbnns_index_join(gbnns_index* index);
 
 /* Convenience form of the above: NET mode, host buffers, synchronous. */
 int gbnns_search_batch(gbnns_index* index, const float* queries, size_t n_q, int ef,

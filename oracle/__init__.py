@@ -18,6 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "liboracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libgbnns_ref.so")
+REF_FAST_SO = os.path.join(_HERE, "_ref", "libgbnns_ref_fast.so")  # the README's -Ofast -march=native build (timing only)
 
 L2, NEG_DOT = 0, 1
 MODE_NET, MODE_LOWQ, MODE_PLAIN = 0, 1, 2
@@ -37,6 +38,10 @@ def build(force=False):
 
 def have_ref():
     return os.path.exists(REF_SO)
+
+
+def have_ref_fast():
+    return os.path.exists(REF_FAST_SO)
 
 
 def _p(a, typ):
@@ -81,10 +86,11 @@ class _Base:
 class Oracle(_Base):
     prefix = "gbo_"
 
-    def __init__(self):
-        if not os.path.exists(ORACLE_SO):
+    def __init__(self, so=None):
+        so = so or os.environ.get("GBNNS_ORACLE_SO") or ORACLE_SO
+        if so == ORACLE_SO and not os.path.exists(ORACLE_SO):
             build()
-        self.lib = C.CDLL(ORACLE_SO)
+        self.lib = C.CDLL(so)
         self._l2 = self._fn("l2", C.c_float, [_f32p, _f32p, C.c_uint64])
         self._negdot = self._fn("negdot", C.c_float, [_f32p, _f32p, C.c_uint64])
         self._project = self._fn("project", None, [_f32p] * 5 + [C.c_uint64] + [C.c_int] * 4)
@@ -218,10 +224,11 @@ class Ref(_Base):
     """The compiled reference (oracle/_ref).  Same numpy API as Oracle."""
     prefix = "ref_"
 
-    def __init__(self):
-        if not have_ref():
-            raise FileNotFoundError(REF_SO)
-        self.lib = C.CDLL(REF_SO)
+    def __init__(self, so=None):
+        so = so or os.environ.get("GBNNS_REF_SO") or REF_SO
+        if not os.path.exists(so):
+            raise FileNotFoundError(so)
+        self.lib = C.CDLL(so)
         self._l2 = self._fn("l2", C.c_float, [_f32p, _f32p, C.c_uint64])
         self._negdot = self._fn("negdot", C.c_float, [_f32p, _f32p, C.c_uint64])
         self._graph_create = self._fn("graph_create", C.c_void_p, [_u64p, _u32p, C.c_uint64])

@@ -3,6 +3,7 @@ to run without a GPU (no CPU fallback), and its host-side graph builder matches 
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -146,3 +147,27 @@ def test_graph_builder_vs_oracle(lib, orc, M, rev):
     a = g.build_graph_gd(koff, knbr, c.base, M, reverse=rev, threads=4)
     b = orc.hnswlike_gd(koff, knbr, c.base, M, reverse=rev, threads=2)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_bench_launches_its_own_workers():
+    """`python bench.py --gpus N` without WORLD_SIZE (how the driver calls it) must start N workers itself: the launch
+    command, and -- with the --launch-probe hook, which needs no GPU -- the whole path: two fresh processes, a gloo
+    rendezvous on 127.0.0.1, one JSON line from rank 0, exit status of the workers."""
+    import json
+    import subprocess
+    import bench
+    assert bench.launcher_command(1, ["--gpus", "1"], {}) is None
+    assert bench.launcher_command(8, ["--gpus", "8"], {"WORLD_SIZE": "8"}) is None  # already a worker
+    cmd = bench.launcher_command(8, ["--gpus", "8", "--steps", "5"], {})
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-1].endswith("bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-probe"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"launch_probe": True, "ranks_seen": 2, "world_size": 2}
+    # a failing worker's status is the launcher's status
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-probe"],
+                       env=dict(env, GBNNS_PROBE_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0

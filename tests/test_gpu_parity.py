@@ -407,6 +407,75 @@ def test_one_handle_on_alternating_streams(g, orc):
     ix.close()
 
 
+def test_deferred_join_pipeline(g, orc):
+    """GBNNS_FLAG_DEFER_JOIN (gbnns.h, "Batches in flight"): consecutive batches alternate between the handle's two
+    internal streams and the caller's stream waits for batch i only at call i+1 / gbnns_index_join.  A pipelined run of
+    different batches and beams -- mixed with plain calls, a change of the caller's stream, hand-overs forced through
+    tiny visited sets -- must leave exactly what one-at-a-time calls leave (every array against the oracle)."""
+    import torch
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    c, off, nbr, db_low, ent = _oracle_case(orc, 841, 20000, 3000, 40, 32, 64)
+    ix = g.Index(t(c.base), off, nbr, db_low=t(db_low), net=tuple(t(x) for x in c.net))
+    qs = [t(c.queries[i * 1000:(i + 1) * 1000]) for i in range(3)]
+    es = [t(ent[i * 1000:(i + 1) * 1000].astype(np.int32)) for i in range(3)]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(dev)
+    plan = [(0, 64, True, None), (1, 8, True, None), (2, 64, True, None), (0, 200, True, None), (1, 64, False, None),
+            (2, 16, True, None), (0, 64, True, side), (1, 64, True, side), (2, 100, False, side), (0, 64, True, None),
+            (1, 600, True, None)]
+    outs = []
+    for i, (b, ef, defer, st) in enumerate(plan):
+        outs.append(ix.search(qs[b], ef, entry_ids=es[b], want=("hops", "dist_calc", "cand"), stream=st, out={},
+                              flags=g.FLAG_DEFER_JOIN if defer else 0, hash_capacity=128 if i in (3, 8) else 0))
+    ix.join()
+    torch.cuda.synchronize()
+    for (b, ef, defer, st), r in zip(plan, outs):
+        sl = slice(b * 1000, (b + 1) * 1000)
+        s = orc.search_batch(orc_mod.MODE_NET, c.queries[sl], c.base, off, nbr, ef, db_low=db_low, net=c.net,
+                             entries=ent[sl], threads=8)
+        w = orc.walk(orc.project(c.net, c.queries[sl]), db_low, off, nbr, ef, entries=ent[sl], threads=8)
+        assert np.array_equal(r["ids"].cpu().numpy().view(np.uint32), s["ids"]), (b, ef, defer)
+        assert np.array_equal(r["hops"].cpu().numpy(), s["hops"]), (b, ef, defer)
+        assert np.array_equal(r["dist_calc"].cpu().numpy() + ef, s["dist_calc"]), (b, ef, defer)
+        assert np.array_equal(r["cand"].cpu().numpy().view(np.uint32), w["ids"]), (b, ef, defer)
+    # a consumer enqueued on the caller's stream after join() sees the answers without any host synchronisation
+    r = ix.search(qs[0], 64, entry_ids=es[0], want=(), out={}, flags=g.FLAG_DEFER_JOIN)
+    ix.join()
+    copy = r["ids"].clone()          # torch's current stream = the stream of the call
+    torch.cuda.synchronize()
+    assert np.array_equal(copy.cpu().numpy(), outs[0]["ids"].cpu().numpy())
+    # host buffers and profiling ignore the flag (plain call)
+    rh = ix.search(c.queries[:1000], 64, entry_ids=ent[:1000], want=(), flags=g.FLAG_DEFER_JOIN)
+    assert np.array_equal(rh["ids"].view(np.uint32), outs[0]["ids"].cpu().numpy().view(np.uint32))
+    ix.close()
+
+
+def test_bench_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` as the driver calls it (no external launcher): the process starts its two workers
+    itself before touching the GPU.  GBNNS_BENCH_REHEARSAL=1 puts both ranks on cuda:0 with gloo for the collective --
+    the N > 1 control flow (sharded queries, deferred joins, all-gather per step, max over ranks) on a one-GPU box;
+    not a measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GBNNS_BENCH_REHEARSAL="1", GBNNS_CACHE="/tmp/gbnns_cache_rehearsal")
+    env.pop("WORLD_SIZE", None)
+    for extra in ([], ["--config", "deep", "--ef", "40"]):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                            "--n", "60000", "--nq", "3000", "--no-extras", "--no-cpu-baseline"] + extra,
+                           env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        r = json.loads(lines[0])
+        assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["steps"] == 3
+        assert r["value"] > 0 and r["roofline"]["frac"] > 0
+        assert r["scaling"] == ("strong" if extra else "weak")
+
+
 def test_multi_replicas_equal_single_handle(g, orc):
     """gbnns_multi_* (query-sharded replicas below Python).  A one-GPU box cannot hold two devices, so the replicas
     sit on device 0 twice / three times (own handle, host thread and HIP stream each) -- the block arithmetic, the
