@@ -339,9 +339,15 @@ hipError_t launch_knn_m(const KnnParams& p, hipStream_t s) {
     if (p.dim <= 32) return launch_knn_t<METRIC, 8, 2>(p, s);
     if (p.dim <= 64) return launch_knn_t<METRIC, 16, 2>(p, s);
     if (p.dim <= 128) return launch_knn_t<METRIC, 32, 1>(p, s);
-    // wide rows: tiles of 16 (L2) / 8 (dot) rows with their running sums in registers; the LDS tile bounds d
-    if constexpr (METRIC == 0) return launch_knn_wide<0, 16>(p, s);
-    else return launch_knn_wide<1, 8>(p, s);
+    // wide rows: tiles of 16 (L2) / 8 (dot) rows with their running sums in registers; the [R][d] tile must fit the
+    // 160 KB of LDS (64 d bytes at R = 16), so very wide rows take fewer rows per tile: d <= 2560 / 5120 / 8192
+    const size_t row_bytes = (size_t)(((p.dim >> 2) + 7u) & ~7u) * 16;
+    if constexpr (METRIC == 0) {
+        if (16 * row_bytes <= 160 * 1024) return launch_knn_wide<0, 16>(p, s);
+    }
+    if (8 * row_bytes <= 160 * 1024) return launch_knn_wide<METRIC, 8>(p, s);
+    if (4 * row_bytes <= 160 * 1024) return launch_knn_wide<METRIC, 4>(p, s);
+    return hipErrorInvalidValue;  // d > 10240: refused by gbnns_exact_knn (d <= 8192) before it gets here
 }
 
 }  // namespace

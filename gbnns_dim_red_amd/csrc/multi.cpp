@@ -21,6 +21,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -41,12 +42,21 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool load(std::string& why) {
         if (so) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (so) break;
+        // GBNNS_RCCL_LIB names the library instead of the usual places (also how the tests reach the failure path)
+        const char* forced = getenv("GBNNS_RCCL_LIB");
+        const char* usual[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        const char* first_err = nullptr;
+        std::string kept;
+        for (size_t i = 0; i < (forced ? 1u : 3u) && !so; ++i) {
+            so = dlopen(forced ? forced : usual[i], RTLD_NOW | RTLD_LOCAL);
+            if (!so && !first_err) {
+                const char* e = dlerror();  // ONE call: dlerror() hands the message out once and clears it
+                kept = e ? e : "librccl.so not found";
+                first_err = kept.c_str();
+            }
         }
         if (!so) {
-            why = dlerror() ? dlerror() : "librccl.so not found";
+            why = first_err ? kept : std::string("librccl.so not found");
             return false;
         }
         auto sym = [&](const char* n) { return dlsym(so, n); };
@@ -58,6 +68,8 @@ struct Rccl {
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
         if (!CommInitAll || !CommDestroy || !AllGather || !GroupStart || !GroupEnd) {
             why = "librccl.so lacks an expected symbol";
+            dlclose(so);
+            so = nullptr;
             return false;
         }
         return true;
@@ -222,6 +234,15 @@ int gbnns_multi_search_ex(gbnns_multi* m, const gbnns_search_args* a) {
     if (a->mem_kind != GBNNS_MEM_HOST)
         return mfail(GBNNS_ERR_INVALID, "gbnns_multi_search_ex takes HOST buffers (device blocks: gbnns_multi_search_device)");
     if (a->n_q == 0) return GBNNS_OK;
+    // everything a replica would refuse is refused here, once, before any pointer is offset: a replica r > 0 handed
+    // "NULL + lo" would take it for a buffer
+    if (a->mode < GBNNS_MODE_NET || a->mode > GBNNS_MODE_PLAIN) return mfail(GBNNS_ERR_INVALID, "bad mode");
+    if (a->ef <= 0) return mfail(GBNNS_ERR_INVALID, "ef must be >= 1");
+    if (a->n_q >= (1ull << 31)) return mfail(GBNNS_ERR_INVALID, "n_q too large");
+    if (!a->queries || !a->out_ids) return mfail(GBNNS_ERR_INVALID, "queries / out_ids missing");
+    if (a->mode == GBNNS_MODE_LOWQ && !a->queries_low) return mfail(GBNNS_ERR_INVALID, "queries_low missing");
+    if (a->n_entries > 1 && !a->entry_ids) return mfail(GBNNS_ERR_INVALID, "n_entries > 1 needs entry_ids");
+    if (a->n_entries > 4096) return mfail(GBNNS_ERR_INVALID, "n_entries too large");
     const int R = (int)m->replicas.size();
     const uint32_t n_ent = a->n_entries ? a->n_entries : 1u;
     const int kk = a->mode == GBNNS_MODE_PLAIN ? (a->k > 0 ? (a->k < a->ef ? a->k : a->ef) : 1) : a->ef;  // candidate row width
@@ -337,6 +358,16 @@ int gbnns_multi_synchronize(gbnns_multi* m) {
         if (hipSetDevice(m->devices[r]) != hipSuccess || hipStreamSynchronize(m->streams[r]) != hipSuccess)
             return mfail(GBNNS_ERR_HIP, "synchronising replica %zu failed", r);
     }
+    return GBNNS_OK;
+}
+
+// Diagnostic (not in gbnns.h; tests/test_cabi_cpu.py): loads RCCL the way gbnns_multi_search_device does on first
+// use with more than one replica.  0 = loaded, GBNNS_ERR_UNSUPPORTED + message otherwise.
+int gbnns_internal_rccl_probe(void) {
+    Rccl r;
+    std::string why;
+    if (!r.load(why)) return mfail(GBNNS_ERR_UNSUPPORTED, "RCCL unavailable: %s", why.c_str());
+    dlclose(r.so);
     return GBNNS_OK;
 }
 

@@ -78,6 +78,7 @@ int main(int argc, char** argv) {
     const string output_s = resultsDir + "/final_results_" + datasetName + ".txt";
     const char* output = output_s.c_str();
     remove(output);
+    remove((string(output) + ".json").c_str());  // the machine-readable sidecar is rewritten with the result file
 
     L2Metric l2 = L2Metric();
     std::mt19937 random_gen;

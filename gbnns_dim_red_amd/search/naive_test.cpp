@@ -95,6 +95,7 @@ int main(int argc, char** argv) {
     const string output_s = resultsDir + "/naive_results_" + datasetName + ".txt";
     const char* output = output_s.c_str();
     remove(output);
+    remove((string(output) + ".json").c_str());  // the machine-readable sidecar is rewritten with the result file
 
     performRealTests(n, d, d, n_q, n_tr, efs_hnsw_origin, random_gen, hnsw, hnsw, db, queries, db, queries, truth,
                      output, &l2, "hnsw", false, false, numberExper, numberThreads);

@@ -79,6 +79,12 @@ inline std::map<gbnns_index*, gbnns_multi*>& gbnnsMultiOf() {
     return m;
 }
 
+// auxiliary graph (by address) currently attached to a handle
+inline std::map<gbnns_index*, const void*>& gbnnsAttached() {
+    static std::map<gbnns_index*, const void*> m;
+    return m;
+}
+
 // devices the drop-in searches on: GBNNS_DEVICES (comma list; "all" = every visible device), else GBNNS_DEVICE, else 0
 inline vector<int32_t> gbnnsDevices() {
     vector<int32_t> devs;
@@ -121,6 +127,24 @@ inline gbnns_index* gbnnsIndexFor(vector<vector<uint32_t>>& graph, const float* 
     const GbnnsKey key(db, db_low, &graph, net, n, d, d_low, metric->gbnnsMetric(), fp);
     auto it = gbnnsCache().find(key);
     if (it != gbnnsCache().end()) return it->second;
+    // same buffers, other contents (a caller refilled a vector in place): the old device copy is dead weight
+    for (auto old = gbnnsCache().begin(); old != gbnnsCache().end();) {
+        const GbnnsKey& k = old->first;
+        if (std::get<0>(k) == std::get<0>(key) && std::get<1>(k) == std::get<1>(key) && std::get<2>(k) == std::get<2>(key) &&
+            std::get<3>(k) == std::get<3>(key) && std::get<7>(k) == std::get<7>(key)) {
+            gbnnsAttached().erase(old->second);
+            auto mi = gbnnsMultiOf().find(old->second);
+            if (mi != gbnnsMultiOf().end()) {
+                gbnns_multi_destroy(mi->second);
+                gbnnsMultiOf().erase(mi);
+            } else {
+                gbnns_index_destroy(old->second);
+            }
+            old = gbnnsCache().erase(old);
+        } else {
+            ++old;
+        }
+    }
     const GbnnsCsr csr = gbnnsToCsr(graph);
     gbnns_index_desc desc = {};
     desc.struct_size = sizeof desc;
@@ -173,7 +197,7 @@ struct GbnnsAux {
 // cache) and returns the flags of the search call.
 inline uint32_t gbnnsAttachAux(gbnns_index* ix, const GbnnsAux& aux) {
     if (!aux.use) return 0;
-    static std::map<gbnns_index*, const void*> attached;
+    std::map<gbnns_index*, const void*>& attached = gbnnsAttached();
     if (attached[ix] != (const void*)aux.graph) {
         const GbnnsCsr csr = gbnnsToCsr(*aux.graph);
         auto mi = gbnnsMultiOf().find(ix);
@@ -211,7 +235,8 @@ inline vector<uint32_t> gbnnsEntries(const vector<vector<uint32_t>>& inter_point
 // mode PLAIN: walk in the space of the index's `db` with (ef, k), answer = top of the heap trimmed to k (:174-181).
 inline void gbnnsBatch(gbnns_index* ix, int mode, const float* queries, const float* queries_low,
                        size_t n_q, int ef, int k, const vector<uint32_t>& entries, vector<uint32_t>& ans,
-                       vector<int32_t>& hops, vector<int32_t>& dist_calc, const GbnnsAux& aux, uint32_t n_entries = 1) {
+                       vector<int32_t>& hops, vector<int32_t>& dist_calc, const GbnnsAux& aux, uint32_t n_entries = 1,
+                       vector<int32_t>* edges = nullptr) {
     gbnns_search_args a = {};
     a.n_entries = n_entries;
     a.flags = gbnnsAttachAux(ix, aux);
@@ -228,6 +253,7 @@ inline void gbnnsBatch(gbnns_index* ix, int mode, const float* queries, const fl
     a.out_ids = ans.data();
     a.out_hops = hops.data();
     a.out_dist_calc = dist_calc.data();
+    if (edges) a.out_edges = edges->data();  // neighbour ids read: feeds the sidecar's byte count
     auto mi = gbnnsMultiOf().find(ix);
     if (mi != gbnnsMultiOf().end()) {  // GBNNS_DEVICES: contiguous query blocks, one per replica / device
         if (gbnns_multi_search_ex(mi->second, &a)) {
@@ -318,18 +344,37 @@ inline void gbnnsScore(const vector<uint32_t>& ans, vector<float>& ds, vector<ui
     }
 }
 
+// What one query moves, SURVEY.md section 8(d): low-dim (walked) rows gathered + neighbour ids read + row offsets +
+// the query and its result, plus -- two-stage -- the re-ranked original-space rows, the original query and the answer.
+struct GbnnsTraffic {
+    double walk_dist_calc;  // mean distances of the walk (without the "+ recheck_size" the harness adds, :362)
+    double edges;           // mean neighbour ids read
+    int walked_dim;         // dimension of the walked space
+    bool rerank;            // original-space re-rank of `ef` candidates
+};
+
 // one JSON object per sweep point, appended to <output_txt>.json
 inline void gbnnsSidecar(const char* output_txt, const string& graph_name, int ef, int k, int recheck_size, double acc,
-                         double hops, double dist_calc, double sec_per_query, int num_exp, int n_q, int n, int d, int d_low) {
+                         double hops, double dist_calc, double sec_per_query, int num_exp, int n_q, int n, int d, int d_low,
+                         const GbnnsTraffic& t) {
     if (!output_txt) return;
     std::ofstream js((string(output_txt) + ".json").c_str(), std::ios_base::app);
     const vector<int32_t> devs = gbnnsDevices();
+    const double walk_bytes = t.walk_dist_calc * 4.0 * t.walked_dim + 4.0 * t.edges + 8.0 * hops + 4.0 * t.walked_dim + 4.0 * ef;
+    const double rerank_bytes = t.rerank ? (double)ef * 4.0 * d + 4.0 * d + 4.0 * ef + 4.0 : 0.0;
+    const double gbps = sec_per_query > 0 ? (walk_bytes + rerank_bytes) / sec_per_query * 1e-9 : 0.0;
+    const double peak_gbps = 8000.0 * (double)devs.size();  // MI355X HBM3E: 8 TB/s per device
     js << "{\"graph_type\": \"" << graph_name << "\", \"ef\": " << ef << ", \"k\": " << k << ", \"recheck_size\": " << recheck_size
        << ", \"n\": " << n << ", \"n_q\": " << n_q << ", \"d\": " << d << ", \"d_low\": " << d_low
        << ", \"repeats\": " << num_exp << ", \"recall_at_1\": " << acc << ", \"mean_hops\": " << hops
        << ", \"mean_dist_calc\": " << dist_calc << ", \"sec_per_query\": " << sec_per_query
        << ", \"queries_per_s\": " << (sec_per_query > 0 ? 1.0 / sec_per_query : 0.0)
        << ", \"timed_region\": \"host buffers in, answers out (H2D + kernels + D2H), as search_function.h:346-387\""
+       << ", \"algorithmic_bytes_per_query\": " << (walk_bytes + rerank_bytes)
+       << ", \"algorithmic_bytes_walk_part\": " << walk_bytes << ", \"mean_edges_read\": " << t.edges
+       << ", \"GBps\": " << gbps << ", \"roofline_peak_GBps\": " << peak_gbps
+       << ", \"roofline_frac\": " << gbps / peak_gbps
+       << ", \"roofline_note\": \"algorithmic bytes (SURVEY 8d) over the WHOLE timed region incl. PCIe copies; the kernel-level figure is bench.py's roofline.frac\""
        << ", \"devices\": [";
     for (size_t i = 0; i < devs.size(); ++i) js << (i ? ", " : "") << devs[i];
     js << "], \"backend\": \"libgbnns_hip (gfx950)\"}" << std::endl;
@@ -383,23 +428,27 @@ void performTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>>& 
     float acc = 0;
     float work_time = 0;
     int num_exp = 0;
-    vector<int32_t> q_hops(n_q), q_dc(n_q);
+    vector<int32_t> q_hops(n_q), q_dc(n_q), q_edges(n_q);
+    long long walk_dc = 0, edges = 0;
     for (int v = 0; v < number_exper; ++v) {
         num_exp += 1;
         vector<uint32_t> ans(n_q);
         StopW stopw = StopW();
-        gbnnsBatch(ix, mode, q_main, q_low, n_q, run_ef, run_k, entries, ans, q_hops, q_dc, aux, n_entries);
+        gbnnsBatch(ix, mode, q_main, q_low, n_q, run_ef, run_k, entries, ans, q_hops, q_dc, aux, n_entries, &q_edges);
         work_time += stopw.getElapsedTimeMicro();
         for (int i = 0; i < n_q; ++i) {
             hops += q_hops[i];
             dist_calc += q_dc[i] + (mode == GBNNS_MODE_LOWQ ? recheck_size : 0);
+            walk_dc += q_dc[i];
+            edges += q_edges[i];
         }
         gbnnsScore(ans, ds, truth, d, n_q, n_tr, metric, acc);
     }
     gbnnsReport(outfile, graph_name, acc, hops, dist_calc, work_time, num_exp, n_q);
-    gbnnsSidecar(output_txt, graph_name, run_ef, run_k, recheck_size, acc / ((double)num_exp * n_q),
-                 (double)hops / ((double)num_exp * n_q), (double)dist_calc / ((double)num_exp * n_q),
-                 work_time / (num_exp * 1e6 * n_q), num_exp, n_q, n, d, d_low);
+    const double per = (double)num_exp * n_q;
+    const GbnnsTraffic traffic = {walk_dc / per, edges / per, d != d_low ? d_low : d, mode == GBNNS_MODE_LOWQ};
+    gbnnsSidecar(output_txt, graph_name, run_ef, run_k, recheck_size, acc / per, (double)hops / per, (double)dist_calc / per,
+                 work_time / (num_exp * 1e6 * n_q), num_exp, n_q, n, d, d_low, traffic);
 }
 
 inline vector<vector<uint32_t>> gbnnsInterPoints(int n, int n_q, std::mt19937& random_gen, const string& graph_name) {
@@ -491,7 +540,8 @@ void performNetTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>
     float acc = 0;
     float work_time = 0;
     int num_exp = 0;
-    vector<int32_t> q_hops(n_q), q_dc(n_q);
+    vector<int32_t> q_hops(n_q), q_dc(n_q), q_edges(n_q);
+    long long walk_dc = 0, edges = 0;
     vector<float> q_low;
     for (int v = 0; v < number_exper; ++v) {
         num_exp += 1;
@@ -499,25 +549,31 @@ void performNetTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>
         StopW stopw = StopW();
         if (two_stage) {
             gbnnsBatch(ix, GBNNS_MODE_NET, queries.data(), nullptr, n_q, recheck_size, recheck_size, entries, ans,
-                       q_hops, q_dc, aux, n_entries);
+                       q_hops, q_dc, aux, n_entries, &q_edges);
         } else if (low_only) {
             q_low.resize((size_t)n_q * d_low);
             if (gbnns_project(ix, queries.data(), n_q, q_low.data(), GBNNS_MEM_HOST, nullptr)) gbnnsDie("gbnns_project");
-            gbnnsBatch(ix_low, GBNNS_MODE_PLAIN, q_low.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux, n_entries);
+            gbnnsBatch(ix_low, GBNNS_MODE_PLAIN, q_low.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux, n_entries,
+                       &q_edges);
         } else {
-            gbnnsBatch(ix, GBNNS_MODE_PLAIN, queries.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux, n_entries);
+            gbnnsBatch(ix, GBNNS_MODE_PLAIN, queries.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux, n_entries,
+                       &q_edges);
         }
         work_time += stopw.getElapsedTimeMicro();
         for (int i = 0; i < n_q; ++i) {
             hops += q_hops[i];
             dist_calc += q_dc[i] + (two_stage ? recheck_size : 0);
+            walk_dc += q_dc[i];
+            edges += q_edges[i];
         }
         gbnnsScore(ans, ds, truth, d, n_q, n_tr, metric, acc);
     }
     gbnnsReport(outfile, graph_name, acc, hops, dist_calc, work_time, num_exp, n_q);
+    const double per = (double)num_exp * n_q;
+    const GbnnsTraffic traffic = {walk_dc / per, edges / per, d != d_low ? d_low : d, two_stage};
     gbnnsSidecar(output_txt, graph_name, two_stage ? recheck_size : ef, two_stage ? recheck_size : k, recheck_size,
-                 acc / ((double)num_exp * n_q), (double)hops / ((double)num_exp * n_q),
-                 (double)dist_calc / ((double)num_exp * n_q), work_time / (num_exp * 1e6 * n_q), num_exp, n_q, n, d, d_low);
+                 acc / per, (double)hops / per, (double)dist_calc / per, work_time / (num_exp * 1e6 * n_q), num_exp, n_q, n, d,
+                 d_low, traffic);
 }
 
 void performRealNetTests(int n, int d, int d_low, int n_q, int n_tr, vector<int> efs, std::mt19937 random_gen,

@@ -414,6 +414,27 @@ class Ref(_Base):
         f = self._util("fill_const_degree", [_u64p, _u32p, _u64p, _u32p, C.c_uint64, C.c_int])
         return self._fetch(n, f(_p(aoff, _u64p), _p(anbr, _u32p), _p(boff, _u64p), _p(bnbr, _u32p), n, degree))
 
+    def make_step(self, db, query, nb, ef, top, cand, visited, metric=L2):
+        """The reference's makeStep once: top / cand = (keys f32, ids u32) heap contents, visited = marked ids.
+        Returns dict(dist_calc, found, marked, top=(keys, ids) in pop order, cand=(keys, ids) in pop order)."""
+        db, query = _f32(db), _f32(query)
+        nb, visited = _u32(nb), _u32(visited)
+        tk, ti, ck, ci = _f32(top[0]), _u32(top[1]), _f32(cand[0]), _u32(cand[1])
+        cap = len(tk) + len(ck) + len(nb) + 1
+        info = np.zeros(5, np.int32)
+        otk, oti = np.zeros(cap, np.float32), np.zeros(cap, np.uint32)
+        ock, oci = np.zeros(cap, np.float32), np.zeros(cap, np.uint32)
+        f = self.lib.ref_make_step
+        f.restype = None
+        f.argtypes = [_f32p, C.c_uint64, C.c_int, _f32p, _u32p, C.c_int, C.c_int, _f32p, _u32p, C.c_int, _f32p, _u32p,
+                      C.c_int, _u32p, C.c_int, C.c_int, _i32p, _f32p, _u32p, _f32p, _u32p]
+        f(_p(db, _f32p), db.shape[0], db.shape[1], _p(query, _f32p), _p(nb, _u32p), len(nb), ef, _p(tk, _f32p),
+          _p(ti, _u32p), len(tk), _p(ck, _f32p), _p(ci, _u32p), len(ck), _p(visited, _u32p), len(visited), metric,
+          _p(info, _i32p), _p(otk, _f32p), _p(oti, _u32p), _p(ock, _f32p), _p(oci, _u32p))
+        nt, nc = int(info[2]), int(info[3])
+        return dict(dist_calc=int(info[0]), found=bool(info[1]), marked=int(info[4]), top=(otk[:nt], oti[:nt]),
+                    cand=(ock[:nc], oci[:nc]))
+
     def kl_build(self, which, l, ds, sqrt_n, seed, metric=L2):
         ds = _f32(ds)
         n, d = ds.shape

@@ -289,6 +289,32 @@ void ref_get_truth(const float* base, uint64_t n, const float* queries, uint64_t
 
 int ref_max_threads() { return omp_get_max_threads(); }
 
+// One call of the reference's makeStep (search_function.h:15-40) on caller-supplied state: the heaps as (key, id)
+// pairs, the ids already marked visited.  Results: both heaps in pop order, dist_calc, found, number of marked ids.
+void ref_make_step(const float* db, uint64_t n, int d, const float* query, const uint32_t* nb, int n_nb, int ef,
+                   const float* top_key, const uint32_t* top_id, int n_top, const float* cand_key, const uint32_t* cand_id,
+                   int n_cand, const uint32_t* visited, int n_vis, int metric, int32_t* out_info, float* out_top_key,
+                   uint32_t* out_top_id, float* out_cand_key, uint32_t* out_cand_id) {
+    priority_queue<pair<float, int>> top, cand;
+    for (int i = 0; i < n_top; ++i) top.emplace(top_key[i], (int)top_id[i]);
+    for (int i = 0; i < n_cand; ++i) cand.emplace(cand_key[i], (int)cand_id[i]);
+    VisitedListPool* pool = new VisitedListPool(1, n);
+    VisitedList* vl = pool->getFreeVisitedList();
+    for (int i = 0; i < n_vis; ++i) vl->mass[visited[i]] = vl->curV;
+    vector<uint32_t> level(nb, nb + n_nb);
+    int dist_calc = 0, k = 1;
+    bool found = false;
+    makeStep(level, query, db, top, cand, pick_metric(metric), (uint32_t)d, dist_calc, found, ef, k, vl);
+    int marked = 0;
+    for (uint64_t i = 0; i < n; ++i) marked += vl->mass[i] == vl->curV;
+    out_info[0] = dist_calc; out_info[1] = found ? 1 : 0; out_info[2] = (int)top.size(); out_info[3] = (int)cand.size();
+    out_info[4] = marked;
+    for (int i = 0; !top.empty(); ++i, top.pop()) { out_top_key[i] = top.top().first; out_top_id[i] = (uint32_t)top.top().second; }
+    for (int i = 0; !cand.empty(); ++i, cand.pop()) { out_cand_key[i] = cand.top().first; out_cand_id[i] = (uint32_t)cand.top().second; }
+    pool->releaseVisitedList(vl);
+    delete pool;
+}
+
 // ---- graph utilities around the search path (golden vectors for the drop-in's graph_utils.h / support_classes.h) ----
 // Each call leaves its adjacency-list result in g_gd_result; ref_hnswlike_gd_fetch copies it out as CSR.
 static uint64_t keep_lists(vector<vector<uint32_t>> lists) {

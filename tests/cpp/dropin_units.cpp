@@ -10,6 +10,11 @@
 //   dropin_units kl       <which> <l> <ds.fvecs> <n> <d> <sqrtN> <seed> <out.ivecs>
 //   dropin_units uniform  <n> <d> <seed> <out.fvecs>
 //   dropin_units bvecs    <prefix> <n> <d> <out.fvecs>                                  loadVectorsAny (fvecs / bvecs / mmap)
+//   dropin_units makestep <case.bin> <out.bin>                                          one makeStep on given heaps (host shim)
+//   dropin_units vlpool   <n>                                                           VisitedListPool stand-in: get / reset / release
+// and, on a GPU box (tests/test_dropin_cpp.py):
+//   dropin_units nettest   <dir> <n> <n_q> <n_tr> <d> <d_low> <d_hidden> <ef> <recheck_size> <out.txt>   performNetTest
+//   dropin_units synthetic <dir> <n> <n_q> <n_tr> <d> <out.txt>                                          performSyntheticTests
 #include "../../gbnns_dim_red_amd/search/search_function.h"
 
 int main(int argc, char** argv) {
@@ -60,6 +65,101 @@ int main(int argc, char** argv) {
         vector<float> v = loadVectorsAny(argv[2], d, n);
         std::ofstream out(argv[5], std::ios::binary);
         writeXvec<float>(out, v.data(), d, n);
+    } else if (cmd == "makestep" && argc == 4) {
+        // case file (u32 / f32 little endian): n d ef n_nb n_top n_cand n_vis | db[n*d] | query[d] | nb[n_nb] |
+        // top[n_top] (dist, id) | cand[n_cand] (-dist, id) | visited[n_vis]
+        std::ifstream in(argv[2], std::ios::binary);
+        uint32_t h[7];
+        in.read((char*)h, sizeof h);
+        const uint32_t n = h[0], d = h[1];
+        int ef = (int)h[2], k = 1;
+        vector<float> db((size_t)n * d), q(d);
+        in.read((char*)db.data(), db.size() * 4);
+        in.read((char*)q.data(), q.size() * 4);
+        vector<uint32_t> nb(h[3]);
+        in.read((char*)nb.data(), nb.size() * 4);
+        priority_queue<pair<float, int>> top, cand;
+        for (uint32_t i = 0; i < h[4] + h[5]; ++i) {
+            float f;
+            uint32_t id;
+            in.read((char*)&f, 4);
+            in.read((char*)&id, 4);
+            (i < h[4] ? top : cand).emplace(f, (int)id);
+        }
+        VisitedListPool pool(1, (int)n);
+        VisitedList* vl = pool.getFreeVisitedList();
+        for (uint32_t i = 0; i < h[6]; ++i) {
+            uint32_t id;
+            in.read((char*)&id, 4);
+            vl->mass[id] = vl->curV;
+        }
+        if (!in) return 3;
+        int dist_calc = 0;
+        bool found = false;
+        makeStep(nb, q.data(), db.data(), top, cand, &l2, d, dist_calc, found, ef, k, vl);
+        uint32_t marked = 0;
+        for (uint32_t i = 0; i < n; ++i) marked += vl->mass[i] == vl->curV;
+        pool.releaseVisitedList(vl);
+        std::ofstream out(argv[3], std::ios::binary);
+        const uint32_t oh[5] = {(uint32_t)dist_calc, found ? 1u : 0u, (uint32_t)top.size(), (uint32_t)cand.size(), marked};
+        out.write((const char*)oh, sizeof oh);
+        for (int w = 0; w < 2; ++w) {
+            priority_queue<pair<float, int>>& pq = w ? cand : top;
+            while (!pq.empty()) {
+                const float f = pq.top().first;
+                const uint32_t id = (uint32_t)pq.top().second;
+                out.write((const char*)&f, 4);
+                out.write((const char*)&id, 4);
+                pq.pop();
+            }
+        }
+    } else if (cmd == "vlpool" && argc == 3) {
+        // the stand-in for visited_list_pool.h: lists are handed out, reset (epoch wrap included) and returned;
+        // destroying the pool frees what it allocated with the matching operator (the reference's :30 does not)
+        const int n = atoi(argv[2]);
+        VisitedListPool* pool = new VisitedListPool(2, n);
+        VisitedList* a = pool->getFreeVisitedList();
+        VisitedList* b = pool->getFreeVisitedList();
+        VisitedList* c = pool->getFreeVisitedList();  // beyond the initial two: allocated on demand
+        long stale = 0;
+        for (int round = 0; round < 70000; ++round) {  // more resets than vl_type holds epochs
+            a->reset();
+            stale += a->mass[(round + n - 1) % n] == a->curV;  // the previous round's mark must not survive a reset
+            a->mass[round % n] = a->curV;
+        }
+        b->mass[n - 1] = b->curV;
+        c->mass[0] = c->curV;
+        pool->releaseVisitedList(a);
+        pool->releaseVisitedList(b);
+        pool->releaseVisitedList(c);
+        delete pool;
+        cout << "vlpool ok stale " << stale << endl;
+    } else if (cmd == "nettest" && argc == 12) {
+        const string dir = argv[2];
+        const int n = atoi(argv[3]), n_q = atoi(argv[4]), n_tr = atoi(argv[5]), d = atoi(argv[6]), d_low = atoi(argv[7]);
+        const size_t d_hidden = (size_t)atoi(argv[8]);
+        const int ef = atoi(argv[9]), recheck = atoi(argv[10]);
+        vector<float> db = loadXvecs<float>((dir + "/base.fvecs").c_str(), d, n);
+        vector<float> queries = loadXvecs<float>((dir + "/query.fvecs").c_str(), d, n_q);
+        vector<uint32_t> truth = loadXvecs<uint32_t>((dir + "/truth.ivecs").c_str(), n_tr, n_q);
+        vector<float> db_low = loadXvecs<float>((dir + "/base_low.fvecs").c_str(), d_low, n);
+        vector<vector<uint32_t>> graph = loadEdges((dir + "/graph.ivecs").c_str(), n, "graph");
+        Net net = {loadXvecs<float>((dir + "/net_1.fvecs").c_str(), d + 1, d_hidden),
+                   loadXvecs<float>((dir + "/net_2.fvecs").c_str(), d_hidden + 1, d_hidden),
+                   loadXvecs<float>((dir + "/net_3.fvecs").c_str(), d_hidden + 1, d_low)};
+        vector<vector<uint32_t>> inter_points(n_q, vector<uint32_t>(1, 0u));
+        performNetTest(graph, graph, db, queries, db_low, &net, d_hidden, truth, n, d, d_low, n_q, n_tr, ef, 1, "hnsw_unit", &l2,
+                       argv[11], inter_points, false, false, 50, 0, recheck, 2, 1);
+    } else if (cmd == "synthetic" && argc == 8) {
+        const string dir = argv[2];
+        const int n = atoi(argv[3]), n_q = atoi(argv[4]), n_tr = atoi(argv[5]), d = atoi(argv[6]);
+        vector<float> db = loadXvecs<float>((dir + "/base.fvecs").c_str(), d, n);
+        vector<float> queries = loadXvecs<float>((dir + "/query.fvecs").c_str(), d, n_q);
+        vector<uint32_t> truth = loadXvecs<uint32_t>((dir + "/truth.ivecs").c_str(), n_tr, n_q);
+        vector<vector<uint32_t>> knn = loadEdges((dir + "/knn.ivecs").c_str(), n, "knn");
+        vector<vector<uint32_t>> kl;
+        std::mt19937 gen(7);
+        performSyntheticTests(n, d, n_q, n_tr, gen, knn, kl, db, queries, truth, argv[7], &l2, "knn_synth", false, false, true);
     } else {
         std::cerr << "bad command line" << std::endl;
         return 2;

@@ -171,3 +171,21 @@ def test_bench_launches_its_own_workers():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-probe"],
                        env=dict(env, GBNNS_PROBE_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
+
+
+def test_rccl_load_failure_is_an_error_not_a_crash(lib):
+    """gbnns_multi_search_device loads librccl on first use with more than one replica.  When the library cannot be
+    loaded the call must fail with GBNNS_ERR_UNSUPPORTED and a message (the first formulation called dlerror() twice
+    and handed NULL to std::string).  GBNNS_RCCL_LIB points the loader at a file that does not exist."""
+    lib.gbnns_multi_last_error.restype = ctypes.c_char_p
+    old = os.environ.get("GBNNS_RCCL_LIB")
+    os.environ["GBNNS_RCCL_LIB"] = "/nonexistent/librccl_missing.so"
+    try:
+        assert lib.gbnns_internal_rccl_probe() == 5  # GBNNS_ERR_UNSUPPORTED
+        msg = lib.gbnns_multi_last_error().decode()
+        assert "RCCL unavailable" in msg and "librccl_missing" in msg
+    finally:
+        if old is None:
+            os.environ.pop("GBNNS_RCCL_LIB")
+        else:
+            os.environ["GBNNS_RCCL_LIB"] = old

@@ -7,6 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import datagen
 import golden_util as gu
 import oracle as orc_mod
 
@@ -184,3 +185,94 @@ def test_prepare_graph_builds_missing_knn_on_device(tmp_path, orc):
     want = np.concatenate([np.concatenate([[int(off[i + 1] - off[i])], nbr[int(off[i]):int(off[i + 1])]])
                            for i in range(c.n)]).astype(np.uint32)
     assert np.array_equal(got, want)
+
+
+@pytest.fixture(scope="module")
+def units_exe(tmp_path_factory):
+    """tests/cpp/dropin_units.cpp built against the drop-in headers and the product library (as test_dropin_units.py)."""
+    libdir = os.path.join(ROOT, "gbnns_dim_red_amd", "lib")
+    exe = str(tmp_path_factory.mktemp("units_gpu") / "dropin_units")
+    subprocess.check_call(["g++", "-O2", "-std=c++11", "-ffp-contract=off", "-fno-fast-math", "-w", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "dropin_units.cpp"), "-L" + libdir, "-lgbnns_hip",
+                           "-Wl,-rpath," + libdir, "-lpthread"])
+    return exe
+
+
+def _score(ans, truth, base):
+    # search_function.h:391-400: hit on GT[0], or on GT[1] when GT[0] and GT[1] are exact duplicates
+    t0, t1 = truth[:, 0], truth[:, 1]
+    dup = (((base[t0] - base[t1]) ** 2).sum(1) == 0) & (t0 != t1)
+    return int(((ans == t0) | (dup & (ans == t1))).sum())
+
+
+def _line_fields(ln):
+    tok = ln.split()
+    assert tok[0] == "graph_type" and tok[2] == "acc" and tok[4] == "hops" and tok[6] == "dist_calc" and tok[8] == "work_time"
+    return tok[1], float(tok[3]), int(tok[5]), int(tok[7]), float(tok[9])
+
+
+def test_perform_net_test_without_rerank(tmp_path, orc, units_exe):
+    """performNetTest's `recheck_size <= 0` branch (search_function.h:363-372): project the query, walk the low-dim
+    graph with (ef, k), answer = top of the trimmed heap, NO re-rank, nothing added to dist_calc.  Expectation: the
+    oracle's plain walk over the projected queries in the low-dim space; and, as a cross-check, recheck_size = ef
+    (the two-stage branch) through the same driver against the oracle's two-stage answers."""
+    gd = gu.load("sift_toy")
+    c = gd.case
+    off, nbr = gd.graph
+    db_low = orc.project(c.net, c.base, threads=4)
+    q_low = orc.project(c.net, c.queries)
+    truth = gd["truth"]
+    write_xvecs(tmp_path / "base.fvecs", c.base)
+    write_xvecs(tmp_path / "query.fvecs", c.queries)
+    write_xvecs(tmp_path / "truth.ivecs", truth)
+    write_xvecs(tmp_path / "base_low.fvecs", db_low)
+    write_edges(tmp_path / "graph.ivecs", off, nbr)
+    for i, layer in enumerate(c.net, 1):
+        write_xvecs(tmp_path / f"net_{i}.fvecs", layer)
+    for ef, recheck in ((8, -1), (64, -1), (64, 0), (20, 20)):
+        out = tmp_path / f"res_{ef}_{recheck}.txt"
+        p = subprocess.run([units_exe, "nettest", str(tmp_path), str(c.n), str(c.nq), str(truth.shape[1]), str(c.d), str(c.dlow),
+                            str(c.dh), str(ef), str(recheck), str(out)], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        name, acc, hops, dc, wt = _line_fields(open(out).read().splitlines()[-1])
+        if recheck > 0:
+            e = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, recheck, db_low=db_low, net=c.net, threads=4)
+        else:
+            e = orc.search_batch(orc_mod.MODE_PLAIN, q_low, db_low, off, nbr, ef, k=1, threads=4)
+        assert name == "hnsw_unit" and wt > 0
+        assert abs(acc - _score(e["ids"].astype(np.int64), truth.astype(np.int64), c.base) / c.nq) < 2e-6, (ef, recheck)
+        assert hops == int(e["hops"].astype(np.int64).sum()) // c.nq, (ef, recheck)
+        assert dc == int(e["dist_calc"].astype(np.int64).sum()) // c.nq, (ef, recheck)
+
+
+def test_perform_synthetic_tests_smoke(tmp_path, orc, units_exe):
+    """performSyntheticTests (search_function.h:214-287; no caller in the reference): d = 5 beam-search sweep over
+    ef 7 ... 30 on the kNN graph cut to its average degree, every query entering at node 0 -- six result lines, each
+    equal to the oracle's plain walk on the same cut graph."""
+    c = datagen.Case("syn", 6100, 3000, 200, 5, 4, 8)
+    K = 12
+    knn, _ = orc.exact_knn(c.base, c.base, K, 0, self_offset=0, threads=8)
+    truth, _ = orc.exact_knn(c.base, c.queries, 2, 0, threads=8)
+    koff = np.arange(c.n + 1, dtype=np.uint64) * np.uint64(K)
+    write_xvecs(tmp_path / "base.fvecs", c.base)
+    write_xvecs(tmp_path / "query.fvecs", c.queries)
+    write_xvecs(tmp_path / "truth.ivecs", truth)
+    write_edges(tmp_path / "knn.ivecs", koff, knn.reshape(-1))
+    # the graph the sweep walks: cutKNNbyK at the average degree (pinned on the reference by test_dropin_units.py)
+    subprocess.check_call([units_exe, "cutk", str(tmp_path / "knn.ivecs"), str(tmp_path / "base.fvecs"), str(c.n), str(c.d),
+                           str(K), str(tmp_path / "cut.ivecs")])
+    raw = np.fromfile(tmp_path / "cut.ivecs", np.uint32).reshape(c.n, K + 1)
+    assert (raw[:, 0] == K).all()
+    cut = raw[:, 1:].reshape(-1).copy()
+    out = tmp_path / "syn.txt"
+    p = subprocess.run([units_exe, "synthetic", str(tmp_path), str(c.n), str(c.nq), "2", str(c.d), str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = open(out).read().splitlines()
+    assert len(lines) == 6
+    for ln, ef in zip(lines, (7, 10, 15, 22, 25, 30)):
+        name, acc, hops, dc, wt = _line_fields(ln)
+        e = orc.search_batch(orc_mod.MODE_PLAIN, c.queries, c.base, koff, cut, ef, k=1, threads=4)
+        assert name == "knn_synth" and wt > 0
+        assert abs(acc - _score(e["ids"].astype(np.int64), truth.astype(np.int64), c.base) / c.nq) < 2e-6, ef
+        assert hops == int(e["hops"].astype(np.int64).sum()) // c.nq and dc == int(e["dist_calc"].astype(np.int64).sum()) // c.nq, ef

@@ -25,7 +25,10 @@ def unit(tmp_path_factory):
     import gbnns_dim_red_amd as g
     g.build_library()
     exe = str(tmp_path_factory.mktemp("units") / "dropin_units")
-    subprocess.check_call(["g++", "-O2", "-std=c++11", "-ffp-contract=off", "-fno-fast-math", "-w", "-o", exe,
+    # GBNNS_UNITS_SAN=1 (tests/test_sanitizers.py): the same driver with AddressSanitizer + UBSan
+    opt = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] \
+        if os.environ.get("GBNNS_UNITS_SAN") == "1" else ["-O2"]
+    subprocess.check_call(["g++"] + opt + ["-std=c++11", "-ffp-contract=off", "-fno-fast-math", "-w", "-o", exe,
                            os.path.join(ROOT, "tests", "cpp", "dropin_units.cpp"), "-L" + LIBDIR, "-lgbnns_hip",
                            "-Wl,-rpath," + LIBDIR, "-lpthread"])
 
@@ -166,3 +169,71 @@ def test_vector_loaders_fvecs_bvecs_mmap(unit, data):
     # wrong dimension in the file -> the reference's fatal path ("file error", exit 1)
     with pytest.raises(AssertionError):
         unit("bvecs", d / "w", n, dim + 1, d / "w_bad.fvecs")
+
+
+def test_make_step_shim_vs_reference(unit, tmp_path):
+    """makeStep (search_function.h:15-40) as a host shim of the drop-in: one step on random heaps, visited marks and
+    neighbour lists -- part-filled and full result heaps, neighbours already visited, exact ties on a lattice --
+    against the compiled reference's makeStep: dist_calc, found, marks, both heaps in pop order (keys bit for bit)."""
+    import oracle
+    if not oracle.have_ref():
+        pytest.skip("compiled reference (oracle/_ref) not present")
+    ref = oracle.Ref()
+    rng = np.random.Generator(np.random.PCG64(77))
+    for case in range(40):
+        n, d = int(rng.integers(30, 200)), int(rng.choice([4, 8, 13, 32]))
+        db = (rng.integers(-4, 5, size=(n, d)) / 2.0).astype(np.float32) if case % 2 else rng.standard_normal((n, d)).astype(np.float32)
+        q = db[int(rng.integers(0, n))] + (0 if case % 4 == 1 else rng.standard_normal(d).astype(np.float32) * 0.1)
+        q = q.astype(np.float32)
+        ef = int(rng.integers(1, 12))
+        ids = rng.permutation(n)
+        n_top = int(rng.integers(1, ef + 1))
+        top_id = ids[:n_top].astype(np.uint32)
+        top_key = np.array([ref.l2(q, db[i]) for i in top_id], np.float32)
+        n_cand = int(rng.integers(0, 6))
+        cand_id = ids[n_top:n_top + n_cand].astype(np.uint32)
+        cand_key = -np.array([ref.l2(q, db[i]) for i in cand_id], np.float32)
+        visited = np.concatenate([top_id, cand_id, ids[40:40 + int(rng.integers(0, 10))].astype(np.uint32)])
+        nb = rng.choice(n, size=int(rng.integers(0, 25)), replace=False).astype(np.uint32)
+        want = ref.make_step(db, q, nb, ef, (top_key, top_id), (cand_key, cand_id), visited)
+        blob = tmp_path / "case.bin"
+        with open(blob, "wb") as f:
+            np.array([n, d, ef, len(nb), n_top, n_cand, len(visited)], np.uint32).tofile(f)
+            db.tofile(f)
+            q.tofile(f)
+            nb.tofile(f)
+            for k, i in list(zip(top_key, top_id)) + list(zip(cand_key, cand_id)):
+                np.array([k], np.float32).tofile(f)
+                np.array([i], np.uint32).tofile(f)
+            visited.tofile(f)
+        unit("makestep", blob, tmp_path / "out.bin")
+        raw = np.fromfile(tmp_path / "out.bin", np.uint32)
+        dc, found, nt, nc, marked = (int(x) for x in raw[:5])
+        pairs = raw[5:].reshape(-1, 2)
+        assert (dc, bool(found), marked) == (want["dist_calc"], want["found"], want["marked"]), case
+        assert nt == len(want["top"][0]) and nc == len(want["cand"][0]), case
+        assert np.array_equal(pairs[:nt, 0], want["top"][0].view(np.uint32)) and np.array_equal(pairs[:nt, 1], want["top"][1]), case
+        assert np.array_equal(pairs[nt:, 0], want["cand"][0].view(np.uint32)) and np.array_equal(pairs[nt:, 1], want["cand"][1]), case
+
+
+def test_visited_list_pool_stand_in(unit):
+    """The source-compatibility VisitedList / VisitedListPool (the device keeps its visited sets in LDS): hand-out,
+    on-demand growth, epoch reset across the uint16 wrap, release, destruction (new[] / delete[] paired, unlike the
+    reference's visited_list_pool.h:30 -- which the sanitizer run of this test would flag)."""
+    assert unit("vlpool", 97).strip() == "vlpool ok stale 0"
+
+
+def test_reference_drivers_compile_against_dropin_headers(tmp_path):
+    """The boundary pin: the reference's OWN drivers (final_test.cpp, naive_test.cpp, prepare_graph.cpp), copied to a
+    scratch directory so that their `#include "search_function.h"` resolves to the drop-in headers, must compile
+    unchanged.  Skipped where /root/reference is absent (the GPU box)."""
+    refdir = "/root/reference/search"
+    if not os.path.exists(os.path.join(refdir, "final_test.cpp")):
+        pytest.skip("reference sources not present")
+    import shutil
+    for name in ("final_test.cpp", "naive_test.cpp", "prepare_graph.cpp"):
+        shutil.copy(os.path.join(refdir, name), tmp_path / name)
+        p = subprocess.run(["g++", "-std=c++11", "-fopenmp", "-fsyntax-only", "-w", "-I",
+                            os.path.join(ROOT, "gbnns_dim_red_amd", "search"), str(tmp_path / name)],
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, name + "\n" + p.stderr[-3000:]

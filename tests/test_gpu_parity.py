@@ -910,6 +910,12 @@ def test_exact_knn_vs_get_truth_and_oracle(g, orc):
         a = g.exact_knn(c.base, c.base[:half], k, self_offset=0)
         b = g.exact_knn(c.base, c.base[half:], k, self_offset=half)
         assert np.array_equal(np.concatenate([a, b]), want), d
+    # the widest rows the entry point advertises (d <= 8192): the [rows][d] LDS tile takes 8 / 4 rows there; both metrics
+    for d, n, metric in ((4096, 300, 0), (8192, 200, 0), (3000, 250, 0), (4096, 260, 1), (8192, 150, 1)):
+        c = datagen.Case("k", 4100 + d + metric, n, 30, d, 4, 8)
+        ids, dist = g.exact_knn(c.base, c.queries, 7, metric=metric, want_dist=True)
+        oi, od = orc.exact_knn(c.base, c.queries, 7, metric, threads=8)
+        assert np.array_equal(ids, oi) and np.array_equal(gu.bits(dist), gu.bits(od)), (d, metric)
     # more neighbours asked for than rows exist; device buffers give the same answer as host buffers
     c = datagen.Case("k", 4999, 40, 70, 16, 4, 8, kind="lattice")
     ids, dist = g.exact_knn(c.base, c.queries, 64, want_dist=True)

@@ -110,3 +110,44 @@ def test_hot_kernel_gather_does_not_wait_for_the_prefetch(kernels):
             between = insts[back[-1] + 1:gi]
             assert not any(re.match(r"s_waitcnt vmcnt\(0\)", s) for s in between), \
                 "the gather waits for the adjacency prefetch (vmcnt(0)) in " + name
+
+
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def test_hot_kernel_register_budgets(tmp_path):
+    """The hand-laid-out walk kernels claim fixed VGPRs above the compiler's own (kernels.hip, hot_expand); their
+    occupancy -- 26 wavefronts per CU at ef = 64 -- rests on the allocation staying at 72 registers (7 wavefronts per
+    SIMD of 512) and on nothing spilling.  A compiler update that pushed them over would cost a wavefront per SIMD
+    silently; this test reads the kernel descriptors' metadata of the shipped code objects and fails instead."""
+    if not os.path.exists(READELF) or not os.path.exists(OBJDUMP):
+        pytest.skip("ROCm llvm tools not found")
+    lib = shutil.copy(LIB, tmp_path)
+    subprocess.run([OBJDUMP, "--offloading", lib], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    meta = {}
+    for f in os.listdir(tmp_path):
+        if not f.endswith("gfx950"):
+            continue
+        text = subprocess.run([READELF, "--notes", os.path.join(tmp_path, f)], check=True, capture_output=True, text=True).stdout
+        for block in text.split("  - .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", block)
+            if not name:
+                continue
+            meta[name.group(1)] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
+                                   for k in ("vgpr_count", "sgpr_count", "private_segment_fixed_size", "vgpr_spill_count")
+                                   if re.search(r"\.%s:\s+(\d+)" % k, block)}
+    # (substring of the mangled name, VGPR ceiling): waves per SIMD = floor(512 / ceil8(vgprs))
+    budgets = [("15walk_hot_kernelE", 72), ("16walk_hot2_kernelE", 72), ("19walk_hot_big_kernelE", 84)]
+    for sub, cap in budgets:
+        hits = {k: v for k, v in meta.items() if sub in k}
+        assert hits, sub
+        for k, v in hits.items():
+            assert v["vgpr_count"] <= cap, (k, v)
+            assert v["private_segment_fixed_size"] == 0 and v.get("vgpr_spill_count", 0) == 0, (k, v)
+    # no bit-exact distance kernel may spill to scratch at all (a spill in a latency chain is a hidden HBM round trip),
+    # and the generic two-list / bitmap walks stay within 3 wavefronts per SIMD (<= 168 registers)
+    for k, v in meta.items():
+        if any(c in k for c in ("walk_", "rerank_")):
+            assert v["private_segment_fixed_size"] == 0 and v.get("vgpr_spill_count", 0) == 0, (k, v)
+            if "walk_general" not in k and "walk_fast" not in k:
+                assert v["vgpr_count"] <= 176, (k, v)
