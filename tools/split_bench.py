@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Tuning tool (not a test, not the bench): step time of a bench workload for the call layouts of gbnns_search_ex --
-device buffers plain / deferred join (alternating lanes), host buffers pageable / page-locked (serial, halves, other
-GBNNS_SPLIT plans).  python tools/split_bench.py [--config sift] [--ef 64]"""
+device buffers plain / deferred join (alternating lanes), pageable host buffers; four distinct batches rotating.
+python tools/split_bench.py [--config sift] [--ef 64]"""
 import argparse
 import os
 import sys
@@ -21,7 +21,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="sift")
     ap.add_argument("--ef", type=int, default=None)
-    ap.add_argument("--plans", default="0;5000;3334;4000,6000;6000,4000;2500")
     ap.add_argument("--reps", type=int, default=60)
     ap.add_argument("--modes", default="device,defer,host")
     args = ap.parse_args()
@@ -37,20 +36,13 @@ def main():
     ix = ds.index()
     qs = [torch.roll(ds.queries, shifts=-i * (ds.nq // 4), dims=0).contiguous() for i in range(4)]
     qh = [q.cpu().numpy() for q in qs]
-    qp = [q.copy() for q in qh]
-    for a in qp:
-        g.host_register(a)
     ref = [ix.search(q, ef, want=())["ids"].cpu().numpy().astype(np.int64) for q in qs]
     for _ in range(8):
         ix.search(qs[0], ef, want=())
     torch.cuda.synchronize()
 
-    def run(batches, flags=0, pinned_out=False):
+    def run(batches, flags=0):
         outs = [{}, {}]
-        if pinned_out:
-            for o in outs:
-                o["ids"] = np.empty(ds.nq, np.uint32)
-                g.host_register(o["ids"])
         for i in range(10):
             ix.search(batches[i & 3], ef, want=(), out=outs[i & 1], flags=flags)
         ix.join()
@@ -63,9 +55,6 @@ def main():
         dt = (time.perf_counter() - t0) / args.reps
         ids = r["ids"] if isinstance(r["ids"], np.ndarray) else r["ids"].cpu().numpy()
         ok = bool((ids.astype(np.int64) == ref[(args.reps - 1) & 3]).all())
-        if pinned_out:
-            for o in outs:
-                g.host_unregister(o["ids"])
         return "%.4f ms (%.2f M/s)%s" % (dt * 1e3, ds.nq / dt / 1e6, "" if ok else " WRONG")
 
     if "device" in args.modes:
@@ -74,12 +63,6 @@ def main():
         print("device defer-join   ", run(qs, g.FLAG_DEFER_JOIN), flush=True)
     if "host" in args.modes:
         print("host pageable       ", run(qh), flush=True)
-        print("host pinned serial  ", run(qp, g.FLAG_SERIAL, True), flush=True)
-        for plan in args.plans.split(";"):
-            os.environ["GBNNS_SPLIT"] = plan
-            print("host pinned plan %-12s" % plan, run(qp, 0, True), flush=True)
-        os.environ.pop("GBNNS_SPLIT")
-        print("host pinned default ", run(qp, 0, True), flush=True)
 
 
 if __name__ == "__main__":
