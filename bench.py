@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--hash-capacity", type=int, default=0, help="0 = library default (tuning knob)")
     ap.add_argument("--bitmap-pass", action="store_true", help="force the HBM-bitmap first pass (tuning knob: GBNNS_FLAG_BITMAP_PASS)")
     ap.add_argument("--sweep", action="store_true", help="also time every reference ef (stderr)")
+    ap.add_argument("--depth", type=int, default=None,
+                    help="batches in flight inside the library (GBNNS_FLAG_DEFER_JOIN, defer_depth 2..4); default 3, the measured "
+                         "optimum on every configuration (tools/split_bench.py)")
     ap.add_argument("--serial", action="store_true",
                     help="timed steps one batch at a time on one stream (no GBNNS_FLAG_DEFER_JOIN pipelining)")
     ap.add_argument("--cache-dir", default=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"))
@@ -261,21 +264,23 @@ def main():
     # the same rows every step, the friendliest case for L2 / Infinity Cache.
     nb = max(1, min(args.batches, args.steps))
     batches = [q] + [synth.more_queries(ds, nq_rank, batch=rank * 64 + j) for j in range(1, nb)]
-    # Steps are pipelined two deep inside the library (GBNNS_FLAG_DEFER_JOIN, include/gbnns.h): batch i runs on one
-    # of the handle's two internal streams and the caller's stream is made to wait for it by call i+1, after batch
-    # i+1 has been released -- the projection of batch i+1 runs in the half-empty tail of batch i's walk kernel.
-    # Two sets of output buffers used alternately; the all-gather of step i (RCCL's own stream) is issued once the
-    # stream has joined batch i and runs beside the kernels of step i+1; step i+2 reuses step i's buffers and
-    # therefore waits for that gather first (a stream-level wait, the host never blocks).
-    outs = [{}, {}]
-    gathered = [None, None]
-    pending = [None, None]
-    nstep = 0
-    pad = sharding.shard_pad(nq_total, world) if strong else nq_rank  # equal-sized pieces for the all-gather
-
+    # Steps are pipelined `depth` deep inside the library (GBNNS_FLAG_DEFER_JOIN, include/gbnns.h): batch i runs on one
+    # of the handle's internal streams and the caller's stream is made to wait for it by call i+depth-1, after that
+    # call's batch has been released -- the projection of batch i+1 runs in the half-empty tail of batch i's walk
+    # kernel, and batches too small to fill the machine run side by side.
+    # `depth` sets of output buffers in rotation; the all-gather of step i (RCCL's own stream) is issued once the
+    # stream has joined batch i and runs beside the kernels of the following steps; the step that reuses step i's
+    # buffers waits for that gather first (a stream-level wait, the host never blocks).
     tune_flags = g.FLAG_BITMAP_PASS if args.bitmap_pass else 0
     pipelined = args.hash_capacity == 0 and not args.bitmap_pass and not args.serial
+    depth = max(2, min(4, args.depth or 3)) if pipelined else 1
     step_flags = tune_flags | (g.FLAG_DEFER_JOIN if pipelined else 0)
+    nbuf = max(depth, 2)
+    outs = [{} for _ in range(nbuf)]
+    gathered = [None] * nbuf
+    pending = [None] * nbuf
+    nstep = 0
+    pad = sharding.shard_pad(nq_total, world) if strong else nq_rank  # equal-sized pieces for the all-gather
 
     def gather(b):
         # the path's only exchange step: all-gather of the int32 answer ids over RCCL/xGMI
@@ -292,24 +297,26 @@ def main():
     def step():
         nonlocal nstep
         i = nstep
-        b = i & 1
+        b = i % nbuf
         nstep += 1
         if pending[b] is not None:
             pending[b].wait()
             pending[b] = None
-        r = ix.search(batches[i % nb], ef, want=want, out=outs[b], hash_capacity=args.hash_capacity, flags=step_flags)
+        r = ix.search(batches[i % nb], ef, want=want, out=outs[b], hash_capacity=args.hash_capacity, flags=step_flags,
+                      defer_depth=depth if pipelined else 0)
         if world > 1:
             if not pipelined:
                 gather(b)
-            elif i > 0:
-                gather(b ^ 1)  # that call made the stream wait for batch i-1: its answers are complete in stream order
+            elif i >= depth - 1:
+                gather((i - (depth - 1)) % nbuf)  # that call made the stream wait for batch i-depth+1: its answers are complete in stream order
         return r
 
     def drain():
-        ix.join()  # the stream waits for the last batch
-        if world > 1 and pipelined and nstep > 0 and pending[(nstep - 1) & 1] is None:
-            gather((nstep - 1) & 1)
-        for b in (0, 1):
+        ix.join()  # the stream waits for the batches still unjoined
+        if world > 1 and pipelined:
+            for j in range(max(0, nstep - (depth - 1)), nstep):
+                gather(j % nbuf)
+        for b in range(nbuf):
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
@@ -317,7 +324,7 @@ def main():
     # The library sizes its visited sets from the walks it has seen and drops the retry launch once a few batches
     # of a configuration were quiet: let that settle before the W warm-up steps, whatever W is.
     for j in range(8 if nq_rank <= 20_000 else 3):
-        ix.search(batches[j % nb], ef, want=(), hash_capacity=args.hash_capacity, flags=step_flags)
+        ix.search(batches[j % nb], ef, want=(), hash_capacity=args.hash_capacity, flags=step_flags, defer_depth=depth)
         ix.join()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -353,7 +360,7 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for i in range(args.steps):
-        ix.search(batches[i % nb], ef, want=want, out=outs[i & 1], hash_capacity=args.hash_capacity, flags=tune_flags)
+        ix.search(batches[i % nb], ef, want=want, out=outs[i % nbuf], hash_capacity=args.hash_capacity, flags=tune_flags)
     torch.cuda.synchronize()
     elapsed_serial = time.perf_counter() - t1
     prof = ix.profile_read(reset=True)
@@ -411,6 +418,7 @@ def main():
         "kernels_ms": rl["kernels_ms"],
         "batches_rotated": nb,
         "pipelined": bool(pipelined),
+        "batches_in_flight": depth,
         # the same K steps one batch at a time on one stream, kernels back to back (what round 1 / 2 reported as `value`)
         "serial": {"ms_per_step": round(elapsed_serial * 1e3 / args.steps, 4),
                    "queries_per_s": round(nq_rank * args.steps / elapsed_serial, 1),
@@ -419,8 +427,8 @@ def main():
         # survey_8d_value below (filled at N = 1 unless --no-extras)
         "value_definition": "queries of all ranks / wall time of K steps, inputs and outputs resident in HBM (device "
                             "buffers), %s; the PCIe-inclusive rate of the host-buffer call is survey_8d_value" % (
-                                "steps pipelined two deep inside the library (GBNNS_FLAG_DEFER_JOIN: batch i+1 is released "
-                                "before the stream waits for batch i), %d distinct batches rotating" % nb if pipelined
+                                "steps pipelined %d deep inside the library (GBNNS_FLAG_DEFER_JOIN: later batches are released "
+                                "before the stream waits for batch i), %d distinct batches rotating" % (depth, nb) if pipelined
                                 else "one batch at a time"),
     }
     if gate_failed:

@@ -59,7 +59,7 @@ class _SearchArgs(C.Structure):
         ("out_ids", C.c_void_p), ("out_hops", C.c_void_p), ("out_dist_calc", C.c_void_p),
         ("out_cand", C.c_void_p), ("out_cand_dist", C.c_void_p), ("out_q_low", C.c_void_p),
         ("out_edges", C.c_void_p), ("stream", C.c_void_p), ("flags", C.c_uint32),
-        ("hops_bound", C.c_uint32), ("n_entries", C.c_uint32), ("reserved2", C.c_uint32),
+        ("hops_bound", C.c_uint32), ("n_entries", C.c_uint32), ("defer_depth", C.c_uint32),
     ]
 
 
@@ -414,7 +414,7 @@ class Index:
     # -- search ------------------------------------------------------------------------------
     def search(self, queries, ef, mode=MODE_NET, k=1, queries_low=None, entry_ids=None,
                want=("hops", "dist_calc"), hash_capacity=0, stream=None, out=None, flags=0,
-               aux=False, llf=False, hops_bound=50):
+               aux=False, llf=False, hops_bound=50, defer_depth=0):
         """Runs one batch.  numpy queries -> synchronous call, numpy results.  torch CUDA queries
         -> enqueued on `stream` (torch stream or None = current), torch results, no sync.
         `want` may also name "cand", "cand_dist", "q_low", "edges".  Returns a dict with "ids" + wanted.
@@ -460,7 +460,7 @@ class Index:
                         mem_kind=MEM_DEVICE if dev else MEM_HOST, hash_capacity=hash_capacity,
                         n_q=nq, queries=_ptr(queries), queries_low=_ptr(queries_low),
                         entry_ids=_ptr(entry_ids), out_ids=_ptr(ids), stream=sptr, flags=flags,
-                        hops_bound=hops_bound if aux else 0, n_entries=n_entries)
+                        hops_bound=hops_bound if aux else 0, n_entries=n_entries, defer_depth=defer_depth)
         if "hops" in want:
             a.out_hops = _ptr(alloc("hops", (nq,), i32))
         if "dist_calc" in want:

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cxxabi.h>
+#include <deque>
 #include <map>
 #include <new>
 #include <string>
@@ -87,7 +88,7 @@ struct ProfCall {
     bool has_project, has_rerank;
 };
 
-constexpr int kMaxLanes = 2;
+constexpr int kMaxLanes = 4;
 
 // One workspace of per-batch buffers + control words.  A handle has several so that the sub-batches of one call can be
 // in flight side by side on internal streams (the tail of one sub-batch's walk -- a 10 k batch is < 2 "rounds" of
@@ -146,9 +147,7 @@ struct gbnns_index {
     std::map<int, int> calm_streak;   // per (ef, mode): consecutive observed batches without hand-over / resize
     uint32_t stats_tick = 0;
     // a split call whose join (caller's stream waits for the lanes) has been deferred to the next call / gbnns_index_join
-    bool join_pending = false;
-    hipStream_t join_stream = nullptr;
-    int join_lanes = 0;                // bit mask
+    std::deque<std::pair<int, hipStream_t>> joins;  // (lane, caller's stream) of the deferred calls not yet joined, oldest first
     int next_lane = 0;
     // stream of the last call that left work in flight (the workspace and the control words are ordered by
     // stream order only: a call on another stream first waits for that work, see enter_stream)
@@ -805,19 +804,22 @@ void plan_call(gbnns_index* ix, const gbnns_search_args* a, int& lanes, int& lan
 #endif
     if ((a->flags & GBNNS_FLAG_SERIAL) || ix->profiling) return;
     if (a->mem_kind != GBNNS_MEM_DEVICE || !(a->flags & GBNNS_FLAG_DEFER_JOIN)) return;
-    lanes = 2;
-    lane = ix->next_lane;
-    ix->next_lane ^= 1;
+    lanes = a->defer_depth ? (int)std::min<uint32_t>(std::max<uint32_t>(a->defer_depth, 2u), (uint32_t)kMaxLanes) : 3;  // measured best: 3
+    lane = ix->next_lane % lanes;
+    ix->next_lane = (lane + 1) % lanes;
 }
 
-// The caller's stream waits for the lanes of a split call whose join was deferred.
-int flush_join(gbnns_index* ix) {
-    if (!ix->join_pending) return GBNNS_OK;
-    ix->join_pending = false;
-    for (int i = 0; i < kMaxLanes; ++i)
-        if (ix->join_lanes & (1 << i)) HIP_TRY(hipStreamWaitEvent(ix->join_stream, ix->lanes[i].done_ev, 0));
+// The callers' streams wait for deferred calls, oldest first, until at most `keep` of them remain unjoined.
+int flush_joins(gbnns_index* ix, size_t keep) {
+    while (ix->joins.size() > keep) {
+        const std::pair<int, hipStream_t> j = ix->joins.front();
+        ix->joins.pop_front();
+        HIP_TRY(hipStreamWaitEvent(j.second, ix->lanes[j.first].done_ev, 0));
+    }
     return GBNNS_OK;
 }
+
+int flush_join(gbnns_index* ix) { return flush_joins(ix, 0); }
 
 // One (sub-)batch on one lane's workspace, enqueued on stream s; arguments validated by gbnns_search_ex.  With HOST
 // buffers the copies in and out are enqueued on s too and, when sync_host, waited for.
@@ -1197,11 +1199,14 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     if ((rc = ensure_lane(ix, lane))) return rc;
     Lane& L = ix->lanes[lane];
     if (!ix->fork_ev) HIP_TRY(hipEventCreateWithFlags(&ix->fork_ev, hipEventDisableTiming));
-    if (ix->join_pending && ix->join_stream == s && ix->last_stream == s) {
-        // the previous call's join is still owed to this very stream: fork first, so that this batch is released
-        // beside the previous one, then let the stream wait for the previous one
+    bool same_stream = !ix->joins.empty() && ix->last_stream == s;
+    for (const auto& j : ix->joins) same_stream = same_stream && j.second == s;
+    if (same_stream) {
+        // earlier calls' joins are still owed to this very stream: fork first, so that this batch is released beside
+        // them, then let the stream wait for the oldest ones -- all but depth - 2, so that with this call at most
+        // depth - 1 stay unjoined and `depth` batches are in flight
         HIP_TRY(hipEventRecord(ix->fork_ev, s));
-        if ((rc = flush_join(ix))) return rc;
+        if ((rc = flush_joins(ix, (size_t)n_lanes - 2))) return rc;
     } else {
         if ((rc = enter_stream(ix, s))) return rc;
         HIP_TRY(hipEventRecord(ix->fork_ev, s));
@@ -1215,9 +1220,7 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
         return rc;
     }
     HIP_TRY(hipEventRecord(L.done_ev, L.stream));
-    ix->join_pending = true;
-    ix->join_stream = s;
-    ix->join_lanes = 1 << lane;
+    ix->joins.emplace_back(lane, s);
     return GBNNS_OK;
 }
 

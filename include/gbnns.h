@@ -135,7 +135,7 @@ typedef struct {
                                   one.  More than one: one walk per entry point over a shared result heap, exactly
                                   as :54-93 -- served by the general kernel (exact, not tuned: no driver of the
                                   reference uses it) */
-    uint32_t reserved2;
+    uint32_t defer_depth;      /* with GBNNS_FLAG_DEFER_JOIN: batches in flight, 2 .. 4 (0 = 3, the measured optimum) */
 } gbnns_search_args;
 
 /* Throughput option, off by default: run the MLP projection on the matrix cores (f32 MFMA).  The
@@ -166,16 +166,19 @@ typedef struct {
  * table would allow.  Same results. */
 #define GBNNS_FLAG_BITMAP_PASS 32u
 
-/* Batches in flight.  A handle owns two workspaces with an internal HIP stream each ("lanes"); plain calls use the
- * first one on the caller's stream.  Every query is independent (search_function.h:348), so the answers never
+/* Batches in flight.  A handle owns up to four workspaces with an internal HIP stream each ("lanes"); plain calls use
+ * the first one on the caller's stream.  Every query is independent (search_function.h:348), so the answers never
  * depend on how a call is laid out.
- *   GBNNS_FLAG_DEFER_JOIN  DEVICE buffers: the batch runs on the next lane (consecutive calls alternate) after what
- *                          was enqueued on args->stream before the call, and the call returns WITHOUT making
- *                          args->stream wait for it; that wait is enqueued by the next call on this handle -- after
- *                          the new batch has been released, so the tail of batch i (a 10 k batch is < 2 "rounds" of
- *                          resident wavefronts) runs beside the projection and the head of batch i+1 -- or by
- *                          gbnns_index_join.  Until then the outputs of the call must not be read and its inputs /
- *                          outputs must not be reused: a serving loop alternates two sets of buffers.
+ *   GBNNS_FLAG_DEFER_JOIN  DEVICE buffers: the batch runs on the next of `defer_depth` lanes (consecutive calls rotate)
+ *                          after what was enqueued on args->stream before the call, and the call returns WITHOUT
+ *                          making args->stream wait for it.  That wait is enqueued by the (defer_depth - 1)-th following
+ *                          call on this handle -- after that call's own batch has been released, so `defer_depth`
+ *                          batches are in flight: the half-empty tail of batch i's walk kernel (a 10 k batch is < 2
+ *                          "rounds" of resident wavefronts) runs beside the projection and the head of batch i+1, and
+ *                          batches too small to fill the machine (the reference's 1 000 GIST queries are one
+ *                          wavefront per SIMD) run side by side -- or by gbnns_index_join, or by any call without the
+ *                          flag.  Until then the outputs of the call must not be read and its inputs / outputs must
+ *                          not be reused: a serving loop rotates `defer_depth` sets of buffers.
  *   GBNNS_FLAG_SERIAL      the caller's stream, kernels back to back, whatever else is asked (what per-kernel timing
  *                          needs; gbnns_profile_enable(..., 1) implies it).  HOST-buffer calls always run this way. */
 #define GBNNS_FLAG_SERIAL 64u
@@ -187,8 +190,8 @@ typedef struct {
  * enqueued on args->stream and the call returns without synchronising. */
 int gbnns_search_ex(gbnns_index* index, const gbnns_search_args* args);
 
-/* Enqueues, on the stream of the last GBNNS_FLAG_DEFER_JOIN call, the wait for that call's pieces (no-op when
- * nothing is owed).  Everything enqueued on that stream afterwards sees the call's outputs. */
+/* Enqueues, on the streams of the GBNNS_FLAG_DEFER_JOIN calls not yet joined, the waits for their batches (no-op when
+ * nothing is owed).  Everything enqueued on those streams afterwards sees the calls' outputs. */
 int gbnns_index_join(gbnns_index* index);
 
 /* Convenience form of the above: NET mode, host buffers, synchronous. */

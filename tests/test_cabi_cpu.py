@@ -35,7 +35,7 @@ def test_exports_every_declared_symbol(lib):
 def test_struct_sizes_match_header(lib):
     # 8-byte aligned C layouts as declared in include/gbnns.h
     assert ctypes.sizeof(binding._IndexDesc) == 96
-    assert ctypes.sizeof(binding._SearchArgs) == 136  # + n_entries, reserved2
+    assert ctypes.sizeof(binding._SearchArgs) == 136  # + n_entries, defer_depth
     assert ctypes.sizeof(binding.Profile) == 160  # + walk_kernel[96]
 
 

@@ -427,7 +427,12 @@ def test_deferred_join_pipeline(g, orc):
     outs = []
     for i, (b, ef, defer, st) in enumerate(plan):
         outs.append(ix.search(qs[b], ef, entry_ids=es[b], want=("hops", "dist_calc", "cand"), stream=st, out={},
-                              flags=g.FLAG_DEFER_JOIN if defer else 0, hash_capacity=128 if i in (3, 8) else 0))
+                              flags=g.FLAG_DEFER_JOIN if defer else 0, hash_capacity=128 if i in (3, 8) else 0,
+                              defer_depth=(0, 2, 3, 4)[i % 4]))
+    ix.join()
+    # ... and a run that keeps four batches in flight throughout
+    deep = [ix.search(qs[i % 3], 64, entry_ids=es[i % 3], want=("hops",), out={}, flags=g.FLAG_DEFER_JOIN, defer_depth=4)
+            for i in range(9)]
     ix.join()
     torch.cuda.synchronize()
     for (b, ef, defer, st), r in zip(plan, outs):
@@ -439,6 +444,11 @@ def test_deferred_join_pipeline(g, orc):
         assert np.array_equal(r["hops"].cpu().numpy(), s["hops"]), (b, ef, defer)
         assert np.array_equal(r["dist_calc"].cpu().numpy() + ef, s["dist_calc"]), (b, ef, defer)
         assert np.array_equal(r["cand"].cpu().numpy().view(np.uint32), w["ids"]), (b, ef, defer)
+    e64 = [orc.search_batch(orc_mod.MODE_NET, c.queries[b * 1000:(b + 1) * 1000], c.base, off, nbr, 64, db_low=db_low, net=c.net,
+                            entries=ent[b * 1000:(b + 1) * 1000], threads=8) for b in range(3)]
+    for i, r in enumerate(deep):
+        assert np.array_equal(r["ids"].cpu().numpy().view(np.uint32), e64[i % 3]["ids"]), i
+        assert np.array_equal(r["hops"].cpu().numpy(), e64[i % 3]["hops"]), i
     # a consumer enqueued on the caller's stream after join() sees the answers without any host synchronisation
     r = ix.search(qs[0], 64, entry_ids=es[0], want=(), out={}, flags=g.FLAG_DEFER_JOIN)
     ix.join()

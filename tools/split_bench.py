@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--ef", type=int, default=None)
     ap.add_argument("--reps", type=int, default=60)
     ap.add_argument("--modes", default="device,defer,host")
+    ap.add_argument("--depths", default="2,3,4")
     args = ap.parse_args()
     cfg = bench.CONFIGS[args.config]
     ef = args.ef or cfg["ef"]
@@ -41,15 +42,16 @@ def main():
         ix.search(qs[0], ef, want=())
     torch.cuda.synchronize()
 
-    def run(batches, flags=0):
-        outs = [{}, {}]
-        for i in range(10):
-            ix.search(batches[i & 3], ef, want=(), out=outs[i & 1], flags=flags)
+    def run(batches, flags=0, depth=0):
+        outs = [{} for _ in range(max(depth, 2))]
+        nb = len(outs)
+        for i in range(12):
+            ix.search(batches[i & 3], ef, want=(), out=outs[i % nb], flags=flags, defer_depth=depth)
         ix.join()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.reps):
-            r = ix.search(batches[i & 3], ef, want=(), out=outs[i & 1], flags=flags)
+            r = ix.search(batches[i & 3], ef, want=(), out=outs[i % nb], flags=flags, defer_depth=depth)
         ix.join()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.reps
@@ -60,7 +62,8 @@ def main():
     if "device" in args.modes:
         print("device plain        ", run(qs), flush=True)
     if "defer" in args.modes:
-        print("device defer-join   ", run(qs, g.FLAG_DEFER_JOIN), flush=True)
+        for dpt in args.depths.split(","):
+            print("device defer-join, %s in flight" % dpt, run(qs, g.FLAG_DEFER_JOIN, int(dpt)), flush=True)
     if "host" in args.modes:
         print("host pageable       ", run(qh), flush=True)
 
