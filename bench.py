@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--nq", type=int, default=None, help="override the batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the diagnostic sections (separate stages, MFMA option, host buffers, ef sweep): profiling runs")
+                    help="skip the diagnostic sections (separate stages, host buffers, ef sweep): profiling runs")
     ap.add_argument("--hash-capacity", type=int, default=0, help="0 = library default (tuning knob)")
     ap.add_argument("--bitmap-pass", action="store_true", help="force the HBM-bitmap first pass (tuning knob: GBNNS_FLAG_BITMAP_PASS)")
     ap.add_argument("--sweep", action="store_true", help="also time every reference ef (stderr)")
@@ -465,25 +465,6 @@ def main():
             "walk_GBps": round(rl["walk_bytes"] / (wu * 1e-3) / 1e9, 1) if wu > 0 else None,
             "rerank_GBps": round(rl["rerank_bytes"] / (ru_ms * 1e-3) / 1e9, 1) if ru_ms > 0 else None,
             "answers_identical": bool((ru["ids"] == res["ids"]).all().item()),
-        }
-
-    # ---- opt-in matrix-core projection (not bit-exact): how fast, and how many answers change --------
-    if extras and small:
-        for _ in range(3):
-            rm = ix.search(q, ef, want=(), flags=g.FLAG_MFMA_PROJECT)
-        torch.cuda.synchronize()
-        ix.profile_read(reset=True)
-        ix.profile_enable(True)
-        for _ in range(10):
-            rm = ix.search(q, ef, want=(), flags=g.FLAG_MFMA_PROJECT)
-        torch.cuda.synchronize()
-        pm = ix.profile_read(reset=True)
-        ix.profile_enable(False)
-        result["mfma_project_option"] = {
-            "project_ms": round(pm["project_ms"] / max(pm["calls"], 1), 4),
-            "answers_changed": int((rm["ids"] != res["ids"]).sum().item()),
-            "recall_at_1": round(recall_of(rm["ids"]), 4),
-            "note": "f32 MFMA fma-chain rounding; off by default, default path is bit-exact",
         }
 
     # ---- PCIe-inclusive rate (host buffers in, ids out: what the C++ drop-in times, and SURVEY 8d's

@@ -14,7 +14,6 @@ _LIB_PATH = os.path.join(_HERE, "lib", "libgbnns_hip.so")
 METRIC_L2, METRIC_NEG_DOT = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
 MODE_NET, MODE_LOWQ, MODE_PLAIN = 0, 1, 2
-FLAG_MFMA_PROJECT = 1
 FLAG_NO_FUSED_RERANK = 2
 FLAG_AUX_GRAPH = 4
 FLAG_LLF = 8

@@ -560,12 +560,12 @@ namespace {
 
 // MLP over rows x [nx x xstride] (device) -> out [nx x dl_pad] (device); h1/h2 are scratch.
 int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint32_t nx, float* out,
-                hipStream_t s, bool mfma = false) {
+                hipStream_t s) {
     // GBNNS_FUSED_MLP=1: one launch for the whole net when its activations fit the LDS (project.hip; identical
     // outputs).  Off by default: measured 0.084 ms against 0.071 ms for the three per-layer launches on the SIFT
     // shape -- two wavefronts per SIMD do not hide the LDS latency of its 3 x 4-output register tile.
     static const bool fused = getenv("GBNNS_FUSED_MLP") && atoi(getenv("GBNNS_FUSED_MLP"));
-    if (!mfma && fused) {
+    if (fused) {
         FusedMlpParams f{};
         size_t lds = 0;
         f.rows_per_wave = mlp_fused_plan(ix->d, ix->d_hidden, ix->d_low, nx, &f.lda, &f.ldb, &lds);
@@ -585,7 +585,7 @@ int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint
     LayerParams p{};
     p.x = x; p.xstride = xstride; p.w = ix->w1; p.wstride = ix->ws1; p.bias = ix->b1;
     p.out = L.h1.as<float>(); p.ostride = ix->d_hidden; p.nq = nx; p.din = ix->d;
-    p.dout = ix->d_hidden; p.relu = 1; p.mfma = mfma ? 1 : 0;
+    p.dout = ix->d_hidden; p.relu = 1;
     HIP_TRY(launch_mlp_layer(p, s));
     p.x = L.h1.as<float>(); p.xstride = ix->d_hidden; p.w = ix->w2; p.wstride = ix->ws2;
     p.bias = ix->b2; p.out = L.h2.as<float>(); p.din = ix->d_hidden;
@@ -892,7 +892,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         if ((rc = L.q_low.ensure((size_t)nq * ix->dl_pad * 4))) return rc;
         float* ql = L.q_low.as<float>();
         if (a->mode == GBNNS_MODE_NET) {
-            if ((rc = run_project(ix, L, q_dev, ix->d, nq, ql, s, (a->flags & GBNNS_FLAG_MFMA_PROJECT) != 0))) return rc;
+            if ((rc = run_project(ix, L, q_dev, ix->d, nq, ql, s))) return rc;
             w.q = ql; w.qstride = ix->dl_pad;
         } else if (host) {
             HIP_TRY(hipMemcpyAsync(ql, a->queries_low, (size_t)nq * ix->d_low * 4, hipMemcpyHostToDevice, s));

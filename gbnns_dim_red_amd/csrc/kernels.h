@@ -127,7 +127,6 @@ struct LayerParams {
     uint32_t ostride;
     uint32_t nq, din, dout;
     int32_t relu;
-    int32_t mfma;            // 1: matrix-core variant (k-ordered fma chain: not bit-exact, opt-in)
     int32_t normalize;       // 1: follow the layer by normalizeVector over its dout outputs (fused when dout <= 64)
 };
 hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s);

@@ -3754,89 +3754,6 @@ __global__ __launch_bounds__(256) void mlp_narrow_kernel(LayerParams p) {
     }
 }
 
-// Throughput variant of the projection layer on the matrix cores (opt-in, NOT bit-exact):
-// v_mfma_f32_32x32x2_f32 computes each dot product as one k-ordered f32 fma chain, which differs
-// from the reference's 8 separately rounded running sums in the last ulp.  Block = 4 wavefronts =
-// 64 queries x 64 neurons, each wavefront one 32x32 accumulator tile; x / W tiles of 32 k-values
-// through LDS with a row stride of 33 floats (the 32 lanes of an operand read distinct banks).
-// bench.py reports how many answers of the batch change when this variant is switched on.
-constexpr int kMT = 64, kMK = 32, kMLd = kMK + 1;
-typedef float mfma_acc16 __attribute__((ext_vector_type(16)));
-
-template <bool RELU, bool VEC>
-__global__ __launch_bounds__(256) void mlp_layer_mfma_kernel(LayerParams p) {
-    __shared__ float xs[kMT * kMLd];
-    __shared__ float ws[kMT * kMLd];
-    const int t = threadIdx.x;
-    const int wave = t >> 6, lane = t & 63;
-    const uint32_t qbase = blockIdx.x * kMT, obase = blockIdx.y * kMT;
-    const int wq = (wave >> 1) * 32, wo = (wave & 1) * 32;  // this wavefront's 32x32 sub-tile
-    const int li = lane & 31, lk = lane >> 5;
-    // staging role (VEC: 16-B loads, operands 16-B aligned): rows t/8 and t/8 + 32, columns 4*(t%8)..+3
-    const int srow = t >> 3, sc4 = (t & 7) * 4;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fetch = [&](uint32_t k0, float4 (&f)[4]) {
-        const bool kin = k0 + sc4 < p.din;  // VEC requires din % 4 == 0: a float4 is wholly in or out
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t qg = qbase + srow + 32 * h, og = obase + srow + 32 * h;
-            f[h] = (kin && qg < p.nq) ? *reinterpret_cast<const float4*>(p.x + (size_t)qg * p.xstride + k0 + sc4) : zero4;
-            f[2 + h] = (kin && og < p.dout) ? *reinterpret_cast<const float4*>(p.w + (size_t)og * p.wstride + k0 + sc4) : zero4;
-        }
-    };
-    auto put = [&](const float4 (&f)[4]) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float* xd = &xs[(srow + 32 * h) * kMLd + sc4];
-            float* wd = &ws[(srow + 32 * h) * kMLd + sc4];
-            xd[0] = f[h].x; xd[1] = f[h].y; xd[2] = f[h].z; xd[3] = f[h].w;
-            wd[0] = f[2 + h].x; wd[1] = f[2 + h].y; wd[2] = f[2 + h].z; wd[3] = f[2 + h].w;
-        }
-    };
-    mfma_acc16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float4 f[4];
-    if constexpr (VEC) fetch(0, f);
-    for (uint32_t k0 = 0; k0 < p.din; k0 += kMK) {
-        if constexpr (VEC) {
-            put(f);
-        } else {
-            for (int e = t; e < kMT * kMK; e += 256) {
-                const int r = e / kMK, c = e % kMK;
-                const uint32_t qg = qbase + r, og = obase + r, kg = k0 + c;
-                xs[r * kMLd + c] = (qg < p.nq && kg < p.din) ? p.x[(size_t)qg * p.xstride + kg] : 0.f;
-                ws[r * kMLd + c] = (og < p.dout && kg < p.din) ? p.w[(size_t)og * p.wstride + kg] : 0.f;
-            }
-        }
-        __syncthreads();
-        if constexpr (VEC) {
-            if (k0 + kMK < p.din) fetch(k0 + kMK, f);  // next chunk in flight during the MFMAs
-        }
-#pragma unroll
-        for (int kk = 0; kk < kMK; kk += 2) {
-            const float a = xs[(wq + li) * kMLd + kk + lk];  // A[i = lane&31][k = lane>>5]
-            const float b = ws[(wo + li) * kMLd + kk + lk];  // B[k = lane>>5][j = lane&31]
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // C/D layout of the 32x32 tile: column j = lane & 31, row i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const uint32_t og = obase + wo + li;
-    if (og < p.dout) {
-        const float bias = p.bias[og];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t qg = qbase + wq + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (qg < p.nq) {
-                float v = acc[r] + bias;
-                if (RELU && v < 0.f) v = 0.f;
-                p.out[(size_t)qg * p.ostride + og] = v;
-            }
-        }
-    }
-}
-
 // support_func.h:636-642 normalizeVector: norm = sqrt(L2Metric.Dist(y, zeros)); y[i] /= norm.
 __global__ __launch_bounds__(256) void normalize_kernel(float* y, uint32_t stride, uint32_t dim,
                                                         uint32_t nq) {
@@ -4286,24 +4203,6 @@ hipError_t launch_rerank(const RerankParams& p, int metric, hipStream_t s) {
 
 hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s) {
     if (p.nq == 0 || p.dout == 0) return hipSuccess;
-    const bool aligned4 = p.xstride % 4 == 0 && p.wstride % 4 == 0 && p.din % 4 == 0 &&
-                          (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;
-    if (p.mfma) {
-        const dim3 gm((p.nq + kMT - 1) / kMT, (p.dout + kMT - 1) / kMT);
-        if (aligned4) {
-            if (p.relu) hipLaunchKernelGGL((mlp_layer_mfma_kernel<true, true>), gm, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((mlp_layer_mfma_kernel<false, true>), gm, dim3(256), 0, s, p);
-        } else {
-            if (p.relu) hipLaunchKernelGGL((mlp_layer_mfma_kernel<true, false>), gm, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((mlp_layer_mfma_kernel<false, false>), gm, dim3(256), 0, s, p);
-        }
-        if (p.normalize) {
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return e;
-            return launch_normalize(p.out, p.ostride, p.dout, p.nq, s);
-        }
-        return hipGetLastError();
-    }
     const dim3 grid((p.nq + kTQ - 1) / kTQ, (p.dout + kTO - 1) / kTO);
     const bool aligned = p.xstride % 4 == 0 && p.wstride % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 &&
                          (reinterpret_cast<uintptr_t>(p.w) & 15) == 0;

@@ -138,13 +138,10 @@ typedef struct {
     uint32_t defer_depth;      /* with GBNNS_FLAG_DEFER_JOIN: batches in flight, 2 .. 4 (0 = 3, the measured optimum) */
 } gbnns_search_args;
 
-/* Throughput option, off by default: run the MLP projection on the matrix cores (f32 MFMA).  The
- * dot products then round differently from support_func.h:131-163 (one fma chain instead of 8
- * separately rounded sums), so projected queries differ in the last ulp and an answer can differ
- * where two candidates are nearly tied; everything downstream is unchanged.  bench.py reports the
- * number of changed answers.  Without this flag results are bit-identical to the reference. */
-#define GBNNS_FLAG_MFMA_PROJECT 1u
-
+/* (Flag bit 1 is retired.  Rounds 1-2 offered the projection on the matrix cores -- v_mfma_f32_32x32x2_f32, a k-ordered
+ * fma chain, not bit-exact -- as an opt-in: 17 % matrix-pipe utilisation, 0.069 against 0.071 ms on the SIFT net, 0.154
+ * against 0.160 ms on the GIST net, and nothing once batches are in flight, where the projection hides under the
+ * previous batch's walk.  Removed in round 3; DESIGN.md section 5.3 has the counters.  The bit is ignored.) */
 /* Diagnostic: keep the re-rank (getRealNearest, search_function.h:105-125) in its own kernel launch even
  * where the walk kernels could re-rank each query at the end of its walk.  Results are identical either
  * way; the flag exists for A/B measurements and for timing the two stages separately. */

@@ -778,28 +778,6 @@ def test_calm_batches_then_surprise(g, orc):
     ix.close()
 
 
-def test_mfma_projection_option(g, orc):
-    """The opt-in matrix-core projection is a throughput variant, not part of the bit-exact
-    contract: its projected queries must agree with the exact path to f32 rounding (tolerance
-    2e-6 absolute on unit-norm outputs = a few ulp of the k-ordered fma chain vs 8 separate sums),
-    and the default path must stay bit-exact when the flag is off."""
-    c, off, nbr, db_low, ent = _oracle_case(orc, 1201, 10000, 512, 128, 32, 256)
-    ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
-    exact = ix.search(c.queries, 32, want=("q_low",))
-    fast = ix.search(c.queries, 32, want=("q_low",), flags=g.FLAG_MFMA_PROJECT)
-    assert np.array_equal(gu.bits(exact["q_low"]), gu.bits(orc.project(c.net, c.queries)))
-    err = np.abs(fast["q_low"] - exact["q_low"]).max()
-    assert 0 < err < 2e-6, err          # really a different rounding, and only that
-    assert (fast["ids"] != exact["ids"]).mean() < 0.01
-    # odd shapes go through the same kernel (zero padded tiles)
-    c2, off2, nbr2, db_low2, _ = _oracle_case(orc, 1202, 3000, 70, 45, 14, 27)
-    ix2 = g.Index(c2.base, off2, nbr2, db_low=db_low2, net=c2.net)
-    f2 = ix2.search(c2.queries, 8, want=("q_low",), flags=g.FLAG_MFMA_PROJECT)
-    assert np.abs(f2["q_low"] - orc.project(c2.net, c2.queries)).max() < 2e-6
-    ix.close()
-    ix2.close()
-
-
 def test_golden_auxiliary_graph(g, orc):
     """use_second_graph / llf / hops_bound (search_function.h:73-89) against the compiled reference's outputs
     (tests/golden/aux_toy.npz): walks, two-stage answers, plain answers, on clustered and tie-heavy data."""

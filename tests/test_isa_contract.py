@@ -80,7 +80,7 @@ def test_projection_kernels_fma_only_in_div_sqrt_expansion(kernels):
     """The MLP layers (support_func.h:624-633) are under the same contract; the correctly rounded divide / sqrt of
     normalizeVector (:636-642) legitimately expand to fma sequences -- only the NORM variants may contain any."""
     for name, insts in kernels.items():
-        if "mlp_" not in name or "mfma" in name:  # the opt-in matrix-core variant is outside the contract
+        if "mlp_" not in name:
             continue
         n_fma = sum(1 for i in insts if FUSED.match(i))
         if n_fma:
