@@ -15,7 +15,7 @@ STEPS=10
 OUT=gpurun_out/prof_${TAG}_${CFG}_ef${EF}
 mkdir -p $OUT
 export GBNNS_CACHE=/tmp/gbnns_cache
-ARGS="bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-extras $*"
+ARGS="bench.py --config $CFG --steps $STEPS --warmup 2 --no-cpu-baseline --no-extras --serial $*"
 [ "$EF" != "0" ] && ARGS="$ARGS --ef $EF"
 cd /tmp >/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 python3 $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
