@@ -142,7 +142,7 @@ def main():
             except Exception:
                 allc = {}
             allc["%s:ef%d" % (a.config, ef)] = {
-                "source": "profiles/%s_%s_ef%d_summary.txt (rocprofv3 --pmc, separate passes, bench.py --config %s --ef %d --steps %d --no-extras)"
+                "source": "profiles/%s_%s_ef%d_summary.txt (rocprofv3 --pmc, separate passes, bench.py --config %s --ef %d --steps %d --no-extras --serial)"
                           % (a.tag, a.config, ef, a.config, ef, last),
                 "kernel": dom, "kernel_us_profiled": w.get("timed_avg_us"),
                 "FETCH_SIZE_KiB": w["FETCH_SIZE"], "WRITE_SIZE_KiB": w.get("WRITE_SIZE", 0.0),
