@@ -583,6 +583,10 @@ def test_full_size_properties(g):
     dict(name="glove", n=30000, nq=300, d=200, dlow=32, dh=64, efs=(64, 300), metric=1),
     dict(name="deep", n=40000, nq=400, d=96, dlow=32, dh=64, efs=(40, 120), metric=0),
     dict(name="deep48", n=20000, nq=200, d=96, dlow=48, dh=64, efs=(40, 200), metric=0),  # reference's own deep row
+    # GIST with the hidden width the reference's parameter file names (second_part ... w_1024), and GloVe walked /
+    # re-ranked with L2 on its 200-float rows (what final_test.cpp:20 does)
+    dict(name="gist1024", n=6000, nq=100, d=960, dlow=64, dh=1024, efs=(200,), metric=0),
+    dict(name="glove-l2", n=30000, nq=300, d=200, dlow=32, dh=64, efs=(64, 300), metric=0),
 ])
 def test_config_shapes_vs_oracle(g, orc, shape):
     c = datagen.Case(shape["name"], 900 + len(shape["name"]), shape["n"], shape["nq"], shape["d"],
