@@ -19,7 +19,8 @@
  * which stream a call was given.  To overlap batches use one handle per stream (handles may share borrowed
  * device tensors).
  *
- * Device memory per handle besides the index data: per-batch buffers (n_q x (d_low + ef + 6) x 4 bytes at
+ * Device memory per handle besides the index data, per workspace ("lane": one for plain calls, one more per batch in
+ * flight with GBNNS_FLAG_DEFER_JOIN, at most four): per-batch buffers (n_q x (d_low + 2 d_hidden + ef + 6) x 4 bytes at
  * most) plus the exact fall-back walk's 64 slots of two n-bit sets and an ef-entry list: 16 n + 512 ef bytes
  * (16 MB at n = 10^6, 160 MB at 10^7).  The large-ef first pass (ef >= 385, deep batches) adds one n-bit set
  * per resident wavefront, capped at 8 GiB.
@@ -175,7 +176,8 @@ typedef struct {
  *                          batches too small to fill the machine (the reference's 1 000 GIST queries are one
  *                          wavefront per SIMD) run side by side -- or by gbnns_index_join, or by any call without the
  *                          flag.  Until then the outputs of the call must not be read and its inputs / outputs must
- *                          not be reused: a serving loop rotates `defer_depth` sets of buffers.
+ *                          not be reused: a serving loop rotates `defer_depth` sets of buffers.  args->stream must
+ *                          stay alive until the call has been joined.
  *   GBNNS_FLAG_SERIAL      the caller's stream, kernels back to back, whatever else is asked (what per-kernel timing
  *                          needs; gbnns_profile_enable(..., 1) implies it).  HOST-buffer calls always run this way. */
 #define GBNNS_FLAG_SERIAL 64u

@@ -1187,3 +1187,44 @@ def test_two_list_kernels_by_name(g, orc):
             launched = ix.profile_read(reset=True)["walk_kernel"]
             assert launched.startswith(kname), (key, launched)
         ix.close()
+
+
+def test_deferred_join_edge_cases(g, orc):
+    """Batches in flight meet the rest of the API: an empty batch, profiling switched on in the middle (profiled calls run
+    serialised), a projection / re-rank / auxiliary-graph change while deferred batches are unjoined, destroying a handle
+    with batches in flight, and a handle created after all that -- every answer still the oracle's."""
+    import torch
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    c, off, nbr, db_low, ent = _oracle_case(orc, 851, 12000, 900, 40, 32, 64)
+    want = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, 32, db_low=db_low, net=c.net, threads=8)
+    q_low = orc.project(c.net, c.queries)
+    for round_ in range(2):
+        ix = g.Index(t(c.base), off, nbr, db_low=t(db_low), net=tuple(t(x) for x in c.net))
+        q = t(c.queries)
+        empty = ix.search(q[:0], 32, want=(), out={}, flags=g.FLAG_DEFER_JOIN)
+        assert empty["ids"].numel() == 0
+        a = ix.search(q, 32, want=("hops",), out={}, flags=g.FLAG_DEFER_JOIN, defer_depth=4)
+        b = ix.search(q, 32, want=("hops",), out={}, flags=g.FLAG_DEFER_JOIN, defer_depth=4)
+        ix.profile_enable(True)                       # from here on calls are serialised (and join what is in flight)
+        p1 = ix.search(q, 32, want=("hops",), out={}, flags=g.FLAG_DEFER_JOIN)
+        prof = ix.profile_read(reset=True)
+        assert prof["calls"] == 1 and prof["walk_ms"] > 0
+        ix.profile_enable(False)
+        d = ix.search(q, 32, want=("hops",), out={}, flags=g.FLAG_DEFER_JOIN)
+        low = ix.project(q)                           # plain entry points join first
+        torch.cuda.synchronize()
+        assert np.array_equal(gu.bits(low.cpu().numpy()), gu.bits(q_low))
+        e = ix.search(q, 32, want=("hops",), out={}, flags=g.FLAG_DEFER_JOIN)
+        ix.set_aux_graph(off, nbr)                    # synchronises the device
+        f = ix.search(q, 32, want=("hops",), out={}, flags=g.FLAG_DEFER_JOIN)
+        ix.join()
+        torch.cuda.synchronize()
+        for r in (a, b, p1, d, e, f):
+            assert np.array_equal(r["ids"].cpu().numpy().view(np.uint32), want["ids"])
+            assert np.array_equal(r["hops"].cpu().numpy(), want["hops"])
+        # leave batches in flight and destroy the handle: the results that were joined before stay valid, nothing hangs
+        outs = [ix.search(q, 32, want=(), out={}, flags=g.FLAG_DEFER_JOIN, defer_depth=3) for _ in range(3)]
+        ix.close()
+        torch.cuda.synchronize()
+        del outs
