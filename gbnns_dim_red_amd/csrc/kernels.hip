@@ -2750,7 +2750,9 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
 // R = list registers per lane = ceil(ef / 64): 1 (every block hand-laid-out) .. 8 (ef <= 512): the same hop
 // -- one-block expansion, packed visited set, both prefetches -- around the generic selection and merge of
 // multi-register lists.
-template <int R>
+// WIDE: adjacency rows of 33 .. 64 slots (the level-0 lists of hnswlib M = 18 / 20 graphs, prepare_graph.cpp's M = 30):
+// the same hop with a second expansion pass over slots 32 .. 63 when the node has that many neighbours.
+template <int R, bool WIDE = false>
 __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, unsigned char* smem) {
     const int lane = lane_id();
     const uint32_t slot = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;  // lane = 2 * adjacency slot + row half
@@ -2792,14 +2794,17 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
 
     const uint64_t lmask = RegList<R>::lane_mask(0, ef);
     const uint32_t ell_row_bytes = p.ell_stride * 4u;
-    const bool slot_ok = slot < p.ell_stride;             // ell_stride is 16 or 32 here
+    const bool slot_ok = slot < p.ell_stride;             // ell_stride is 16 or 32 here (WIDE: 48 or 64)
     const uint32_t slot_off = slot_ok ? slot * 4u : 0u;    // lanes beyond the row read slot 0 and are masked
+    const bool slotw_ok = WIDE && slot + 32u < p.ell_stride;  // second pass: slots 32 .. 63
+    const uint32_t slotw_off = slotw_ok ? (slot + 32u) * 4u : 0u;
     const char* ell_base = reinterpret_cast<const char*>(p.ell);
     const char* db_base = reinterpret_cast<const char*>(p.db);
-    const uint32_t dc_limit = p.hash_limit >= 32u ? p.hash_limit - 32u : 0u;  // at most 32 new ids per hop
+    const uint32_t dc_limit = p.hash_limit >= 32u ? p.hash_limit - 32u : 0u;  // at most 32 new ids per pass
     bool handed_over = false;
     uint32_t pf_node = kInvalidId, pf_val = kInvalidId;    // prefetch 1: the runner-up of the selection
     uint32_t pf2_node = kInvalidId, pf2_val = kInvalidId;  // prefetch 2: the closest new survivor (see below)
+    uint32_t pf_valw = kInvalidId, pf2_valw = kInvalidId;  // WIDE: the rows' second halves
 
     while (true) {
         // ---- next node: closest unexpanded entry (ties -> largest id), and the runner-up as prediction
@@ -2880,17 +2885,32 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
         }
 
         // ---- adjacency row of `node` (prefetched, or loaded now), then the prefetch for the next hop
-        uint32_t nb;
-        if (node == pf_node) nb = pf_val;
-        else if (node == pf2_node) nb = pf2_val;
-        else nb = *reinterpret_cast<const uint32_t*>(ell_base + node * ell_row_bytes + slot_off);
+        uint32_t nb, nbw = kInvalidId;
+        if (node == pf_node) {
+            nb = pf_val;
+            if constexpr (WIDE) nbw = pf_valw;
+        } else if (node == pf2_node) {
+            nb = pf2_val;
+            if constexpr (WIDE) nbw = pf2_valw;
+        } else {
+            nb = *reinterpret_cast<const uint32_t*>(ell_base + node * ell_row_bytes + slot_off);
+            if constexpr (WIDE) nbw = *reinterpret_cast<const uint32_t*>(ell_base + node * ell_row_bytes + slotw_off);
+        }
         nb = slot_ok ? nb : kInvalidId;
+        if constexpr (WIDE) nbw = slotw_ok ? nbw : kInvalidId;
         pf2_node = kInvalidId;
-        const uint64_t mv = __ballot(nb != kInvalidId);
+        // (the ballots come before the prefetch loads below: their wait must cover this row only)
+        const uint64_t mv0 = __ballot(nb != kInvalidId);
+        const uint64_t mv1 = WIDE ? __ballot(nbw != kInvalidId) : 0ull;
         pf_node = pred;
-        if (pred != kInvalidId) pf_val = *reinterpret_cast<const uint32_t*>(ell_base + pred * ell_row_bytes + slot_off);
-        if (__builtin_expect(mv != 0, 1)) {
-            if (__builtin_expect((uint32_t)dist_calc > dc_limit, 0)) { handed_over = true; break; }
+        if (pred != kInvalidId) {
+            pf_val = *reinterpret_cast<const uint32_t*>(ell_base + pred * ell_row_bytes + slot_off);
+            if constexpr (WIDE) pf_valw = *reinterpret_cast<const uint32_t*>(ell_base + pred * ell_row_bytes + slotw_off);
+        }
+        // one expansion pass over <= 32 adjacency slots (lane = 2 * slot + row half); false = the query is handed over
+        auto expand_pass = [&](const uint32_t nb, const uint64_t mv) -> bool {
+            if (__builtin_expect(mv == 0, 0)) return true;
+            if (__builtin_expect((uint32_t)dist_calc > dc_limit, 0)) return false;
             edges += __popcll(mv & 0x5555555555555555ull);
             // ---- gather (speculative: before the visited test), visited test, distances -----------
             uint64_t mclaimed;
@@ -2916,6 +2936,10 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
                         if (me != 0 && (me & (me - 1)) == 0) {
                             pf2_node = readlane_u32(nb, __ffsll((unsigned long long)me) - 1);
                             pf2_val = *reinterpret_cast<const uint32_t*>(ell_base + pf2_node * ell_row_bytes + slot_off);
+                            if constexpr (WIDE) {
+                                pf2_valw = *reinterpret_cast<const uint32_t*>(ell_base + pf2_node * ell_row_bytes + slotw_off);
+                                h2 = dmin;  // the second pass overrides the prediction only with something closer still
+                            }
                         }
                     }
                 }
@@ -2928,14 +2952,15 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
                     do {
                         const int l = __ffsll((unsigned long long)m) - 1;
                         m &= m - 1;
-                        if (!reg_offer<R>(readlane_u32(dk, l), readlane_u32(nb, l) << 1, L, size, worst, tsize, tie, ef, lane)) {
-                            handed_over = true;
-                            break;
-                        }
+                        if (!reg_offer<R>(readlane_u32(dk, l), readlane_u32(nb, l) << 1, L, size, worst, tsize, tie, ef, lane)) return false;
                     } while (m);
-                    if (handed_over) break;
                 }
             }
+            return true;
+        };
+        if (!expand_pass(nb, mv0)) { handed_over = true; break; }
+        if constexpr (WIDE) {
+            if (!expand_pass(nbw, mv1)) { handed_over = true; break; }
         }
         hops += 1;
     }
@@ -2954,6 +2979,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     }
 }
 
+template <bool WIDE = false>
 __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, unsigned char* smem) {
     const int lane = lane_id();
 #ifdef GBNNS_STAMPS  // diagnostic build: cycles per segment of the hop (tools/stamps.py)
@@ -2999,11 +3025,14 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
     const uint32_t ell_row_bytes = p.ell_stride * 4u;
     const bool slot_ok = slot < p.ell_stride;
     const uint32_t slot_off = slot_ok ? slot * 4u : 0u;
+    const bool slotw_ok = WIDE && slot + 32u < p.ell_stride;  // second pass: slots 32 .. 63 (see walk_hot_one)
+    const uint32_t slotw_off = slotw_ok ? (slot + 32u) * 4u : 0u;
     const char* ell_base = reinterpret_cast<const char*>(p.ell);
     const char* db_base = reinterpret_cast<const char*>(p.db);
     const uint32_t dc_limit = p.hash_limit >= 32u ? p.hash_limit - 32u : 0u;
     bool handed_over = false;
     uint32_t pf_node = kInvalidId, pf_val = kInvalidId, pf2_node = kInvalidId, pf2_val = kInvalidId;
+    uint32_t pf_valw = kInvalidId, pf2_valw = kInvalidId;
 
     while (true) {
         uint32_t node, pred, h2;
@@ -3014,19 +3043,33 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
         STAMP_ADD(0, t0, t1)
 
         // ---- adjacency row of `node` (prefetched, or loaded now), then the prefetch for the next hop
-        uint32_t nb;
-        if (node == pf_node) nb = pf_val;
-        else if (node == pf2_node) nb = pf2_val;
-        else nb = *reinterpret_cast<const uint32_t*>(ell_base + node * ell_row_bytes + slot_off);
+        uint32_t nb, nbw = kInvalidId;
+        if (node == pf_node) {
+            nb = pf_val;
+            if constexpr (WIDE) nbw = pf_valw;
+        } else if (node == pf2_node) {
+            nb = pf2_val;
+            if constexpr (WIDE) nbw = pf2_valw;
+        } else {
+            nb = *reinterpret_cast<const uint32_t*>(ell_base + node * ell_row_bytes + slot_off);
+            if constexpr (WIDE) nbw = *reinterpret_cast<const uint32_t*>(ell_base + node * ell_row_bytes + slotw_off);
+        }
         nb = slot_ok ? nb : kInvalidId;
+        if constexpr (WIDE) nbw = slotw_ok ? nbw : kInvalidId;
         pf2_node = kInvalidId;
-        const uint64_t mv = __ballot(nb != kInvalidId);
+        const uint64_t mv0 = __ballot(nb != kInvalidId);
+        const uint64_t mv1 = WIDE ? __ballot(nbw != kInvalidId) : 0ull;
         STAMP(t2)
         STAMP_ADD(1, t1, t2)
         pf_node = pred;
-        if (pred != kInvalidId) pf_val = *reinterpret_cast<const uint32_t*>(ell_base + pred * ell_row_bytes + slot_off);
-        if (__builtin_expect(mv != 0, 1)) {
-            if (__builtin_expect((uint32_t)dist_calc > dc_limit, 0)) { handed_over = true; break; }
+        if (pred != kInvalidId) {
+            pf_val = *reinterpret_cast<const uint32_t*>(ell_base + pred * ell_row_bytes + slot_off);
+            if constexpr (WIDE) pf_valw = *reinterpret_cast<const uint32_t*>(ell_base + pred * ell_row_bytes + slotw_off);
+        }
+        // one expansion pass over <= 32 adjacency slots; false = the query is handed over
+        auto expand_pass = [&](const uint32_t nb, const uint64_t mv) -> bool {
+            if (__builtin_expect(mv == 0, 0)) return true;
+            if (__builtin_expect((uint32_t)dist_calc > dc_limit, 0)) return false;
             edges += __popcll(mv & 0x5555555555555555ull);
             STAMP(t3)
             STAMP_ADD(2, t2, t3)
@@ -3052,16 +3095,25 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
                         if (me != 0 && (me & (me - 1)) == 0) {
                             pf2_node = readlane_u32(nb, __ffsll((unsigned long long)me) - 1);
                             pf2_val = *reinterpret_cast<const uint32_t*>(ell_base + pf2_node * ell_row_bytes + slot_off);
+                            if constexpr (WIDE) {
+                                pf2_valw = *reinterpret_cast<const uint32_t*>(ell_base + pf2_node * ell_row_bytes + slotw_off);
+                                h2 = dmin;
+                            }
                         }
                     }
                 }
-                if (!B.insert(m, dk, nb, lane)) { handed_over = true; break; }
+                if (!B.insert(m, dk, nb, lane)) return false;
             }
             STAMP(t6)
             STAMP_ADD(5, t5, t6)
 #ifdef GBNNS_STAMPS
             t_prev = t6;
 #endif
+            return true;
+        };
+        if (!expand_pass(nb, mv0)) { handed_over = true; break; }
+        if constexpr (WIDE) {
+            if (!expand_pass(nbw, mv1)) { handed_over = true; break; }
         }
         hops += 1;
     }
@@ -3103,6 +3155,22 @@ __global__ __launch_bounds__(64) void walk_hot_big_kernel(WalkParams p) {  // 12
 __global__ __launch_bounds__(64) void walk_hot_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<1>(p, blockIdx.x, smem);
+}
+
+// the same three for adjacency rows of 33 .. 64 slots (two expansion passes per hop)
+__global__ __launch_bounds__(64) void walk_hotw_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_hot_one<1, true>(p, blockIdx.x, smem);
+}
+
+__global__ __launch_bounds__(64) void walk_hotw2_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_hot_one<2, true>(p, blockIdx.x, smem);
+}
+
+__global__ __launch_bounds__(64) void walk_hotw_big_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_hot_big<true>(p, blockIdx.x, smem);
 }
 
 template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R, bool ONE_CHUNK = false, bool AUX = false>
@@ -3912,8 +3980,8 @@ __global__ __launch_bounds__(64) void gd_prune_kernel(GdParams p) {
 // launchers
 // ------------------------------------------------------------------------------------------
 
-// Shape served by walk_hot_kernel (first pass only): L2, 128-byte rows, ef <= 64, adjacency rows of one
-// 32-slot pass, 32-bit byte offsets.
+// Shape served by the walk_hot* kernels (first pass only): L2, 128-byte rows, adjacency rows of one 32-slot pass
+// (walk_hotw*: 33 .. 64 slots, two passes), 32-bit byte offsets.
 static bool walk_off32(const WalkParams& p) {  // "compact" index: every table the walk indexes is < 4 GiB, ids fit 24 bits
     return !p.force_wide && (uint64_t)p.n * p.dstride * 4 < (1ull << 32) && (uint64_t)p.n * p.ell_stride * 4 < (1ull << 32) &&
            (!p.aux_ell || (uint64_t)p.n * p.aux_stride * 4 < (1ull << 32)) && p.n <= 0xFFFFFFu;
@@ -3925,7 +3993,7 @@ bool walk_uses_lds_list(const WalkParams& p) { return p.ef > kRegListMaxEf || (p
 
 bool walk_uses_hot(const WalkParams& p, int metric) {
     const bool off32 = walk_off32(p);
-    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= kBigMaxEf && p.ell_stride <= 32u && off32 && (!p.stamps_on || (p.ef > kHot2MaxEf && !getenv("GBNNS_STAMPS_GENERIC"))) &&
+    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= kBigMaxEf && p.ell_stride <= 64u && off32 && (!p.stamps_on || (p.ef > kHot2MaxEf && !getenv("GBNNS_STAMPS_GENERIC"))) &&
            !p.aux_ell;  // (off32 includes n < 2^24: its visited set stores 24-bit ids)
 }
 
@@ -3994,7 +4062,8 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
         // ef > 128: base list in LDS + front list in one register (walk_reg_big_one), whatever the shape
         if constexpr (METRIC == 0 && STEPS == 8) {
             if (!retry && walk_uses_hot(p, METRIC))
-                return launch_walk_k(walk_hot_big_kernel, p, false, walk_fast_lds_bytes(p, true), s);
+                return p.ell_stride > 32u ? launch_walk_k(walk_hotw_big_kernel, p, false, walk_fast_lds_bytes(p, true), s)
+                                          : launch_walk_k(walk_hot_big_kernel, p, false, walk_fast_lds_bytes(p, true), s);
         }
         if (p.aux_ell)
             return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, true, true>, p, true, lds, s)
@@ -4017,7 +4086,8 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
         // 128-byte rows with L2 additionally the hand-laid-out hop of walk_hot_one
         if constexpr (METRIC == 0 && STEPS == 8) {
             if (!retry && walk_uses_hot(p, METRIC))
-                return launch_walk_k(walk_hot_kernel, p, false, walk_fast_lds_bytes(p, true), s);
+                return p.ell_stride > 32u ? launch_walk_k(walk_hotw_kernel, p, false, walk_fast_lds_bytes(p, true), s)
+                                          : launch_walk_k(walk_hot_kernel, p, false, walk_fast_lds_bytes(p, true), s);
         }
         if (off32 && !retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16) && METRIC == 0)) ? 32u : 64u))  // pair form: 32 slots per pass
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
@@ -4025,7 +4095,8 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
     if constexpr (R == 2 && METRIC == 0 && STEPS == 8) {
         // the hot shape, 64 < ef <= 128: two list registers (measured: 0.85 ms against 0.93 ms with the two-list structure)
         if (!retry && walk_uses_hot(p, METRIC))
-            return launch_walk_k(walk_hot2_kernel, p, false, walk_fast_lds_bytes(p, true), s);
+            return p.ell_stride > 32u ? launch_walk_k(walk_hotw2_kernel, p, false, walk_fast_lds_bytes(p, true), s)
+                                      : launch_walk_k(walk_hot2_kernel, p, false, walk_fast_lds_bytes(p, true), s);
     }
     if (off32)
         return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, true, R>, p, true, lds, s)

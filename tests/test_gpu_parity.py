@@ -1164,7 +1164,12 @@ def test_two_list_kernels_by_name(g, orc):
         (128, 64, 128, 0, 30, [(64, 0, "walk_reg_kernel<0, 16,"), (200, 0, "walk_reg_big_kernel<0, 16,"),
                                (1000, 0, "walk_reg_big_kernel<0, 16,"), (600, "bitmap", "walk_bitmap_big_kernel<0, 16,")]),
         (96, 48, 64, 0, 30, [(200, 0, "walk_reg_big_kernel<0, 12,")]),
-        (64, 32, 64, 0, 70, [(300, 0, "walk_reg_big_kernel<0, 8,")]),  # adjacency rows of several passes: generic kernel
+        (64, 32, 64, 0, 70, [(300, 0, "walk_reg_big_kernel<0, 8,")]),  # adjacency rows of more than 64 slots: generic kernel
+        # adjacency rows of 33 .. 64 slots (hnswlib M = 18 / 20 level-0 lists, prepare_graph.cpp's M = 30): the hot
+        # instances with a second expansion pass
+        (64, 32, 64, 0, 60, [(8, 0, "walk_hotw_kernel"), (64, 0, "walk_hotw_kernel"), (100, 0, "walk_hotw2_kernel"),
+                             (200, 0, "walk_hotw_big_kernel"), (700, 0, "walk_hotw_big_kernel")]),
+        (64, 32, 64, 0, 40, [(64, 0, "walk_hotw_kernel"), (180, 0, "walk_hotw_big_kernel")]),   # 48-slot rows
     ]
     for si, (d, dlow, dh, metric, deg, cases) in enumerate(shapes):
         c, off, nbr, db_low, ent = _oracle_case(orc, 2300 + si, 6000, 120, d, dlow, dh, deg=(2, deg))
@@ -1177,7 +1182,7 @@ def test_two_list_kernels_by_name(g, orc):
             s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net,
                                  entries=ent, metric=metric, threads=8)
             ix.profile_read(reset=True)
-            r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), flags=flags)
+            r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist", "edges"), flags=flags)
             key = (d, dlow, metric, deg, ef, fl)
             assert np.array_equal(r["cand"], w["ids"]), key
             assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
