@@ -2616,7 +2616,11 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
     return true;
 }
 
-template <typename QP>
+// METRIC 0: L2Metric::Dist, the lane holds 64 contiguous bytes of the row (roff = row + half * 64, loads at 0 / 16 / 32 / 48).
+// METRIC 1: Angular::Dist, the lane holds the even (odd) 16-byte pieces (roff = row + half * 16, loads at 0 / 32 / 64 / 96):
+// its eight running sums are independent chains, the even lane runs sums 0..3, the odd lane sums 4..7, and the fold
+// m_j = c_{j+4} + c_j happens once, in the odd lane (dot_pair_from_regs).
+template <int METRIC = 0, typename QP>
 __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t roff, uint32_t nb, uint64_t valid, uint32_t lds_base,
                                                uint32_t nbuckets, QP qh, uint64_t& claimed) {
     const uint32_t end = lds_base + (nbuckets << 4);
@@ -2627,6 +2631,7 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 r0, r1, r2, r3;
 #define GBNNS_Q(T) [qa##T] "v"(f32x2{qh[T].x, qh[T].y}), [qb##T] "v"(f32x2{qh[T].z, qh[T].w})
+    if constexpr (METRIC == 0) {
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[valid]\n\t"
@@ -2742,6 +2747,117 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
           [nb] "s"(nbuckets), [roff] "v"(roff), [db] "s"(db_base), GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
         : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",
           "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
+    } else {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[valid]\n\t"
+        "global_load_dwordx4 v[48:51], %[roff], %[db]\n\t"
+        "global_load_dwordx4 v[52:55], %[roff], %[db] offset:32\n\t"
+        "global_load_dwordx4 v[56:59], %[roff], %[db] offset:64\n\t"
+        "global_load_dwordx4 v[60:63], %[roff], %[db] offset:96\n\t"
+        // ---- visited set: even lanes of `valid`.  Packed table: a 16-byte bucket holds five 24-bit ids (bits
+        // 24k .. 24k+23, all-ones = empty) and, in its top byte, the number of slots handed out.  An id is in the
+        // set iff it is found in a bucket of its probe sequence before a bucket with a free slot; a new id takes
+        // the slot index an atomic add on that counter returns (unique per lane, so no compare-and-swap and no
+        // retry inside a bucket) and writes its three bytes.
+        "v_mul_lo_u32 %[t0], %[id], %[mulc]\n\t"
+        "s_and_b32 exec_lo, exec_lo, 0x55555555\n\t"
+        "s_and_b32 exec_hi, exec_hi, 0x55555555\n\t"
+        "s_mov_b64 %[fresh], 0\n\t"
+        "v_mul_hi_u32 %[t0], %[t0], %[nb]\n\t"
+        "v_lshl_add_u32 %[addr], %[t0], 4, %[basev]\n"
+        "1:\n\t"
+        "ds_read_b128 v[68:71], %[addr]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bfe_u32 v64, v68, 0, 24\n\t"                        // slot 0
+        "v_alignbit_b32 v65, v69, v68, 24\n\t"                 // slot 1 (bits 24..47) in the low 24 bits
+        "v_alignbit_b32 v66, v70, v69, 16\n\t"                 // slot 2 (bits 48..71)
+        "v_lshrrev_b32 v67, 8, v70\n\t"                        // slot 3 (bits 72..95)
+        "v_bfe_u32 %[t1], v71, 0, 24\n\t"                      // slot 4 (bits 96..119)
+        "v_bfe_u32 v65, v65, 0, 24\n\t"
+        "v_bfe_u32 v66, v66, 0, 24\n\t"
+        "v_xor_b32 v64, v64, %[id]\n\t"
+        "v_xor_b32 v65, v65, %[id]\n\t"
+        "v_xor_b32 v66, v66, %[id]\n\t"
+        "v_xor_b32 v67, v67, %[id]\n\t"
+        "v_xor_b32 %[t1], %[t1], %[id]\n\t"
+        "v_min3_u32 v64, v64, v65, v66\n\t"
+        "v_min3_u32 v64, v64, v67, %[t1]\n\t"                  // 0 <=> id is in the bucket
+        "v_lshrrev_b32 %[t1], 24, v71\n\t"                     // slots handed out
+        "v_cmp_ne_u32 vcc, 0, v64\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"                        // lanes that found their id are done
+        "s_cbranch_execz 9f\n\t"
+        "s_mov_b64 %[act], exec\n\t"
+        "v_cmp_gt_u32 vcc, 5, %[t1]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"                        // the bucket had room when it was read
+        "s_cbranch_execz 3f\n\t"
+        "ds_add_rtn_u32 %[t0], %[addr], %[inc] offset:12\n\t"  // take a slot number
+        "v_lshrrev_b32 %[t2], 8, %[id]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_lshrrev_b32 %[t0], 24, %[t0]\n\t"
+        "v_cmp_gt_u32 vcc, 5, %[t0]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"                        // lanes whose number is a real slot
+        "s_cbranch_execz 3f\n\t"
+        "v_mad_u32_u24 %[t0], %[t0], 3, %[addr]\n\t"           // byte address of the slot
+        "ds_write_b8 %[t0], %[id]\n\t"
+        "ds_write_b8 %[t0], %[t2] offset:1\n\t"
+        "ds_write_b8_d16_hi %[t0], %[id] offset:2\n\t"
+        "s_or_b64 %[fresh], %[fresh], exec\n\t"
+        "s_andn2_b64 %[act], %[act], exec\n"
+        "3:\n\t"
+        "s_mov_b64 exec, %[act]\n\t"                           // absent and unplaced: their bucket is full
+        "s_cbranch_execz 9f\n\t"
+        "v_add_u32 %[addr], 16, %[addr]\n\t"
+        "v_cmp_eq_u32 vcc, %[end], %[addr]\n\t"
+        "v_cndmask_b32 %[addr], %[addr], %[basev], vcc\n\t"
+        "s_branch 1b\n"
+        "9:\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        // ---- pair distance (dot_pair_from_regs), all lanes: products, then four running sums from +0 in load order
+        "v_mov_b32 v64, 0\n\t"
+        "v_mov_b32 v65, 0\n\t"
+        "s_waitcnt vmcnt(3)\n\t"
+        "v_pk_mul_f32 v[48:49], v[48:49], %[qa0]\n\t"
+        "v_pk_mul_f32 v[50:51], v[50:51], %[qb0]\n\t"
+        "v_pk_add_f32 v[68:69], v[64:65], v[48:49]\n\t"      // 0 + p: a product of -0 must not make the sum -0
+        "v_pk_add_f32 v[70:71], v[64:65], v[50:51]\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_pk_mul_f32 v[52:53], v[52:53], %[qa1]\n\t"
+        "v_pk_mul_f32 v[54:55], v[54:55], %[qb1]\n\t"
+        "v_pk_add_f32 v[68:69], v[68:69], v[52:53]\n\t"
+        "v_pk_add_f32 v[70:71], v[70:71], v[54:55]\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_pk_mul_f32 v[56:57], v[56:57], %[qa2]\n\t"
+        "v_pk_mul_f32 v[58:59], v[58:59], %[qb2]\n\t"
+        "v_pk_add_f32 v[68:69], v[68:69], v[56:57]\n\t"
+        "v_pk_add_f32 v[70:71], v[70:71], v[58:59]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_pk_mul_f32 v[60:61], v[60:61], %[qa3]\n\t"
+        "v_pk_mul_f32 v[62:63], v[62:63], %[qb3]\n\t"
+        "v_pk_add_f32 v[68:69], v[68:69], v[60:61]\n\t"
+        "v_pk_add_f32 v[70:71], v[70:71], v[62:63]\n\t"
+        "s_nop 1\n\t"
+        "v_mov_b32_dpp v64, v68 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"   // the even lane's sums 0..3
+        "v_mov_b32_dpp v65, v69 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v66, v70 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v67, v71 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_pk_add_f32 v[64:65], v[68:69], v[64:65]\n\t"      // odd lane: m_j = c_{j+4} + c_j
+        "v_pk_add_f32 v[66:67], v[70:71], v[66:67]\n\t"
+        "v_add_f32 %[key], v64, v65\n\t"                       // (m0 + m1) + (m2 + m3)
+        "v_add_f32 %[t0], v66, v67\n\t"
+        "v_add_f32 %[key], %[key], %[t0]\n\t"
+        "v_xor_b32 %[key], 0x80000000, %[key]\n\t"             // Angular::Dist = -(x . y)
+        "v_add_f32 %[key], 0, %[key]\n\t"                      // fkey: -0 -> +0,
+        "v_ashrrev_i32 %[t0], 31, %[key]\n\t"                  // then flip all bits of a negative value, the sign bit of a positive one
+        "v_or_b32 %[t0], 0x80000000, %[t0]\n\t"
+        "v_xor_b32 %[key], %[key], %[t0]"
+        : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+          [addr] "=&v"(addr), [key] "=&v"(key)
+        : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [inc] "v"(inc), [mulc] "s"(mulc),
+          [nb] "s"(nbuckets), [roff] "v"(roff), [db] "s"(db_base), GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",
+          "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
+    }
 #undef GBNNS_Q
     claimed = fresh;
     return key;
@@ -2752,7 +2868,7 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
 // multi-register lists.
 // WIDE: adjacency rows of 33 .. 64 slots (the level-0 lists of hnswlib M = 18 / 20 graphs, prepare_graph.cpp's M = 30):
 // the same hop with a second expansion pass over slots 32 .. 63 when the node has that many neighbours.
-template <int R, bool WIDE = false>
+template <int R, bool WIDE = false, int METRIC = 0>
 __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, unsigned char* smem) {
     const int lane = lane_id();
     const uint32_t slot = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;  // lane = 2 * adjacency slot + row half
@@ -2771,9 +2887,9 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     packed_table_init(hash, nbuckets, 0u, lane);
     if (lane < 32) qf[lane] = p.q[(size_t)qi * p.qstride + lane];
     wave_sync();
-    RowRegs<4> qreg;  // this lane's half of the query
+    RowRegs<4> qreg;  // this lane's half of the query: 64 contiguous bytes (L2) / the even or odd 16-byte pieces (dot)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) qreg.v[t] = qs[4 * half + t];
+    for (int t = 0; t < 4; ++t) qreg.v[t] = METRIC == 0 ? qs[4 * half + t] : qs[2 * t + half];
 
     RegList<R> L;
     L.clear();
@@ -2782,7 +2898,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     const uint32_t entry = p.entries ? p.entries[qi] : 0u;
     if (entry >= p.n) { write_bad_entry(p, qi, lane); return; }
     {
-        const float d0 = walk_dist<0, 8>(qs, row_ptr<true>(p.db, entry, 32u), 32u);
+        const float d0 = walk_dist<METRIC, 8>(qs, row_ptr<true>(p.db, entry, 32u), 32u);
         worst = fkey(d0);
         if (lane == 0) {
             L.hi[0] = worst;
@@ -2914,7 +3030,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
             edges += __popcll(mv & 0x5555555555555555ull);
             // ---- gather (speculative: before the visited test), visited test, distances -----------
             uint64_t mclaimed;
-            const uint32_t kd = hot_expand(db_base, (nb << 7) + half * 64u, nb, mv, hash_lds, nbuckets, qreg.v, mclaimed);
+            const uint32_t kd = hot_expand<METRIC>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, mclaimed);
             const uint64_t mfresh = mclaimed << 1;  // odd lanes hold the distances
             const uint32_t dk = __builtin_amdgcn_inverse_ballot_w64(mfresh) ? kd : 0xFFFFFFFFu;
             dist_calc += __popcll(mfresh);
@@ -2979,7 +3095,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     }
 }
 
-template <bool WIDE = false>
+template <bool WIDE = false, int METRIC = 0>
 __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, unsigned char* smem) {
     const int lane = lane_id();
 #ifdef GBNNS_STAMPS  // diagnostic build: cycles per segment of the hop (tools/stamps.py)
@@ -3003,7 +3119,7 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
     wave_sync();
     RowRegs<4> qreg;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) qreg.v[t] = qs[4 * half + t];
+    for (int t = 0; t < 4; ++t) qreg.v[t] = METRIC == 0 ? qs[4 * half + t] : qs[2 * t + half];
 
     int hops = 0, dist_calc = 1, edges = 0;
     // (every lane computes the same entry id and distance; readfirstlane tells the compiler they are wave-uniform --
@@ -3012,7 +3128,7 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
     const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p.entries ? p.entries[qi] : 0u));
     if (entry >= p.n) { write_bad_entry(p, qi, lane); return; }
     {
-        const float d0 = walk_dist<0, 8>(qs, row_ptr<true>(p.db, entry, 32u), 32u);
+        const float d0 = walk_dist<METRIC, 8>(qs, row_ptr<true>(p.db, entry, 32u), 32u);
         B.worst = B.fworst = (uint32_t)__builtin_amdgcn_readfirstlane((int)fkey(d0));
         if (lane == 0) {
             B.F.hi[0] = B.worst;
@@ -3074,7 +3190,7 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
             STAMP(t3)
             STAMP_ADD(2, t2, t3)
             uint64_t mclaimed;
-            const uint32_t kd = hot_expand(db_base, (nb << 7) + half * 64u, nb, mv, hash_lds, nbuckets, qreg.v, mclaimed);
+            const uint32_t kd = hot_expand<METRIC>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, mclaimed);
             const uint64_t mfresh = mclaimed << 1;  // odd lanes hold the distances
             const uint32_t dk = __builtin_amdgcn_inverse_ballot_w64(mfresh) ? kd : 0xFFFFFFFFu;
             dist_calc += __popcll(mfresh);
@@ -3171,6 +3287,19 @@ __global__ __launch_bounds__(64) void walk_hotw2_kernel(WalkParams p) {
 __global__ __launch_bounds__(64) void walk_hotw_big_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_big<true>(p, blockIdx.x, smem);
+}
+
+// ... and the negative-dot metric (Angular::Dist) on the same shapes (round 3): R = 1 / 2 list registers, or the two-list form
+template <int R, bool WIDE>
+__global__ __launch_bounds__(64) void walk_hot_dot_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_hot_one<R, WIDE, 1>(p, blockIdx.x, smem);
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(64) void walk_hot_dot_big_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_hot_big<WIDE, 1>(p, blockIdx.x, smem);
 }
 
 template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R, bool ONE_CHUNK = false, bool AUX = false>
@@ -3993,7 +4122,7 @@ bool walk_uses_lds_list(const WalkParams& p) { return p.ef > kRegListMaxEf || (p
 
 bool walk_uses_hot(const WalkParams& p, int metric) {
     const bool off32 = walk_off32(p);
-    return metric == 0 && p.dim == 32u && p.dstride == 32u && p.ef <= kBigMaxEf && p.ell_stride <= 64u && off32 && (!p.stamps_on || (p.ef > kHot2MaxEf && !getenv("GBNNS_STAMPS_GENERIC"))) &&
+    return (metric == 0 || metric == 1) && p.dim == 32u && p.dstride == 32u && p.ef <= kBigMaxEf && p.ell_stride <= 64u && off32 && (!p.stamps_on || (p.ef > kHot2MaxEf && !getenv("GBNNS_STAMPS_GENERIC"))) &&
            !p.aux_ell;  // (off32 includes n < 2^24: its visited set stores 24-bit ids)
 }
 
@@ -4065,6 +4194,11 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
                 return p.ell_stride > 32u ? launch_walk_k(walk_hotw_big_kernel, p, false, walk_fast_lds_bytes(p, true), s)
                                           : launch_walk_k(walk_hot_big_kernel, p, false, walk_fast_lds_bytes(p, true), s);
         }
+        if constexpr (METRIC == 1 && STEPS == 8) {
+            if (!retry && walk_uses_hot(p, METRIC))
+                return p.ell_stride > 32u ? launch_walk_k(walk_hot_dot_big_kernel<true>, p, false, walk_fast_lds_bytes(p, true), s)
+                                          : launch_walk_k(walk_hot_dot_big_kernel<false>, p, false, walk_fast_lds_bytes(p, true), s);
+        }
         if (p.aux_ell)
             return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, true, true>, p, true, lds, s)
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, true>, p, false, lds, s);
@@ -4089,6 +4223,11 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
                 return p.ell_stride > 32u ? launch_walk_k(walk_hotw_kernel, p, false, walk_fast_lds_bytes(p, true), s)
                                           : launch_walk_k(walk_hot_kernel, p, false, walk_fast_lds_bytes(p, true), s);
         }
+        if constexpr (METRIC == 1 && STEPS == 8) {
+            if (!retry && walk_uses_hot(p, METRIC))
+                return p.ell_stride > 32u ? launch_walk_k(walk_hot_dot_kernel<1, true>, p, false, walk_fast_lds_bytes(p, true), s)
+                                          : launch_walk_k(walk_hot_dot_kernel<1, false>, p, false, walk_fast_lds_bytes(p, true), s);
+        }
         if (off32 && !retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16) && METRIC == 0)) ? 32u : 64u))  // pair form: 32 slots per pass
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
     }
@@ -4097,6 +4236,11 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
         if (!retry && walk_uses_hot(p, METRIC))
             return p.ell_stride > 32u ? launch_walk_k(walk_hotw2_kernel, p, false, walk_fast_lds_bytes(p, true), s)
                                       : launch_walk_k(walk_hot2_kernel, p, false, walk_fast_lds_bytes(p, true), s);
+    }
+    if constexpr (R == 2 && METRIC == 1 && STEPS == 8) {
+        if (!retry && walk_uses_hot(p, METRIC))
+            return p.ell_stride > 32u ? launch_walk_k(walk_hot_dot_kernel<2, true>, p, false, walk_fast_lds_bytes(p, true), s)
+                                      : launch_walk_k(walk_hot_dot_kernel<2, false>, p, false, walk_fast_lds_bytes(p, true), s);
     }
     if (off32)
         return retry ? launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, true, R>, p, true, lds, s)

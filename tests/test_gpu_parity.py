@@ -1159,8 +1159,12 @@ def test_two_list_kernels_by_name(g, orc):
     shapes = [  # d, d_low, d_hidden, metric, max degree, [(ef, flags, expected kernel-name prefix)]
         (64, 32, 64, 0, 30, [(100, 0, "walk_hot2_kernel"), (200, 0, "walk_hot_big_kernel"), (1024, 0, "walk_hot_big_kernel"),
                              (300, "bitmap", "walk_bitmap_big_kernel<0, 8,")]),
-        (64, 32, 64, 1, 30, [(100, 0, "walk_reg_kernel<1, 8,"), (200, 0, "walk_reg_big_kernel<1, 8,"),
+        (64, 32, 64, 1, 30, [(8, 0, "walk_hot_dot_kernel<1, false>"), (64, 0, "walk_hot_dot_kernel<1, false>"),
+                             (100, 0, "walk_hot_dot_kernel<2, false>"), (200, 0, "walk_hot_dot_big_kernel<false>"),
                              (700, "bitmap", "walk_bitmap_big_kernel<1, 8,")]),
+        (64, 32, 64, 1, 60, [(64, 0, "walk_hot_dot_kernel<1, true>"), (100, 0, "walk_hot_dot_kernel<2, true>"),
+                             (300, 0, "walk_hot_dot_big_kernel<true>")]),
+        (64, 32, 64, 1, 90, [(64, 0, "walk_reg_kernel<1, 8,"), (200, 0, "walk_reg_big_kernel<1, 8,")]),  # > 64 slots: generic
         (128, 64, 128, 0, 30, [(64, 0, "walk_reg_kernel<0, 16,"), (200, 0, "walk_reg_big_kernel<0, 16,"),
                                (1000, 0, "walk_reg_big_kernel<0, 16,"), (600, "bitmap", "walk_bitmap_big_kernel<0, 16,")]),
         (96, 48, 64, 0, 30, [(200, 0, "walk_reg_big_kernel<0, 12,")]),

@@ -139,7 +139,9 @@ def test_hot_kernel_register_budgets(tmp_path):
     # (substring of the mangled name, VGPR ceiling): waves per SIMD = floor(512 / ceil8(vgprs))
     budgets = [("15walk_hot_kernelE", 72), ("16walk_hot2_kernelE", 72), ("19walk_hot_big_kernelE", 84),
                # the instances for adjacency rows of 33 .. 64 slots (second expansion pass)
-               ("16walk_hotw_kernelE", 72), ("17walk_hotw2_kernelE", 72), ("20walk_hotw_big_kernelE", 88)]
+               ("16walk_hotw_kernelE", 72), ("17walk_hotw2_kernelE", 72), ("20walk_hotw_big_kernelE", 88),
+               # the negative-dot metric on the same shapes (6 wavefronts per SIMD: 80 registers)
+               ("19walk_hot_dot_kernelI", 80), ("23walk_hot_dot_big_kernelI", 88)]
     for sub, cap in budgets:
         hits = {k: v for k, v in meta.items() if sub in k}
         assert hits, sub
