@@ -1,10 +1,10 @@
 // api.cpp -- host side of libgbnns_hip.so: the C ABI declared in include/gbnns.h.
 //
-// Owns device memory (index data in HBM, a growable per-index workspace), converts the reference's
+// Owns device memory (index data in HBM, growable per-index workspaces: "lanes"), converts the reference's
 // host-side data structures to the device layouts, and sequences the kernels of one batch call on
-// one HIP stream:
-//     [MLP layer x3 + normalise] -> walk (LDS kernel) -> walk (general kernel, hand-over list)
-//     -> re-rank
+// one HIP stream -- the caller's, or with GBNNS_FLAG_DEFER_JOIN a lane's own, several batches in flight:
+//     [MLP layer x3 + normalise] -> walk (first pass, fused re-rank) [-> retry pass] -> walk (general kernel,
+//     hand-over list) [-> re-rank]
 // There is no CPU fallback anywhere in this file: if HIP is unusable every entry point fails.
 
 #include "../../include/gbnns.h"
@@ -90,12 +90,12 @@ struct ProfCall {
 
 constexpr int kMaxLanes = 4;
 
-// One workspace of per-batch buffers + control words.  A handle has several so that the sub-batches of one call can be
-// in flight side by side on internal streams (the tail of one sub-batch's walk -- a 10 k batch is < 2 "rounds" of
+// One workspace of per-batch buffers + control words.  A handle has several so that consecutive batches can be
+// in flight side by side on internal streams (the tail of one batch's walk -- a 10 k batch is < 2 "rounds" of
 // resident wavefronts -- then runs beside the projection and the first round of the next one).
 struct Lane {
-    hipStream_t stream = nullptr;      // internal stream (created on first split call)
-    hipEvent_t done_ev = nullptr;      // recorded after the lane's last sub-batch of a call
+    hipStream_t stream = nullptr;      // internal stream (created on the lane's first deferred call)
+    hipEvent_t done_ev = nullptr;      // recorded after the lane's batch of a deferred call
     DevBuf q_in, q_low, h1, h2, cand, cand_dist, cnt, hops, dc, edges, out, entries, ovf_list, ovf2_list, ctrl;
     DevBuf g_bitmap, g_keys, fp_bitmap;
     // visited-set sizing feedback: stats of an earlier call arrive asynchronously in pinned memory
@@ -132,7 +132,7 @@ struct gbnns_index {
     bool has_net = false;
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     uint32_t ws1 = 0, ws2 = 0, ws3 = 0;
-    // workspaces: lane 0 serves serialised calls on the caller's stream; sub-batches of a split call run on
+    // workspaces: lane 0 serves plain calls on the caller's stream; the batches of deferred calls rotate over
     // lanes 0 .. n_lanes-1, each on its own internal stream (see gbnns_search_ex)
     Lane lanes[kMaxLanes];
     hipEvent_t fork_ev = nullptr;      // caller's stream -> lanes
@@ -146,7 +146,6 @@ struct gbnns_index {
     std::map<int, uint32_t> maxdc_for_ef;  // largest dist_calc seen per (ef, mode, aux, wide): the raw figure behind cap_for_ef
     std::map<int, int> calm_streak;   // per (ef, mode): consecutive observed batches without hand-over / resize
     uint32_t stats_tick = 0;
-    // a split call whose join (caller's stream waits for the lanes) has been deferred to the next call / gbnns_index_join
     std::deque<std::pair<int, hipStream_t>> joins;  // (lane, caller's stream) of the deferred calls not yet joined, oldest first
     int next_lane = 0;
     // stream of the last call that left work in flight (the workspace and the control words are ordered by
@@ -243,7 +242,7 @@ constexpr size_t kMaxLds = 160 * 1024;
 int flush_join(gbnns_index* ix);
 
 int enter_stream(gbnns_index* ix, hipStream_t s) {
-    int rc = flush_join(ix);  // a split call's deferred join: its stream first waits for its lanes
+    int rc = flush_join(ix);  // deferred calls not yet joined: their streams first wait for their lanes
     if (rc) return rc;
     if (ix->in_flight && ix->last_stream != s) {
         hipError_t e = hipSuccess;
@@ -772,7 +771,7 @@ int gbnns_rerank(gbnns_index* ix, const float* queries, uint64_t n_q, const uint
 
 namespace {
 
-// Makes lane i usable for split calls: its internal stream, its "done" event and its zeroed control words.
+// Makes lane i usable for deferred calls: its internal stream, its "done" event and its zeroed control words.
 int ensure_lane(gbnns_index* ix, int i) {
     Lane& L = ix->lanes[i];
     if (!L.stream) HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
