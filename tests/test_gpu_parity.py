@@ -1237,3 +1237,20 @@ def test_deferred_join_edge_cases(g, orc):
         ix.close()
         torch.cuda.synchronize()
         del outs
+
+
+def test_serving_loop_cpp(tmp_path):
+    """tests/cpp/serving_loop.cpp: the batches-in-flight contract of the C ABI from the host language itself -- three
+    sets of device buffers rotating through gbnns_search_ex(GBNNS_FLAG_DEFER_JOIN, depth 3) on one HIP stream, batch i-2
+    consumed on that stream right after call i without any host synchronisation, every batch equal to the plain call's."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "gbnns_dim_red_amd", "lib")
+    exe = str(tmp_path / "serving_loop")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "serving_loop.cpp"),
+                           "-L" + libdir, "-lgbnns_hip", "-Wl,-rpath," + libdir])
+    for args in (("20000", "64", "32", "64", "3000", "10", "32"), ("5000", "40", "32", "64", "700", "2", "100")):
+        p = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "mismatches 0" in p.stdout
