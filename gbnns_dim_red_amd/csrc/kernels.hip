@@ -377,7 +377,11 @@ __device__ __forceinline__ float dpp_from_odd(float x) {  // even lane <- its od
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xF5, 0xf, 0xf, false));
 }
 
-template <int METRIC, typename IdAt>
+// DEEP > 8 (L2 only): that many 16-byte loads in flight per lane before the first one is consumed.  A lone wavefront
+// streams its candidates' rows at (bytes in flight) / latency: 200 rows of 960 floats (GIST, ef = 200) take it 0.095 ms
+// with 8 loads in flight and 0.070 ms with 24 (rocprofv3, one-query launches).  The generic wide-row walk kernels and
+// the stand-alone kernel have the registers for 24 (same operations, same order).
+template <int METRIC, int DEEP = 8, typename IdAt>
 __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi, int cnt, float* qf, int lane, IdAt id_at) {
     const uint32_t half = (uint32_t)lane & 1u, slot = (uint32_t)lane >> 1;
     const float4* qs = reinterpret_cast<const float4*>(qf);
@@ -422,6 +426,24 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
         }
         float u0, u1, u2, u3, v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
         uint32_t k = 0;
+        if constexpr (DEEP > 8) {
+            for (; k + DEEP <= pairs; k += DEEP) {
+                float4 rv[DEEP];
+#pragma unroll
+                for (int j = 0; j < DEEP; ++j) rv[j] = row[2 * (k + j)];
+#pragma unroll
+                for (int j = 0; j < DEEP; ++j) {
+                    const float4 qv = qh[2 * (k + j)];
+                    float e;
+                    e = rv[j].x - qv.x; const float p0 = e * e;
+                    e = rv[j].y - qv.y; const float p1 = e * e;
+                    e = rv[j].z - qv.z; const float p2 = e * e;
+                    e = rv[j].w - qv.w; const float p3 = e * e;
+                    u0 = dpp_swap_pair(v0) + p0; u1 = dpp_swap_pair(v1) + p1; u2 = dpp_swap_pair(v2) + p2; u3 = dpp_swap_pair(v3) + p3;
+                    v0 = dpp_swap_pair(u0) + p0; v1 = dpp_swap_pair(u1) + p1; v2 = dpp_swap_pair(u2) + p2; v3 = dpp_swap_pair(u3) + p3;
+                }
+            }
+        }
         for (; k + 8 <= pairs; k += 8) {  // eight 16-B loads in flight per lane
             float4 rv[8];
 #pragma unroll
@@ -486,7 +508,7 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
 // list rank kept-1-r) instead of leaving them to a second kernel -- the re-rank's memory-bound work then
 // runs beside other wavefronts' walks and fills the slots the last "round" of a batch leaves idle.  The
 // walk's LDS is dead by now and stages the original-space query.
-template <typename IdAtRank>
+template <int DEEP = 8, typename IdAtRank>
 __device__ __forceinline__ void fused_rerank(const WalkParams& p, uint32_t qi, int kept, unsigned char* smem, int lane,
                                              IdAtRank id_at_rank) {
     RerankSrc a{p.rr_q, p.rr_qstride, p.rr_db, p.rr_dstride, p.rr_dim, p.rr_n};
@@ -495,7 +517,7 @@ __device__ __forceinline__ void fused_rerank(const WalkParams& p, uint32_t qi, i
     if (p.rr_metric == 1)
         win = rerank_pairs_core<1>(a, qi, kept, reinterpret_cast<float*>(smem), lane, [&](int r) { return id_at_rank(kept - 1 - r); });
     else
-        win = rerank_pairs_core<0>(a, qi, kept, reinterpret_cast<float*>(smem), lane, [&](int r) { return id_at_rank(kept - 1 - r); });
+        win = rerank_pairs_core<0, DEEP>(a, qi, kept, reinterpret_cast<float*>(smem), lane, [&](int r) { return id_at_rank(kept - 1 - r); });
     const uint32_t ans = id_at_rank(win >= 0 ? kept - 1 - win : 0);
     if (lane == 0) p.rr_out[qi] = win >= 0 ? ans : kInvalidId;
 }
@@ -1876,6 +1898,7 @@ struct BigList {
     // End of a walk: one sorted list (flush), the outputs in POP order (rank i goes to position kept - 1 - i), and --
     // when the walk kernels re-rank -- getRealNearest on this query with the original-space query staged in
     // `rr_scratch` (LDS that the walk no longer needs; the base list must stay readable).
+    template <int DEEP = 8>
     __device__ __forceinline__ void finish(const WalkParams& p, uint32_t qi, int hops, int dist_calc, int edges,
                                            unsigned char* rr_scratch, int lane) {
         flush(lane);
@@ -1897,7 +1920,7 @@ struct BigList {
         }
         if (p.rr_db) {
             const uint64_t* b = base;
-            fused_rerank(p, qi, kept, rr_scratch, lane, [&](int rank) { return key_id(b[rank]); });
+            fused_rerank<DEEP>(p, qi, kept, rr_scratch, lane, [&](int rank) { return key_id(b[rank]); });
         }
     }
 
@@ -2513,7 +2536,8 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
         }
         return;
     }
-    B.finish(p, qi, hops, dist_calc, edges, after_q, lane);
+    // (wide walked rows = the wide original rows of GIST: the re-rank keeps 24 loads in flight per lane, rerank_pairs_core)
+    B.template finish<(STEPS >= 12 ? 24 : 8)>(p, qi, hops, dist_calc, edges, after_q, lane);
 }
 
 template <int METRIC, int STEPS, bool OFF32, bool RETRY, bool AUX = false, bool ONE_PASS = false>
@@ -3547,7 +3571,9 @@ __global__ __launch_bounds__(64) void rerank_pair_kernel(RerankParams p) {
     const int cnt = p.count[qi];
     const uint32_t* cand = p.cand + (size_t)qi * p.cand_stride;
     RerankSrc a{p.q, p.qstride, p.db, p.dstride, p.dim, p.n};
-    const int win = rerank_pairs_core<METRIC>(a, qi, cnt, reinterpret_cast<float*>(smem), lane, [&](int r) { return cand[r]; });
+    const int win = (METRIC == 0 && p.dim >= 384u)
+                        ? rerank_pairs_core<METRIC, 24>(a, qi, cnt, reinterpret_cast<float*>(smem), lane, [&](int r) { return cand[r]; })
+                        : rerank_pairs_core<METRIC>(a, qi, cnt, reinterpret_cast<float*>(smem), lane, [&](int r) { return cand[r]; });
     if (lane == 0) p.out[qi] = (win >= 0) ? cand[win] : kInvalidId;
 }
 
