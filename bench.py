@@ -351,6 +351,17 @@ def main():
 
     ms_per_step = elapsed * 1e3 / args.steps
     qps = nq_total * args.steps / elapsed
+    # every rank's own piece of the last gathered id vectors equals what it searched itself (the buffers of the last
+    # `nbuf` steps are all still in place): a wrong join / gather order in the pipelined loop would show here
+    gather_ok = None
+    if world > 1:
+        good = True
+        for b in range(nbuf):
+            if gathered[b] is not None and "ids" in outs[b]:
+                good = good and bool((gathered[b][rank * pad: rank * pad + nq_rank] == outs[b]["ids"][:nq_rank]).all().item())
+        tg = torch.tensor([1.0 if good else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MIN)
+        gather_ok = bool(tg.item() == 1.0)
 
     # ---- the same K steps serialised (GBNNS_FLAG_SERIAL semantics: profiling implies it): one batch at a time on one
     # stream, kernels back to back, with the library's hipEvent pairs around every stage on the launch stream.  This is
@@ -414,6 +425,7 @@ def main():
             "recipe": ds.recipe,
         },
         "ranks_seen": dist.get_world_size() if world > 1 else 1,
+        "gather_self_check": gather_ok,
         "roofline": rl["roofline"],
         "kernels_ms": rl["kernels_ms"],
         "batches_rotated": nb,

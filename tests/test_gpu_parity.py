@@ -481,7 +481,7 @@ def test_bench_two_ranks_rehearsal():
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         assert len(lines) == 1, p.stdout[-2000:]
         r = json.loads(lines[0])
-        assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["steps"] == 3
+        assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["steps"] == 3 and r["gather_self_check"] is True
         assert r["value"] > 0 and r["roofline"]["frac"] > 0
         assert r["scaling"] == ("strong" if extra else "weak")
 
