@@ -74,6 +74,7 @@ struct WalkParams {
     uint32_t aux_stride;
     uint32_t hops_bound;
     int32_t llf;
+    const uint32_t* order;   // optional [nq]: work item b of a first pass runs query order[b] (a permutation: locality order of a deep batch)
     int32_t force_wide;      // diagnostic: treat the index as a large one (64-bit offsets, 4-byte visited-set slots)
     unsigned long long* stamps;  // diagnostic builds only (GBNNS_STAMPS): [32] segment cycle sums / histograms
     int32_t stamps_on;           // 1 in diagnostic builds: use the instrumented generic kernel
@@ -182,6 +183,10 @@ struct GdParams {
     uint32_t* deg;           // [n]
 };
 hipError_t launch_gd_prune(const GdParams& p, int metric, hipStream_t s);
+
+// Locality order of a batch (counting sort on the sign bits of the first 12 walked-space coordinates):
+// hist [4096] u32 scratch, order [nq] u32 out.
+hipError_t launch_query_order(const float* q, uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t* hist, uint32_t* order, hipStream_t s);
 
 // helpers
 hipError_t launch_fill_u32(uint32_t* p, uint32_t v, size_t count, hipStream_t s);

@@ -29,6 +29,14 @@ namespace {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+// Query that work item `b` of a first pass runs: b itself, or -- deep batches (WalkParams::order) -- the b-th query in
+// locality order, so that the wavefronts resident together walk neighbouring regions of the graph and find each
+// other's rows in the L2 / Infinity Cache.  Queries are independent: the order changes nothing but the time.
+template <typename P>
+__device__ __forceinline__ uint32_t walk_query_of(const P& p, uint32_t b) {
+    return p.order ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p.order[b]) : b;
+}
+
 // One wavefront per workgroup: the barrier degenerates to a wave-local fence that orders LDS /
 // global traffic between lanes of the wave.
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
@@ -912,7 +920,7 @@ __global__ __launch_bounds__(64) void walk_fast_kernel(WalkParams p) {
     if constexpr (RETRY) {
         retry_loop(p, [&](uint32_t qi) { walk_fast_one<METRIC, STEPS, PACKED>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
     } else {
-        walk_fast_one<METRIC, STEPS, PACKED>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
+        walk_fast_one<METRIC, STEPS, PACKED>(p, walk_query_of(p, blockIdx.x), smem, p.ovf_count, p.ovf_list);
     }
 }
 
@@ -927,7 +935,7 @@ __global__ __launch_bounds__(64) void walk_bitmap_kernel(WalkParams p) {
         if (lane_id() == 0) w = atomicAdd(p.fp_cursor, 1u);
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
         if (w >= p.nq) break;
-        walk_fast_one<METRIC, STEPS, false, true>(p, w, smem, p.ovf_count, p.ovf_list, bitmap);
+        walk_fast_one<METRIC, STEPS, false, true>(p, walk_query_of(p, w), smem, p.ovf_count, p.ovf_list, bitmap);
         wave_sync();
     }
 }
@@ -2546,7 +2554,7 @@ __global__ __launch_bounds__(64) void walk_reg_big_kernel(WalkParams p) {
     if constexpr (RETRY) {
         retry_loop(p, [&](uint32_t qi) { walk_reg_big_one<METRIC, STEPS, OFF32, AUX>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
     } else {
-        walk_reg_big_one<METRIC, STEPS, OFF32, AUX, false, ONE_PASS>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
+        walk_reg_big_one<METRIC, STEPS, OFF32, AUX, false, ONE_PASS>(p, walk_query_of(p, blockIdx.x), smem, p.ovf_count, p.ovf_list);
     }
 }
 
@@ -3284,46 +3292,46 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
 
 __global__ __launch_bounds__(64) void walk_hot2_kernel(WalkParams p) {  // 64 < ef <= 128: two list registers per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    walk_hot_one<2>(p, blockIdx.x, smem);
+    walk_hot_one<2>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
 __global__ __launch_bounds__(64) void walk_hot_big_kernel(WalkParams p) {  // 128 < ef <= 1024
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    walk_hot_big(p, blockIdx.x, smem);
+    walk_hot_big(p, walk_query_of(p, blockIdx.x), smem);
 }
 
 __global__ __launch_bounds__(64) void walk_hot_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    walk_hot_one<1>(p, blockIdx.x, smem);
+    walk_hot_one<1>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
 // the same three for adjacency rows of 33 .. 64 slots (two expansion passes per hop)
 __global__ __launch_bounds__(64) void walk_hotw_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    walk_hot_one<1, true>(p, blockIdx.x, smem);
+    walk_hot_one<1, true>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
 __global__ __launch_bounds__(64) void walk_hotw2_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    walk_hot_one<2, true>(p, blockIdx.x, smem);
+    walk_hot_one<2, true>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
 __global__ __launch_bounds__(64) void walk_hotw_big_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    walk_hot_big<true>(p, blockIdx.x, smem);
+    walk_hot_big<true>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
 // ... and the negative-dot metric (Angular::Dist) on the same shapes (round 3): R = 1 / 2 list registers, or the two-list form
 template <int R, bool WIDE>
 __global__ __launch_bounds__(64) void walk_hot_dot_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    walk_hot_one<R, WIDE, 1>(p, blockIdx.x, smem);
+    walk_hot_one<R, WIDE, 1>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
 template <bool WIDE>
 __global__ __launch_bounds__(64) void walk_hot_dot_big_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    walk_hot_big<WIDE, 1>(p, blockIdx.x, smem);
+    walk_hot_big<WIDE, 1>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
 template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R, bool ONE_CHUNK = false, bool AUX = false>
@@ -3332,7 +3340,7 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
     if constexpr (RETRY) {
         retry_loop(p, [&](uint32_t qi) { walk_reg_one<METRIC, STEPS, OFF32, R, false, AUX>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
     } else {
-        walk_reg_one<METRIC, STEPS, OFF32, R, ONE_CHUNK, AUX>(p, blockIdx.x, smem, p.ovf_count, p.ovf_list);
+        walk_reg_one<METRIC, STEPS, OFF32, R, ONE_CHUNK, AUX>(p, walk_query_of(p, blockIdx.x), smem, p.ovf_count, p.ovf_list);
     }
 }
 
@@ -3346,7 +3354,7 @@ __global__ __launch_bounds__(64) void walk_bitmap_reg_kernel(WalkParams p) {
         if (lane_id() == 0) w = atomicAdd(p.fp_cursor, 1u);
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
         if (w >= p.nq) break;
-        walk_reg_one<METRIC, 8, true, R, false, false, true>(p, w, smem, p.ovf_count, p.ovf_list, bitmap);
+        walk_reg_one<METRIC, 8, true, R, false, false, true>(p, walk_query_of(p, w), smem, p.ovf_count, p.ovf_list, bitmap);
         wave_sync();
     }
 }
@@ -3360,7 +3368,7 @@ __global__ __launch_bounds__(64) void walk_bitmap_big_kernel(WalkParams p) {
         if (lane_id() == 0) w = atomicAdd(p.fp_cursor, 1u);
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
         if (w >= p.nq) break;
-        walk_reg_big_one<METRIC, STEPS, true, false, true, ONE_PASS>(p, w, smem, p.ovf_count, p.ovf_list, bitmap);
+        walk_reg_big_one<METRIC, STEPS, true, false, true, ONE_PASS>(p, walk_query_of(p, w), smem, p.ovf_count, p.ovf_list, bitmap);
         wave_sync();
     }
 }
@@ -4131,6 +4139,55 @@ __global__ __launch_bounds__(64) void gd_prune_kernel(GdParams p) {
     if (lane == 0) p.deg[i] = deg;
 }
 
+#if GBNNS_TU == 0
+// ------------------------------------------------------------------------------------------
+// locality order of a deep batch (WalkParams::order)
+// ------------------------------------------------------------------------------------------
+// key = the sign bits of the first 12 coordinates of the query in the walked space (4 096 buckets: queries of one
+// bucket lie in one orthant, their walks end in the same region); counting sort in three small launches -- histogram,
+// scan of the 4 096 counters by one workgroup, scatter (the order inside a bucket is whatever the atomics give: it
+// does not matter).  Only the ORDER of the work changes; answers go to the queries' own output slots.
+constexpr int kOrderBits = 12, kOrderBuckets = 1 << kOrderBits;
+
+__device__ __forceinline__ uint32_t order_key(const float* q, uint32_t dim) {
+    uint32_t k = 0;
+    const uint32_t m = dim < (uint32_t)kOrderBits ? dim : (uint32_t)kOrderBits;
+    for (uint32_t j = 0; j < m; ++j) k |= (q[j] > 0.f ? 1u : 0u) << j;
+    return k;
+}
+
+__global__ __launch_bounds__(256) void order_hist_kernel(const float* q, uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t* hist) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < nq) atomicAdd(&hist[order_key(q + (size_t)i * qstride, dim)], 1u);
+}
+
+// exclusive scan of the 4 096 counters in place (they become the buckets' cursors)
+__global__ __launch_bounds__(1024) void order_scan_kernel(uint32_t* hist) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = hist[4 * t + j]; sum += v[j]; }
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    uint32_t base = part[t] - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hist[4 * t + j] = base; base += v[j]; }
+}
+
+__global__ __launch_bounds__(256) void order_scatter_kernel(const float* q, uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t* cursor,
+                                                            uint32_t* order) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < nq) order[atomicAdd(&cursor[order_key(q + (size_t)i * qstride, dim)], 1u)] = i;
+}
+#endif  // GBNNS_TU == 0
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -4482,6 +4539,17 @@ hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
         return launch_normalize(p.out, p.ostride, p.dout, p.nq, s);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_query_order(const float* q, uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t* hist, uint32_t* order, hipStream_t s) {
+    if (nq == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)kOrderBuckets * 4, s);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (nq + 255u) / 256u;
+    hipLaunchKernelGGL(order_hist_kernel, dim3(grid), dim3(256), 0, s, q, qstride, dim, nq, hist);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, s, hist);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(grid), dim3(256), 0, s, q, qstride, dim, nq, hist, order);
     return hipGetLastError();
 }
 

@@ -1254,3 +1254,29 @@ def test_serving_loop_cpp(tmp_path):
         p = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stdout + p.stderr
         assert "mismatches 0" in p.stdout
+
+
+def test_deep_batch_locality_order(g, orc):
+    """Batches of >= 32 768 queries are walked in locality order (counting sort on sign bits of the walked-space query:
+    WalkParams::order) -- work item b runs query order[b], answers go to the queries' own slots.  A 40 000-query batch
+    (two-stage, precomputed low-dim queries, the HBM-bitmap first pass, random entry points) against the oracle, and
+    against the same queries searched in small batches (no ordering there)."""
+    c = datagen.Case("ord", 7100, 20000, 40000, 32, 32, 64)
+    rng = np.random.Generator(np.random.PCG64(7101))
+    off, nbr = datagen.random_graph(rng, c.n, 4, 28)
+    db_low = orc.project(c.net, c.base, threads=8)
+    ent = rng.integers(0, c.n, size=c.nq).astype(np.uint32)
+    ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+    for ef, flags in ((8, 0), (64, 0), (40, g.FLAG_BITMAP_PASS)):
+        s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net, entries=ent, threads=8)
+        r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc"), flags=flags)
+        assert np.array_equal(r["ids"], s["ids"]), ef
+        assert np.array_equal(r["hops"], s["hops"]), ef
+        assert np.array_equal(r["dist_calc"] + ef, s["dist_calc"]), ef
+        small = np.concatenate([ix.search(c.queries[i:i + 8000], ef, entry_ids=ent[i:i + 8000], want=())["ids"] for i in range(0, c.nq, 8000)])
+        assert np.array_equal(small, r["ids"]), ef
+    q_low = orc.project(c.net, c.queries, threads=8)
+    r1 = ix.search(c.queries, 16, mode=g.MODE_LOWQ, queries_low=q_low, entry_ids=ent)
+    s1 = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, 16, db_low=db_low, net=c.net, entries=ent, threads=8)
+    assert np.array_equal(r1["ids"], s1["ids"])
+    ix.close()
