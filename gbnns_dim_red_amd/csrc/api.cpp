@@ -911,10 +911,11 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     // regions and find each other's rows in the caches: -8 % kernel time on a 4 M-node index, -3 % on 1 M -- which the
     // sort's launches would eat on a 10 000-query batch, so only from GBNNS_ORDER_MIN queries on (default 32 768).
     static const uint32_t order_min = getenv("GBNNS_ORDER_MIN") ? (uint32_t)strtoul(getenv("GBNNS_ORDER_MIN"), nullptr, 10) : 32768u;
-    if (!plain && nq >= order_min && order_min > 0) {
+    static const uint32_t order_bits = getenv("GBNNS_ORDER_BITS") ? (uint32_t)atoi(getenv("GBNNS_ORDER_BITS")) : 12u;  // tuning: 10 .. 16
+    if (!plain && nq >= order_min && order_min > 0 && w.dim >= 16u) {
         if ((rc = L.order.ensure((size_t)nq * 4))) return rc;
-        if ((rc = L.order_hist.ensure(4096 * 4))) return rc;
-        HIP_TRY(launch_query_order(w.q, w.qstride, w.dim, nq, L.order_hist.as<uint32_t>(), L.order.as<uint32_t>(), s));
+        if ((rc = L.order_hist.ensure((size_t)4 << 16))) return rc;
+        HIP_TRY(launch_query_order(w.q, w.qstride, w.dim, nq, order_bits, L.order_hist.as<uint32_t>(), L.order.as<uint32_t>(), s));
         w.order = L.order.as<uint32_t>();
     }
     if (prof) HIP_TRY(hipEventRecord(pc.ev[1], s));

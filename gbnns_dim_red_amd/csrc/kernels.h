@@ -184,9 +184,10 @@ struct GdParams {
 };
 hipError_t launch_gd_prune(const GdParams& p, int metric, hipStream_t s);
 
-// Locality order of a batch (counting sort on the sign bits of the first 12 walked-space coordinates):
-// hist [4096] u32 scratch, order [nq] u32 out.
-hipError_t launch_query_order(const float* q, uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t* hist, uint32_t* order, hipStream_t s);
+// Locality order of a batch (counting sort on the sign bits of the first `bits` = 10 .. 16 walked-space coordinates;
+// dim >= bits): hist [2^bits] u32 scratch, order [nq] u32 out.
+hipError_t launch_query_order(const float* q, uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t bits, uint32_t* hist, uint32_t* order,
+                              hipStream_t s);
 
 // helpers
 hipError_t launch_fill_u32(uint32_t* p, uint32_t v, size_t count, hipStream_t s);

@@ -4143,31 +4143,27 @@ __global__ __launch_bounds__(64) void gd_prune_kernel(GdParams p) {
 // ------------------------------------------------------------------------------------------
 // locality order of a deep batch (WalkParams::order)
 // ------------------------------------------------------------------------------------------
-// key = the sign bits of the first 12 coordinates of the query in the walked space (4 096 buckets: queries of one
-// bucket lie in one orthant, their walks end in the same region); counting sort in three small launches -- histogram,
-// scan of the 4 096 counters by one workgroup, scatter (the order inside a bucket is whatever the atomics give: it
+// key = the sign bits of the first `bits` (10 .. 16, default 12) coordinates of the query in the walked space (queries of
+// one bucket lie in one orthant, their walks end in the same region); counting sort in three small launches -- histogram,
+// scan of the counters by one workgroup, scatter (the order inside a bucket is whatever the atomics give: it
 // does not matter).  Only the ORDER of the work changes; answers go to the queries' own output slots.
-constexpr int kOrderBits = 12, kOrderBuckets = 1 << kOrderBits;
-
-__device__ __forceinline__ uint32_t order_key(const float* q, uint32_t dim) {
+__device__ __forceinline__ uint32_t order_key(const float* q, uint32_t bits) {  // bits <= dim
     uint32_t k = 0;
-    const uint32_t m = dim < (uint32_t)kOrderBits ? dim : (uint32_t)kOrderBits;
-    for (uint32_t j = 0; j < m; ++j) k |= (q[j] > 0.f ? 1u : 0u) << j;
+    for (uint32_t j = 0; j < bits; ++j) k |= (q[j] > 0.f ? 1u : 0u) << (bits - 1u - j);  // coordinate 0 = most significant
     return k;
 }
 
-__global__ __launch_bounds__(256) void order_hist_kernel(const float* q, uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t* hist) {
+__global__ __launch_bounds__(256) void order_hist_kernel(const float* q, uint32_t qstride, uint32_t bits, uint32_t nq, uint32_t* hist) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < nq) atomicAdd(&hist[order_key(q + (size_t)i * qstride, dim)], 1u);
+    if (i < nq) atomicAdd(&hist[order_key(q + (size_t)i * qstride, bits)], 1u);
 }
 
-// exclusive scan of the 4 096 counters in place (they become the buckets' cursors)
-__global__ __launch_bounds__(1024) void order_scan_kernel(uint32_t* hist) {
+// exclusive scan of the 2^bits counters (a multiple of 1 024) in place: they become the buckets' cursors
+__global__ __launch_bounds__(1024) void order_scan_kernel(uint32_t* hist, uint32_t per) {
     __shared__ uint32_t part[1024];
     const uint32_t t = threadIdx.x;
-    uint32_t v[4], sum = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[j] = hist[4 * t + j]; sum += v[j]; }
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; ++j) sum += hist[per * t + j];
     part[t] = sum;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
@@ -4177,14 +4173,17 @@ __global__ __launch_bounds__(1024) void order_scan_kernel(uint32_t* hist) {
         __syncthreads();
     }
     uint32_t base = part[t] - sum;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { hist[4 * t + j] = base; base += v[j]; }
+    for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t v = hist[per * t + j];
+        hist[per * t + j] = base;
+        base += v;
+    }
 }
 
-__global__ __launch_bounds__(256) void order_scatter_kernel(const float* q, uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t* cursor,
+__global__ __launch_bounds__(256) void order_scatter_kernel(const float* q, uint32_t qstride, uint32_t bits, uint32_t nq, uint32_t* cursor,
                                                             uint32_t* order) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < nq) order[atomicAdd(&cursor[order_key(q + (size_t)i * qstride, dim)], 1u)] = i;
+    if (i < nq) order[atomicAdd(&cursor[order_key(q + (size_t)i * qstride, bits)], 1u)] = i;
 }
 #endif  // GBNNS_TU == 0
 
@@ -4542,14 +4541,17 @@ hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_query_order(const float* q, uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t* hist, uint32_t* order, hipStream_t s) {
+hipError_t launch_query_order(const float* q, uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t bits, uint32_t* hist, uint32_t* order,
+                              hipStream_t s) {
     if (nq == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(hist, 0, (size_t)kOrderBuckets * 4, s);
+    bits = bits < 10u ? 10u : (bits > 16u ? 16u : bits);
+    if (dim < bits) return hipErrorInvalidValue;  // (the caller orders only when the walked space has that many coordinates)
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)4 << bits, s);
     if (e != hipSuccess) return e;
     const unsigned grid = (nq + 255u) / 256u;
-    hipLaunchKernelGGL(order_hist_kernel, dim3(grid), dim3(256), 0, s, q, qstride, dim, nq, hist);
-    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, s, hist);
-    hipLaunchKernelGGL(order_scatter_kernel, dim3(grid), dim3(256), 0, s, q, qstride, dim, nq, hist, order);
+    hipLaunchKernelGGL(order_hist_kernel, dim3(grid), dim3(256), 0, s, q, qstride, bits, nq, hist);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, s, hist, (1u << bits) / 1024u);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(grid), dim3(256), 0, s, q, qstride, bits, nq, hist, order);
     return hipGetLastError();
 }
 

@@ -186,7 +186,10 @@ typedef struct {
 /* Replaces the timed query loop of performNetTest (search_function.h:346-387) / performTest
  * (:151-188): one call = the whole batch.  With HOST buffers the call copies in, runs and
  * copies out synchronously (what the drop-in harness times).  With DEVICE buffers everything is
- * enqueued on args->stream and the call returns without synchronising. */
+ * enqueued on args->stream and the call returns without synchronising.
+ * Queries are independent (the reference's loop is an OpenMP parallel for over them): the order in which the device
+ * serves the queries of a batch is the library's business -- batches of >= 32 768 queries are walked in a locality
+ * order -- and every output row i always belongs to query i. */
 int gbnns_search_ex(gbnns_index* index, const gbnns_search_args* args);
 
 /* Enqueues, on the streams of the GBNNS_FLAG_DEFER_JOIN calls not yet joined, the waits for their batches (no-op when

@@ -35,7 +35,7 @@ def short(name):
     if "walk_hotN_kernel" in name:
         return "walk_hotN_kernel<" + name[name.find("<") + 1:name.find(">")] + ">"
     for key in ("walk_hot_kernel", "walk_general_kernel", "rerank_pair_kernel", "rerank_kernel", "mlp_layer_mfma_kernel", "mlp_layer_vec_kernel", "mlp_layer_kernel",
-                "normalize_kernel", "fill_u32_kernel"):
+                "normalize_kernel", "fill_u32_kernel", "order_hist_kernel", "order_scan_kernel", "order_scatter_kernel"):
         if key in name:
             return key
     return name[:60]
@@ -71,7 +71,7 @@ def main():
         stats[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print("%-28s %6s %11s %10s %10s %10s | timed launches only (last %d): %8s %8s %8s" % (
         "kernel", "calls", "total_us", "avg_us", "min_us", "max_us", last, "avg_us", "min_us", "max_us"))
-    ours = lambda k: any(x in k for x in ("walk_", "mlp_", "rerank", "normalize", "knn_scan", "gd_prune", "fill_u32", "gbnns"))
+    ours = lambda k: any(x in k for x in ("walk_", "mlp_", "rerank", "normalize", "knn_scan", "gd_prune", "fill_u32", "order_", "gbnns"))
     for k, v in sorted(stats.items(), key=lambda kv: -sum(kv[1][-last:])):
         if not ours(k):
             continue
