@@ -492,6 +492,33 @@ def main():
         result["host_buffers_qps"] = round(5 * nq_rank / (time.perf_counter() - t1), 1)
         # SURVEY 8d defines the metric's rate over one batch call INCLUDING H2D of the queries and D2H of the ids
         result["survey_8d_value"] = result["host_buffers_qps"]
+        # ... and as a stream of host batches (gbnns.h "Host batches in flight"): page-locked buffers, HOST mem_kind +
+        # GBNNS_FLAG_DEFER_JOIN, three batches in flight, six sets of result buffers and gbnns_index_wait(5) after every
+        # call (the set about to be reused is the one that call waited for: the host never blocks on a batch that is
+        # still among the three running) -- queries start in host memory, ids end there, the wire time of a batch
+        # passes under its neighbours' kernels
+        hdepth = int(os.environ.get("GBNNS_BENCH_HDEPTH", "3"))  # measured: 2 / 3 / 4 in flight -> 23.3 / 28.4 / 17.6 M queries/s
+        hsets = 2 * hdepth
+        hq = [b.cpu().pin_memory() for b in batches]
+        houts = [{} for _ in range(hsets)]
+
+        def host_stream(count):
+            for i in range(count):
+                ix.search(hq[i % len(hq)], ef, want=(), out=houts[i % hsets], flags=g.FLAG_DEFER_JOIN, defer_depth=hdepth)
+                ix.wait(hsets - 1)
+            ix.wait(0)
+
+        host_stream(24)  # (the first copy out of each page-locked buffer costs the runtime ~6 ms, once)
+        reps = 96
+        t1 = time.perf_counter()
+        host_stream(reps)
+        result["host_batches_in_flight_qps"] = round(reps * nq_rank / (time.perf_counter() - t1), 1)
+        result["survey_8d_in_flight"] = result["host_batches_in_flight_qps"]
+        ix.join()
+        torch.cuda.synchronize()
+        refs = [ix.search(b, ef, want=())["ids"].cpu() for b in batches]   # the last `hsets` batches are still in their buffers
+        result["host_batches_in_flight_ids_identical"] = all(
+            bool((houts[j % hsets]["ids"] == refs[j % len(hq)]).all().item()) for j in range(reps - hsets, reps))
 
     # ---- CPU baseline (rank 0, N = 1 only): the compiled reference if present, else the port ----
     if world == 1 and not args.no_cpu_baseline:

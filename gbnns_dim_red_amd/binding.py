@@ -24,7 +24,7 @@ FLAG_DEFER_JOIN = 128
 
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "gbnns_index_create", "gbnns_index_destroy", "gbnns_index_set_aux_graph", "gbnns_search_ex", "gbnns_search_batch", "gbnns_index_join",
+    "gbnns_index_create", "gbnns_index_destroy", "gbnns_index_set_aux_graph", "gbnns_search_ex", "gbnns_search_batch", "gbnns_index_join", "gbnns_index_wait",
     "gbnns_project", "gbnns_rerank", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd", "gbnns_build_graph_gd_device",
     "gbnns_free", "gbnns_exact_knn", "gbnns_device_count", "gbnns_version", "gbnns_last_error",
     "gbnns_index_n", "gbnns_index_d", "gbnns_index_d_low", "gbnns_index_device",
@@ -99,6 +99,7 @@ def load_library():
     lib.gbnns_index_set_aux_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gbnns_search_ex.argtypes = [C.c_void_p, C.POINTER(_SearchArgs)]
     lib.gbnns_index_join.argtypes = [C.c_void_p]
+    lib.gbnns_index_wait.argtypes = [C.c_void_p, C.c_uint32]
     lib.gbnns_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gbnns_project.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int,
@@ -176,8 +177,9 @@ def _prep(x, dtype, torch_dtype_name):
         want = getattr(torch, torch_dtype_name)
         if x.dtype != want:
             raise TypeError(f"expected torch.{torch_dtype_name}, got {x.dtype}")
-        if not x.is_cuda:
-            raise TypeError("device buffers must be CUDA/ROCm tensors")
+        if not x.is_cuda and not x.is_pinned():
+            raise TypeError("torch buffers must be CUDA/ROCm tensors (device buffers) or pinned CPU tensors "
+                            "(page-locked host buffers); pass numpy arrays for pageable host memory")
         return x.contiguous()
     return _host(x, dtype)
 
@@ -415,12 +417,15 @@ class Index:
                want=("hops", "dist_calc"), hash_capacity=0, stream=None, out=None, flags=0,
                aux=False, llf=False, hops_bound=50, defer_depth=0):
         """Runs one batch.  numpy queries -> synchronous call, numpy results.  torch CUDA queries
-        -> enqueued on `stream` (torch stream or None = current), torch results, no sync.
+        -> enqueued on `stream` (torch stream or None = current), torch results, no sync.  Pinned torch CPU queries ->
+        HOST buffers in page-locked memory, pinned torch results: synchronous, or with FLAG_DEFER_JOIN a host batch in
+        flight (copy in, kernels and ids out on a lane's stream; wait() / join() + stream.synchronize() to read them).
         `want` may also name "cand", "cand_dist", "q_low", "edges".  Returns a dict with "ids" + wanted.
         aux / llf / hops_bound: the reference's use_second_graph walk over set_aux_graph()'s graph."""
         if aux:
             flags |= FLAG_AUX_GRAPH | (FLAG_LLF if llf else 0)
-        dev = _is_dev(queries)
+        dev = _is_dev(queries) and queries.is_cuda
+        pinned = _is_dev(queries) and not queries.is_cuda
         queries = _prep(queries, np.float32, "float32")
         queries_low = _prep(queries_low, np.float32, "float32")
         nq = int(queries.shape[0])
@@ -442,6 +447,19 @@ class Index:
             if stream is None:
                 stream = torch.cuda.current_stream(tdev)
             sptr = stream.cuda_stream
+        elif pinned:
+            import torch
+            if entry_ids is not None and not (_is_dev(entry_ids) and entry_ids.dtype == torch.int32 and entry_ids.is_pinned()):
+                raise TypeError("entry_ids must be a pinned int32 tensor beside pinned queries")
+
+            def alloc(name, shape, dtype):
+                if name not in res:
+                    res[name] = torch.empty(shape, dtype=dtype, pin_memory=True)
+                return res[name]
+            i32, f32 = torch.int32, torch.float32
+            if stream is None:
+                stream = torch.cuda.current_stream()
+            sptr = stream.cuda_stream
         else:
             entry_ids = None if entry_ids is None else _host(entry_ids, np.uint32)
 
@@ -454,7 +472,7 @@ class Index:
         n_entries = 0
         if entry_ids is not None and len(entry_ids.shape) == 2:
             n_entries = int(entry_ids.shape[1])   # several entry points per query (row-major)
-        ids = alloc("ids", (nq,), i32 if dev else np.uint32)
+        ids = alloc("ids", (nq,), i32 if (dev or pinned) else np.uint32)
         a = _SearchArgs(struct_size=C.sizeof(_SearchArgs), mode=mode, ef=ef, k=kk,
                         mem_kind=MEM_DEVICE if dev else MEM_HOST, hash_capacity=hash_capacity,
                         n_q=nq, queries=_ptr(queries), queries_low=_ptr(queries_low),
@@ -465,7 +483,7 @@ class Index:
         if "dist_calc" in want:
             a.out_dist_calc = _ptr(alloc("dist_calc", (nq,), i32))
         if "cand" in want:
-            a.out_cand = _ptr(alloc("cand", (nq, kk), i32 if dev else np.uint32))
+            a.out_cand = _ptr(alloc("cand", (nq, kk), i32 if (dev or pinned) else np.uint32))
         if "cand_dist" in want:
             a.out_cand_dist = _ptr(alloc("cand_dist", (nq, kk), f32))
         if "q_low" in want:
@@ -475,6 +493,10 @@ class Index:
         _check(self._lib.gbnns_search_ex(self._h, C.byref(a)))
         self._last = (queries, queries_low, entry_ids)  # keep device inputs alive until next call
         return res
+
+    def wait(self, keep=0):
+        """gbnns_index_wait: blocks until every FLAG_DEFER_JOIN batch but the `keep` most recent has finished."""
+        _check(self._lib.gbnns_index_wait(self._h, keep))
 
     def join(self):
         """gbnns_index_join: the stream of the last FLAG_DEFER_JOIN call waits for that call's pieces."""

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -90,12 +91,37 @@ struct ProfCall {
 
 constexpr int kMaxLanes = 4;
 
+// GBNNS_SLOW_US=<microseconds>: a search call whose HOST side (enqueueing; no waiting in a deferred call) takes longer
+// is reported on stderr with the time spent before each checkpoint.  Diagnostic; off by default.
+struct SlowLog {
+    using clock = std::chrono::steady_clock;
+    long limit_us;
+    clock::time_point t0;
+    int n = 0;
+    const char* name[24];
+    long us[24];
+    SlowLog() : limit_us(getenv("GBNNS_SLOW_US") ? atol(getenv("GBNNS_SLOW_US")) : 0) {}
+    void start() { if (limit_us) { t0 = clock::now(); n = 0; } }
+    void mark(const char* what) {
+        if (limit_us && n < 24) { name[n] = what; us[n++] = (long)std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - t0).count(); }
+    }
+    void finish() {
+        if (!limit_us || n == 0 || us[n - 1] < limit_us) return;
+        std::fprintf(stderr, "gbnns slow call:");
+        for (int i = 0; i < n; ++i) std::fprintf(stderr, " %s@%ld", name[i], us[i]);
+        std::fprintf(stderr, " us\n");
+    }
+};
+thread_local SlowLog g_slow;
+
 // One workspace of per-batch buffers + control words.  A handle has several so that consecutive batches can be
 // in flight side by side on internal streams (the tail of one batch's walk -- a 10 k batch is < 2 "rounds" of
 // resident wavefronts -- then runs beside the projection and the first round of the next one).
 struct Lane {
     hipStream_t stream = nullptr;      // internal stream (created on the lane's first deferred call)
     hipEvent_t done_ev = nullptr;      // recorded after the lane's batch of a deferred call
+    hipEvent_t prev_ev = nullptr;      // ... and the one of the lane's batch before (the two alternate)
+    uint64_t ticket = 0, prev_ticket = 0;  // serial numbers of those two batches (0 = none), for gbnns_index_wait
     DevBuf q_in, q_low, h1, h2, cand, cand_dist, cnt, hops, dc, edges, out, entries, ovf_list, ovf2_list, ctrl;
     DevBuf g_bitmap, g_keys, fp_bitmap, order, order_hist;
     // visited-set sizing feedback: stats of an earlier call arrive asynchronously in pinned memory
@@ -146,8 +172,9 @@ struct gbnns_index {
     std::map<int, uint32_t> maxdc_for_ef;  // largest dist_calc seen per (ef, mode, aux, wide): the raw figure behind cap_for_ef
     std::map<int, int> calm_streak;   // per (ef, mode): consecutive observed batches without hand-over / resize
     uint32_t stats_tick = 0;
-    std::deque<std::pair<int, hipStream_t>> joins;  // (lane, caller's stream) of the deferred calls not yet joined, oldest first
+    std::deque<std::pair<hipEvent_t, hipStream_t>> joins;  // (batch's event, caller's stream) of the deferred calls not yet joined, oldest first
     int next_lane = 0;
+    uint64_t issued = 0;               // deferred calls so far
     // stream of the last call that left work in flight (the workspace and the control words are ordered by
     // stream order only: a call on another stream first waits for that work, see enter_stream)
     hipStream_t last_stream = nullptr;
@@ -543,6 +570,7 @@ int gbnns_index_destroy(gbnns_index* ix) {
     for (Lane& L : ix->lanes) {
         if (L.stats_ev) (void)hipEventDestroy(L.stats_ev);
         if (L.done_ev) (void)hipEventDestroy(L.done_ev);
+        if (L.prev_ev) (void)hipEventDestroy(L.prev_ev);
         if (L.h_stats) (void)hipHostFree(L.h_stats);
         if (L.stream) (void)hipStreamDestroy(L.stream);
         for (int i = 0; DevBuf* b = L.bufs(i); ++i) b->release();
@@ -776,6 +804,7 @@ int ensure_lane(gbnns_index* ix, int i) {
     Lane& L = ix->lanes[i];
     if (!L.stream) HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     if (!L.done_ev) HIP_TRY(hipEventCreateWithFlags(&L.done_ev, hipEventDisableTiming));
+    if (!L.prev_ev) HIP_TRY(hipEventCreateWithFlags(&L.prev_ev, hipEventDisableTiming));
     if (!L.ctrl_ready) {
         int rc = L.ctrl.ensure(512);
         if (rc) return rc;
@@ -795,6 +824,20 @@ int ensure_lane(gbnns_index* ix, int i) {
 // has workgroups to dispatch (its single wavefronts take the LDS as it frees up), so the pieces queue behind one
 // another: 0.43 ms (halves) ... 0.52 ms (quarters) against 0.40 ms undivided.  The same holds with page-locked HOST
 // buffers, where the halves' copies do overlap: 0.55 against 0.52 ms.
+// The device-visible alias of a page-locked host pointer (hipHostMalloc / hipHostRegister memory); nullptr for pageable
+// memory.  Stores through the alias are visible to the host once the storing stream's work has completed.
+template <class T>
+T* pinned_alias(const T* host_ptr) {
+    if (!host_ptr) return nullptr;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, host_ptr) != hipSuccess) {
+        (void)hipGetLastError();  // (unregistered memory is an error for some runtimes, a type for others)
+        return nullptr;
+    }
+    if (at.type != hipMemoryTypeHost) return nullptr;
+    return static_cast<T*>(at.devicePointer);
+}
+
 void plan_call(gbnns_index* ix, const gbnns_search_args* a, int& lanes, int& lane) {
     lanes = 1;
     lane = 0;
@@ -802,7 +845,7 @@ void plan_call(gbnns_index* ix, const gbnns_search_args* a, int& lanes, int& lan
     return;
 #endif
     if ((a->flags & GBNNS_FLAG_SERIAL) || ix->profiling) return;
-    if (a->mem_kind != GBNNS_MEM_DEVICE || !(a->flags & GBNNS_FLAG_DEFER_JOIN)) return;
+    if (!(a->flags & GBNNS_FLAG_DEFER_JOIN)) return;  // (HOST buffers: page-locked, checked by gbnns_search_ex)
     lanes = a->defer_depth ? (int)std::min<uint32_t>(std::max<uint32_t>(a->defer_depth, 2u), (uint32_t)kMaxLanes) : 3;  // measured best: 3
     lane = ix->next_lane % lanes;
     ix->next_lane = (lane + 1) % lanes;
@@ -811,9 +854,9 @@ void plan_call(gbnns_index* ix, const gbnns_search_args* a, int& lanes, int& lan
 // The callers' streams wait for deferred calls, oldest first, until at most `keep` of them remain unjoined.
 int flush_joins(gbnns_index* ix, size_t keep) {
     while (ix->joins.size() > keep) {
-        const std::pair<int, hipStream_t> j = ix->joins.front();
+        const std::pair<hipEvent_t, hipStream_t> j = ix->joins.front();
         ix->joins.pop_front();
-        HIP_TRY(hipStreamWaitEvent(j.second, ix->lanes[j.first].done_ev, 0));
+        HIP_TRY(hipStreamWaitEvent(j.second, j.first, 0));
     }
     return GBNNS_OK;
 }
@@ -842,7 +885,10 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         if ((rc = L.cand.ensure((size_t)nq * cstride * 4))) return rc;
     if (a->out_cand_dist && host)
         if ((rc = L.cand_dist.ensure((size_t)nq * cstride * 4))) return rc;
-    if (host)
+    // ids into HOST memory: page-locked memory takes the kernels' stores directly (40 KB of a 10 000-query batch: no
+    // copy launch behind the walk), pageable memory gets a copy out of the lane's buffer
+    uint32_t* const ids_alias = host ? pinned_alias(a->out_ids) : nullptr;
+    if (host && !ids_alias)
         if ((rc = L.out.ensure((size_t)nq * 4))) return rc;
     if (host && a->out_edges)
         if ((rc = L.edges.ensure((size_t)nq * 4))) return rc;
@@ -857,6 +903,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     }
     if ((rc = L.g_keys.ensure((size_t)kGeneralSlots * ((size_t)ef + n_ent - 1) * 8))) return rc;
 
+    g_slow.mark("workspace");
     // ---- inputs -------------------------------------------------------------------------
     const float* q_dev = a->queries;
     if (host) {
@@ -875,6 +922,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
             if (a->entry_ids[i] >= ix->n) return fail(GBNNS_ERR_INVALID, "entry id %u >= n", a->entry_ids[i]);
     }
 
+    g_slow.mark("copy_in");
     ProfCall pc{};
     const bool prof = ix->profiling;
     if (prof) {
@@ -931,7 +979,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     w.hops = (!host && a->out_hops) ? a->out_hops : L.hops.as<int32_t>();
     w.dist_calc = (!host && a->out_dist_calc) ? a->out_dist_calc : L.dc.as<int32_t>();
     w.edges = a->out_edges ? (host ? L.edges.as<int32_t>() : a->out_edges) : nullptr;
-    uint32_t* out_dev = host ? L.out.as<uint32_t>() : a->out_ids;
+    uint32_t* out_dev = host ? (ids_alias ? ids_alias : L.out.as<uint32_t>()) : a->out_ids;
     w.best = plain ? out_dev : nullptr;
     // Control words, two per-call blocks used alternately: [0] list A count, [1] general cursor,
     // [2] max dist_calc, [3] list B count, [4] retry cursor, [6] bitmap-pass cursor.  A call works on one block while its
@@ -959,6 +1007,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     // 17/15 x the largest dist_calc of earlier batches, doubled whenever a batch handed queries
     // over), find how many wavefronts per CU that allows, then give each wavefront the whole
     // 160 KB / wavefronts share (capacity need not be a power of two: slot = mulhi(hash, cap)).
+    g_slow.mark("stage1");
     if (L.stats_pending && hipEventQuery(L.stats_ev) == hipSuccess) {
         L.stats_pending = false;
         const uint32_t ovf = L.h_stats[0], maxdc = L.h_stats[2];
@@ -1118,7 +1167,9 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         }
         std::snprintf(ix->acc.walk_kernel, sizeof(ix->acc.walk_kernel), "%s", name.c_str());
     }
+    g_slow.mark("walk");
     HIP_TRY(launch_walk_general(w, ix->metric, s));
+    g_slow.mark("general");
     L.ctrl_clean[cur ^ 1] = true;  // cleared by that launch
     if (prof) HIP_TRY(hipEventRecord(pc.ev[3], s));
     // statistics of this call (hand-over counts, largest walk), read back asynchronously: every call until
@@ -1136,6 +1187,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         L.stats_cap = cap;
     }
 
+    g_slow.mark("stats");
     // ---- stage 3: re-rank in the original space ------------------------------------------
     if (!plain && !fuse) {
         RerankParams r{};
@@ -1150,7 +1202,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
 
     // ---- outputs ----------------------------------------------------------------------
     if (host) {
-        HIP_TRY(hipMemcpyAsync(a->out_ids, out_dev, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        if (!ids_alias) HIP_TRY(hipMemcpyAsync(a->out_ids, out_dev, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
         if (a->out_hops) HIP_TRY(hipMemcpyAsync(a->out_hops, w.hops, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
         if (a->out_dist_calc)
             HIP_TRY(hipMemcpyAsync(a->out_dist_calc, w.dist_calc, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
@@ -1159,6 +1211,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
             HIP_TRY(hipMemcpyAsync(a->out_cand, w.cand, (size_t)nq * cstride * 4, hipMemcpyDeviceToHost, s));
         if (a->out_cand_dist)
             HIP_TRY(hipMemcpyAsync(a->out_cand_dist, w.cand_dist, (size_t)nq * cstride * 4, hipMemcpyDeviceToHost, s));
+        g_slow.mark("copy_out");
         if (sync_host) {
             HIP_TRY(hipStreamSynchronize(s));
             ix->in_flight = false;
@@ -1200,7 +1253,17 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     hipStream_t s = static_cast<hipStream_t>(a->stream);
     int rc;
     int n_lanes = 1, lane = 0;
+    g_slow.start();
     plan_call(ix, a, n_lanes, lane);
+    if (n_lanes > 1 && a->mem_kind == GBNNS_MEM_HOST) {
+        // a deferred call returns before its copies have run: every buffer has to be page-locked (a copy from or to
+        // pageable memory is staged by the runtime, synchronously).  Pageable buffers: the flag is ignored, plain call.
+        const void* bufs[] = {a->queries, a->queries_low, a->entry_ids, a->out_ids, a->out_hops, a->out_dist_calc,
+                              a->out_edges, a->out_cand, a->out_cand_dist, a->out_q_low};
+        for (const void* b : bufs)
+            if (b && !pinned_alias(static_cast<const char*>(b))) n_lanes = 1;
+        if (n_lanes == 1) ix->next_lane = lane;  // (the rotation did not advance)
+    }
     if (n_lanes <= 1) {
         if ((rc = enter_stream(ix, s))) return rc;
         return search_core(ix, ix->lanes[0], a, s, true);
@@ -1225,13 +1288,33 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     ix->last_stream = s;
     ix->in_flight = true;
     HIP_TRY(hipStreamWaitEvent(L.stream, ix->fork_ev, 0));
+    g_slow.mark("fork");
     if ((rc = search_core(ix, L, a, L.stream, false))) {
         (void)hipDeviceSynchronize();  // leave nothing in flight behind an error
         ix->in_flight = false;
         return rc;
     }
+    // (the join of the lane's batch before last -- the previous user of prev_ev -- has been enqueued by now: at most
+    // depth - 1 joins stay owed, and that batch is at least depth calls old)
+    std::swap(L.done_ev, L.prev_ev);
+    L.prev_ticket = L.ticket;
     HIP_TRY(hipEventRecord(L.done_ev, L.stream));
-    ix->joins.emplace_back(lane, s);
+    L.ticket = ++ix->issued;
+    ix->joins.emplace_back(L.done_ev, s);
+    g_slow.mark("recorded");
+    g_slow.finish();
+    return GBNNS_OK;
+}
+
+int gbnns_index_wait(gbnns_index* ix, uint32_t keep) {
+    if (!ix) return fail(GBNNS_ERR_INVALID, "null index");
+    HIP_TRY(hipSetDevice(ix->device));
+    const uint64_t upto = ix->issued > keep ? ix->issued - keep : 0;
+    // a lane's stream runs its batches in order: its newest batch within the range covers the older ones
+    for (Lane& L : ix->lanes) {
+        if (L.ticket && L.ticket <= upto) HIP_TRY(hipEventSynchronize(L.done_ev));
+        else if (L.prev_ticket && L.prev_ticket <= upto) HIP_TRY(hipEventSynchronize(L.prev_ev));
+    }
     return GBNNS_OK;
 }
 

@@ -179,7 +179,8 @@ typedef struct {
  *                          not be reused: a serving loop rotates `defer_depth` sets of buffers.  args->stream must
  *                          stay alive until the call has been joined.
  *   GBNNS_FLAG_SERIAL      the caller's stream, kernels back to back, whatever else is asked (what per-kernel timing
- *                          needs; gbnns_profile_enable(..., 1) implies it).  HOST-buffer calls always run this way. */
+ *                          needs; gbnns_profile_enable(..., 1) implies it).  HOST-buffer calls run this way and
+ *                          synchronously unless they ask for GBNNS_FLAG_DEFER_JOIN with page-locked buffers (below). */
 #define GBNNS_FLAG_SERIAL 64u
 #define GBNNS_FLAG_DEFER_JOIN 128u
 
@@ -195,6 +196,18 @@ int gbnns_search_ex(gbnns_index* index, const gbnns_search_args* args);
 /* Enqueues, on the streams of the GBNNS_FLAG_DEFER_JOIN calls not yet joined, the waits for their batches (no-op when
  * nothing is owed).  Everything enqueued on those streams afterwards sees the calls' outputs. */
 int gbnns_index_join(gbnns_index* index);
+
+/* Host batches in flight.  GBNNS_FLAG_DEFER_JOIN also takes HOST buffers when every one of them is page-locked
+ * (hipHostMalloc / hipHostRegister; with a pageable buffer among them the flag is ignored and the call is the plain
+ * synchronous one -- a caller that follows the protocol below is correct either way): the copy of the queries to the device, the kernels and
+ * the copies out all go to the lane's stream and the call returns at once, so the wire time of batch i+1 (0.10 ms of
+ * a 0.54 ms synchronous call for 10 000 x 128 floats) passes under the kernels of batches i and i-1.  The ids are
+ * stored by the kernel straight into the page-locked out_ids (so are they in a synchronous HOST call whose out_ids
+ * happens to be page-locked).  gbnns_index_wait blocks the calling thread until every deferred batch but the `keep`
+ * most recent has finished: their host buffers then hold the results and may be refilled (keep = depth - 1 after
+ * each call keeps the pipeline full; keep = 0 drains it).  Defined in terms of the reference: each call is still one
+ * run of the timed loop of search_function.h:346-387 over its own batch. */
+int gbnns_index_wait(gbnns_index* index, uint32_t keep);
 
 /* Convenience form of the above: NET mode, host buffers, synchronous. */
 int gbnns_search_batch(gbnns_index* index, const float* queries, size_t n_q, int ef,

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -83,7 +84,49 @@ int main(int argc, char** argv) {
     size_t bad = 0;
     for (int i = 0; i < batches; ++i)
         for (uint64_t k = 0; k < nq; ++k) bad += seen[(size_t)i * nq + k] != want[i][k];
+    // ---- host batches in flight: page-locked buffers, GBNNS_MEM_HOST + GBNNS_FLAG_DEFER_JOIN, gbnns_index_wait ----------
+    // Three sets of page-locked buffers; after call i the host waits until all but the two newest batches have
+    // finished, reads batch i-2's ids (and hop counts) from host memory and refills that set with batch i+1.
+    float* q_pin[kDepth];
+    uint32_t* ids_pin[kDepth];
+    int32_t* hops_pin[kDepth];
+    for (int b = 0; b < kDepth; ++b) {
+        CK(hipHostMalloc((void**)&q_pin[b], nq * d * 4, hipHostMallocDefault));
+        CK(hipHostMalloc((void**)&ids_pin[b], nq * 4, hipHostMallocDefault));
+        CK(hipHostMalloc((void**)&hops_pin[b], nq * 4, hipHostMallocDefault));
+    }
+    std::vector<std::vector<int32_t>> want_hops(batches, std::vector<int32_t>(nq));
+    for (int i = 0; i < batches; ++i)
+        GB(gbnns_search_batch(ix, q[i].data(), nq, ef, nullptr, want[i].data(), want_hops[i].data(), nullptr, nullptr));
+    gbnns_search_args h = {};
+    h.struct_size = sizeof h; h.mode = GBNNS_MODE_NET; h.ef = ef; h.k = ef; h.mem_kind = GBNNS_MEM_HOST; h.n_q = nq;
+    h.stream = s; h.flags = GBNNS_FLAG_DEFER_JOIN; h.defer_depth = kDepth;
+    size_t bad_host = 0;
+    auto check = [&](int j) {
+        for (uint64_t k = 0; k < nq; ++k)
+            bad_host += ids_pin[j % kDepth][k] != want[j][k] || hops_pin[j % kDepth][k] != want_hops[j][k];
+    };
+    for (int i = 0; i < batches; ++i) {
+        const int b = i % kDepth;
+        std::copy(q[i].begin(), q[i].end(), q_pin[b]);  // (set b's previous batch, i-3, was waited for after call i-1)
+        for (uint64_t k = 0; k < nq; ++k) ids_pin[b][k] = 0xffffffffu;
+        h.queries = q_pin[b]; h.out_ids = ids_pin[b]; h.out_hops = hops_pin[b];
+        GB(gbnns_search_ex(ix, &h));
+        GB(gbnns_index_wait(ix, kDepth - 1));
+        if (i >= kDepth - 1) check(i - (kDepth - 1));
+    }
+    GB(gbnns_index_wait(ix, 0));
+    for (int j = batches - (kDepth - 1) < 0 ? 0 : batches - (kDepth - 1); j < batches; ++j) check(j);
+    // a pageable buffer among them: the flag is ignored, the call is the plain synchronous one
+    std::vector<uint32_t> ids_pageable(nq, 0xffffffffu);
+    h.queries = q[0].data(); h.out_ids = ids_pageable.data(); h.out_hops = nullptr;
+    GB(gbnns_search_ex(ix, &h));
+    size_t bad_pageable = 0;
+    for (uint64_t k = 0; k < nq; ++k) bad_pageable += ids_pageable[k] != want[0][k];
+    GB(gbnns_index_join(ix));
+    CK(hipStreamSynchronize(s));
     GB(gbnns_index_destroy(ix));
-    std::printf("serving_loop batches %d depth %d mismatches %zu\n", batches, kDepth, bad);
-    return bad ? 1 : 0;
+    std::printf("serving_loop batches %d depth %d mismatches %zu host_mismatches %zu pageable_mismatches %zu\n", batches, kDepth, bad, bad_host,
+                bad_pageable);
+    return (bad || bad_host || bad_pageable) ? 1 : 0;
 }

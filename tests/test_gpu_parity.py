@@ -1253,7 +1253,54 @@ def test_serving_loop_cpp(tmp_path):
     for args in (("20000", "64", "32", "64", "3000", "10", "32"), ("5000", "40", "32", "64", "700", "2", "100")):
         p = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stdout + p.stderr
-        assert "mismatches 0" in p.stdout
+        assert "mismatches 0 host_mismatches 0 pageable_mismatches 0" in p.stdout
+
+
+def test_host_batches_in_flight(g, orc):
+    """GBNNS_MEM_HOST + GBNNS_FLAG_DEFER_JOIN with page-locked buffers (pinned torch CPU tensors through the binding):
+    five distinct batches rotating over three buffer sets, gbnns_index_wait(depth - 1) after every call; ids, hops and
+    dist_calc equal to the oracle's.  A synchronous HOST call with a page-locked out_ids (the kernels store the ids
+    straight into host memory) gives the same; with pageable buffers the flag is ignored."""
+    import torch
+    c = datagen.Case("hostfl", 7300, 6000, 1500, 48, 32, 64)
+    rng = np.random.Generator(np.random.PCG64(7301))
+    off, nbr = datagen.random_graph(rng, c.n, 4, 24)
+    db_low = orc.project(c.net, c.base, threads=8)
+    ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+    batches = [np.ascontiguousarray(rng.standard_normal((c.nq, c.d)).astype(np.float32)) for _ in range(5)]
+    ef = 24
+    want = [orc.search_batch(orc_mod.MODE_NET, b, c.base, off, nbr, ef, db_low=db_low, net=c.net, threads=8) for b in batches]
+    depth = 3
+    qp = [torch.empty((c.nq, c.d), dtype=torch.float32, pin_memory=True) for _ in range(depth)]
+    outs = [dict() for _ in range(depth)]
+
+    def check(j):
+        o = outs[j % depth]
+        assert np.array_equal(o["ids"].numpy().astype(np.uint32), want[j]["ids"]), j
+        assert np.array_equal(o["hops"].numpy(), want[j]["hops"]), j
+        assert np.array_equal(o["dist_calc"].numpy() + ef, want[j]["dist_calc"]), j
+
+    for i, b in enumerate(batches):
+        k = i % depth
+        qp[k].copy_(torch.from_numpy(b))
+        if "ids" in outs[k]:
+            outs[k]["ids"].fill_(-1)
+        ix.search(qp[k], ef, out=outs[k], flags=g.FLAG_DEFER_JOIN, defer_depth=depth)
+        ix.wait(depth - 1)
+        if i >= depth - 1:
+            check(i - (depth - 1))
+    ix.wait(0)
+    for j in range(len(batches) - (depth - 1), len(batches)):
+        check(j)
+    ix.join()
+    torch.cuda.synchronize()
+    # synchronous HOST call, page-locked buffers
+    r = ix.search(qp[(len(batches) - 1) % depth], ef)
+    assert np.array_equal(r["ids"].numpy().astype(np.uint32), want[-1]["ids"])
+    # pageable buffers + the flag: ignored, plain synchronous call
+    rp = ix.search(batches[0], ef, flags=g.FLAG_DEFER_JOIN)
+    assert np.array_equal(rp["ids"], want[0]["ids"])
+    ix.close()
 
 
 def test_deep_batch_locality_order(g, orc):
