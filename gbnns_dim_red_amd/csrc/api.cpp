@@ -1040,10 +1040,40 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     const bool hot = walk_uses_hot(w, ix->metric);
     const bool packed = walk_uses_packed(w);
     const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride, hot, walk_uses_lds_list(w));
+    // The hot first pass may keep its visited set in the quotient form (kernels.hip, GBNNS_VS_ASM: seven 16-bit entries
+    // per bucket instead of five 24-bit ids): ids are told apart inside a home bucket by W - floor(log2 buckets) <= 12
+    // bits (n <= 2^W), so the table needs at least 2^(W-12) buckets.
+    uint32_t idbits = 1;
+    while (idbits < 32 && (1ull << idbits) < ix->n) ++idbits;
+    const bool quotient_on = !(getenv("GBNNS_QUOTIENT") && atoi(getenv("GBNNS_QUOTIENT")) == 0);  // tuning / A-B runs, tests
+    constexpr uint32_t kStashBuckets = 4;  // (kernels.hip: the table's last four "buckets" are the stash)
+    const uint32_t quotient_min = 7u * ((idbits > 12 ? 1u << (idbits - 12) : 1u) + kStashBuckets + 8u);  // entries (>= 8 real buckets: probe steps of up to 8)
     uint32_t cap;
+    int form = packed ? 1 : 0;
     const bool auto_cap = a->hash_capacity == 0;
+    // visited-set capacity for `need` entries in the given form, and the wavefronts per CU it leaves (0: no fit)
+    auto size_table = [&](int f, uint32_t need, size_t& slots) -> uint32_t {
+        uint32_t floor_entries = f == 2 ? quotient_min : 0u;
+        need = std::max(need, floor_entries);
+        const size_t gran = 512;  // LDS allocation granularity
+        const size_t want = (lds_fixed + walk_hash_bytes(need + 4, f) + gran - 1) / gran * gran;
+        slots = std::min<size_t>(32, kMaxLds / want);
+        if (slots == 0) return need;  // does not fit LDS at all: the general kernel takes the batch
+        // One more wavefront per CU when it costs only part of the margin: `need` keeps 1/16 of headroom over the
+        // largest walk seen; a share that still leaves 1/32 is taken (a later, longer walk is handed over once and
+        // raises the requirement for good -- it never shrinks).
+        if (slots < 32 && ix->maxdc_for_ef.count(skey)) {
+            const uint32_t m = ix->maxdc_for_ef[skey];
+            const uint32_t need_min = std::max((m + m / 32 + 64) / 15 * 16 + 16, floor_entries);
+            const size_t share1 = kMaxLds / (slots + 1) / gran * gran;
+            if (share1 > lds_fixed && walk_hash_entries(share1 - lds_fixed, f) >= need_min + 4) slots += 1;
+        }
+        const size_t share = kMaxLds / slots / gran * gran;
+        return walk_hash_entries(share - lds_fixed, f);
+    };
     if (!auto_cap) {
         cap = (uint32_t)a->hash_capacity;
+        if (hot && quotient_on && cap >= quotient_min) form = 2;  // (an explicit capacity is a number of entries, whatever the form)
     } else {
         uint32_t need;
         if (ix->cap_for_ef.count(skey)) {
@@ -1052,30 +1082,39 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
             const uint32_t target = std::max<uint32_t>(512u, 32u * (uint32_t)ef);
             need = target + target / 3 + 64;
         }
-        const size_t gran = 512;  // LDS allocation granularity
-        const size_t want = (lds_fixed + walk_hash_bytes(need + 4, packed) + gran - 1) / gran * gran;
-        size_t slots = std::min<size_t>(32, kMaxLds / want);
-        if (slots == 0) {
-            cap = need;  // does not fit LDS at all: the general kernel takes the batch
-        } else {
-            // One more wavefront per CU when it costs only part of the margin: `need` keeps 1/16 of headroom over the
-            // largest walk seen; a share that still leaves 1/32 is taken (a later, longer walk is handed over once and
-            // raises the requirement for good -- it never shrinks).
-            if (slots < 32 && ix->maxdc_for_ef.count(skey)) {
-                const uint32_t m = ix->maxdc_for_ef[skey];
-                const uint32_t need_min = (m + m / 32 + 64) / 15 * 16 + 16;
-                const size_t share1 = kMaxLds / (slots + 1) / gran * gran;
-                if (share1 > lds_fixed && walk_hash_entries(share1 - lds_fixed, packed) >= need_min + 4) slots += 1;
+        size_t slots = 0;
+        cap = size_table(form, need, slots);
+        if (hot && quotient_on) {
+            // the quotient form when it leaves at least as many wavefronts per CU (its bucket test is the shorter one)
+            size_t slots_q = 0;
+            const uint32_t cap_q = size_table(2, need, slots_q);
+            if (slots_q >= slots && slots_q > 0) {
+                form = 2;
+                cap = cap_q;
+                slots = slots_q;
             }
-            const size_t share = kMaxLds / slots / gran * gran;
-            cap = walk_hash_entries(share - lds_fixed, packed);
-            static const bool dbg = getenv("GBNNS_DEBUG_SIZING") != nullptr;  // diagnostic: the sizing decision of every call
-            if (dbg)
-                std::fprintf(stderr, "[gbnns sizing] ef %d need %u maxdc %u fixed %zu want %zu slots %zu share %zu cap %u\n", ef, need,
-                             ix->maxdc_for_ef.count(skey) ? ix->maxdc_for_ef[skey] : 0u, lds_fixed, want, slots, share, cap);
+        }
+        static const bool dbg = getenv("GBNNS_DEBUG_SIZING") != nullptr;  // diagnostic: the sizing decision of every call
+        if (dbg)
+            std::fprintf(stderr, "[gbnns sizing] ef %d need %u maxdc %u fixed %zu form %d slots %zu cap %u\n", ef, need,
+                         ix->maxdc_for_ef.count(skey) ? ix->maxdc_for_ef[skey] : 0u, lds_fixed, form, slots, cap);
+    }
+    cap = walk_hash_entries(walk_hash_bytes(cap, form), form);  // whole buckets
+    w.vs_shr = 0;
+    if (form == 2) {
+        const uint32_t buckets = cap / 7u > kStashBuckets ? cap / 7u - kStashBuckets : 0u;
+        uint32_t lg = 0;
+        while ((2u << lg) <= buckets) ++lg;  // floor(log2 buckets)
+        lg = std::min(lg, idbits - 1u);      // (more buckets than ids: a smaller shift only keeps more bits)
+        if (buckets == 0 || idbits > lg + 12) {
+            form = packed ? 1 : 0;  // (an explicit capacity too small for the form)
+            cap = walk_hash_entries(walk_hash_bytes(cap, form), form);
+        } else {
+            // (tests: GBNNS_DEBUG_VS_DISP=<1..15> makes probe sequences give up that early, to exercise the hand-over)
+            const uint32_t disp = getenv("GBNNS_DEBUG_VS_DISP") ? (uint32_t)std::min(15, std::max(1, atoi(getenv("GBNNS_DEBUG_VS_DISP")))) : 15u;
+            w.vs_shr = (32u - idbits + lg) | (32u - idbits) << 8 | disp << 28;
         }
     }
-    cap = walk_hash_entries(walk_hash_bytes(cap, packed), packed);  // whole buckets
     w.hash_cap = cap;
     w.hash_limit = cap - cap / 16;
     w.all_general = (walk_fast_lds_bytes(w, hot) > kMaxLds || n_ent > 1) ? 1 : 0;  // several entry points: general kernel only

@@ -74,6 +74,11 @@ struct WalkParams {
     uint32_t aux_stride;
     uint32_t hops_bound;
     int32_t llf;
+    // visited-set form of the walk_hot* first pass: vs_shr == 0 -> five 24-bit ids per 16-byte bucket; else the quotient
+    // form (seven 16-bit entries per bucket; n <= 2^W): vs_shr = (32 - W + floor(log2 buckets)) | (32 - W) << 8 | 15 << 28
+    // (top four bits: a probe sequence gives up -- hand-over -- when its displacement from the home bucket reaches that
+    // many buckets; less than 15 in test runs)
+    uint32_t vs_shr;
     const uint32_t* order;   // optional [nq]: work item b of a first pass runs query order[b] (a permutation: locality order of a deep batch)
     int32_t force_wide;      // diagnostic: treat the index as a large one (64-bit offsets, 4-byte visited-set slots)
     unsigned long long* stamps;  // diagnostic builds only (GBNNS_STAMPS): [32] segment cycle sums / histograms
@@ -84,8 +89,10 @@ bool walk_uses_hot(const WalkParams& p, int metric);           // first pass run
 bool walk_uses_lds_list(const WalkParams& p);                   // result list in LDS (walk_fast_kernel) instead of registers
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot);
 bool walk_uses_packed(const WalkParams& p);                     // visited set of 24-bit ids, five per 16-byte bucket
-size_t walk_hash_bytes(uint32_t entries, bool packed);          // LDS bytes of a visited set of `entries` ids
-uint32_t walk_hash_entries(size_t bytes, bool packed);          // ids that fit into `bytes` (whole buckets)
+// `form` of a visited set: 0 = 4-byte slots, 1 = five 24-bit ids per 16-byte bucket, 2 = quotient form (seven 16-bit entries)
+size_t walk_hash_bytes(uint32_t entries, int form);             // LDS bytes of a visited set of `entries` ids
+uint32_t walk_hash_entries(size_t bytes, int form);             // ids that fit into `bytes` (whole buckets)
+int walk_hash_form(const WalkParams& p, bool hot);              // the form the first pass uses (p.vs_shr chooses 2 for the hot kernels)
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list = false);  // everything but the visited set
                                                                                              // (lds_list: walk_uses_lds_list)
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s);

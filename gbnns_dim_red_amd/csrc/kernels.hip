@@ -353,6 +353,46 @@ __device__ __forceinline__ void packed_table_put_first(uint32_t* hash, uint32_t 
     hash[4u * b] = 0xFF000000u | entry;   // slot 0 (slot 1's low byte stays empty)
     hash[4u * b + 3u] = 0x01FFFFFFu;      // one slot handed out
 }
+// The same two for the quotient form of the table (GBNNS_VS_ASM: seven 16-bit entries + 0xF000 | count per bucket).
+// Its last kStashBuckets x 16 bytes are not buckets but an exact list of up to kStashIds ids whose probe sequences
+// ran out (stash_claim): rare -- a 10 000-query batch at ef = 140 sees a handful -- but each one would otherwise cost
+// a hand-over, i.e. a retry launch behind the batch.
+constexpr uint32_t kStashBuckets = 4, kStashIds = kStashBuckets * 4 - 1;  // (the last word counts them)
+// The lanes of `movf` (odd bits: hot_expand's report) look their ids up in the stash behind the table's `nbuckets`
+// buckets and append the new ones; those are added to `claimed` (even bits).  false: the stash is full -- hand the
+// query over.
+__device__ __forceinline__ bool stash_claim(uint32_t hash_lds, uint32_t nbuckets, uint64_t movf, uint32_t nb, uint64_t& claimed, int lane) {
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* const stash = (lds_u32*)(size_t)(hash_lds + 16u * nbuckets);  // (hash_lds: the table's LDS byte address)
+    int stash_n = (int)stash[kStashIds];
+    uint64_t mo = movf >> 1;
+    while (mo) {
+        const int l = __ffsll((unsigned long long)mo) - 1;
+        mo &= mo - 1;
+        const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)nb, l);
+        const bool hit = lane < stash_n && stash[lane] == id;  // (kStashIds <= 64)
+        if (__ballot(hit) != 0) continue;
+        if (stash_n == (int)kStashIds) return false;
+        if (lane == 0) {
+            stash[stash_n] = id;
+            stash[kStashIds] = (uint32_t)stash_n + 1u;
+        }
+        stash_n += 1;
+        claimed |= 1ull << l;
+        wave_sync();
+    }
+    return true;
+}
+__device__ __forceinline__ void quotient_table_init(uint32_t* hash, uint32_t nbuckets, int lane) {
+    for (uint32_t i = lane; i < nbuckets * 4u; i += 64) hash[i] = (i & 3u) == 3u ? 0xF000FFFFu : 0xFFFFFFFFu;
+    if (lane == 0) hash[nbuckets * 4u + kStashIds] = 0u;  // the stash behind the buckets is empty
+}
+__device__ __forceinline__ void quotient_table_put_first(uint32_t* hash, uint32_t nbuckets, uint32_t entry, uint32_t shr) {
+    const uint32_t h = entry * (0x9E3779B1u << ((shr >> 8) & 31u));
+    const uint32_t b = __umulhi(h, nbuckets);
+    hash[4u * b] = 0xFFFF0000u | ((h * nbuckets) >> (shr & 31u));  // slot 0, displacement 0
+    hash[4u * b + 3u] = 0xF001FFFFu;                       // one slot handed out
+}
 
 // ------------------------------------------------------------------------------------------
 // re-rank, pair form (search_function.h:105-125 getRealNearest) -- shared by rerank_pair_kernel and by the
@@ -2648,16 +2688,148 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
     return true;
 }
 
+// The visited-set section of hot_expand's asm block (shared by its two metric forms): even lanes of `valid` test and
+// claim their id; %[fresh] = lanes whose id was new (even bits) and, shifted to their odd neighbours' bits, lanes that
+// ran out of probe range (quotient form only).
+//
+// Packed form (%[shr] == 0): a 16-byte bucket holds five 24-bit ids (bits
+// 24k .. 24k+23, all-ones = empty) and, in its top byte, the number of slots handed out.  An id is in the set iff it is
+// found in a bucket of its probe sequence before a bucket with a free slot; a new id takes the slot index an atomic
+// add on that counter returns (unique per lane, so no compare-and-swap and no retry inside a bucket) and writes its
+// three bytes.  3.2 bytes per id.
+//
+// Quotient form (%[shr] != 0: shift count in its low five bits, 32 - W in bits 8 .. 12, displacement limit -- 15 -- in
+// its top four; n <= 2^W): H = id * (0x9E3779B1 << (32 - W)) is a
+// bijection of the ids onto the multiples of 2^(32-W); the home bucket is mulhi(H, buckets) and the low word of that
+// product, shifted right by 32 - W + floor(log2 buckets), tells the ids of one home bucket apart in
+// W - floor(log2 buckets) <= 12 bits (the host checks).  A bucket holds seven 16-bit entries -- displacement from the
+// home bucket (0 .. 14) << 12 | those bits; 0xFFFF = empty -- and in its top halfword 0xF000 | slots handed out (no
+// key has displacement 15, so neither that halfword nor an empty slot ever compares equal).  Same protocol as above;
+// 2.29 bytes per id and nine instead of fifteen instructions per bucket test.  The "displacement" is the probe number:
+// probe j + 1 looks 1 .. 8 buckets (by the key's low three bits) beyond probe j, so ids of neighbouring home buckets
+// do not queue up behind one run of full buckets (with steps of one bucket a 10 000-query batch at ef = 140 handed a
+// few queries over every time).  A probe sequence longer than fifteen buckets gives up: the lane is reported and the
+// query is handed over to the retry pass.
+#define GBNNS_VS_ASM                                                                                                   \
+        "s_bfe_u32 %[mulc], %[shr], 0x50008\n\t"               /* 32 - W (0 in the packed form) */                     \
+        "s_lshl_b32 %[mulc], 0x9E3779B1, %[mulc]\n\t"                                                                  \
+        "v_mul_lo_u32 %[t0], %[id], %[mulc]\n\t"                                                                       \
+        "s_and_b32 exec_lo, exec_lo, 0x55555555\n\t"                                                                   \
+        "s_and_b32 exec_hi, exec_hi, 0x55555555\n\t"                                                                   \
+        "s_mov_b64 %[fresh], 0\n\t"                                                                                    \
+        "s_cmp_lg_u32 %[shr], 0\n\t"                                                                                   \
+        "v_mul_hi_u32 %[t1], %[t0], %[nb]\n\t"                                                                         \
+        "v_lshl_add_u32 %[addr], %[t1], 4, %[basev]\n\t"                                                               \
+        "s_cbranch_scc1 4f\n"                                                                                          \
+        "1:\n\t"                                                                                                       \
+        "ds_read_b128 v[68:71], %[addr]\n\t"                                                                           \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+        "v_bfe_u32 v64, v68, 0, 24\n\t"                        /* slot 0 */                                            \
+        "v_alignbit_b32 v65, v69, v68, 24\n\t"                 /* slot 1 (bits 24..47) in the low 24 bits */           \
+        "v_alignbit_b32 v66, v70, v69, 16\n\t"                 /* slot 2 (bits 48..71) */                              \
+        "v_lshrrev_b32 v67, 8, v70\n\t"                        /* slot 3 (bits 72..95) */                              \
+        "v_bfe_u32 %[t1], v71, 0, 24\n\t"                      /* slot 4 (bits 96..119) */                             \
+        "v_bfe_u32 v65, v65, 0, 24\n\t"                                                                                \
+        "v_bfe_u32 v66, v66, 0, 24\n\t"                                                                                \
+        "v_xor_b32 v64, v64, %[id]\n\t"                                                                                \
+        "v_xor_b32 v65, v65, %[id]\n\t"                                                                                \
+        "v_xor_b32 v66, v66, %[id]\n\t"                                                                                \
+        "v_xor_b32 v67, v67, %[id]\n\t"                                                                                \
+        "v_xor_b32 %[t1], %[t1], %[id]\n\t"                                                                            \
+        "v_min3_u32 v64, v64, v65, v66\n\t"                                                                            \
+        "v_min3_u32 v64, v64, v67, %[t1]\n\t"                  /* 0 <=> id is in the bucket */                         \
+        "v_lshrrev_b32 %[t1], 24, v71\n\t"                     /* slots handed out */                                  \
+        "v_cmp_ne_u32 vcc, 0, v64\n\t"                                                                                 \
+        "s_and_b64 exec, exec, vcc\n\t"                        /* lanes that found their id are done */                \
+        "s_cbranch_execz 9f\n\t"                                                                                       \
+        "s_mov_b64 %[act], exec\n\t"                                                                                   \
+        "v_cmp_gt_u32 vcc, 5, %[t1]\n\t"                                                                               \
+        "s_and_b64 exec, exec, vcc\n\t"                        /* the bucket had room when it was read */              \
+        "s_cbranch_execz 3f\n\t"                                                                                       \
+        "v_mov_b32 %[t1], 0x1000000\n\t"                                                                               \
+        "ds_add_rtn_u32 %[t0], %[addr], %[t1] offset:12\n\t"   /* take a slot number */                                \
+        "v_lshrrev_b32 %[t2], 8, %[id]\n\t"                                                                            \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+        "v_lshrrev_b32 %[t0], 24, %[t0]\n\t"                                                                           \
+        "v_cmp_gt_u32 vcc, 5, %[t0]\n\t"                                                                               \
+        "s_and_b64 exec, exec, vcc\n\t"                        /* lanes whose number is a real slot */                 \
+        "s_cbranch_execz 3f\n\t"                                                                                       \
+        "v_mad_u32_u24 %[t0], %[t0], 3, %[addr]\n\t"           /* byte address of the slot */                          \
+        "ds_write_b8 %[t0], %[id]\n\t"                                                                                 \
+        "ds_write_b8 %[t0], %[t2] offset:1\n\t"                                                                        \
+        "ds_write_b8_d16_hi %[t0], %[id] offset:2\n\t"                                                                 \
+        "s_or_b64 %[fresh], %[fresh], exec\n\t"                                                                        \
+        "s_andn2_b64 %[act], %[act], exec\n"                                                                           \
+        "3:\n\t"                                                                                                       \
+        "s_mov_b64 exec, %[act]\n\t"                           /* absent and unplaced: their bucket is full */         \
+        "s_cbranch_execz 9f\n\t"                                                                                       \
+        "v_add_u32 %[addr], 16, %[addr]\n\t"                                                                           \
+        "v_cmp_eq_u32 vcc, %[end], %[addr]\n\t"                                                                        \
+        "v_cndmask_b32 %[addr], %[addr], %[basev], vcc\n\t"                                                            \
+        "s_branch 1b\n"                                                                                                \
+        "4:\n\t"                                               /* ---- quotient form ---- */                           \
+        "s_lshl_b32 %[mulc], %[nb], 4\n\t"                                                                             \
+        "v_mul_lo_u32 %[t0], %[t0], %[nb]\n\t"                 /* place inside the home bucket's range */              \
+        "v_lshrrev_b32 %[t0], %[shr], %[t0]\n\t"               /* < 2^12 */                                            \
+        "v_lshl_or_b32 %[t2], %[t0], 16, %[t0]\n"              /* the key in both halves, displacement 0 */            \
+        "5:\n\t"                                                                                                       \
+        "ds_read_b128 v[68:71], %[addr]\n\t"                                                                           \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+        "v_xor_b32 v64, v68, %[t2]\n\t"                                                                                \
+        "v_xor_b32 v65, v69, %[t2]\n\t"                                                                                \
+        "v_xor_b32 v66, v70, %[t2]\n\t"                                                                                \
+        "v_xor_b32 v67, v71, %[t2]\n\t"                                                                                \
+        "v_pk_min_u16 v64, v64, v65\n\t"                                                                               \
+        "v_pk_min_u16 v66, v66, v67\n\t"                                                                               \
+        "v_bfe_u32 %[t1], v71, 16, 12\n\t"                     /* slots handed out */                                  \
+        "v_pk_min_u16 v64, v64, v66\n\t"                                                                               \
+        "v_mad_u32_u16 v64, v64, v64, 0 op_sel:[0,1,0,0]\n\t"  /* low half x high half: 0 <=> the key is in the bucket */ \
+        "v_cmp_ne_u32 vcc, 0, v64\n\t"                                                                                 \
+        "s_and_b64 exec, exec, vcc\n\t"                                                                                \
+        "s_cbranch_execz 9f\n\t"                                                                                       \
+        "s_mov_b64 %[act], exec\n\t"                                                                                   \
+        "v_cmp_gt_u32 vcc, 7, %[t1]\n\t"                                                                               \
+        "s_and_b64 exec, exec, vcc\n\t"                                                                                \
+        "s_cbranch_execz 6f\n\t"                                                                                       \
+        "v_mov_b32 %[t1], 0x10000\n\t"                                                                                 \
+        "ds_add_rtn_u32 %[t0], %[addr], %[t1] offset:12\n\t"                                                           \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+        "v_bfe_u32 %[t0], %[t0], 16, 12\n\t"                                                                           \
+        "v_cmp_gt_u32 vcc, 7, %[t0]\n\t"                                                                               \
+        "s_and_b64 exec, exec, vcc\n\t"                                                                                \
+        "s_cbranch_execz 6f\n\t"                                                                                       \
+        "v_lshl_add_u32 %[t0], %[t0], 1, %[addr]\n\t"                                                                  \
+        "ds_write_b16 %[t0], %[t2]\n\t"                                                                                \
+        "s_or_b64 %[fresh], %[fresh], exec\n\t"                                                                        \
+        "s_andn2_b64 %[act], %[act], exec\n"                                                                           \
+        "6:\n\t"                                                                                                       \
+        "s_mov_b64 exec, %[act]\n\t"                                                                                   \
+        "s_cbranch_execz 9f\n\t"                                                                                       \
+        "v_and_b32 %[t0], 7, %[t2]\n\t"                        /* next probe: 1 .. 8 buckets on, by the key's low bits */ \
+        "v_lshl_add_u32 %[t0], %[t0], 4, 16\n\t"               /* (no runs of full buckets shared by neighbouring homes) */ \
+        "v_add_u32 %[addr], %[addr], %[t0]\n\t"                                                                        \
+        "v_add_u32 %[t2], 0x10001000, %[t2]\n\t"               /* one probe further from home */                       \
+        "v_cmp_le_u32 vcc, %[end], %[addr]\n\t"                                                                        \
+        "v_subrev_u32 %[t0], %[mulc], %[addr]\n\t"             /* (%[mulc] holds the table's bytes by now) */          \
+        "v_cndmask_b32 %[addr], %[addr], %[t0], vcc\n\t"                                                               \
+        "v_cmp_gt_u32 vcc, %[shr], %[t2]\n\t"                  /* displacement still in range (below %[shr] >> 28) */  \
+        "s_andn2_b64 %[act], exec, vcc\n\t"                    /* lanes out of range: reported in the odd bits of %[fresh] */ \
+        "s_lshl_b64 %[act], %[act], 1\n\t"                                                                             \
+        "s_or_b64 %[fresh], %[fresh], %[act]\n\t"                                                                      \
+        "s_and_b64 exec, exec, vcc\n\t"                                                                                \
+        "s_cbranch_execnz 5b\n"                                                                                        \
+        "9:\n\t"                                                                                                       \
+        "s_mov_b64 exec, %[sv]\n\t"
+
 // METRIC 0: L2Metric::Dist, the lane holds 64 contiguous bytes of the row (roff = row + half * 64, loads at 0 / 16 / 32 / 48).
 // METRIC 1: Angular::Dist, the lane holds the even (odd) 16-byte pieces (roff = row + half * 16, loads at 0 / 32 / 64 / 96):
 // its eight running sums are independent chains, the even lane runs sums 0..3, the odd lane sums 4..7, and the fold
 // m_j = c_{j+4} + c_j happens once, in the odd lane (dot_pair_from_regs).
 template <int METRIC = 0, typename QP>
 __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t roff, uint32_t nb, uint64_t valid, uint32_t lds_base,
-                                               uint32_t nbuckets, QP qh, uint64_t& claimed) {
+                                               uint32_t nbuckets, QP qh, uint64_t& claimed, uint32_t shr, uint64_t& overflowed) {
     const uint32_t end = lds_base + (nbuckets << 4);
-    const uint32_t mulc = 0x9E3779B1u;
-    uint32_t basev = lds_base, inc = 1u << 24, addr, t0, t1, t2, key;
+    uint32_t basev = lds_base, addr, t0, t1, t2, key, mulc;
     uint64_t fresh, act, sv;
     f32x2 ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3;  // row halves, then their squared differences
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -2671,64 +2843,7 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
         "global_load_dwordx4 v[52:55], %[roff], %[db] offset:16\n\t"
         "global_load_dwordx4 v[56:59], %[roff], %[db] offset:32\n\t"
         "global_load_dwordx4 v[60:63], %[roff], %[db] offset:48\n\t"
-        // ---- visited set: even lanes of `valid`.  Packed table: a 16-byte bucket holds five 24-bit ids (bits
-        // 24k .. 24k+23, all-ones = empty) and, in its top byte, the number of slots handed out.  An id is in the
-        // set iff it is found in a bucket of its probe sequence before a bucket with a free slot; a new id takes
-        // the slot index an atomic add on that counter returns (unique per lane, so no compare-and-swap and no
-        // retry inside a bucket) and writes its three bytes.
-        "v_mul_lo_u32 %[t0], %[id], %[mulc]\n\t"
-        "s_and_b32 exec_lo, exec_lo, 0x55555555\n\t"
-        "s_and_b32 exec_hi, exec_hi, 0x55555555\n\t"
-        "s_mov_b64 %[fresh], 0\n\t"
-        "v_mul_hi_u32 %[t0], %[t0], %[nb]\n\t"
-        "v_lshl_add_u32 %[addr], %[t0], 4, %[basev]\n"
-        "1:\n\t"
-        "ds_read_b128 v[68:71], %[addr]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_bfe_u32 v64, v68, 0, 24\n\t"                        // slot 0
-        "v_alignbit_b32 v65, v69, v68, 24\n\t"                 // slot 1 (bits 24..47) in the low 24 bits
-        "v_alignbit_b32 v66, v70, v69, 16\n\t"                 // slot 2 (bits 48..71)
-        "v_lshrrev_b32 v67, 8, v70\n\t"                        // slot 3 (bits 72..95)
-        "v_bfe_u32 %[t1], v71, 0, 24\n\t"                      // slot 4 (bits 96..119)
-        "v_bfe_u32 v65, v65, 0, 24\n\t"
-        "v_bfe_u32 v66, v66, 0, 24\n\t"
-        "v_xor_b32 v64, v64, %[id]\n\t"
-        "v_xor_b32 v65, v65, %[id]\n\t"
-        "v_xor_b32 v66, v66, %[id]\n\t"
-        "v_xor_b32 v67, v67, %[id]\n\t"
-        "v_xor_b32 %[t1], %[t1], %[id]\n\t"
-        "v_min3_u32 v64, v64, v65, v66\n\t"
-        "v_min3_u32 v64, v64, v67, %[t1]\n\t"                  // 0 <=> id is in the bucket
-        "v_lshrrev_b32 %[t1], 24, v71\n\t"                     // slots handed out
-        "v_cmp_ne_u32 vcc, 0, v64\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"                        // lanes that found their id are done
-        "s_cbranch_execz 9f\n\t"
-        "s_mov_b64 %[act], exec\n\t"
-        "v_cmp_gt_u32 vcc, 5, %[t1]\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"                        // the bucket had room when it was read
-        "s_cbranch_execz 3f\n\t"
-        "ds_add_rtn_u32 %[t0], %[addr], %[inc] offset:12\n\t"  // take a slot number
-        "v_lshrrev_b32 %[t2], 8, %[id]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_lshrrev_b32 %[t0], 24, %[t0]\n\t"
-        "v_cmp_gt_u32 vcc, 5, %[t0]\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"                        // lanes whose number is a real slot
-        "s_cbranch_execz 3f\n\t"
-        "v_mad_u32_u24 %[t0], %[t0], 3, %[addr]\n\t"           // byte address of the slot
-        "ds_write_b8 %[t0], %[id]\n\t"
-        "ds_write_b8 %[t0], %[t2] offset:1\n\t"
-        "ds_write_b8_d16_hi %[t0], %[id] offset:2\n\t"
-        "s_or_b64 %[fresh], %[fresh], exec\n\t"
-        "s_andn2_b64 %[act], %[act], exec\n"
-        "3:\n\t"
-        "s_mov_b64 exec, %[act]\n\t"                           // absent and unplaced: their bucket is full
-        "s_cbranch_execz 9f\n\t"
-        "v_add_u32 %[addr], 16, %[addr]\n\t"
-        "v_cmp_eq_u32 vcc, %[end], %[addr]\n\t"
-        "v_cndmask_b32 %[addr], %[addr], %[basev], vcc\n\t"
-        "s_branch 1b\n"
-        "9:\n\t"
-        "s_mov_b64 exec, %[sv]\n\t"
+        GBNNS_VS_ASM
         // ---- pair distance (l2_pair_from_regs), all lanes
         "s_waitcnt vmcnt(3)\n\t"                               // loads return in order: square each step as it lands
         "v_pk_add_f32 v[48:49], v[48:49], %[qa0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
@@ -2773,9 +2888,9 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
         "v_add_f32 %[key], %[key], v66\n\t"
         "v_add_f32 %[key], %[key], v67\n\t"
         "v_or_b32 %[key], 0x80000000, %[key]"                  // fkey of a non-negative float
-        : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+        : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [mulc] "=&s"(mulc), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
           [addr] "=&v"(addr), [key] "=&v"(key)
-        : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [inc] "v"(inc), [mulc] "s"(mulc),
+        : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [shr] "s"(shr),
           [nb] "s"(nbuckets), [roff] "v"(roff), [db] "s"(db_base), GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
         : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",
           "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
@@ -2787,64 +2902,7 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
         "global_load_dwordx4 v[52:55], %[roff], %[db] offset:32\n\t"
         "global_load_dwordx4 v[56:59], %[roff], %[db] offset:64\n\t"
         "global_load_dwordx4 v[60:63], %[roff], %[db] offset:96\n\t"
-        // ---- visited set: even lanes of `valid`.  Packed table: a 16-byte bucket holds five 24-bit ids (bits
-        // 24k .. 24k+23, all-ones = empty) and, in its top byte, the number of slots handed out.  An id is in the
-        // set iff it is found in a bucket of its probe sequence before a bucket with a free slot; a new id takes
-        // the slot index an atomic add on that counter returns (unique per lane, so no compare-and-swap and no
-        // retry inside a bucket) and writes its three bytes.
-        "v_mul_lo_u32 %[t0], %[id], %[mulc]\n\t"
-        "s_and_b32 exec_lo, exec_lo, 0x55555555\n\t"
-        "s_and_b32 exec_hi, exec_hi, 0x55555555\n\t"
-        "s_mov_b64 %[fresh], 0\n\t"
-        "v_mul_hi_u32 %[t0], %[t0], %[nb]\n\t"
-        "v_lshl_add_u32 %[addr], %[t0], 4, %[basev]\n"
-        "1:\n\t"
-        "ds_read_b128 v[68:71], %[addr]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_bfe_u32 v64, v68, 0, 24\n\t"                        // slot 0
-        "v_alignbit_b32 v65, v69, v68, 24\n\t"                 // slot 1 (bits 24..47) in the low 24 bits
-        "v_alignbit_b32 v66, v70, v69, 16\n\t"                 // slot 2 (bits 48..71)
-        "v_lshrrev_b32 v67, 8, v70\n\t"                        // slot 3 (bits 72..95)
-        "v_bfe_u32 %[t1], v71, 0, 24\n\t"                      // slot 4 (bits 96..119)
-        "v_bfe_u32 v65, v65, 0, 24\n\t"
-        "v_bfe_u32 v66, v66, 0, 24\n\t"
-        "v_xor_b32 v64, v64, %[id]\n\t"
-        "v_xor_b32 v65, v65, %[id]\n\t"
-        "v_xor_b32 v66, v66, %[id]\n\t"
-        "v_xor_b32 v67, v67, %[id]\n\t"
-        "v_xor_b32 %[t1], %[t1], %[id]\n\t"
-        "v_min3_u32 v64, v64, v65, v66\n\t"
-        "v_min3_u32 v64, v64, v67, %[t1]\n\t"                  // 0 <=> id is in the bucket
-        "v_lshrrev_b32 %[t1], 24, v71\n\t"                     // slots handed out
-        "v_cmp_ne_u32 vcc, 0, v64\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"                        // lanes that found their id are done
-        "s_cbranch_execz 9f\n\t"
-        "s_mov_b64 %[act], exec\n\t"
-        "v_cmp_gt_u32 vcc, 5, %[t1]\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"                        // the bucket had room when it was read
-        "s_cbranch_execz 3f\n\t"
-        "ds_add_rtn_u32 %[t0], %[addr], %[inc] offset:12\n\t"  // take a slot number
-        "v_lshrrev_b32 %[t2], 8, %[id]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_lshrrev_b32 %[t0], 24, %[t0]\n\t"
-        "v_cmp_gt_u32 vcc, 5, %[t0]\n\t"
-        "s_and_b64 exec, exec, vcc\n\t"                        // lanes whose number is a real slot
-        "s_cbranch_execz 3f\n\t"
-        "v_mad_u32_u24 %[t0], %[t0], 3, %[addr]\n\t"           // byte address of the slot
-        "ds_write_b8 %[t0], %[id]\n\t"
-        "ds_write_b8 %[t0], %[t2] offset:1\n\t"
-        "ds_write_b8_d16_hi %[t0], %[id] offset:2\n\t"
-        "s_or_b64 %[fresh], %[fresh], exec\n\t"
-        "s_andn2_b64 %[act], %[act], exec\n"
-        "3:\n\t"
-        "s_mov_b64 exec, %[act]\n\t"                           // absent and unplaced: their bucket is full
-        "s_cbranch_execz 9f\n\t"
-        "v_add_u32 %[addr], 16, %[addr]\n\t"
-        "v_cmp_eq_u32 vcc, %[end], %[addr]\n\t"
-        "v_cndmask_b32 %[addr], %[addr], %[basev], vcc\n\t"
-        "s_branch 1b\n"
-        "9:\n\t"
-        "s_mov_b64 exec, %[sv]\n\t"
+        GBNNS_VS_ASM
         // ---- pair distance (dot_pair_from_regs), all lanes: products, then four running sums from +0 in load order
         "v_mov_b32 v64, 0\n\t"
         "v_mov_b32 v65, 0\n\t"
@@ -2883,15 +2941,16 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
         "v_ashrrev_i32 %[t0], 31, %[key]\n\t"                  // then flip all bits of a negative value, the sign bit of a positive one
         "v_or_b32 %[t0], 0x80000000, %[t0]\n\t"
         "v_xor_b32 %[key], %[key], %[t0]"
-        : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+        : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [mulc] "=&s"(mulc), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
           [addr] "=&v"(addr), [key] "=&v"(key)
-        : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [inc] "v"(inc), [mulc] "s"(mulc),
+        : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [shr] "s"(shr),
           [nb] "s"(nbuckets), [roff] "v"(roff), [db] "s"(db_base), GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
         : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",
           "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
     }
 #undef GBNNS_Q
-    claimed = fresh;
+    claimed = fresh & 0x5555555555555555ull;
+    overflowed = fresh & 0xAAAAAAAAAAAAAAAAull;
     return key;
 }
 
@@ -2914,9 +2973,12 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     const uint32_t cap = p.hash_cap;
     const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
 
-    // packed visited set (hot_expand): cap / 5 buckets of 16 bytes, five 24-bit ids + a counter byte each
-    const uint32_t nbuckets = cap / 5u;
-    packed_table_init(hash, nbuckets, 0u, lane);
+    // visited set (hot_expand, GBNNS_VS_ASM): cap / 5 buckets of 16 bytes with five 24-bit ids + a counter byte each,
+    // or (p.vs_shr != 0) cap / 7 buckets with seven 16-bit quotient entries + a counter halfword
+    const uint32_t vs_shr = p.vs_shr;
+    const uint32_t nbuckets = vs_shr ? cap / 7u - kStashBuckets : cap / 5u;
+    if (vs_shr) quotient_table_init(hash, nbuckets, lane);
+    else packed_table_init(hash, nbuckets, 0u, lane);
     if (lane < 32) qf[lane] = p.q[(size_t)qi * p.qstride + lane];
     wave_sync();
     RowRegs<4> qreg;  // this lane's half of the query: 64 contiguous bytes (L2) / the even or odd 16-byte pieces (dot)
@@ -2935,7 +2997,8 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
         if (lane == 0) {
             L.hi[0] = worst;
             L.lo[0] = entry << 1;
-            packed_table_put_first(hash, nbuckets, entry);
+            if (vs_shr) quotient_table_put_first(hash, nbuckets, entry, vs_shr);
+            else packed_table_put_first(hash, nbuckets, entry);
         }
         wave_sync();
     }
@@ -3061,8 +3124,13 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
             if (__builtin_expect((uint32_t)dist_calc > dc_limit, 0)) return false;
             edges += __popcll(mv & 0x5555555555555555ull);
             // ---- gather (speculative: before the visited test), visited test, distances -----------
-            uint64_t mclaimed;
-            const uint32_t kd = hot_expand<METRIC>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, mclaimed);
+            uint64_t mclaimed, movf;
+            const uint32_t kd = hot_expand<METRIC>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, mclaimed, vs_shr, movf);
+            if (__builtin_expect(movf != 0, 0)) {  // a probe sequence ran out (quotient form): the stash takes the id
+                // (the two-pass instances are at their scalar-register budget -- tests/test_isa_contract.py -- and hand over)
+                if constexpr (WIDE) return false;
+                else if (!stash_claim(hash_lds, nbuckets, movf, nb, mclaimed, lane)) return false;
+            }
             const uint64_t mfresh = mclaimed << 1;  // odd lanes hold the distances
             const uint32_t dk = __builtin_amdgcn_inverse_ballot_w64(mfresh) ? kd : 0xFFFFFFFFu;
             dist_calc += __popcll(mfresh);
@@ -3145,8 +3213,10 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
     const float4* qs = reinterpret_cast<const float4*>(qf);
     const uint32_t cap = p.hash_cap;
     const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
-    const uint32_t nbuckets = cap / 5u;
-    packed_table_init(hash, nbuckets, 0u, lane);
+    const uint32_t vs_shr = p.vs_shr;  // (walk_hot_one: the two forms of the table)
+    const uint32_t nbuckets = vs_shr ? cap / 7u - kStashBuckets : cap / 5u;
+    if (vs_shr) quotient_table_init(hash, nbuckets, lane);
+    else packed_table_init(hash, nbuckets, 0u, lane);
     if (lane < 32) qf[lane] = p.q[(size_t)qi * p.qstride + lane];
     wave_sync();
     RowRegs<4> qreg;
@@ -3165,7 +3235,8 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
         if (lane == 0) {
             B.F.hi[0] = B.worst;
             B.F.lo[0] = entry << 1;
-            packed_table_put_first(hash, nbuckets, entry);
+            if (vs_shr) quotient_table_put_first(hash, nbuckets, entry, vs_shr);
+            else packed_table_put_first(hash, nbuckets, entry);
         }
         wave_sync();
     }
@@ -3221,8 +3292,13 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
             edges += __popcll(mv & 0x5555555555555555ull);
             STAMP(t3)
             STAMP_ADD(2, t2, t3)
-            uint64_t mclaimed;
-            const uint32_t kd = hot_expand<METRIC>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, mclaimed);
+            uint64_t mclaimed, movf;
+            const uint32_t kd = hot_expand<METRIC>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, mclaimed, vs_shr, movf);
+            if (__builtin_expect(movf != 0, 0)) {  // a probe sequence ran out (quotient form): the stash takes the id
+                // (the two-pass instances are at their scalar-register budget -- tests/test_isa_contract.py -- and hand over)
+                if constexpr (WIDE) return false;
+                else if (!stash_claim(hash_lds, nbuckets, movf, nb, mclaimed, lane)) return false;
+            }
             const uint64_t mfresh = mclaimed << 1;  // odd lanes hold the distances
             const uint32_t dk = __builtin_amdgcn_inverse_ballot_w64(mfresh) ? kd : 0xFFFFFFFFu;
             dist_calc += __popcll(mfresh);
@@ -4225,15 +4301,21 @@ size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_li
 
 // Visited set of `entries` ids: 4-byte slots in 4-slot buckets; the hot kernel packs five 24-bit ids and a
 // counter byte into each 16-byte bucket (3.2 bytes per id).
-size_t walk_hash_bytes(uint32_t entries, bool packed) { return packed ? (size_t)(entries / 5u) * 16 : (size_t)entries * 4; }
-uint32_t walk_hash_entries(size_t bytes, bool packed) { return packed ? (uint32_t)(bytes / 16) * 5u : ((uint32_t)(bytes / 4) & ~3u); }
+// The quotient form (hot first pass, small enough n: GBNNS_VS_ASM) packs seven 16-bit entries per bucket (2.29 bytes per id).
+size_t walk_hash_bytes(uint32_t entries, int form) {
+    return form == 2 ? (size_t)(entries / 7u) * 16 : form == 1 ? (size_t)(entries / 5u) * 16 : (size_t)entries * 4;
+}
+uint32_t walk_hash_entries(size_t bytes, int form) {
+    return form == 2 ? (uint32_t)(bytes / 16) * 7u : form == 1 ? (uint32_t)(bytes / 16) * 5u : ((uint32_t)(bytes / 4) & ~3u);
+}
+int walk_hash_form(const WalkParams& p, bool hot) { return hot && p.vs_shr ? 2 : (walk_uses_packed(p) ? 1 : 0); }
 
 // Every LDS kernel packs its visited set when ids fit 24 bits (the register-list kernels: in their compact,
 // 32-bit-offset instantiations).
 bool walk_uses_packed(const WalkParams& p) { return walk_uses_lds_list(p) ? (p.n <= 0xFFFFFFu && !p.force_wide) : walk_off32(p); }
 
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot) {
-    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p)) + walk_hash_bytes(p.hash_cap, walk_uses_packed(p));
+    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p)) + walk_hash_bytes(p.hash_cap, walk_hash_form(p, hot));
 }
 
 #endif  // GBNNS_TU == 0
@@ -4405,7 +4487,7 @@ size_t walk_bitmap_lds_bytes(const WalkParams& p, int metric) {
 // Room the fused re-rank has for the original-space query (it is staged once the walk is over).
 size_t walk_rr_room(const WalkParams& p, int metric, bool hot, bool bitmap_pass) {
     if (bitmap_pass) return walk_bitmap_uses_reg(p, metric) && p.ef > kHot2MaxEf ? (size_t)p.rr_reserve : walk_bitmap_lds_bytes(p, metric);
-    if (p.ef > kHot2MaxEf && !walk_uses_lds_list(p)) return walk_hash_bytes(p.hash_cap, walk_uses_packed(p));  // two-list kernels: the visited-set area
+    if (p.ef > kHot2MaxEf && !walk_uses_lds_list(p)) return walk_hash_bytes(p.hash_cap, walk_hash_form(p, hot));  // two-list kernels: the visited-set area
     return walk_fast_lds_bytes(p, hot);
 }
 

@@ -1198,6 +1198,40 @@ def test_two_list_kernels_by_name(g, orc):
         ix.close()
 
 
+def test_visited_set_forms_of_the_hot_kernels(g, orc, monkeypatch):
+    """The walk_hot* first pass keeps its visited set either as five 24-bit ids or -- when the table has at least
+    2^(W-12) buckets, n <= 2^W -- as seven 16-bit quotient entries per 16-byte bucket (GBNNS_VS_ASM).  Both forms
+    (GBNNS_QUOTIENT=0 forces the first), automatic and explicit capacities, both metrics, one- and two-pass adjacency
+    rows, and the quotient form with probe sequences cut short (GBNNS_DEBUG_VS_DISP: queries are handed over to the
+    retry pass and the general kernel): ids, pop order, distance bits, hops and dist_calc equal the oracle's."""
+    for si, (metric, deg) in enumerate(((0, 30), (1, 30), (0, 60))):
+        c, off, nbr, db_low, ent = _oracle_case(orc, 7400 + si, 30000, 700, 64, 32, 64, deg=(2, deg))
+        q_low = orc.project(c.net, c.queries)
+        ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net, metric=metric)
+        for ef in (8, 64, 100, 200, 380):
+            w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, metric=metric, threads=8)
+            s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net,
+                                 entries=ent, metric=metric, threads=8)
+            maxdc = int(w["dist_calc"].max())
+            for env, cap in (({}, 0), ({"GBNNS_QUOTIENT": "0"}, 0), ({}, maxdc + maxdc // 8 + 64), ({}, max(128, maxdc // 2)),
+                             ({"GBNNS_DEBUG_VS_DISP": "1"}, 0), ({"GBNNS_DEBUG_VS_DISP": "2"}, maxdc + maxdc // 8 + 64)):
+                for k in ("GBNNS_QUOTIENT", "GBNNS_DEBUG_VS_DISP"):
+                    monkeypatch.delenv(k, raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                for rep in range(2):  # (the second call runs with the capacity the first one's statistics ask for)
+                    r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), hash_capacity=cap)
+                    key = (metric, deg, ef, tuple(env.items()), cap, rep)
+                    assert np.array_equal(r["cand"], w["ids"]), key
+                    assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
+                    assert np.array_equal(r["hops"], w["hops"]), key
+                    assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
+                    assert np.array_equal(r["ids"], s["ids"]), key
+        for k in ("GBNNS_QUOTIENT", "GBNNS_DEBUG_VS_DISP"):
+            monkeypatch.delenv(k, raising=False)
+        ix.close()
+
+
 def test_deferred_join_edge_cases(g, orc):
     """Batches in flight meet the rest of the API: an empty batch, profiling switched on in the middle (profiled calls run
     serialised), a projection / re-rank / auxiliary-graph change while deferred batches are unjoined, destroying a handle
