@@ -1132,7 +1132,10 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // (4.3 vs 5.5 ms), ef = 400 with the bitmap pass (7.1 vs 9.4 ms); SIFT-like ef <= 180 clearly the former
         // (with the register-list variant of the pass: ef = 300 4.2 vs 4.3 ms, a tie; SIFT-like ef 140 .. 180 5.2 .. 4.3
         // against 8.5 .. 6.0 M queries/s on the hot instances -- clearing n/8 bytes per query is not free there)
-        const int min_ef = 385;
+        // with the quotient form of the table (round 3) the crossover moved up: GloVe-like ef = 400 3.85 ms (table) against
+        // 4.85 (bitmap pass), ef = 500 5.61 / 5.51, ef = 600 8.86 / 6.83; SIFT-like ef = 450 4.41 / 4.68, ef = 500 5.30 / 5.29
+        static const int min_ef_env = getenv("GBNNS_BITMAP_MIN_EF") ? atoi(getenv("GBNNS_BITMAP_MIN_EF")) : 0;  // (tuning runs)
+        const int min_ef = min_ef_env ? min_ef_env : (form == 2 ? 480 : 385);
         const bool forced = (a->flags & GBNNS_FLAG_BITMAP_PASS) != 0;  // diagnostic: whatever ef and batch size
         if (!w.all_general && (ef >= min_ef || forced) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && (a->hash_capacity == 0 || forced)) {
             const size_t gran = 512;
