@@ -1053,8 +1053,8 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     const bool auto_cap = a->hash_capacity == 0;
     // visited-set capacity for `need` entries in the given form, and the wavefronts per CU it leaves (0: no fit)
     auto size_table = [&](int f, uint32_t need, size_t& slots) -> uint32_t {
-        uint32_t floor_entries = f == 2 ? quotient_min : 0u;
-        need = std::max(need, floor_entries);
+        const uint32_t floor_entries = f == 2 ? quotient_min : 0u, extra = f == 2 ? 7u * kStashBuckets : 0u;  // (the stash's four "buckets" hold no slots)
+        need = std::max(need + extra, floor_entries);
         const size_t gran = 512;  // LDS allocation granularity
         const size_t want = (lds_fixed + walk_hash_bytes(need + 4, f) + gran - 1) / gran * gran;
         slots = std::min<size_t>(32, kMaxLds / want);
@@ -1064,7 +1064,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // raises the requirement for good -- it never shrinks).
         if (slots < 32 && ix->maxdc_for_ef.count(skey)) {
             const uint32_t m = ix->maxdc_for_ef[skey];
-            const uint32_t need_min = std::max((m + m / 32 + 64) / 15 * 16 + 16, floor_entries);
+            const uint32_t need_min = std::max((m + m / 32 + 64) / 15 * 16 + 16 + extra, floor_entries);
             const size_t share1 = kMaxLds / (slots + 1) / gran * gran;
             if (share1 > lds_fixed && walk_hash_entries(share1 - lds_fixed, f) >= need_min + 4) slots += 1;
         }
@@ -1117,6 +1117,10 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     }
     w.hash_cap = cap;
     w.hash_limit = cap - cap / 16;
+    if (w.vs_shr) {  // quotient form: the last four of the cap / 7 buckets are the stash, not slots
+        const uint32_t slots = cap - 7u * kStashBuckets;
+        w.hash_limit = slots - slots / 16;
+    }
     w.all_general = (walk_fast_lds_bytes(w, hot) > kMaxLds || n_ent > 1) ? 1 : 0;  // several entry points: general kernel only
     // Fused re-rank: with a register-list first pass (ef <= 512; and its retry / general successors) every
     // wavefront re-ranks its own query when its walk ends; no re-rank launch.  Needs the pair form
