@@ -1046,6 +1046,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     uint32_t idbits = 1;
     while (idbits < 32 && (1ull << idbits) < ix->n) ++idbits;
     const bool quotient_on = !(getenv("GBNNS_QUOTIENT") && atoi(getenv("GBNNS_QUOTIENT")) == 0);  // tuning / A-B runs, tests
+    const bool vs_ok = walk_knows_quotient(w, ix->metric);
     constexpr uint32_t kStashBuckets = 4;  // (kernels.hip: the table's last four "buckets" are the stash)
     const uint32_t quotient_min = 7u * ((idbits > 12 ? 1u << (idbits - 12) : 1u) + kStashBuckets + 8u);  // entries (>= 8 real buckets: probe steps of up to 8)
     uint32_t cap;
@@ -1073,7 +1074,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     };
     if (!auto_cap) {
         cap = (uint32_t)a->hash_capacity;
-        if (hot && quotient_on && cap >= quotient_min) form = 2;  // (an explicit capacity is a number of entries, whatever the form)
+        if (vs_ok && quotient_on && cap >= quotient_min) form = 2;  // (an explicit capacity is a number of entries, whatever the form)
     } else {
         uint32_t need;
         if (ix->cap_for_ef.count(skey)) {
@@ -1084,7 +1085,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         }
         size_t slots = 0;
         cap = size_table(form, need, slots);
-        if (hot && quotient_on) {
+        if (vs_ok && quotient_on) {
             // the quotient form when it leaves at least as many wavefronts per CU (its bucket test is the shorter one)
             size_t slots_q = 0;
             const uint32_t cap_q = size_table(2, need, slots_q);
@@ -1184,6 +1185,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         if (!bitmap_pass) HIP_TRY(launch_walk_fast(w, ix->metric, s));
         // retry pass: hand-overs of the first pass, one wavefront per CU with all the LDS
         WalkParams w2 = w;
+        w2.vs_shr = 0;  // (the retry kernels keep the packed form)
         const size_t gran = 512;
         w2.hash_cap = walk_hash_entries(kMaxLds / gran * gran - walk_fast_lds_fixed_bytes(ef, w.dstride, false, walk_uses_lds_list(w)), packed);
         w2.hash_limit = w2.hash_cap - w2.hash_cap / 16;

@@ -92,6 +92,7 @@ bool walk_uses_packed(const WalkParams& p);                     // visited set o
 // `form` of a visited set: 0 = 4-byte slots, 1 = five 24-bit ids per 16-byte bucket, 2 = quotient form (seven 16-bit entries)
 size_t walk_hash_bytes(uint32_t entries, int form);             // LDS bytes of a visited set of `entries` ids
 uint32_t walk_hash_entries(size_t bytes, int form);             // ids that fit into `bytes` (whole buckets)
+bool walk_knows_quotient(const WalkParams& p, int metric);      // the first-pass kernel of this shape reads p.vs_shr
 int walk_hash_form(const WalkParams& p, bool hot);              // the form the first pass uses (p.vs_shr chooses 2 for the hot kernels)
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list = false);  // everything but the visited set
                                                                                              // (lds_list: walk_uses_lds_list)

@@ -344,6 +344,83 @@ __device__ __forceinline__ uint64_t visited_claim_mask_packed(uint32_t lds_base,
     return fresh;
 }
 
+// Quotient form of the table (see GBNNS_VS_ASM further down for the layout and the protocol; this is the same code
+// outside hot_expand, for the generic two-list kernel): the lanes of `valid` claim `id`; returns the lanes whose id was
+// new, `overflowed` = lanes whose probe sequence ran out (stash_claim takes those).  `ctl` = WalkParams::vs_shr.
+__device__ __forceinline__ uint64_t visited_claim_mask_quotient(uint32_t lds_base, uint32_t nbuckets, uint32_t id, uint64_t valid, uint32_t ctl,
+                                                              uint64_t& overflowed) {
+    const uint32_t end = lds_base + (nbuckets << 4);
+    uint32_t basev = lds_base, addr, t0, t1, t2, mulc;
+    uint64_t fresh, act, sv, ovf;
+    asm volatile(
+        "s_bfe_u32 %[mulc], %[shr], 0x50008\n\t"
+        "s_lshl_b32 %[mulc], 0x9E3779B1, %[mulc]\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[valid]\n\t"
+        "v_mul_lo_u32 %[t0], %[id], %[mulc]\n\t"
+        "s_mov_b64 %[fresh], 0\n\t"
+        "s_mov_b64 %[ovf], 0\n\t"
+        "s_lshl_b32 %[mulc], %[nb], 4\n\t"                  // the table's bytes
+        "v_mul_hi_u32 %[t1], %[t0], %[nb]\n\t"
+        "v_mul_lo_u32 %[t0], %[t0], %[nb]\n\t"
+        "v_lshl_add_u32 %[addr], %[t1], 4, %[basev]\n\t"
+        "v_lshrrev_b32 %[t0], %[shr], %[t0]\n\t"
+        "v_lshl_or_b32 %[t2], %[t0], 16, %[t0]\n"
+        "5:\n\t"
+        "ds_read_b128 v[92:95], %[addr]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_xor_b32 v88, v92, %[t2]\n\t"
+        "v_xor_b32 v89, v93, %[t2]\n\t"
+        "v_xor_b32 v90, v94, %[t2]\n\t"
+        "v_xor_b32 v91, v95, %[t2]\n\t"
+        "v_pk_min_u16 v88, v88, v89\n\t"
+        "v_pk_min_u16 v90, v90, v91\n\t"
+        "v_bfe_u32 %[t1], v95, 16, 12\n\t"
+        "v_pk_min_u16 v88, v88, v90\n\t"
+        "v_mad_u32_u16 v88, v88, v88, 0 op_sel:[0,1,0,0]\n\t"
+        "v_cmp_ne_u32 vcc, 0, v88\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 9f\n\t"
+        "s_mov_b64 %[act], exec\n\t"
+        "v_cmp_gt_u32 vcc, 7, %[t1]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 6f\n\t"
+        "v_mov_b32 %[t1], 0x10000\n\t"
+        "ds_add_rtn_u32 %[t0], %[addr], %[t1] offset:12\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_bfe_u32 %[t0], %[t0], 16, 12\n\t"
+        "v_cmp_gt_u32 vcc, 7, %[t0]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execz 6f\n\t"
+        "v_lshl_add_u32 %[t0], %[t0], 1, %[addr]\n\t"
+        "ds_write_b16 %[t0], %[t2]\n\t"
+        "s_or_b64 %[fresh], %[fresh], exec\n\t"
+        "s_andn2_b64 %[act], %[act], exec\n"
+        "6:\n\t"
+        "s_mov_b64 exec, %[act]\n\t"
+        "s_cbranch_execz 9f\n\t"
+        "v_and_b32 %[t0], 7, %[t2]\n\t"
+        "v_lshl_add_u32 %[t0], %[t0], 4, 16\n\t"
+        "v_add_u32 %[addr], %[addr], %[t0]\n\t"
+        "v_add_u32 %[t2], 0x10001000, %[t2]\n\t"
+        "v_cmp_le_u32 vcc, %[end], %[addr]\n\t"
+        "v_subrev_u32 %[t0], %[mulc], %[addr]\n\t"
+        "v_cndmask_b32 %[addr], %[addr], %[t0], vcc\n\t"
+        "v_cmp_gt_u32 vcc, %[shr], %[t2]\n\t"
+        "s_andn2_b64 %[act], exec, vcc\n\t"
+        "s_or_b64 %[ovf], %[ovf], %[act]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "s_cbranch_execnz 5b\n"
+        "9:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [ovf] "=&s"(ovf), [mulc] "=&s"(mulc), [t0] "=&v"(t0), [t1] "=&v"(t1),
+          [t2] "=&v"(t2), [addr] "=&v"(addr)
+        : [id] "v"(id), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [shr] "s"(ctl), [nb] "s"(nbuckets)
+        : "vcc", "scc", "memory", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+    overflowed = ovf;
+    return fresh;
+}
+
 // Initial state of a packed table of `nbuckets` buckets holding `entry` (every lane calls; no sync inside).
 __device__ __forceinline__ void packed_table_init(uint32_t* hash, uint32_t nbuckets, uint32_t entry, int lane) {
     for (uint32_t i = lane; i < nbuckets * 4u; i += 64) hash[i] = (i & 3u) == 3u ? 0x00FFFFFFu : 0xFFFFFFFFu;
@@ -358,14 +435,12 @@ __device__ __forceinline__ void packed_table_put_first(uint32_t* hash, uint32_t 
 // ran out (stash_claim): rare -- a 10 000-query batch at ef = 140 sees a handful -- but each one would otherwise cost
 // a hand-over, i.e. a retry launch behind the batch.
 constexpr uint32_t kStashBuckets = 4, kStashIds = kStashBuckets * 4 - 1;  // (the last word counts them)
-// The lanes of `movf` (odd bits: hot_expand's report) look their ids up in the stash behind the table's `nbuckets`
-// buckets and append the new ones; those are added to `claimed` (even bits).  false: the stash is full -- hand the
-// query over.
-__device__ __forceinline__ bool stash_claim(uint32_t hash_lds, uint32_t nbuckets, uint64_t movf, uint32_t nb, uint64_t& claimed, int lane) {
+// The lanes of `mo` (whose probe sequences ran out) look their ids up in the stash behind the table's `nbuckets`
+// buckets and append the new ones; those are added to `claimed`.  false: the stash is full -- hand the query over.
+__device__ __forceinline__ bool stash_claim(uint32_t hash_lds, uint32_t nbuckets, uint64_t mo, uint32_t nb, uint64_t& claimed, int lane) {
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     lds_u32* const stash = (lds_u32*)(size_t)(hash_lds + 16u * nbuckets);  // (hash_lds: the table's LDS byte address)
     int stash_n = (int)stash[kStashIds];
-    uint64_t mo = movf >> 1;
     while (mo) {
         const int l = __ffsll((unsigned long long)mo) - 1;
         mo &= mo - 1;
@@ -2383,7 +2458,9 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
     const uint32_t cap = p.hash_cap;
     const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
     constexpr bool packed = OFF32;
-    const uint32_t nbuckets = packed ? cap / 5u : cap >> 2;
+    // (first pass of a compact index: the host may ask for the quotient form of the table -- p.vs_shr, GBNNS_VS_ASM)
+    const uint32_t vs_shr = (packed && !BITMAP && !AUX) ? p.vs_shr : 0u;
+    const uint32_t nbuckets = vs_shr ? cap / 7u - kStashBuckets : (packed ? cap / 5u : cap >> 2);
     if constexpr (BITMAP) {
         // 16 bytes per lane and store (n / 8 bytes per query: 150 KB at n = 1.2 M); not unrolled: the unrolled form's address
         // registers were the kernel's register peak
@@ -2393,6 +2470,7 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
         for (uint32_t i = lane; i < n4; i += 64) b4[i] = make_uint4(0u, 0u, 0u, 0u);
         for (uint32_t i = (n4 << 2) + lane; i < p.bitmap_words; i += 64) bitmap[i] = 0u;
     }
+    else if (vs_shr) quotient_table_init(hash, nbuckets, lane);
     else if constexpr (packed) packed_table_init(hash, nbuckets, 0u, lane);
     else for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
     for (uint32_t i = lane; i < p.dstride; i += 64)
@@ -2430,6 +2508,7 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
         B.F.lo[0] = lane == 0 ? entry << 1 : B.F.lo[0];
         if (lane == 0) {
             if constexpr (BITMAP) bitmap[entry >> 5] = 1u << (entry & 31u);
+            else if (vs_shr) quotient_table_put_first(hash, nbuckets, entry, vs_shr);
             else if constexpr (packed) packed_table_put_first(hash, nbuckets, entry);
             else hash[4u * __umulhi(entry * 0x9E3779B1u, nbuckets)] = entry;
         }
@@ -2511,6 +2590,12 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                     fr = !(atomicOr(&bitmap[nb >> 5], bit) & bit);
                 }
                 mclaimed = __ballot(fr);
+            } else if (vs_shr) {
+                uint64_t movf;
+                mclaimed = visited_claim_mask_quotient(hash_lds, nbuckets, nb, mv & kSlotLanes, vs_shr, movf);
+                if (__builtin_expect(movf != 0, 0)) {
+                    if (!stash_claim(hash_lds, nbuckets, movf, nb, mclaimed, lane)) { status = 2; break; }
+                }
             } else if constexpr (packed) mclaimed = visited_claim_mask_packed(hash_lds, nbuckets, nb, mv & kSlotLanes);
             else mclaimed = visited_claim_mask(hash_lds, nbuckets, nb, mv & kSlotLanes);
             const uint64_t mfresh = kPair ? (mclaimed << 1) : mclaimed;
@@ -3129,7 +3214,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
             if (__builtin_expect(movf != 0, 0)) {  // a probe sequence ran out (quotient form): the stash takes the id
                 // (the two-pass instances are at their scalar-register budget -- tests/test_isa_contract.py -- and hand over)
                 if constexpr (WIDE) return false;
-                else if (!stash_claim(hash_lds, nbuckets, movf, nb, mclaimed, lane)) return false;
+                else if (!stash_claim(hash_lds, nbuckets, movf >> 1, nb, mclaimed, lane)) return false;  // (reported in the odd bits)
             }
             const uint64_t mfresh = mclaimed << 1;  // odd lanes hold the distances
             const uint32_t dk = __builtin_amdgcn_inverse_ballot_w64(mfresh) ? kd : 0xFFFFFFFFu;
@@ -3297,7 +3382,7 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
             if (__builtin_expect(movf != 0, 0)) {  // a probe sequence ran out (quotient form): the stash takes the id
                 // (the two-pass instances are at their scalar-register budget -- tests/test_isa_contract.py -- and hand over)
                 if constexpr (WIDE) return false;
-                else if (!stash_claim(hash_lds, nbuckets, movf, nb, mclaimed, lane)) return false;
+                else if (!stash_claim(hash_lds, nbuckets, movf >> 1, nb, mclaimed, lane)) return false;  // (reported in the odd bits)
             }
             const uint64_t mfresh = mclaimed << 1;  // odd lanes hold the distances
             const uint32_t dk = __builtin_amdgcn_inverse_ballot_w64(mfresh) ? kd : 0xFFFFFFFFu;
@@ -4308,7 +4393,11 @@ size_t walk_hash_bytes(uint32_t entries, int form) {
 uint32_t walk_hash_entries(size_t bytes, int form) {
     return form == 2 ? (uint32_t)(bytes / 16) * 7u : form == 1 ? (uint32_t)(bytes / 16) * 5u : ((uint32_t)(bytes / 4) & ~3u);
 }
-int walk_hash_form(const WalkParams& p, bool hot) { return hot && p.vs_shr ? 2 : (walk_uses_packed(p) ? 1 : 0); }
+int walk_hash_form(const WalkParams& p, bool) { return p.vs_shr ? 2 : (walk_uses_packed(p) ? 1 : 0); }  // (vs_shr is set only where the first-pass kernel reads it)
+// First-pass kernels that know the quotient form: the walk_hot* family and the generic two-list kernel of a compact index.
+bool walk_knows_quotient(const WalkParams& p, int metric) {
+    return walk_uses_hot(p, metric) || (walk_off32(p) && !walk_uses_lds_list(p) && p.ef > kHot2MaxEf && !p.aux_ell);
+}
 
 // Every LDS kernel packs its visited set when ids fit 24 bits (the register-list kernels: in their compact,
 // 32-bit-offset instantiations).
