@@ -1232,6 +1232,29 @@ def test_visited_set_forms_of_the_hot_kernels(g, orc, monkeypatch):
         ix.close()
 
 
+@pytest.mark.parametrize("n", [300, 4096, 4097, 8191, 65536, 65537, 131073])
+def test_quotient_form_id_range_edges(g, orc, n):
+    """The quotient form's hash is a bijection of [0, 2^W) with n <= 2^W: index sizes at and beside powers of two (W
+    changes, the remainder shift changes), a tiny index (more buckets than ids), 128-byte and 256-byte rows (the hot and
+    the generic two-list kernels), small and large beams -- walks equal to the oracle's."""
+    for si, (d, dlow) in enumerate(((40, 32), (96, 64))):
+        c, off, nbr, db_low, ent = _oracle_case(orc, 7600 + si + n % 97, n, 200, d, dlow, 48, deg=(2, 30))
+        q_low = orc.project(c.net, c.queries)
+        ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+        for ef in (12, 70, 150, 400):
+            w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, threads=8)
+            s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net, entries=ent, threads=8)
+            for rep in range(2):
+                r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"))
+                key = (n, dlow, ef, rep)
+                assert np.array_equal(r["cand"], w["ids"]), key
+                assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
+                assert np.array_equal(r["hops"], w["hops"]), key
+                assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
+                assert np.array_equal(r["ids"], s["ids"]), key
+        ix.close()
+
+
 def test_deferred_join_edge_cases(g, orc):
     """Batches in flight meet the rest of the API: an empty batch, profiling switched on in the middle (profiled calls run
     serialised), a projection / re-rank / auxiliary-graph change while deferred batches are unjoined, destroying a handle
