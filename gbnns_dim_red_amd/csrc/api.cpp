@@ -1041,14 +1041,14 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     const bool packed = walk_uses_packed(w);
     const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride, hot, walk_uses_lds_list(w));
     // The hot first pass may keep its visited set in the quotient form (kernels.hip, GBNNS_VS_ASM: seven 16-bit entries
-    // per bucket instead of five 24-bit ids): ids are told apart inside a home bucket by W - floor(log2 buckets) <= 12
-    // bits (n <= 2^W), so the table needs at least 2^(W-12) buckets.
+    // per bucket instead of five 24-bit ids): ids are told apart inside a home bucket by W - floor(log2 buckets) <= 13
+    // bits (n <= 2^W), so the table needs at least 2^(W-13) buckets.
     uint32_t idbits = 1;
     while (idbits < 32 && (1ull << idbits) < ix->n) ++idbits;
     const bool quotient_on = !(getenv("GBNNS_QUOTIENT") && atoi(getenv("GBNNS_QUOTIENT")) == 0);  // tuning / A-B runs, tests
     const bool vs_ok = walk_knows_quotient(w, ix->metric);
     constexpr uint32_t kStashBuckets = 4;  // (kernels.hip: the table's last four "buckets" are the stash)
-    const uint32_t quotient_min = 7u * ((idbits > 12 ? 1u << (idbits - 12) : 1u) + kStashBuckets + 8u);  // entries (>= 8 real buckets: probe steps of up to 8)
+    const uint32_t quotient_min = 7u * ((idbits > 13 ? 1u << (idbits - 13) : 1u) + kStashBuckets + 8u);  // entries (>= 8 real buckets: probe steps of up to 8)
     uint32_t cap;
     int form = packed ? 1 : 0;
     const bool auto_cap = a->hash_capacity == 0;
@@ -1107,13 +1107,15 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         uint32_t lg = 0;
         while ((2u << lg) <= buckets) ++lg;  // floor(log2 buckets)
         lg = std::min(lg, idbits - 1u);      // (more buckets than ids: a smaller shift only keeps more bits)
-        if (buckets == 0 || idbits > lg + 12) {
+        if (buckets == 0 || idbits > lg + 13) {
             form = packed ? 1 : 0;  // (an explicit capacity too small for the form)
             cap = walk_hash_entries(walk_hash_bytes(cap, form), form);
         } else {
             // (tests: GBNNS_DEBUG_VS_DISP=<1..15> makes probe sequences give up that early, to exercise the hand-over)
             const uint32_t disp = getenv("GBNNS_DEBUG_VS_DISP") ? (uint32_t)std::min(15, std::max(1, atoi(getenv("GBNNS_DEBUG_VS_DISP")))) : 15u;
-            w.vs_shr = (32u - idbits + lg) | (32u - idbits) << 8 | disp << 28;
+            // twelve remainder bits and a 4-bit probe number when the table has 2^(W-12) buckets, else thirteen and 3 bits
+            const bool r13 = idbits > lg + 12;
+            w.vs_shr = (32u - idbits + lg) | (32u - idbits) << 8 | (r13 ? 1u << 16 | std::min(disp, 7u) << 29 : disp << 28);
         }
     }
     w.hash_cap = cap;

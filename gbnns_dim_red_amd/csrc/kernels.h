@@ -75,9 +75,9 @@ struct WalkParams {
     uint32_t hops_bound;
     int32_t llf;
     // visited-set form of the walk_hot* first pass: vs_shr == 0 -> five 24-bit ids per 16-byte bucket; else the quotient
-    // form (seven 16-bit entries per bucket; n <= 2^W): vs_shr = (32 - W + floor(log2 buckets)) | (32 - W) << 8 | 15 << 28
-    // (top four bits: a probe sequence gives up -- hand-over -- when its displacement from the home bucket reaches that
-    // many buckets; less than 15 in test runs)
+    // form (seven 16-bit entries per bucket; n <= 2^W): vs_shr = (32 - W + floor(log2 buckets)) | (32 - W) << 8 |
+    // (13 remainder bits ? 1 << 16 : 0) | limit << 28 (top four bits: a probe sequence gives up -- stash, hand-over -- when
+    // its probe number reaches 15, or 7 << 1 with 13 remainder bits; less in test runs)
     uint32_t vs_shr;
     const uint32_t* order;   // optional [nq]: work item b of a first pass runs query order[b] (a permutation: locality order of a deep batch)
     int32_t force_wide;      // diagnostic: treat the index as a large one (64-bit offsets, 4-byte visited-set slots)

@@ -402,7 +402,9 @@ __device__ __forceinline__ uint64_t visited_claim_mask_quotient(uint32_t lds_bas
         "v_and_b32 %[t0], 7, %[t2]\n\t"
         "v_lshl_add_u32 %[t0], %[t0], 4, 16\n\t"
         "v_add_u32 %[addr], %[addr], %[t0]\n\t"
-        "v_add_u32 %[t2], 0x10001000, %[t2]\n\t"
+        "s_bfe_u32 vcc_lo, %[shr], 0x10010\n\t"
+        "s_lshl_b32 vcc_lo, 0x10001000, vcc_lo\n\t"
+        "v_add_u32 %[t2], vcc_lo, %[t2]\n\t"
         "v_cmp_le_u32 vcc, %[end], %[addr]\n\t"
         "v_subrev_u32 %[t0], %[mulc], %[addr]\n\t"
         "v_cndmask_b32 %[addr], %[addr], %[t0], vcc\n\t"
@@ -2783,8 +2785,8 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
 // add on that counter returns (unique per lane, so no compare-and-swap and no retry inside a bucket) and writes its
 // three bytes.  3.2 bytes per id.
 //
-// Quotient form (%[shr] != 0: shift count in its low five bits, 32 - W in bits 8 .. 12, displacement limit -- 15 -- in
-// its top four; n <= 2^W): H = id * (0x9E3779B1 << (32 - W)) is a
+// Quotient form (%[shr] != 0: shift count in its low five bits, 32 - W in bits 8 .. 12, bit 16 = thirteen remainder
+// bits instead of twelve, displacement limit -- 15 -- in its top four; n <= 2^W): H = id * (0x9E3779B1 << (32 - W)) is a
 // bijection of the ids onto the multiples of 2^(32-W); the home bucket is mulhi(H, buckets) and the low word of that
 // product, shifted right by 32 - W + floor(log2 buckets), tells the ids of one home bucket apart in
 // W - floor(log2 buckets) <= 12 bits (the host checks).  A bucket holds seven 16-bit entries -- displacement from the
@@ -2793,8 +2795,9 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
 // 2.29 bytes per id and nine instead of fifteen instructions per bucket test.  The "displacement" is the probe number:
 // probe j + 1 looks 1 .. 8 buckets (by the key's low three bits) beyond probe j, so ids of neighbouring home buckets
 // do not queue up behind one run of full buckets (with steps of one bucket a 10 000-query batch at ef = 140 handed a
-// few queries over every time).  A probe sequence longer than fifteen buckets gives up: the lane is reported and the
-// query is handed over to the retry pass.
+// few queries over every time).  A probe sequence longer than fifteen buckets gives up: the lane is reported and its id
+// goes to the stash (stash_claim).  Tables of 2^(W-13) .. 2^(W-12) buckets keep thirteen remainder bits and a 3-bit
+// probe number (seven probes; bit 16 of %[shr]).
 #define GBNNS_VS_ASM                                                                                                   \
         "s_bfe_u32 %[mulc], %[shr], 0x50008\n\t"               /* 32 - W (0 in the packed form) */                     \
         "s_lshl_b32 %[mulc], 0x9E3779B1, %[mulc]\n\t"                                                                  \
@@ -2893,7 +2896,9 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
         "v_and_b32 %[t0], 7, %[t2]\n\t"                        /* next probe: 1 .. 8 buckets on, by the key's low bits */ \
         "v_lshl_add_u32 %[t0], %[t0], 4, 16\n\t"               /* (no runs of full buckets shared by neighbouring homes) */ \
         "v_add_u32 %[addr], %[addr], %[t0]\n\t"                                                                        \
-        "v_add_u32 %[t2], 0x10001000, %[t2]\n\t"               /* one probe further from home */                       \
+        "s_bfe_u32 vcc_lo, %[shr], 0x10010\n\t"                /* 13 remainder bits: the probe number sits one bit higher */ \
+        "s_lshl_b32 vcc_lo, 0x10001000, vcc_lo\n\t"                                                                    \
+        "v_add_u32 %[t2], vcc_lo, %[t2]\n\t"                   /* one probe further from home */                       \
         "v_cmp_le_u32 vcc, %[end], %[addr]\n\t"                                                                        \
         "v_subrev_u32 %[t0], %[mulc], %[addr]\n\t"             /* (%[mulc] holds the table's bytes by now) */          \
         "v_cndmask_b32 %[addr], %[addr], %[t0], vcc\n\t"                                                               \

@@ -1244,9 +1244,11 @@ def test_quotient_form_id_range_edges(g, orc, n):
         for ef in (12, 70, 150, 400):
             w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, threads=8)
             s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net, entries=ent, threads=8)
-            for rep in range(2):
-                r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"))
-                key = (n, dlow, ef, rep)
+            # (explicit small capacities at the smallest beam: tables of fewer than 2^(W-12) buckets keep thirteen
+            # remainder bits and a 3-bit probe number; walks that outgrow them are handed over)
+            for rep, cap in enumerate((0, 0) + ((200, 300, 700) if ef == 12 else ())):
+                r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), hash_capacity=cap)
+                key = (n, dlow, ef, rep, cap)
                 assert np.array_equal(r["cand"], w["ids"]), key
                 assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
                 assert np.array_equal(r["hops"], w["hops"]), key
