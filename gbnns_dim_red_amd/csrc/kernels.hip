@@ -2100,8 +2100,11 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
     // OFF32 instantiations serve "compact" indexes (tables < 4 GiB and n < 2^24, walk_off32): 32-bit byte
     // offsets and the packed visited set (24-bit ids, five per 16-byte bucket)
     constexpr bool packed = OFF32;
-    const uint32_t nbuckets = packed ? cap / 5u : cap >> 2;
+    // (first pass of a compact index: the host may ask for the quotient form of the table -- p.vs_shr, GBNNS_VS_ASM)
+    const uint32_t vs_shr = (packed && !BITMAP && !AUX) ? p.vs_shr : 0u;
+    const uint32_t nbuckets = vs_shr ? cap / 7u - kStashBuckets : (packed ? cap / 5u : cap >> 2);
     if constexpr (BITMAP) { for (uint32_t i = lane; i < p.bitmap_words; i += 64) bitmap[i] = 0u; }
+    else if (vs_shr) quotient_table_init(hash, nbuckets, lane);
     else if constexpr (packed) packed_table_init(hash, nbuckets, 0u, lane);
     else for (uint32_t i = lane; i < cap; i += 64) hash[i] = kInvalidId;
     for (uint32_t i = lane; i < p.dstride; i += 64)
@@ -2129,6 +2132,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             L.hi[0] = worst;
             L.lo[0] = entry << 1;
             if constexpr (BITMAP) bitmap[entry >> 5] = 1u << (entry & 31u);
+            else if (vs_shr) quotient_table_put_first(hash, nbuckets, entry, vs_shr);
             else if constexpr (packed) packed_table_put_first(hash, nbuckets, entry);
             else hash[4u * __umulhi(entry * 0x9E3779B1u, nbuckets)] = entry;  // first slot of its bucket
         }
@@ -2319,6 +2323,12 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                     fr = !(atomicOr(&bitmap[nb >> 5], bit) & bit);
                 }
                 mclaimed = __ballot(fr);
+            } else if (vs_shr) {
+                uint64_t movf;
+                mclaimed = visited_claim_mask_quotient(hash_lds, nbuckets, nb, mv & kSlotLanes, vs_shr, movf);
+                if (__builtin_expect(movf != 0, 0)) {
+                    if (!stash_claim(hash_lds, nbuckets, movf, nb, mclaimed, lane)) { status = 2; break; }
+                }
             } else if constexpr (packed) mclaimed = visited_claim_mask_packed(hash_lds, nbuckets, nb, mv & kSlotLanes);
             else mclaimed = visited_claim_mask(hash_lds, nbuckets, nb, mv & kSlotLanes);
             const uint64_t mfresh = kPair ? (mclaimed << 1) : mclaimed;
@@ -4399,9 +4409,9 @@ uint32_t walk_hash_entries(size_t bytes, int form) {
     return form == 2 ? (uint32_t)(bytes / 16) * 7u : form == 1 ? (uint32_t)(bytes / 16) * 5u : ((uint32_t)(bytes / 4) & ~3u);
 }
 int walk_hash_form(const WalkParams& p, bool) { return p.vs_shr ? 2 : (walk_uses_packed(p) ? 1 : 0); }  // (vs_shr is set only where the first-pass kernel reads it)
-// First-pass kernels that know the quotient form: the walk_hot* family and the generic two-list kernel of a compact index.
+// First-pass kernels that know the quotient form: the walk_hot* family and the generic register-list / two-list kernels of a compact index.
 bool walk_knows_quotient(const WalkParams& p, int metric) {
-    return walk_uses_hot(p, metric) || (walk_off32(p) && !walk_uses_lds_list(p) && p.ef > kHot2MaxEf && !p.aux_ell);
+    return walk_uses_hot(p, metric) || (walk_off32(p) && !walk_uses_lds_list(p) && !p.aux_ell);
 }
 
 // Every LDS kernel packs its visited set when ids fit 24 bits (the register-list kernels: in their compact,
