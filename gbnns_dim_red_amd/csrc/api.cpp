@@ -816,8 +816,9 @@ int ensure_lane(gbnns_index* ix, int i) {
 
 // How one call is laid out over the handle's lanes (workspace + internal stream each).
 //   * default: lane 0 in the caller's stream -- kernels back to back.
-//   * DEVICE buffers + GBNNS_FLAG_DEFER_JOIN: the whole batch on the next of two lanes, consecutive calls alternating,
-//     so that the projection of batch i+1 runs in the half-empty tail of batch i's walk kernel.
+//   * GBNNS_FLAG_DEFER_JOIN (DEVICE buffers, or HOST buffers that are all page-locked): the whole batch on the next of
+//     `defer_depth` lanes, consecutive calls rotating, so that the projection (and, for HOST buffers, the copy-in) of
+//     batch i+1 runs in the half-empty tail of batch i's walk kernel.
 // Measured and NOT done (profiles/r03_split_timelines.txt): cutting one batch into sub-batches on two streams.  A walk
 // kernel of 2 500 queries lasts 0.14 ms -- the latency chain of its longest walk -- where 10 000 queries take 0.33 ms,
 // and the projection blocks of the next piece (4 wavefronts, 14 KB of LDS) are not scheduled while a walk kernel still

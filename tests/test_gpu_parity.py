@@ -455,7 +455,7 @@ def test_deferred_join_pipeline(g, orc):
     copy = r["ids"].clone()          # torch's current stream = the stream of the call
     torch.cuda.synchronize()
     assert np.array_equal(copy.cpu().numpy(), outs[0]["ids"].cpu().numpy())
-    # host buffers and profiling ignore the flag (plain call)
+    # pageable host buffers and profiling ignore the flag (plain call)
     rh = ix.search(c.queries[:1000], 64, entry_ids=ent[:1000], want=(), flags=g.FLAG_DEFER_JOIN)
     assert np.array_equal(rh["ids"].view(np.uint32), outs[0]["ids"].cpu().numpy().view(np.uint32))
     ix.close()
