@@ -519,6 +519,15 @@ def main():
         refs = [ix.search(b, ef, want=())["ids"].cpu() for b in batches]   # the last `hsets` batches are still in their buffers
         result["host_batches_in_flight_ids_identical"] = all(
             bool((houts[j % hsets]["ids"] == refs[j % len(hq)]).all().item()) for j in range(reps - hsets, reps))
+        # ... the same synchronous call on page-locked buffers with the per-query counters asked for too: what the C++
+        # drop-in's perform*Test functions do since round 3 (they pin their vectors before the timed region, gbnns_host_pin)
+        qpin = batches[0].cpu().pin_memory()
+        opin = {}
+        ix.search(qpin, ef, want=("hops", "dist_calc", "edges"), out=opin)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            ix.search(qpin, ef, want=("hops", "dist_calc", "edges"), out=opin)
+        result["host_buffers_pinned_qps"] = round(5 * nq_rank / (time.perf_counter() - t1), 1)
 
     # ---- CPU baseline (rank 0, N = 1 only): the compiled reference if present, else the port ----
     if world == 1 and not args.no_cpu_baseline:

@@ -24,7 +24,7 @@ FLAG_DEFER_JOIN = 128
 
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "gbnns_index_create", "gbnns_index_destroy", "gbnns_index_set_aux_graph", "gbnns_search_ex", "gbnns_search_batch", "gbnns_index_join", "gbnns_index_wait",
+    "gbnns_index_create", "gbnns_index_destroy", "gbnns_index_set_aux_graph", "gbnns_search_ex", "gbnns_search_batch", "gbnns_index_join", "gbnns_index_wait", "gbnns_host_pin", "gbnns_host_unpin",
     "gbnns_project", "gbnns_rerank", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd", "gbnns_build_graph_gd_device",
     "gbnns_free", "gbnns_exact_knn", "gbnns_device_count", "gbnns_version", "gbnns_last_error",
     "gbnns_index_n", "gbnns_index_d", "gbnns_index_d_low", "gbnns_index_device",
@@ -100,6 +100,8 @@ def load_library():
     lib.gbnns_search_ex.argtypes = [C.c_void_p, C.POINTER(_SearchArgs)]
     lib.gbnns_index_join.argtypes = [C.c_void_p]
     lib.gbnns_index_wait.argtypes = [C.c_void_p, C.c_uint32]
+    lib.gbnns_host_pin.argtypes = [C.c_void_p, C.c_size_t]
+    lib.gbnns_host_unpin.argtypes = [C.c_void_p]
     lib.gbnns_search_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gbnns_project.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int,

@@ -977,9 +977,14 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     w.cand_stride = cstride;
     w.zero_dist_bits = ix->metric == GBNNS_METRIC_NEG_DOT ? 0x80000000u : 0u;
     w.count = L.cnt.as<int32_t>();
-    w.hops = (!host && a->out_hops) ? a->out_hops : L.hops.as<int32_t>();
-    w.dist_calc = (!host && a->out_dist_calc) ? a->out_dist_calc : L.dc.as<int32_t>();
-    w.edges = a->out_edges ? (host ? L.edges.as<int32_t>() : a->out_edges) : nullptr;
+    // (per-query counters into page-locked HOST memory are stored there directly, like the ids: written once per
+    // query by the kernel that finishes it)
+    int32_t* const hops_alias = host ? pinned_alias(a->out_hops) : nullptr;
+    int32_t* const dc_alias = host ? pinned_alias(a->out_dist_calc) : nullptr;
+    int32_t* const edges_alias = host ? pinned_alias(a->out_edges) : nullptr;
+    w.hops = host ? (hops_alias ? hops_alias : L.hops.as<int32_t>()) : (a->out_hops ? a->out_hops : L.hops.as<int32_t>());
+    w.dist_calc = host ? (dc_alias ? dc_alias : L.dc.as<int32_t>()) : (a->out_dist_calc ? a->out_dist_calc : L.dc.as<int32_t>());
+    w.edges = a->out_edges ? (host ? (edges_alias ? edges_alias : L.edges.as<int32_t>()) : a->out_edges) : nullptr;
     uint32_t* out_dev = host ? (ids_alias ? ids_alias : L.out.as<uint32_t>()) : a->out_ids;
     w.best = plain ? out_dev : nullptr;
     // Control words, two per-call blocks used alternately: [0] list A count, [1] general cursor,
@@ -1254,10 +1259,10 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     // ---- outputs ----------------------------------------------------------------------
     if (host) {
         if (!ids_alias) HIP_TRY(hipMemcpyAsync(a->out_ids, out_dev, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-        if (a->out_hops) HIP_TRY(hipMemcpyAsync(a->out_hops, w.hops, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-        if (a->out_dist_calc)
+        if (a->out_hops && !hops_alias) HIP_TRY(hipMemcpyAsync(a->out_hops, w.hops, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        if (a->out_dist_calc && !dc_alias)
             HIP_TRY(hipMemcpyAsync(a->out_dist_calc, w.dist_calc, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-        if (a->out_edges) HIP_TRY(hipMemcpyAsync(a->out_edges, w.edges, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        if (a->out_edges && !edges_alias) HIP_TRY(hipMemcpyAsync(a->out_edges, w.edges, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
         if (a->out_cand)
             HIP_TRY(hipMemcpyAsync(a->out_cand, w.cand, (size_t)nq * cstride * 4, hipMemcpyDeviceToHost, s));
         if (a->out_cand_dist)
@@ -1373,6 +1378,19 @@ int gbnns_index_join(gbnns_index* ix) {
     if (!ix) return fail(GBNNS_ERR_INVALID, "null index");
     HIP_TRY(hipSetDevice(ix->device));
     return flush_join(ix);
+}
+
+int gbnns_host_pin(void* ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return fail(GBNNS_ERR_INVALID, "gbnns_host_pin: empty buffer");
+    if (pinned_alias(static_cast<char*>(ptr))) return GBNNS_OK;  // already page-locked (by the caller or an earlier call)
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return GBNNS_OK;
+}
+
+int gbnns_host_unpin(void* ptr) {
+    if (!ptr) return GBNNS_OK;
+    if (hipHostUnregister(ptr) != hipSuccess) (void)hipGetLastError();  // (not registered by gbnns_host_pin: nothing to undo)
+    return GBNNS_OK;
 }
 
 int gbnns_search_batch(gbnns_index* index, const float* queries, size_t n_q, int ef,

@@ -233,6 +233,19 @@ inline vector<uint32_t> gbnnsEntries(const vector<vector<uint32_t>>& inter_point
 
 // One batch on the device.  mode NET / LOWQ: two-stage with ef = recheck_size;
 // mode PLAIN: walk in the space of the index's `db` with (ef, k), answer = top of the heap trimmed to k (:174-181).
+// Page-locks a host buffer for the guard's lifetime (gbnns_host_pin): the buffers the timed device calls read and
+// write.  Set up before the StopW region, where the reference builds its VisitedListPool (:333); a buffer that cannot
+// be pinned is simply used as it is.
+struct GbnnsPin {
+    void* p;
+    GbnnsPin(const void* ptr, size_t bytes) : p(const_cast<void*>(ptr)) {
+        if (!p || bytes == 0 || gbnns_host_pin(p, bytes) != GBNNS_OK) p = nullptr;
+    }
+    ~GbnnsPin() { if (p) gbnns_host_unpin(p); }
+    GbnnsPin(const GbnnsPin&) = delete;
+    GbnnsPin& operator=(const GbnnsPin&) = delete;
+};
+
 inline void gbnnsBatch(gbnns_index* ix, int mode, const float* queries, const float* queries_low,
                        size_t n_q, int ef, int k, const vector<uint32_t>& entries, vector<uint32_t>& ans,
                        vector<int32_t>& hops, vector<int32_t>& dist_calc, const GbnnsAux& aux, uint32_t n_entries = 1,
@@ -430,9 +443,13 @@ void performTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>>& 
     int num_exp = 0;
     vector<int32_t> q_hops(n_q), q_dc(n_q), q_edges(n_q);
     long long walk_dc = 0, edges = 0;
+    vector<uint32_t> ans(n_q);
+    const GbnnsPin pin_q(q_main, (size_t)n_q * (mode == GBNNS_MODE_LOWQ || d == d_low ? d : d_low) * sizeof(float)),
+        pin_ql(q_low, (size_t)n_q * d_low * sizeof(float)), pin_e(entries.data(), entries.size() * sizeof(uint32_t)),
+        pin_a(ans.data(), ans.size() * 4), pin_h(q_hops.data(), q_hops.size() * 4), pin_d(q_dc.data(), q_dc.size() * 4),
+        pin_g(q_edges.data(), q_edges.size() * 4);
     for (int v = 0; v < number_exper; ++v) {
         num_exp += 1;
-        vector<uint32_t> ans(n_q);
         StopW stopw = StopW();
         gbnnsBatch(ix, mode, q_main, q_low, n_q, run_ef, run_k, entries, ans, q_hops, q_dc, aux, n_entries, &q_edges);
         work_time += stopw.getElapsedTimeMicro();
@@ -543,15 +560,18 @@ void performNetTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>
     vector<int32_t> q_hops(n_q), q_dc(n_q), q_edges(n_q);
     long long walk_dc = 0, edges = 0;
     vector<float> q_low;
+    if (low_only) q_low.resize((size_t)n_q * d_low);
+    vector<uint32_t> ans(n_q);
+    const GbnnsPin pin_q(queries.data(), queries.size() * sizeof(float)), pin_ql(q_low.data(), q_low.size() * sizeof(float)),
+        pin_e(entries.data(), entries.size() * sizeof(uint32_t)), pin_a(ans.data(), ans.size() * 4),
+        pin_h(q_hops.data(), q_hops.size() * 4), pin_d(q_dc.data(), q_dc.size() * 4), pin_g(q_edges.data(), q_edges.size() * 4);
     for (int v = 0; v < number_exper; ++v) {
         num_exp += 1;
-        vector<uint32_t> ans(n_q);
         StopW stopw = StopW();
         if (two_stage) {
             gbnnsBatch(ix, GBNNS_MODE_NET, queries.data(), nullptr, n_q, recheck_size, recheck_size, entries, ans,
                        q_hops, q_dc, aux, n_entries, &q_edges);
         } else if (low_only) {
-            q_low.resize((size_t)n_q * d_low);
             if (gbnns_project(ix, queries.data(), n_q, q_low.data(), GBNNS_MEM_HOST, nullptr)) gbnnsDie("gbnns_project");
             gbnnsBatch(ix_low, GBNNS_MODE_PLAIN, q_low.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux, n_entries,
                        &q_edges);

@@ -209,6 +209,15 @@ int gbnns_index_join(gbnns_index* index);
  * run of the timed loop of search_function.h:346-387 over its own batch. */
 int gbnns_index_wait(gbnns_index* index, uint32_t keep);
 
+/* Page-locks (hipHostRegister) / releases a host buffer, for callers that do not link the HIP runtime themselves: HOST
+ * buffers that are page-locked are copied in by DMA without a staging pass, take ids, hop counts, dist_calc and edge
+ * counts straight from the kernels (no copies out), and may be used with GBNNS_FLAG_DEFER_JOIN.  The drop-in's
+ * perform*Test functions pin the query / answer vectors before their timed region (the reference builds its
+ * VisitedListPool there, search_function.h:333) and release them after it.  Pinning an already page-locked buffer
+ * and releasing one that was not pinned here are no-ops. */
+int gbnns_host_pin(void* ptr, size_t bytes);
+int gbnns_host_unpin(void* ptr);
+
 /* Convenience form of the above: NET mode, host buffers, synchronous. */
 int gbnns_search_batch(gbnns_index* index, const float* queries, size_t n_q, int ef,
                        const uint32_t* entry_ids, uint32_t* out_ids, int32_t* out_hops,
