@@ -508,8 +508,11 @@ def main():
                 ix.wait(hsets - 1)
             ix.wait(0)
 
-        host_stream(24)  # (the first copy out of each page-locked buffer costs the runtime ~6 ms, once)
-        reps = 96
+        # (the runtime spends 5-7 ms inside the first hipMemcpyAsync out of each page-locked buffer, and now and then
+        # inside a later one -- GBNNS_SLOW_US shows them as lone slow calls; a window of 96 batches read 24 or 28 M
+        # queries/s depending on whether it caught one: the window is long enough for one to cost ~4 %)
+        host_stream(24)
+        reps = 480
         t1 = time.perf_counter()
         host_stream(reps)
         result["host_batches_in_flight_qps"] = round(reps * nq_rank / (time.perf_counter() - t1), 1)

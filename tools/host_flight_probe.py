@@ -8,6 +8,25 @@ import torch
 import gbnns_dim_red_amd as g
 from gbnns_dim_red_amd import synth
 
+def bind_to_gpu_node(which):
+    """Restricts this process to the CPUs of the GPU's NUMA node ("local") or of another node ("remote"): page-locked
+    buffers allocated afterwards come from that node's memory (first touch)."""
+    p = torch.cuda.get_device_properties(0)
+    bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+    nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
+    if which == "remote":
+        node = [x for x in nodes if x != node][0]
+    cpus = set()
+    for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    os.sched_setaffinity(0, cpus & os.sched_getaffinity(0))
+    print("bound to NUMA node", node, "(GPU", bdf, ")", flush=True)
+
+
+if os.environ.get("GBNNS_PROBE_NODE"):
+    bind_to_gpu_node(os.environ["GBNNS_PROBE_NODE"])
 depth = int(sys.argv[1])
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 g.load_library()
