@@ -2820,24 +2820,24 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
         "v_lshl_add_u32 %[addr], %[t1], 4, %[basev]\n\t"                                                               \
         "s_cbranch_scc1 4f\n"                                                                                          \
         "1:\n\t"                                                                                                       \
-        "ds_read_b128 v[68:71], %[addr]\n\t"                                                                           \
+        "ds_read_b128 v[60:63], %[addr]\n\t"                                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-        "v_bfe_u32 v64, v68, 0, 24\n\t"                        /* slot 0 */                                            \
-        "v_alignbit_b32 v65, v69, v68, 24\n\t"                 /* slot 1 (bits 24..47) in the low 24 bits */           \
-        "v_alignbit_b32 v66, v70, v69, 16\n\t"                 /* slot 2 (bits 48..71) */                              \
-        "v_lshrrev_b32 v67, 8, v70\n\t"                        /* slot 3 (bits 72..95) */                              \
-        "v_bfe_u32 %[t1], v71, 0, 24\n\t"                      /* slot 4 (bits 96..119) */                             \
-        "v_bfe_u32 v65, v65, 0, 24\n\t"                                                                                \
-        "v_bfe_u32 v66, v66, 0, 24\n\t"                                                                                \
-        "v_xor_b32 v64, v64, %[id]\n\t"                                                                                \
-        "v_xor_b32 v65, v65, %[id]\n\t"                                                                                \
-        "v_xor_b32 v66, v66, %[id]\n\t"                                                                                \
-        "v_xor_b32 v67, v67, %[id]\n\t"                                                                                \
+        "v_bfe_u32 v56, v60, 0, 24\n\t"                        /* slot 0 */                                            \
+        "v_alignbit_b32 v57, v61, v60, 24\n\t"                 /* slot 1 (bits 24..47) in the low 24 bits */           \
+        "v_alignbit_b32 v58, v62, v61, 16\n\t"                 /* slot 2 (bits 48..71) */                              \
+        "v_lshrrev_b32 v59, 8, v62\n\t"                        /* slot 3 (bits 72..95) */                              \
+        "v_bfe_u32 %[t1], v63, 0, 24\n\t"                      /* slot 4 (bits 96..119) */                             \
+        "v_bfe_u32 v57, v57, 0, 24\n\t"                                                                                \
+        "v_bfe_u32 v58, v58, 0, 24\n\t"                                                                                \
+        "v_xor_b32 v56, v56, %[id]\n\t"                                                                                \
+        "v_xor_b32 v57, v57, %[id]\n\t"                                                                                \
+        "v_xor_b32 v58, v58, %[id]\n\t"                                                                                \
+        "v_xor_b32 v59, v59, %[id]\n\t"                                                                                \
         "v_xor_b32 %[t1], %[t1], %[id]\n\t"                                                                            \
-        "v_min3_u32 v64, v64, v65, v66\n\t"                                                                            \
-        "v_min3_u32 v64, v64, v67, %[t1]\n\t"                  /* 0 <=> id is in the bucket */                         \
-        "v_lshrrev_b32 %[t1], 24, v71\n\t"                     /* slots handed out */                                  \
-        "v_cmp_ne_u32 vcc, 0, v64\n\t"                                                                                 \
+        "v_min3_u32 v56, v56, v57, v58\n\t"                                                                            \
+        "v_min3_u32 v56, v56, v59, %[t1]\n\t"                  /* 0 <=> id is in the bucket */                         \
+        "v_lshrrev_b32 %[t1], 24, v63\n\t"                     /* slots handed out */                                  \
+        "v_cmp_ne_u32 vcc, 0, v56\n\t"                                                                                 \
         "s_and_b64 exec, exec, vcc\n\t"                        /* lanes that found their id are done */                \
         "s_cbranch_execz 9f\n\t"                                                                                       \
         "s_mov_b64 %[act], exec\n\t"                                                                                   \
@@ -2871,18 +2871,18 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
         "v_lshrrev_b32 %[t0], %[shr], %[t0]\n\t"               /* < 2^12 */                                            \
         "v_lshl_or_b32 %[t2], %[t0], 16, %[t0]\n"              /* the key in both halves, displacement 0 */            \
         "5:\n\t"                                                                                                       \
-        "ds_read_b128 v[68:71], %[addr]\n\t"                                                                           \
+        "ds_read_b128 v[60:63], %[addr]\n\t"                                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-        "v_xor_b32 v64, v68, %[t2]\n\t"                                                                                \
-        "v_xor_b32 v65, v69, %[t2]\n\t"                                                                                \
-        "v_xor_b32 v66, v70, %[t2]\n\t"                                                                                \
-        "v_xor_b32 v67, v71, %[t2]\n\t"                                                                                \
-        "v_pk_min_u16 v64, v64, v65\n\t"                                                                               \
-        "v_pk_min_u16 v66, v66, v67\n\t"                                                                               \
-        "v_bfe_u32 %[t1], v71, 16, 12\n\t"                     /* slots handed out */                                  \
-        "v_pk_min_u16 v64, v64, v66\n\t"                                                                               \
-        "v_mad_u32_u16 v64, v64, v64, 0 op_sel:[0,1,0,0]\n\t"  /* low half x high half: 0 <=> the key is in the bucket */ \
-        "v_cmp_ne_u32 vcc, 0, v64\n\t"                                                                                 \
+        "v_xor_b32 v56, v60, %[t2]\n\t"                                                                                \
+        "v_xor_b32 v57, v61, %[t2]\n\t"                                                                                \
+        "v_xor_b32 v58, v62, %[t2]\n\t"                                                                                \
+        "v_xor_b32 v59, v63, %[t2]\n\t"                                                                                \
+        "v_pk_min_u16 v56, v56, v57\n\t"                                                                               \
+        "v_pk_min_u16 v58, v58, v59\n\t"                                                                               \
+        "v_bfe_u32 %[t1], v63, 16, 12\n\t"                     /* slots handed out */                                  \
+        "v_pk_min_u16 v56, v56, v58\n\t"                                                                               \
+        "v_mad_u32_u16 v56, v56, v56, 0 op_sel:[0,1,0,0]\n\t"  /* low half x high half: 0 <=> the key is in the bucket */ \
+        "v_cmp_ne_u32 vcc, 0, v56\n\t"                                                                                 \
         "s_and_b64 exec, exec, vcc\n\t"                                                                                \
         "s_cbranch_execz 9f\n\t"                                                                                       \
         "s_mov_b64 %[act], exec\n\t"                                                                                   \
@@ -2939,102 +2939,102 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[valid]\n\t"
-        "global_load_dwordx4 v[48:51], %[roff], %[db]\n\t"
-        "global_load_dwordx4 v[52:55], %[roff], %[db] offset:16\n\t"
-        "global_load_dwordx4 v[56:59], %[roff], %[db] offset:32\n\t"
-        "global_load_dwordx4 v[60:63], %[roff], %[db] offset:48\n\t"
+        "global_load_dwordx4 v[40:43], %[roff], %[db]\n\t"
+        "global_load_dwordx4 v[44:47], %[roff], %[db] offset:16\n\t"
+        "global_load_dwordx4 v[48:51], %[roff], %[db] offset:32\n\t"
+        "global_load_dwordx4 v[52:55], %[roff], %[db] offset:48\n\t"
         GBNNS_VS_ASM
         // ---- pair distance (l2_pair_from_regs), all lanes
         "s_waitcnt vmcnt(3)\n\t"                               // loads return in order: square each step as it lands
-        "v_pk_add_f32 v[48:49], v[48:49], %[qa0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[50:51], v[50:51], %[qb0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[40:41], v[40:41], %[qa0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[42:43], v[42:43], %[qb0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 v[40:41], v[40:41], v[40:41]\n\t"
+        "v_pk_mul_f32 v[42:43], v[42:43], v[42:43]\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "v_pk_add_f32 v[44:45], v[44:45], %[qa1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[46:47], v[46:47], %[qb1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_mul_f32 v[44:45], v[44:45], v[44:45]\n\t"
+        "v_pk_mul_f32 v[46:47], v[46:47], v[46:47]\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        "v_pk_add_f32 v[48:49], v[48:49], %[qa2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[50:51], v[50:51], %[qb2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_mul_f32 v[48:49], v[48:49], v[48:49]\n\t"
         "v_pk_mul_f32 v[50:51], v[50:51], v[50:51]\n\t"
-        "s_waitcnt vmcnt(2)\n\t"
-        "v_pk_add_f32 v[52:53], v[52:53], %[qa1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[54:55], v[54:55], %[qb1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_pk_add_f32 v[52:53], v[52:53], %[qa3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 v[54:55], v[54:55], %[qb3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
         "v_pk_mul_f32 v[52:53], v[52:53], v[52:53]\n\t"
         "v_pk_mul_f32 v[54:55], v[54:55], v[54:55]\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        "v_pk_add_f32 v[56:57], v[56:57], %[qa2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[58:59], v[58:59], %[qb2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_mul_f32 v[56:57], v[56:57], v[56:57]\n\t"
-        "v_pk_mul_f32 v[58:59], v[58:59], v[58:59]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_pk_add_f32 v[60:61], v[60:61], %[qa3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[62:63], v[62:63], %[qb3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_mul_f32 v[60:61], v[60:61], v[60:61]\n\t"
-        "v_pk_mul_f32 v[62:63], v[62:63], v[62:63]\n\t"
-        "v_pk_add_f32 v[68:69], v[48:49], v[52:53]\n\t"      // even lane: steps 0..3
-        "v_pk_add_f32 v[70:71], v[50:51], v[54:55]\n\t"
-        "v_pk_add_f32 v[68:69], v[68:69], v[56:57]\n\t"
-        "v_pk_add_f32 v[70:71], v[70:71], v[58:59]\n\t"
-        "v_pk_add_f32 v[68:69], v[68:69], v[60:61]\n\t"
-        "v_pk_add_f32 v[70:71], v[70:71], v[62:63]\n\t"
+        "v_pk_add_f32 v[60:61], v[40:41], v[44:45]\n\t"      // even lane: steps 0..3
+        "v_pk_add_f32 v[62:63], v[42:43], v[46:47]\n\t"
+        "v_pk_add_f32 v[60:61], v[60:61], v[48:49]\n\t"
+        "v_pk_add_f32 v[62:63], v[62:63], v[50:51]\n\t"
+        "v_pk_add_f32 v[60:61], v[60:61], v[52:53]\n\t"
+        "v_pk_add_f32 v[62:63], v[62:63], v[54:55]\n\t"
         "s_nop 1\n\t"
-        "v_mov_b32_dpp v64, v68 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v65, v69 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v66, v70 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v67, v71 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_pk_add_f32 v[64:65], v[64:65], v[48:49]\n\t"      // odd lane: steps 4..7 on top
-        "v_pk_add_f32 v[66:67], v[66:67], v[50:51]\n\t"
-        "v_pk_add_f32 v[64:65], v[64:65], v[52:53]\n\t"
-        "v_pk_add_f32 v[66:67], v[66:67], v[54:55]\n\t"
-        "v_pk_add_f32 v[64:65], v[64:65], v[56:57]\n\t"
-        "v_pk_add_f32 v[66:67], v[66:67], v[58:59]\n\t"
-        "v_pk_add_f32 v[64:65], v[64:65], v[60:61]\n\t"
-        "v_pk_add_f32 v[66:67], v[66:67], v[62:63]\n\t"
-        "v_add_f32 %[key], v64, v65\n\t"
-        "v_add_f32 %[key], %[key], v66\n\t"
-        "v_add_f32 %[key], %[key], v67\n\t"
+        "v_mov_b32_dpp v56, v60 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v57, v61 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v58, v62 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v59, v63 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_pk_add_f32 v[56:57], v[56:57], v[40:41]\n\t"      // odd lane: steps 4..7 on top
+        "v_pk_add_f32 v[58:59], v[58:59], v[42:43]\n\t"
+        "v_pk_add_f32 v[56:57], v[56:57], v[44:45]\n\t"
+        "v_pk_add_f32 v[58:59], v[58:59], v[46:47]\n\t"
+        "v_pk_add_f32 v[56:57], v[56:57], v[48:49]\n\t"
+        "v_pk_add_f32 v[58:59], v[58:59], v[50:51]\n\t"
+        "v_pk_add_f32 v[56:57], v[56:57], v[52:53]\n\t"
+        "v_pk_add_f32 v[58:59], v[58:59], v[54:55]\n\t"
+        "v_add_f32 %[key], v56, v57\n\t"
+        "v_add_f32 %[key], %[key], v58\n\t"
+        "v_add_f32 %[key], %[key], v59\n\t"
         "v_or_b32 %[key], 0x80000000, %[key]"                  // fkey of a non-negative float
         : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [mulc] "=&s"(mulc), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
           [addr] "=&v"(addr), [key] "=&v"(key)
         : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [shr] "s"(shr),
           [nb] "s"(nbuckets), [roff] "v"(roff), [db] "s"(db_base), GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
-        : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",
-          "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
+        : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",
+          "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
     } else {
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[valid]\n\t"
-        "global_load_dwordx4 v[48:51], %[roff], %[db]\n\t"
-        "global_load_dwordx4 v[52:55], %[roff], %[db] offset:32\n\t"
-        "global_load_dwordx4 v[56:59], %[roff], %[db] offset:64\n\t"
-        "global_load_dwordx4 v[60:63], %[roff], %[db] offset:96\n\t"
+        "global_load_dwordx4 v[40:43], %[roff], %[db]\n\t"
+        "global_load_dwordx4 v[44:47], %[roff], %[db] offset:32\n\t"
+        "global_load_dwordx4 v[48:51], %[roff], %[db] offset:64\n\t"
+        "global_load_dwordx4 v[52:55], %[roff], %[db] offset:96\n\t"
         GBNNS_VS_ASM
         // ---- pair distance (dot_pair_from_regs), all lanes: products, then four running sums from +0 in load order
-        "v_mov_b32 v64, 0\n\t"
-        "v_mov_b32 v65, 0\n\t"
+        "v_mov_b32 v56, 0\n\t"
+        "v_mov_b32 v57, 0\n\t"
         "s_waitcnt vmcnt(3)\n\t"
-        "v_pk_mul_f32 v[48:49], v[48:49], %[qa0]\n\t"
-        "v_pk_mul_f32 v[50:51], v[50:51], %[qb0]\n\t"
-        "v_pk_add_f32 v[68:69], v[64:65], v[48:49]\n\t"      // 0 + p: a product of -0 must not make the sum -0
-        "v_pk_add_f32 v[70:71], v[64:65], v[50:51]\n\t"
+        "v_pk_mul_f32 v[40:41], v[40:41], %[qa0]\n\t"
+        "v_pk_mul_f32 v[42:43], v[42:43], %[qb0]\n\t"
+        "v_pk_add_f32 v[60:61], v[56:57], v[40:41]\n\t"      // 0 + p: a product of -0 must not make the sum -0
+        "v_pk_add_f32 v[62:63], v[56:57], v[42:43]\n\t"
         "s_waitcnt vmcnt(2)\n\t"
-        "v_pk_mul_f32 v[52:53], v[52:53], %[qa1]\n\t"
-        "v_pk_mul_f32 v[54:55], v[54:55], %[qb1]\n\t"
-        "v_pk_add_f32 v[68:69], v[68:69], v[52:53]\n\t"
-        "v_pk_add_f32 v[70:71], v[70:71], v[54:55]\n\t"
+        "v_pk_mul_f32 v[44:45], v[44:45], %[qa1]\n\t"
+        "v_pk_mul_f32 v[46:47], v[46:47], %[qb1]\n\t"
+        "v_pk_add_f32 v[60:61], v[60:61], v[44:45]\n\t"
+        "v_pk_add_f32 v[62:63], v[62:63], v[46:47]\n\t"
         "s_waitcnt vmcnt(1)\n\t"
-        "v_pk_mul_f32 v[56:57], v[56:57], %[qa2]\n\t"
-        "v_pk_mul_f32 v[58:59], v[58:59], %[qb2]\n\t"
-        "v_pk_add_f32 v[68:69], v[68:69], v[56:57]\n\t"
-        "v_pk_add_f32 v[70:71], v[70:71], v[58:59]\n\t"
+        "v_pk_mul_f32 v[48:49], v[48:49], %[qa2]\n\t"
+        "v_pk_mul_f32 v[50:51], v[50:51], %[qb2]\n\t"
+        "v_pk_add_f32 v[60:61], v[60:61], v[48:49]\n\t"
+        "v_pk_add_f32 v[62:63], v[62:63], v[50:51]\n\t"
         "s_waitcnt vmcnt(0)\n\t"
-        "v_pk_mul_f32 v[60:61], v[60:61], %[qa3]\n\t"
-        "v_pk_mul_f32 v[62:63], v[62:63], %[qb3]\n\t"
-        "v_pk_add_f32 v[68:69], v[68:69], v[60:61]\n\t"
-        "v_pk_add_f32 v[70:71], v[70:71], v[62:63]\n\t"
+        "v_pk_mul_f32 v[52:53], v[52:53], %[qa3]\n\t"
+        "v_pk_mul_f32 v[54:55], v[54:55], %[qb3]\n\t"
+        "v_pk_add_f32 v[60:61], v[60:61], v[52:53]\n\t"
+        "v_pk_add_f32 v[62:63], v[62:63], v[54:55]\n\t"
         "s_nop 1\n\t"
-        "v_mov_b32_dpp v64, v68 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"   // the even lane's sums 0..3
-        "v_mov_b32_dpp v65, v69 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v66, v70 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v67, v71 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_pk_add_f32 v[64:65], v[68:69], v[64:65]\n\t"      // odd lane: m_j = c_{j+4} + c_j
-        "v_pk_add_f32 v[66:67], v[70:71], v[66:67]\n\t"
-        "v_add_f32 %[key], v64, v65\n\t"                       // (m0 + m1) + (m2 + m3)
-        "v_add_f32 %[t0], v66, v67\n\t"
+        "v_mov_b32_dpp v56, v60 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"   // the even lane's sums 0..3
+        "v_mov_b32_dpp v57, v61 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v58, v62 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v59, v63 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_pk_add_f32 v[56:57], v[60:61], v[56:57]\n\t"      // odd lane: m_j = c_{j+4} + c_j
+        "v_pk_add_f32 v[58:59], v[62:63], v[58:59]\n\t"
+        "v_add_f32 %[key], v56, v57\n\t"                       // (m0 + m1) + (m2 + m3)
+        "v_add_f32 %[t0], v58, v59\n\t"
         "v_add_f32 %[key], %[key], %[t0]\n\t"
         "v_xor_b32 %[key], 0x80000000, %[key]\n\t"             // Angular::Dist = -(x . y)
         "v_add_f32 %[key], 0, %[key]\n\t"                      // fkey: -0 -> +0,
@@ -3045,8 +3045,8 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
           [addr] "=&v"(addr), [key] "=&v"(key)
         : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [shr] "s"(shr),
           [nb] "s"(nbuckets), [roff] "v"(roff), [db] "s"(db_base), GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
-        : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60",
-          "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
+        : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",
+          "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
     }
 #undef GBNNS_Q
     claimed = fresh & 0x5555555555555555ull;
