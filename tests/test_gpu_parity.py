@@ -1359,6 +1359,30 @@ def test_host_batches_in_flight(g, orc):
     # pageable buffers + the flag: ignored, plain synchronous call
     rp = ix.search(batches[0], ef, flags=g.FLAG_DEFER_JOIN)
     assert np.array_equal(rp["ids"], want[0]["ids"])
+    # gbnns_host_pin: ordinary (numpy) buffers page-locked through the C ABI are accepted for a deferred HOST call, take
+    # ids / hops / dist_calc straight from the kernels, and go back to being pageable after gbnns_host_unpin
+    import ctypes as C
+    from gbnns_dim_red_amd import binding as B
+    lib = ix._lib
+    qn = batches[1].copy()
+    ids_n, hops_n, dc_n = np.full(c.nq, 0xFFFFFFFF, np.uint32), np.zeros(c.nq, np.int32), np.zeros(c.nq, np.int32)
+    for arr in (qn, ids_n, hops_n, dc_n):
+        assert lib.gbnns_host_pin(arr.ctypes.data, arr.nbytes) == 0
+    a = B._SearchArgs(struct_size=C.sizeof(B._SearchArgs), mode=g.MODE_NET, ef=ef, k=ef, mem_kind=B.MEM_HOST, n_q=c.nq,
+                      queries=qn.ctypes.data, out_ids=ids_n.ctypes.data, out_hops=hops_n.ctypes.data,
+                      out_dist_calc=dc_n.ctypes.data, stream=None, flags=g.FLAG_DEFER_JOIN, defer_depth=depth)
+    B._check(lib.gbnns_search_ex(ix._h, C.byref(a)))
+    ix.wait(0)
+    assert np.array_equal(ids_n, want[1]["ids"])
+    assert np.array_equal(hops_n, want[1]["hops"])
+    assert np.array_equal(dc_n + ef, want[1]["dist_calc"])
+    ix.join()
+    torch.cuda.synchronize()
+    for arr in (qn, ids_n, hops_n, dc_n):
+        assert lib.gbnns_host_unpin(arr.ctypes.data) == 0
+    ids_n[:] = 0xFFFFFFFF
+    B._check(lib.gbnns_search_ex(ix._h, C.byref(a)))  # pageable again: the plain synchronous call
+    assert np.array_equal(ids_n, want[1]["ids"])
     ix.close()
 
 
