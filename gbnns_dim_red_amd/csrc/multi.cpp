@@ -254,6 +254,7 @@ int gbnns_multi_search_ex(gbnns_multi* m, const gbnns_search_args* a) {
         gbnns_search_args b = *a;
         b.n_q = hi - lo;
         b.stream = m->streams[r];
+        b.flags &= ~GBNNS_FLAG_DEFER_JOIN;  // this call is synchronous: the replicas' blocks are complete when it returns
         b.queries = a->queries + lo * m->d;
         if (a->queries_low) {
             const uint32_t dl = gbnns_index_d_low(m->replicas[r]);
@@ -316,6 +317,7 @@ int gbnns_multi_search_device(gbnns_multi* m, const gbnns_search_args* tmpl, uin
         if (hi == lo) return GBNNS_OK;
         gbnns_search_args b = *tmpl;
         b.mem_kind = GBNNS_MEM_DEVICE;
+        b.flags &= ~GBNNS_FLAG_DEFER_JOIN;  // (the all-gather below reads the answers in the replica stream's order)
         b.n_q = hi - lo;
         b.stream = m->streams[r];
         b.queries = query_blocks[r];
