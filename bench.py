@@ -104,6 +104,7 @@ def launch_probe():
 
 
 def main():
+    t_start = time.time()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--launch-probe", action="store_true", help="test hook: exercise the N-worker launch only (no GPU)")
@@ -129,11 +130,22 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="timed steps one batch at a time on one stream (no GBNNS_FLAG_DEFER_JOIN pipelining)")
     ap.add_argument("--cache-dir", default=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"))
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="CPU baseline on the first N queries only, widest thread count only (what the default run asks of the "
+                         "other configurations' child runs: a quick identical-ids check with its rate)")
+    ap.add_argument("--capi-multi-child", default=None,
+                    help="internal: run the C-ABI multi-replica section (gbnns_multi_*) over --gpus devices in this fresh process; "
+                         "the value is the .npy file with the ranks' answer ids of batch 0 to compare with")
+    ap.add_argument("--no-capi-multi", action="store_true", help="N > 1: skip the C-ABI multi-replica section")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default sift run at N = 1: do not append the gist / glove / glove-dot (/ deep) lines under other_configs")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("GBNNS_BENCH_BUDGET_S", "400")),
+                    help="wall-clock budget of the whole default run; the other configurations are started only while it lasts")
     argv = sys.argv[1:]
     if not argv and os.environ.get("GBNNS_BENCH_ARGV") and "WORLD_SIZE" in os.environ:
         argv = json.loads(os.environ["GBNNS_BENCH_ARGV"])  # a worker started by the branch below
     args = ap.parse_args(argv)
-    cmd = launcher_command(args.gpus, argv, os.environ)
+    cmd = None if args.capi_multi_child else launcher_command(args.gpus, argv, os.environ)
     if cmd is not None:
         # nothing above has touched the GPU (importing torch does not): the workers are fresh processes
         env = dict(os.environ)
@@ -154,6 +166,9 @@ def main():
     if args.nq:
         cfg["nq"] = args.nq
 
+    if args.capi_multi_child:
+        capi_multi_child(args, cfg)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -196,6 +211,7 @@ def main():
     metric_id = g.METRIC_NEG_DOT if cfg.get("negdot") else g.METRIC_L2
     ix = ds.index(device_index=local, metric=metric_id)
     strong = bool(cfg.get("strong"))
+    cold_ef = args.ef or cfg["ef"]
     if strong:
         # ONE batch, contiguous blocks per rank; entry points would shard with it
         lo, hi = sharding.shard_bounds(ds.nq, world, rank)
@@ -223,6 +239,27 @@ def main():
             return float("nan")
         ids = ids.long()[:n_scored]
         return ((ids == gt) | (dup & (ids == gt2))).float().mean().item()
+
+    # ---- cold start (untimed, N = 1): the first calls on the fresh handle, one batch at a time ------------------
+    # The library sizes its visited sets from the batches it has seen and leaves the retry launch out once a few were
+    # calm; the first call also pays the runtime's lazy loading of the code objects and the lanes'
+    # workspace allocations.  What a caller sees before any of that has settled:
+    cold = None
+    if world == 1 and nq_rank <= 20_000:
+        times = []
+        for j in range(12):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ix.search(q, cold_ef, want=())
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t1) * 1e3)
+        steady = sorted(times[-4:])[1]
+        cold = {"first_call_ms": round(times[0], 3), "second_call_ms": round(times[1], 3),
+                "calls_until_steady": next(j for j, t in enumerate(times) if t <= 1.1 * steady) + 1,
+                "steady_call_ms": round(steady, 4), "call_ms": [round(t, 3) for t in times],
+                "note": "fresh handle, ef = %d, one synchronous device-buffer call at a time; `steady` = within 10 %% of the "
+                        "median of calls 9-12; the first call includes the runtime's code-object load and the workspace "
+                        "allocations, calls 2 .. n the visited-set sizing from the previous batches' statistics" % cold_ef}
 
     # ---- recall sweep (untimed) ------------------------------------------------------------
     ef = args.ef or cfg["ef"]
@@ -443,8 +480,27 @@ def main():
                                 "before the stream waits for batch i), %d distinct batches rotating" % (depth, nb) if pipelined
                                 else "one batch at a time"),
     }
+    if cold:
+        result["cold"] = cold
     if gate_failed:
         result["recall_gate_failed"] = True  # `value` is NOT a figure at recall >= 0.95
+
+    # ---- N > 1: the same batch through the C ABI's own multi-device path (gbnns_multi_create + gbnns_multi_search_device:
+    # one host process, one host thread and stream per device, ONE RCCL all-gather of the ids per batch) -- what a C++
+    # host links against.  A fresh child process of rank 0 drives all N devices while every rank is parked at a barrier
+    # (their GPUs idle); never `value`; an RCCL or launch failure is a field of the line, not a failed bench.
+    if world > 1 and not args.no_capi_multi:
+        ref = ix.search(q, ef, want=(), flags=tune_flags | g.FLAG_SERIAL)["ids"].clone()
+        torch.cuda.synchronize()
+        pieces = None
+        if not strong or nq_total % world == 0:   # (equal blocks: one all-gather of the ranks' answers to batch 0)
+            allv = torch.empty(world * nq_rank, dtype=ref.dtype, device=dev)
+            dist.all_gather_into_tensor(allv, ref)
+            pieces = [allv]
+        dist.barrier()
+        if rank == 0:
+            result["capi_multi"] = capi_multi_parent(args, argv, world, pieces, rehearsal)
+        dist.barrier()
 
     extras = world == 1 and not args.no_extras
     small = nq_rank <= 20_000
@@ -456,8 +512,11 @@ def main():
         ok = [e for e in result["ef_sweep"] if e["recall_at_1"] >= 0.95]
         if ok:
             best = max(ok, key=lambda e: e["queries_per_s_in_flight"] or e["queries_per_s"])
+            # the metric's own operating point: the smallest beam of the sweep past the recall gate (same derivation as the
+            # headline's figures: in flight = three batches inside the library, kernel_ms / frac from serialised steps)
             result["best_ef_at_recall_gate"] = {k: best[k] for k in ("ef", "recall_at_1", "queries_per_s", "queries_per_s_in_flight",
-                                                                     "ms_per_step")}
+                                                                     "ms_per_step", "kernel", "kernel_ms",
+                                                                     "algorithmic_bytes_per_launch", "achieved_GBps", "frac")}
 
     # ---- the same step with the re-rank in its own launch (diagnostic flag): per-stage kernel times -------
     if extras and small and rl["fused"]:
@@ -534,7 +593,15 @@ def main():
 
     # ---- CPU baseline (rank 0, N = 1 only): the compiled reference if present, else the port ----
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(ds, q, ef, res["ids"], metric_id)
+        result["cpu_baseline"] = cpu_baseline(ds, q, ef, res["ids"], metric_id, sample=args.cpu_sample)
+
+    # ---- the other BASELINE.json configurations, each as a short run of its own in a child process --------------
+    if world == 1 and args.config == "sift" and not args.no_extras and not args.no_other_configs and not args.n and not args.nq:
+        ix.close()
+        ix = None
+        del ds
+        torch.cuda.empty_cache()
+        result["other_configs"] = other_configs(args, t_start)
 
     if args.sweep and rank == 0:
         for e in REF_EFS:
@@ -549,9 +616,152 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    ix.close()
+    if ix is not None:
+        ix.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def capi_multi_parent(args, argv, world, pieces, rehearsal):
+    """Rank 0, everyone else parked: starts the child below and relays its JSON."""
+    import tempfile
+    ref_path = ""
+    if pieces is not None:
+        fd, ref_path = tempfile.mkstemp(suffix=".npy", prefix="gbnns_rank_ids_")
+        os.close(fd)
+        np.save(ref_path, torch.cat(pieces).cpu().numpy())
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GBNNS_BENCH_ARGV", "MASTER_PORT",
+                                                            "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    child_argv = [a for a in argv if a != "--capi-multi-child"]
+    cmd = [sys.executable, os.path.abspath(__file__)] + child_argv + ["--capi-multi-child", ref_path or "-"]
+    try:
+        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+        if pr.returncode != 0 or not line:
+            return {"failed": "child rc %d: %s" % (pr.returncode, (pr.stderr or "")[-400:])}
+        return json.loads(line[-1])
+    except subprocess.TimeoutExpired:
+        return {"failed": "no answer from the child within 300 s"}
+    finally:
+        if ref_path:
+            try:
+                os.unlink(ref_path)
+            except OSError:
+                pass
+
+
+def capi_multi_child(args, cfg):
+    """`--capi-multi-child <ids.npy>`: one process, N = --gpus replicas through gbnns_multi_* (DESIGN.md 7).  The batch is
+    the concatenation of the ranks' batches 0 (weak) / the one batch (strong), block r resident on device r; K steps of
+    gbnns_multi_search_device (search + one RCCL all-gather of the ids each), synchronised at the end."""
+    import gbnns_dim_red_amd as g
+    from gbnns_dim_red_amd import synth
+    g.load_library()
+    world = args.gpus
+    rehearsal = os.environ.get("GBNNS_BENCH_REHEARSAL") == "1"
+    out = {"ranks": world, "form": "device blocks + RCCL all-gather (gbnns_multi_search_device)", "rccl_loaded": None}
+    try:
+        kw = dict(n=cfg["n"], nq=cfg["nq"], d=cfg["d"], d_low=cfg["d_low"], d_hidden=cfg["d_hidden"], seed=1234,
+                  cache_dir=args.cache_dir, native_knn=bool(cfg.get("native_knn")) and cfg["n"] > 2_000_000)
+        if cfg.get("unit_norm"):
+            kw["unit_norm"] = True
+        if args.graph_M:
+            kw["M"] = args.graph_M
+        if cfg.get("strong"):
+            kw["gt_queries"] = 20_000
+        ds = synth.make_dataset(device="cuda:0", **kw)
+        ef = args.ef or cfg["ef"]
+        metric_id = g.METRIC_NEG_DOT if cfg.get("negdot") else g.METRIC_L2
+        strong = bool(cfg.get("strong"))
+        if strong:
+            whole = ds.queries
+        else:
+            whole = torch.cat([torch.roll(ds.queries, shifts=-((r * ds.nq) // world), dims=0) for r in range(world)])
+        n_q = int(whole.shape[0])
+        devs = [0] * world if rehearsal else list(range(world))
+        mi = g.MultiIndex(ds.base.cpu().numpy(), ds.graph_off, ds.graph_nbr, db_low=ds.db_low.cpu().numpy(),
+                          net=tuple(t.cpu().numpy() for t in ds.net), metric=metric_id, devices=devs)
+        out["devices"] = mi.devices
+        ref = None if args.capi_multi_child in ("", "-") else np.load(args.capi_multi_child)
+        steps = max(1, min(args.steps or 20, 50))
+        if rehearsal:
+            # one GPU: the replicas share it, RCCL needs distinct devices -> the host form (gbnns_multi_search_ex, no collective)
+            out["form"] = "host buffers, no collective (gbnns_multi_search_ex): rehearsal on one GPU"
+            wq = whole.cpu().numpy()
+            r = mi.search(wq, ef, want=())
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                r = mi.search(wq, ef, want=())
+            dt = time.perf_counter() - t1
+            got = r["ids"].astype(np.int64)
+        else:
+            blocks = []
+            for r_ in range(world):
+                lo, hi = mi.shard_bounds(n_q, r_)
+                blocks.append(whole[lo:hi].to("cuda:%d" % mi.devices[r_]).contiguous())
+            for r_ in range(world):
+                torch.cuda.synchronize(mi.devices[r_])
+            outs = mi.search_device(blocks, ef, n_q)
+            mi.synchronize()
+            out["rccl_loaded"] = True
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                outs = mi.search_device(blocks, ef, n_q)
+            mi.synchronize()
+            dt = time.perf_counter() - t1
+            got = outs[0].cpu().numpy().astype(np.int64)
+            out["every_replica_holds_all_ids"] = all(bool((o.cpu().numpy().astype(np.int64) == got).all()) for o in outs)
+        out.update({"queries_per_s": round(steps * n_q / dt, 1), "steps": steps, "ms_per_step": round(dt * 1e3 / steps, 4),
+                    "batch": n_q, "ef": ef,
+                    "ids_identical_to_rank_results": None if ref is None else bool((got == ref.astype(np.int64)).all())})
+        mi.close()
+    except Exception as e:  # RCCL missing / refused, a device out of reach, ...: reported, never fatal
+        msg = str(e)
+        if "RCCL" in msg or "rccl" in msg or "nccl" in msg:
+            out["rccl_loaded"] = False
+        out["failed"] = msg[-400:]
+    print(json.dumps(out), flush=True)
+
+
+def other_configs(args, t_start):
+    """BASELINE.json configurations 3 - 5 as short runs of their own (`python bench.py --config <name> --no-extras
+    --cpu-sample 1000`), each in a fresh child process started after this one has released its index: GIST1M-shaped
+    (ef 200, the reference's 1 000-query batch), GloVe-shaped with the L2 and the negative-dot metric (ef 64) and,
+    while the wall-clock budget lasts, DEEP10M-shaped at full size (n = 10^7, ONE 1 M-query batch).  Per configuration:
+    the same figures as the headline line's (in-flight value, serial rate, first-pass kernel, its time, algorithmic
+    bytes, roofline fraction, recall) and the answers of a 1 000-query sample compared with the compiled reference."""
+    plan = [("gist", 20, 150), ("glove", 20, 120), ("glove-dot", 20, 90), ("deep", 3, 330)]
+    out = {}
+    for name, steps, need_s in plan:
+        left = args.budget_s - (time.time() - t_start)
+        if left < need_s:
+            out[name] = {"skipped": "%.0f s of the %.0f s budget left, this configuration is given %d s" % (left, args.budget_s, need_s)}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "3" if steps > 3 else "1",
+               "--no-extras", "--cpu-sample", "1000", "--cache-dir", args.cache_dir]
+        t1 = time.time()
+        try:
+            pr = subprocess.run(cmd, capture_output=True, text=True, timeout=need_s)
+            line = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+            if pr.returncode != 0 or not line:
+                out[name] = {"failed": "rc %d: %s" % (pr.returncode, (pr.stderr or "")[-300:])}
+                continue
+            j = json.loads(line[-1])
+        except subprocess.TimeoutExpired:
+            out[name] = {"failed": "no line within %d s" % need_s}
+            continue
+        rl, cb = j["roofline"], j.get("cpu_baseline", {})
+        out[name] = {
+            "workload": j["config"]["workload"], "ef": j["config"]["ef"], "recall_at_1": j["config"]["recall_at_1"],
+            "value": j["value"], "serial": j["serial"]["queries_per_s"], "steps": j["steps"], "ms_per_step": j["ms_per_step"],
+            "kernel": rl["kernel"], "kernel_ms": rl["kernel_ms"], "algorithmic_bytes_per_launch": rl["algorithmic_bytes_per_launch"],
+            "achieved_GBps": rl["achieved"], "frac": rl["frac"], "project_ms": j["kernels_ms"]["project"],
+            "gpu_ids_identical": cb.get("gpu_ids_identical"), "cpu_sample": cb.get("sample"), "cpu_value": cb.get("value"),
+            "cpu_cores": cb.get("cores"), "cpu_kind": cb.get("kind"), "wall_s": round(time.time() - t1, 1),
+        }
+        if j.get("recall_gate_failed"):
+            out[name]["recall_gate_failed"] = True
+    return out
 
 
 def counters_for(config, ef):
@@ -683,9 +893,10 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(ds, q, ef, gpu_ids, metric_id):
+def cpu_baseline(ds, q, ef, gpu_ids, metric_id, sample=0):
     """Times the reference's per-query body on host cores over the SAME batch and checks that the
-    GPU answers are identical.  oracle/ is used here only as the reported baseline / checker."""
+    GPU answers are identical.  oracle/ is used here only as the reported baseline / checker.
+    sample > 0: the first `sample` queries on the widest thread count only (the other configurations' child runs)."""
     import oracle
     base = ds.base.cpu().numpy()
     dbl = ds.db_low.cpu().numpy()
@@ -722,6 +933,13 @@ def cpu_baseline(ds, q, ef, gpu_ids, metric_id):
                               metric=metric_id)
         return time.perf_counter() - t0, r
 
+    if sample > 0:
+        ns = min(len(qh), sample)
+        tn, r = run(ns, avail)
+        same = int((r["ids"].astype(np.int64) == gpu_ids[:ns].cpu().numpy().astype(np.int64)).sum())
+        return {"value": round(ns / tn, 1), "unit": "queries/s", "cores": avail, "kind": kind,
+                "sample": "the first %d queries of the batch at ef=%d, OpenMP over queries (search_function.h:152) on %d thread(s)" % (ns, ef, avail),
+                "cpu_model": cpu_model(), "build_flags": flags, "gpu_ids_identical": same == ns, "gpu_id_mismatches": ns - same}
     # 1 thread (what final_test.cpp ships, :71) on a bounded sample sized from a probe (~4 s of work) ...
     probe = min(len(qh), 200)
     t_probe, _ = run(probe, 1)

@@ -3,6 +3,7 @@
 Host buffers are numpy arrays; device buffers are torch CUDA(ROCm) tensors (torch is used only
 as the owner of device memory and streams -- no torch op is on the search path).
 """
+import collections
 import ctypes as C
 import os
 
@@ -25,7 +26,7 @@ FLAG_DEFER_JOIN = 128
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "gbnns_index_create", "gbnns_index_destroy", "gbnns_index_set_aux_graph", "gbnns_search_ex", "gbnns_search_batch", "gbnns_index_join", "gbnns_index_wait", "gbnns_host_pin", "gbnns_host_unpin",
-    "gbnns_project", "gbnns_rerank", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd", "gbnns_build_graph_gd_device",
+    "gbnns_project", "gbnns_rerank", "gbnns_debug_knob", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd", "gbnns_build_graph_gd_device",
     "gbnns_free", "gbnns_exact_knn", "gbnns_device_count", "gbnns_version", "gbnns_last_error",
     "gbnns_index_n", "gbnns_index_d", "gbnns_index_d_low", "gbnns_index_device",
     "gbnns_multi_create", "gbnns_multi_destroy", "gbnns_multi_size", "gbnns_multi_replica", "gbnns_multi_device_of",
@@ -108,6 +109,7 @@ def load_library():
                                   C.c_void_p]
     lib.gbnns_rerank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.gbnns_debug_knob.argtypes = [C.c_char_p, C.c_int]
     lib.gbnns_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.gbnns_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile), C.c_int]
     lib.gbnns_build_graph_gd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -388,6 +390,8 @@ class Index:
             graph_nbrs=_ptr(nbr), net_l1=_ptr(net[0]) if net else None,
             net_l2=_ptr(net[1]) if net else None, net_l3=_ptr(net[2]) if net else None)
         _check(lib.gbnns_index_create(C.byref(desc), C.byref(self._h)))
+        self._in_flight = collections.deque(maxlen=8)  # (inputs, outputs) of the deferred calls not yet joined
+        self._last = None
         self._keep = (db, db_low, net) if dev else None
         self.metric = metric
         self.device = device
@@ -460,7 +464,7 @@ class Index:
                 return res[name]
             i32, f32 = torch.int32, torch.float32
             if stream is None:
-                stream = torch.cuda.current_stream()
+                stream = torch.cuda.current_stream(self.device)  # (the index's device, whatever the current one is)
             sptr = stream.cuda_stream
         else:
             entry_ids = None if entry_ids is None else _host(entry_ids, np.uint32)
@@ -493,16 +497,27 @@ class Index:
         if "edges" in want:
             a.out_edges = _ptr(alloc("edges", (nq,), i32))
         _check(self._lib.gbnns_search_ex(self._h, C.byref(a)))
-        self._last = (queries, queries_low, entry_ids)  # keep device inputs alive until next call
+        # Inputs (and the result buffers handed out) stay referenced while a lane stream may still read / write them: torch's
+        # caching allocators do not know the library's internal streams.  A plain call: until the next call; deferred
+        # calls: the last four (= the most lanes a handle has), until wait() / join() / a plain call joins them.
+        held = (queries, queries_low, entry_ids, res)
+        if flags & FLAG_DEFER_JOIN:
+            self._in_flight.append(held)
+        else:
+            self._in_flight.clear()
+        self._last = held
         return res
 
     def wait(self, keep=0):
         """gbnns_index_wait: blocks until every FLAG_DEFER_JOIN batch but the `keep` most recent has finished."""
         _check(self._lib.gbnns_index_wait(self._h, keep))
+        while len(self._in_flight) > keep:
+            self._in_flight.popleft()
 
     def join(self):
         """gbnns_index_join: the stream of the last FLAG_DEFER_JOIN call waits for that call's pieces."""
         _check(self._lib.gbnns_index_join(self._h))
+        self._in_flight.clear()  # (the caller's stream now waits for the lanes: stream-ordered reuse of the buffers is safe)
 
     def search_batch(self, queries, ef, entry_ids=None, want_cand=False):
         """The plain 9-argument C entry point (NET mode, host buffers)."""

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -22,6 +23,8 @@
 #include <deque>
 #include <map>
 #include <new>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -261,6 +264,19 @@ int build_ell(const uint64_t* off, const uint32_t* nbr, uint64_t n, std::vector<
 }
 
 constexpr size_t kMaxLds = 160 * 1024;
+// LDS is handed out in granules of 1 280 bytes (measured, tools/ubench/occupancy_census.hip: one-wavefront workgroups of
+// 5 120 B -> 32 per CU, 5 121 .. 6 400 B -> 25, 6 401 .. 7 680 B -> 21): a wavefront's share is a multiple of it.
+constexpr size_t kLdsGran = 1280;
+
+// Diagnostic knobs (gbnns_debug_knob; the environment gives their initial values, read once when the library loads):
+// "quotient" 0 = never the quotient form of the visited set (GBNNS_QUOTIENT); "vs_disp" = probe number at which a probe
+// sequence of that form gives up, 1 .. 15 (GBNNS_DEBUG_VS_DISP; 15 = the product's).
+int knob_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+std::atomic<int> g_knob_quotient{knob_env("GBNNS_QUOTIENT", 1)};
+std::atomic<int> g_knob_vs_disp{knob_env("GBNNS_DEBUG_VS_DISP", 15)};
 
 // A handle's workspace (projected queries, candidate lists, hand-over lists, control words) is shared by its
 // calls and ordered by stream order.  When a call names another stream than the last one that left work in
@@ -588,24 +604,8 @@ namespace {
 // MLP over rows x [nx x xstride] (device) -> out [nx x dl_pad] (device); h1/h2 are scratch.
 int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint32_t nx, float* out,
                 hipStream_t s) {
-    // GBNNS_FUSED_MLP=1: one launch for the whole net when its activations fit the LDS (project.hip; identical
-    // outputs).  Off by default: measured 0.084 ms against 0.071 ms for the three per-layer launches on the SIFT
-    // shape -- two wavefronts per SIMD do not hide the LDS latency of its 3 x 4-output register tile.
-    static const bool fused = getenv("GBNNS_FUSED_MLP") && atoi(getenv("GBNNS_FUSED_MLP"));
-    if (fused) {
-        FusedMlpParams f{};
-        size_t lds = 0;
-        f.rows_per_wave = mlp_fused_plan(ix->d, ix->d_hidden, ix->d_low, nx, &f.lda, &f.ldb, &lds);
-        if (f.rows_per_wave) {
-            f.x = x; f.xstride = xstride; f.nq = nx; f.d = ix->d; f.dh = ix->d_hidden; f.dl = ix->d_low;
-            f.xvec = (xstride % 4 == 0 && ix->d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1u : 0u;
-            f.w1 = ix->w1; f.b1 = ix->b1; f.w2 = ix->w2; f.b2 = ix->b2; f.w3 = ix->w3; f.b3 = ix->b3;
-            f.ws1 = ix->ws1; f.ws2 = ix->ws2; f.ws3 = ix->ws3;
-            f.out = out; f.ostride = ix->dl_pad;
-            HIP_TRY(launch_mlp_fused(f, lds, s));
-            return GBNNS_OK;
-        }
-    }
+    // (a one-launch form of the whole net existed through round 3 -- csrc/project.hip, GBNNS_FUSED_MLP=1: 0.084 ms against
+    // 0.071 ms for the three per-layer launches on the SIFT shape, off by default and untested; deleted in round 4)
     int rc = L.h1.ensure((size_t)nx * ix->d_hidden * 4);
     if (!rc) rc = L.h2.ensure((size_t)nx * ix->d_hidden * 4);
     if (rc) return rc;
@@ -681,6 +681,14 @@ int gbnns_debug_merge(int regs, const unsigned long long* entries, int size, con
     HIP_TRY(hipMemcpy(out, d_o, (size_t)64 * regs * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_info, d_i, 12, hipMemcpyDeviceToHost));
     (void)hipFree(d_e); (void)hipFree(d_s); (void)hipFree(d_o); (void)hipFree(d_i);
+    return GBNNS_OK;
+}
+
+int gbnns_debug_knob(const char* name, int value) {
+    if (!name) return fail(GBNNS_ERR_INVALID, "gbnns_debug_knob: null name");
+    if (!std::strcmp(name, "quotient")) g_knob_quotient.store(value, std::memory_order_relaxed);
+    else if (!std::strcmp(name, "vs_disp")) g_knob_vs_disp.store(value <= 0 ? 15 : value, std::memory_order_relaxed);
+    else return fail(GBNNS_ERR_INVALID, "gbnns_debug_knob: unknown knob '%s'", name);
     return GBNNS_OK;
 }
 
@@ -825,18 +833,28 @@ int ensure_lane(gbnns_index* ix, int i) {
 // has workgroups to dispatch (its single wavefronts take the LDS as it frees up), so the pieces queue behind one
 // another: 0.43 ms (halves) ... 0.52 ms (quarters) against 0.40 ms undivided.  The same holds with page-locked HOST
 // buffers, where the halves' copies do overlap: 0.55 against 0.52 ms.
-// The device-visible alias of a page-locked host pointer (hipHostMalloc / hipHostRegister memory); nullptr for pageable
-// memory.  Stores through the alias are visible to the host once the storing stream's work has completed.
+// The device-visible alias of a page-locked host buffer of `bytes` bytes (hipHostMalloc / hipHostRegister memory); nullptr
+// for pageable memory -- and for a buffer whose page-locked range ends before its last byte (a partly registered array, an
+// interior pointer near the end of a registration): both ends must be page-locked and map to one contiguous device range.
+// Stores through the alias are visible to the host once the storing stream's work has completed.
 template <class T>
-T* pinned_alias(const T* host_ptr) {
-    if (!host_ptr) return nullptr;
-    hipPointerAttribute_t at{};
-    if (hipPointerGetAttributes(&at, host_ptr) != hipSuccess) {
-        (void)hipGetLastError();  // (unregistered memory is an error for some runtimes, a type for others)
-        return nullptr;
+T* pinned_alias(const T* host_ptr, size_t bytes) {
+    if (!host_ptr || bytes == 0) return nullptr;
+    auto probe = [](const void* p) -> void* {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+            (void)hipGetLastError();  // (unregistered memory is an error for some runtimes, a type for others)
+            return nullptr;
+        }
+        return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+    };
+    char* const first = static_cast<char*>(probe(host_ptr));
+    if (!first) return nullptr;
+    if (bytes > 1) {
+        char* const last = static_cast<char*>(probe(reinterpret_cast<const char*>(host_ptr) + (bytes - 1)));
+        if (last != first + (bytes - 1)) return nullptr;
     }
-    if (at.type != hipMemoryTypeHost) return nullptr;
-    return static_cast<T*>(at.devicePointer);
+    return reinterpret_cast<T*>(first);
 }
 
 void plan_call(gbnns_index* ix, const gbnns_search_args* a, int& lanes, int& lane) {
@@ -888,7 +906,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         if ((rc = L.cand_dist.ensure((size_t)nq * cstride * 4))) return rc;
     // ids into HOST memory: page-locked memory takes the kernels' stores directly (40 KB of a 10 000-query batch: no
     // copy launch behind the walk), pageable memory gets a copy out of the lane's buffer
-    uint32_t* const ids_alias = host ? pinned_alias(a->out_ids) : nullptr;
+    uint32_t* const ids_alias = host ? pinned_alias(a->out_ids, (size_t)nq * 4) : nullptr;
     if (host && !ids_alias)
         if ((rc = L.out.ensure((size_t)nq * 4))) return rc;
     if (host && a->out_edges)
@@ -979,9 +997,9 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     w.count = L.cnt.as<int32_t>();
     // (per-query counters into page-locked HOST memory are stored there directly, like the ids: written once per
     // query by the kernel that finishes it)
-    int32_t* const hops_alias = host ? pinned_alias(a->out_hops) : nullptr;
-    int32_t* const dc_alias = host ? pinned_alias(a->out_dist_calc) : nullptr;
-    int32_t* const edges_alias = host ? pinned_alias(a->out_edges) : nullptr;
+    int32_t* const hops_alias = host ? pinned_alias(a->out_hops, (size_t)nq * 4) : nullptr;
+    int32_t* const dc_alias = host ? pinned_alias(a->out_dist_calc, (size_t)nq * 4) : nullptr;
+    int32_t* const edges_alias = host ? pinned_alias(a->out_edges, (size_t)nq * 4) : nullptr;
     w.hops = host ? (hops_alias ? hops_alias : L.hops.as<int32_t>()) : (a->out_hops ? a->out_hops : L.hops.as<int32_t>());
     w.dist_calc = host ? (dc_alias ? dc_alias : L.dc.as<int32_t>()) : (a->out_dist_calc ? a->out_dist_calc : L.dc.as<int32_t>());
     w.edges = a->out_edges ? (host ? (edges_alias ? edges_alias : L.edges.as<int32_t>()) : a->out_edges) : nullptr;
@@ -1051,7 +1069,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     // bits (n <= 2^W), so the table needs at least 2^(W-13) buckets.
     uint32_t idbits = 1;
     while (idbits < 32 && (1ull << idbits) < ix->n) ++idbits;
-    const bool quotient_on = !(getenv("GBNNS_QUOTIENT") && atoi(getenv("GBNNS_QUOTIENT")) == 0);  // tuning / A-B runs, tests
+    const bool quotient_on = g_knob_quotient.load(std::memory_order_relaxed) != 0;  // tuning / A-B runs, tests: gbnns_debug_knob
     const bool vs_ok = walk_knows_quotient(w, ix->metric);
     constexpr uint32_t kStashBuckets = 4;  // (kernels.hip: the table's last four "buckets" are the stash)
     const uint32_t quotient_min = 7u * ((idbits > 13 ? 1u << (idbits - 13) : 1u) + kStashBuckets + 8u);  // entries (>= 8 real buckets: probe steps of up to 8)
@@ -1062,7 +1080,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     auto size_table = [&](int f, uint32_t need, size_t& slots) -> uint32_t {
         const uint32_t floor_entries = f == 2 ? quotient_min : 0u, extra = f == 2 ? 7u * kStashBuckets : 0u;  // (the stash's four "buckets" hold no slots)
         need = std::max(need + extra, floor_entries);
-        const size_t gran = 512;  // LDS allocation granularity
+        const size_t gran = kLdsGran;
         const size_t want = (lds_fixed + walk_hash_bytes(need + 4, f) + gran - 1) / gran * gran;
         slots = std::min<size_t>(32, kMaxLds / want);
         if (slots == 0) return need;  // does not fit LDS at all: the general kernel takes the batch
@@ -1117,8 +1135,8 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
             form = packed ? 1 : 0;  // (an explicit capacity too small for the form)
             cap = walk_hash_entries(walk_hash_bytes(cap, form), form);
         } else {
-            // (tests: GBNNS_DEBUG_VS_DISP=<1..15> makes probe sequences give up that early, to exercise the hand-over)
-            const uint32_t disp = getenv("GBNNS_DEBUG_VS_DISP") ? (uint32_t)std::min(15, std::max(1, atoi(getenv("GBNNS_DEBUG_VS_DISP")))) : 15u;
+            // (tests: gbnns_debug_knob("vs_disp", 1..15) makes probe sequences give up that early, to exercise the hand-over)
+            const uint32_t disp = (uint32_t)std::min(15, std::max(1, g_knob_vs_disp.load(std::memory_order_relaxed)));
             // twelve remainder bits and a 4-bit probe number when the table has 2^(W-12) buckets, else thirteen and 3 bits
             const bool r13 = idbits > lg + 12;
             w.vs_shr = (32u - idbits + lg) | (32u - idbits) << 8 | (r13 ? 1u << 16 | std::min(disp, 7u) << 29 : disp << 28);
@@ -1151,7 +1169,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         const int min_ef = min_ef_env ? min_ef_env : (form == 2 ? 480 : 385);
         const bool forced = (a->flags & GBNNS_FLAG_BITMAP_PASS) != 0;  // diagnostic: whatever ef and batch size
         if (!w.all_general && (ef >= min_ef || forced) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && (a->hash_capacity == 0 || forced)) {
-            const size_t gran = 512;
+            const size_t gran = kLdsGran;
             const size_t per_wave = (walk_bitmap_lds_bytes(w, ix->metric) + gran - 1) / gran * gran;
             const size_t per_cu = std::min<size_t>(32, kMaxLds / per_wave);
             const size_t table_waves = std::min<size_t>(32, kMaxLds / ((walk_fast_lds_bytes(w, hot) + gran - 1) / gran * gran));
@@ -1194,7 +1212,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // retry pass: hand-overs of the first pass, one wavefront per CU with all the LDS
         WalkParams w2 = w;
         w2.vs_shr = 0;  // (the retry kernels keep the packed form)
-        const size_t gran = 512;
+        const size_t gran = kLdsGran;
         w2.hash_cap = walk_hash_entries(kMaxLds / gran * gran - walk_fast_lds_fixed_bytes(ef, w.dstride, false, walk_uses_lds_list(w)), packed);
         w2.hash_limit = w2.hash_cap - w2.hash_cap / 16;
         if (skip_retry) {
@@ -1314,10 +1332,14 @@ int gbnns_search_ex(gbnns_index* ix, const gbnns_search_args* a) {
     if (n_lanes > 1 && a->mem_kind == GBNNS_MEM_HOST) {
         // a deferred call returns before its copies have run: every buffer has to be page-locked (a copy from or to
         // pageable memory is staged by the runtime, synchronously).  Pageable buffers: the flag is ignored, plain call.
-        const void* bufs[] = {a->queries, a->queries_low, a->entry_ids, a->out_ids, a->out_hops, a->out_dist_calc,
-                              a->out_edges, a->out_cand, a->out_cand_dist, a->out_q_low};
-        for (const void* b : bufs)
-            if (b && !pinned_alias(static_cast<const char*>(b))) n_lanes = 1;
+        const size_t nq = (size_t)a->n_q, kk = (size_t)std::max(1, std::min(a->mode == GBNNS_MODE_PLAIN ? a->k : a->ef, a->ef));
+        const struct { const void* p; size_t bytes; } bufs[] = {
+            {a->queries, nq * ix->d * 4}, {a->queries_low, nq * ix->d_low * 4},
+            {a->entry_ids, nq * std::max<size_t>(a->n_entries, 1) * 4}, {a->out_ids, nq * 4}, {a->out_hops, nq * 4},
+            {a->out_dist_calc, nq * 4}, {a->out_edges, nq * 4}, {a->out_cand, nq * kk * 4}, {a->out_cand_dist, nq * kk * 4},
+            {a->out_q_low, nq * ix->d_low * 4}};
+        for (const auto& b : bufs)
+            if (b.p && !pinned_alias(static_cast<const char*>(b.p), b.bytes)) n_lanes = 1;
         if (n_lanes == 1) ix->next_lane = lane;  // (the rotation did not advance)
     }
     if (n_lanes <= 1) {
@@ -1380,16 +1402,72 @@ int gbnns_index_join(gbnns_index* ix) {
     return flush_join(ix);
 }
 
+// The registrations made here: whole pages, never overlapping one another (two small heap buffers often share a page, and
+// page-locking a page twice / releasing it under a neighbour is what the runtime's tables are not built for), counted per
+// user buffer -- so that gbnns_host_unpin releases exactly what gbnns_host_pin registered and never a registration the
+// caller made itself.
+namespace {
+constexpr uintptr_t kPage = 4096;
+struct PinRange { uintptr_t hi; int users; };
+std::mutex g_pin_mu;
+std::map<uintptr_t, PinRange> g_pin_ranges;        // lo -> [lo, hi), page-aligned, disjoint
+std::map<const void*, std::vector<uintptr_t>> g_pin_users;  // user pointer -> the ranges (by lo) it holds
+}  // namespace
+
 int gbnns_host_pin(void* ptr, size_t bytes) {
     if (!ptr || bytes == 0) return fail(GBNNS_ERR_INVALID, "gbnns_host_pin: empty buffer");
-    if (pinned_alias(static_cast<char*>(ptr))) return GBNNS_OK;  // already page-locked (by the caller or an earlier call)
-    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (g_pin_users.count(ptr)) return GBNNS_OK;  // pinned here already
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr) & ~(kPage - 1);
+    const uintptr_t hi = (reinterpret_cast<uintptr_t>(ptr) + bytes + kPage - 1) & ~(kPage - 1);
+    // pages of [lo, hi) that an earlier call registered are shared (counted); the gaps between them are registered now
+    std::vector<uintptr_t> held;
+    std::vector<std::pair<uintptr_t, uintptr_t>> gaps;
+    uintptr_t at = lo;
+    auto it = g_pin_ranges.upper_bound(lo);
+    if (it != g_pin_ranges.begin()) {
+        auto prev = std::prev(it);
+        if (prev->second.hi > lo) it = prev;
+    }
+    for (; it != g_pin_ranges.end() && it->first < hi; ++it) {
+        if (it->first > at) gaps.push_back({at, it->first});
+        held.push_back(it->first);
+        at = std::max(at, it->second.hi);
+    }
+    if (at < hi) gaps.push_back({at, hi});
+    if (held.empty() && pinned_alias(static_cast<char*>(ptr), bytes)) return GBNNS_OK;  // page-locked by the caller: nothing to do, nothing to undo
+    for (const auto& gp : gaps) {
+        const hipError_t e = hipHostRegister(reinterpret_cast<void*>(gp.first), gp.second - gp.first, hipHostRegisterDefault);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            // (part of the range is page-locked by someone else, or the pages are not ours to lock: the buffer stays
+            // pageable for the calls that probe it -- pinned_alias -- and what was registered so far is kept for its users)
+            for (uintptr_t h : held) g_pin_ranges[h].users += 1;
+            g_pin_users[ptr] = held;
+            return fail(GBNNS_ERR_HIP, "hipHostRegister: %s", hipGetErrorString(e));
+        }
+        g_pin_ranges[gp.first] = PinRange{gp.second, 0};
+        held.push_back(gp.first);
+    }
+    for (uintptr_t h : held) g_pin_ranges[h].users += 1;
+    g_pin_users[ptr] = held;
     return GBNNS_OK;
 }
 
 int gbnns_host_unpin(void* ptr) {
     if (!ptr) return GBNNS_OK;
-    if (hipHostUnregister(ptr) != hipSuccess) (void)hipGetLastError();  // (not registered by gbnns_host_pin: nothing to undo)
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto u = g_pin_users.find(ptr);
+    if (u == g_pin_users.end()) return GBNNS_OK;  // not registered by gbnns_host_pin: nothing to undo
+    for (uintptr_t h : u->second) {
+        auto r = g_pin_ranges.find(h);
+        if (r == g_pin_ranges.end()) continue;
+        if (--r->second.users <= 0) {
+            if (hipHostUnregister(reinterpret_cast<void*>(h)) != hipSuccess) (void)hipGetLastError();
+            g_pin_ranges.erase(r);
+        }
+    }
+    g_pin_users.erase(u);
     return GBNNS_OK;
 }
 

@@ -139,23 +139,6 @@ struct LayerParams {
     int32_t normalize;       // 1: follow the layer by normalizeVector over its dout outputs (fused when dout <= 64)
 };
 hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s);
-// The three layers + normalizeVector in one launch (project.hip), for nets whose activations fit the LDS.
-struct FusedMlpParams {
-    const float* x;          // [nq x xstride]
-    uint32_t xstride;
-    uint32_t xvec;           // 1: rows of x are 16-B aligned (xstride % 4 == 0, d % 4 == 0, aligned base)
-    uint32_t nq, d, dh, dl;
-    const float *w1, *b1, *w2, *b2, *w3, *b3;  // repacked layers (LayerParams layout)
-    uint32_t ws1, ws2, ws3;
-    float* out;              // [nq x ostride], pad columns written as zero
-    uint32_t ostride;
-    uint32_t rows_per_wave;  // from mlp_fused_plan: a workgroup takes 4 x rows_per_wave queries
-    uint32_t lda, ldb;       // row strides (floats) of the two activation buffers
-};
-// rows per wavefront for a batch of nq queries (0: the net does not fit), strides and dynamic LDS bytes
-uint32_t mlp_fused_plan(uint32_t d, uint32_t dh, uint32_t dl, uint32_t nq, uint32_t* lda, uint32_t* ldb, size_t* lds_bytes);
-hipError_t launch_mlp_fused(const FusedMlpParams& p, size_t lds_bytes, hipStream_t s);
-
 // y [nq x stride]: y /= sqrt(L2(y, 0)) over dim (4-lane order, d%4 tail ignored in the norm),
 // pad columns [dim, stride) are written as zero.
 hipError_t launch_normalize(float* y, uint32_t stride, uint32_t dim, uint32_t nq, hipStream_t s);

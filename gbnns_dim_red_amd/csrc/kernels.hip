@@ -408,7 +408,8 @@ __device__ __forceinline__ uint64_t visited_claim_mask_quotient(uint32_t lds_bas
         "v_cmp_le_u32 vcc, %[end], %[addr]\n\t"
         "v_subrev_u32 %[t0], %[mulc], %[addr]\n\t"
         "v_cndmask_b32 %[addr], %[addr], %[t0], vcc\n\t"
-        "v_cmp_gt_u32 vcc, %[shr], %[t2]\n\t"
+        "s_and_b32 vcc_lo, %[shr], 0xF0000000\n\t"          // the probe-number field alone (the low bits of ctl hold shifts and flags)
+        "v_cmp_gt_u32 vcc, vcc_lo, %[t2]\n\t"
         "s_andn2_b64 %[act], exec, vcc\n\t"
         "s_or_b64 %[ovf], %[ovf], %[act]\n\t"
         "s_and_b64 exec, exec, vcc\n\t"
@@ -506,10 +507,22 @@ __device__ __forceinline__ float dpp_from_odd(float x) {  // even lane <- its od
 // streams its candidates' rows at (bytes in flight) / latency: 200 rows of 960 floats (GIST, ef = 200) take it 0.095 ms
 // with 8 loads in flight and 0.070 ms with 24 (rocprofv3, one-query launches).  The generic wide-row walk kernels and
 // the stand-alone kernel have the registers for 24 (same operations, same order).
+// A 16-byte piece of an original-space row.  Each candidate row is read once per query and the table (n x d floats: 512 MB
+// for SIFT1M, 3.8 GB for GIST1M) is far larger than the 256 MB Infinity Cache, whose lines the WALKED tables (db_low +
+// adjacency: 256 MB at n = 10^6) want: the re-rank's rows are requested non-temporal (`nt`), so that they stream past
+// the caches instead of evicting the rows every other wavefront's next hops will ask for.  GBNNS_RERANK_TEMPORAL: plain loads.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t ld_row16(const float4* p) {
+#ifdef GBNNS_RERANK_TEMPORAL
+    return *reinterpret_cast<const f32x4_t*>(p);
+#else
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+#endif
+}
+
 template <int METRIC, int DEEP = 8, typename IdAt>
 __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi, int cnt, float* qf, int lane, IdAt id_at) {
     const uint32_t half = (uint32_t)lane & 1u, slot = (uint32_t)lane >> 1;
-    const float4* qs = reinterpret_cast<const float4*>(qf);
     for (uint32_t i = lane; i < a.dstride; i += 64)
         qf[i] = (i < a.dim) ? a.q[(size_t)qi * a.qstride + i] : 0.f;
     wave_sync();
@@ -520,15 +533,21 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
         const bool valid = r < cnt;
         uint32_t id = id_at(valid ? r : base);  // lanes beyond the list redo the first row (discarded)
         id = id < a.n ? id : 0u;                // (never dereference an id outside the table)
-        const float4* row = reinterpret_cast<const float4*>(a.db + (size_t)id * a.dstride) + half;
-        const float4* qh = qs + half;
+        // (the table's address is laundered per chunk: left visible, the compiler keeps db + half * 16 and two or three
+        // displaced copies of it in vector-register pairs across the chunks -- loop-invariant, and what pushed the
+        // 64-register walk kernels that re-rank at the end of their walk into scratch)
+        const float* dbp = a.db;
+        uint32_t hoff = half * 4u;  // (floats)
+        asm volatile("" : "+s"(dbp), "+v"(hoff));
+        const float4* row = reinterpret_cast<const float4*>(dbp + ((size_t)id * a.dstride + hoff));
+        const float4* qh = reinterpret_cast<const float4*>(qf + hoff);
         if constexpr (METRIC == 1) {
             float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;  // this lane's four of the eight running sums
             uint32_t k = 0;
             for (; k + 8 <= pairs; k += 8) {
-                float4 rv[8];
+                f32x4_t rv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) rv[j] = row[2 * (k + j)];
+                for (int j = 0; j < 8; ++j) rv[j] = ld_row16(row + 2 * (k + j));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float4 qv = qh[2 * (k + j)];
@@ -536,7 +555,7 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
                 }
             }
             for (; k < pairs; ++k) {
-                const float4 rv = row[2 * k];
+                const f32x4_t rv = ld_row16(row + 2 * k);
                 const float4 qv = qh[2 * k];
                 c0 = c0 + rv.x * qv.x; c1 = c1 + rv.y * qv.y; c2 = c2 + rv.z * qv.z; c3 = c3 + rv.w * qv.w;
             }
@@ -553,9 +572,9 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
         uint32_t k = 0;
         if constexpr (DEEP > 8) {
             for (; k + DEEP <= pairs; k += DEEP) {
-                float4 rv[DEEP];
+                f32x4_t rv[DEEP];
 #pragma unroll
-                for (int j = 0; j < DEEP; ++j) rv[j] = row[2 * (k + j)];
+                for (int j = 0; j < DEEP; ++j) rv[j] = ld_row16(row + 2 * (k + j));
 #pragma unroll
                 for (int j = 0; j < DEEP; ++j) {
                     const float4 qv = qh[2 * (k + j)];
@@ -570,9 +589,9 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
             }
         }
         for (; k + 8 <= pairs; k += 8) {  // eight 16-B loads in flight per lane
-            float4 rv[8];
+            f32x4_t rv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rv[j] = row[2 * (k + j)];
+            for (int j = 0; j < 8; ++j) rv[j] = ld_row16(row + 2 * (k + j));
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float4 qv = qh[2 * (k + j)];
@@ -586,9 +605,9 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
             }
         }
         for (; k + 4 <= pairs; k += 4) {
-            float4 rv[4];
+            f32x4_t rv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rv[j] = row[2 * (k + j)];
+            for (int j = 0; j < 4; ++j) rv[j] = ld_row16(row + 2 * (k + j));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float4 qv = qh[2 * (k + j)];
@@ -602,7 +621,7 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
             }
         }
         for (; k < pairs; ++k) {
-            const float4 rv = row[2 * k];
+            const f32x4_t rv = ld_row16(row + 2 * k);
             const float4 qv = qh[2 * k];
             float e;
             e = rv.x - qv.x; const float p0 = e * e;
@@ -1396,7 +1415,7 @@ __device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk,
     // A lane plays two roles: it holds list entry `lane` and (maybe) a survivor.  One pass over the
     // survivors (hand-scheduled: the compiler's version of this loop is 19 instructions, 13 of them
     // scalar, and the walk is bound by scalar issue): survivor `sl`'s key is broadcast through
-    // s[98:99]; every entry counts the survivors below it (shift), every survivor the survivors below
+    // s[46:47]; every entry counts the survivors below it (shift), every survivor the survivors below
     // it (rank), and the number of entries below survivor `sl` -- the zero bits of the compare mask,
     // because lanes that hold no entry hold all-ones or evicted keys, both greater than any survivor --
     // is dropped into lane `sl` (below).  Keys are distinct (a survivor was never visited).
@@ -1408,12 +1427,12 @@ __device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk,
         "v_mov_b32 %[below], 0\n"
         "1:\n\t"
         "s_ff1_i32_b64 %[sl], %[mm]\n\t"
-        "v_readlane_b32 s99, %[dk], %[sl]\n\t"
-        "v_readlane_b32 s98, %[slo], %[sl]\n\t"
+        "v_readlane_b32 s47, %[dk], %[sl]\n\t"
+        "v_readlane_b32 s46, %[slo], %[sl]\n\t"
         "s_bitset0_b64 %[mm], %[sl]\n\t"
         "s_mov_b32 m0, %[sl]\n\t"
-        "v_cmp_gt_u64_e64 %[ma], %[key], s[98:99]\n\t"
-        "v_cmp_gt_u64_e64 %[mb], %[skey], s[98:99]\n\t"
+        "v_cmp_gt_u64_e64 %[ma], %[key], s[46:47]\n\t"
+        "v_cmp_gt_u64_e64 %[mb], %[skey], s[46:47]\n\t"
         "s_bcnt0_i32_b64 %[t], %[ma]\n\t"
         "v_addc_co_u32_e64 %[shift], vcc, 0, %[shift], %[ma]\n\t"
         "v_addc_co_u32_e64 %[rank], vcc, 0, %[rank], %[mb]\n\t"
@@ -1423,7 +1442,7 @@ __device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk,
         : [shift] "=&v"(shift), [rank] "=&v"(rank), [below] "=&v"(below), [sl] "=&s"(sl_), [t] "=&s"(t_), [ma] "=&s"(ma),
           [mb] "=&s"(mb), [mm] "+s"(mm)
         : [dk] "v"(dk), [slo] "v"(slo), [key] "v"(key), [skey] "v"(skey)
-        : "vcc", "scc", "m0", "s98", "s99");
+        : "vcc", "scc", "m0", "s46", "s47");
     const int dst_e = lane + (int)shift, dst_s = (int)(rank + below);
     const int total = size + ns;
     const int new_size = total < ef ? total : ef;
@@ -2716,10 +2735,16 @@ __device__ __forceinline__ bool reg1_select_slow(RegList<1>& L, uint64_t mu, int
         // tie entries all sit at the worst distance: the largest id among them competes
         uint32_t v = (lane < tsize) ? key_id(tie[lane]) + 1u : 0u;
         int w = lane;
+        // (this rare path must not cost the hop registers: with __shfl_xor the six partner indices lane ^ 32 .. lane ^ 1 and
+        // a second copy of the lane id are loop invariants that the compiler keeps in registers across the whole walk; the
+        // lane id is laundered here so that they are computed on the spot)
+        int lane_here = lane;
+        asm volatile("" : "+v"(lane_here));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const uint32_t ov = (uint32_t)__shfl_xor((int)v, off);
-            const int ow = __shfl_xor(w, off);
+            const int partner = (lane_here ^ off) << 2;
+            const uint32_t ov = (uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)v);
+            const int ow = __builtin_amdgcn_ds_bpermute(partner, w);
             if (ov > v) { v = ov; w = ow; }
         }
         v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
@@ -2762,10 +2787,16 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
         // tie entries all sit at the worst distance: the largest id among them competes
         uint32_t v = (lane < tsize) ? key_id(tie[lane]) + 1u : 0u;
         int w = lane;
+        // (this rare path must not cost the hop registers: with __shfl_xor the six partner indices lane ^ 32 .. lane ^ 1 and
+        // a second copy of the lane id are loop invariants that the compiler keeps in registers across the whole walk; the
+        // lane id is laundered here so that they are computed on the spot)
+        int lane_here = lane;
+        asm volatile("" : "+v"(lane_here));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const uint32_t ov = (uint32_t)__shfl_xor((int)v, off);
-            const int ow = __shfl_xor(w, off);
+            const int partner = (lane_here ^ off) << 2;
+            const uint32_t ov = (uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)v);
+            const int ow = __builtin_amdgcn_ds_bpermute(partner, w);
             if (ov > v) { v = ov; w = ow; }
         }
         v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
@@ -2811,244 +2842,316 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
 #define GBNNS_VS_ASM                                                                                                   \
         "s_bfe_u32 %[mulc], %[shr], 0x50008\n\t"               /* 32 - W (0 in the packed form) */                     \
         "s_lshl_b32 %[mulc], 0x9E3779B1, %[mulc]\n\t"                                                                  \
-        "v_mul_lo_u32 %[t0], %[id], %[mulc]\n\t"                                                                       \
+        "v_mul_lo_u32 v36, %[id], %[mulc]\n\t"                                                                       \
         "s_and_b32 exec_lo, exec_lo, 0x55555555\n\t"                                                                   \
         "s_and_b32 exec_hi, exec_hi, 0x55555555\n\t"                                                                   \
         "s_mov_b64 %[fresh], 0\n\t"                                                                                    \
         "s_cmp_lg_u32 %[shr], 0\n\t"                                                                                   \
-        "v_mul_hi_u32 %[t1], %[t0], %[nb]\n\t"                                                                         \
-        "v_lshl_add_u32 %[addr], %[t1], 4, %[basev]\n\t"                                                               \
+        "v_mul_hi_u32 v37, v36, %[nb]\n\t"                                                                         \
+        "v_lshl_add_u32 v39, v37, 4, %[basev]\n\t"                                                               \
         "s_cbranch_scc1 4f\n"                                                                                          \
         "1:\n\t"                                                                                                       \
-        "ds_read_b128 v[60:63], %[addr]\n\t"                                                                           \
+        "ds_read_b128 v[60:63], v39\n\t"                                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
         "v_bfe_u32 v56, v60, 0, 24\n\t"                        /* slot 0 */                                            \
         "v_alignbit_b32 v57, v61, v60, 24\n\t"                 /* slot 1 (bits 24..47) in the low 24 bits */           \
         "v_alignbit_b32 v58, v62, v61, 16\n\t"                 /* slot 2 (bits 48..71) */                              \
         "v_lshrrev_b32 v59, 8, v62\n\t"                        /* slot 3 (bits 72..95) */                              \
-        "v_bfe_u32 %[t1], v63, 0, 24\n\t"                      /* slot 4 (bits 96..119) */                             \
+        "v_bfe_u32 v37, v63, 0, 24\n\t"                      /* slot 4 (bits 96..119) */                             \
         "v_bfe_u32 v57, v57, 0, 24\n\t"                                                                                \
         "v_bfe_u32 v58, v58, 0, 24\n\t"                                                                                \
         "v_xor_b32 v56, v56, %[id]\n\t"                                                                                \
         "v_xor_b32 v57, v57, %[id]\n\t"                                                                                \
         "v_xor_b32 v58, v58, %[id]\n\t"                                                                                \
         "v_xor_b32 v59, v59, %[id]\n\t"                                                                                \
-        "v_xor_b32 %[t1], %[t1], %[id]\n\t"                                                                            \
+        "v_xor_b32 v37, v37, %[id]\n\t"                                                                            \
         "v_min3_u32 v56, v56, v57, v58\n\t"                                                                            \
-        "v_min3_u32 v56, v56, v59, %[t1]\n\t"                  /* 0 <=> id is in the bucket */                         \
-        "v_lshrrev_b32 %[t1], 24, v63\n\t"                     /* slots handed out */                                  \
+        "v_min3_u32 v56, v56, v59, v37\n\t"                  /* 0 <=> id is in the bucket */                         \
+        "v_lshrrev_b32 v37, 24, v63\n\t"                     /* slots handed out */                                  \
         "v_cmp_ne_u32 vcc, 0, v56\n\t"                                                                                 \
         "s_and_b64 exec, exec, vcc\n\t"                        /* lanes that found their id are done */                \
         "s_cbranch_execz 9f\n\t"                                                                                       \
         "s_mov_b64 %[act], exec\n\t"                                                                                   \
-        "v_cmp_gt_u32 vcc, 5, %[t1]\n\t"                                                                               \
+        "v_cmp_gt_u32 vcc, 5, v37\n\t"                                                                               \
         "s_and_b64 exec, exec, vcc\n\t"                        /* the bucket had room when it was read */              \
         "s_cbranch_execz 3f\n\t"                                                                                       \
-        "v_mov_b32 %[t1], 0x1000000\n\t"                                                                               \
-        "ds_add_rtn_u32 %[t0], %[addr], %[t1] offset:12\n\t"   /* take a slot number */                                \
-        "v_lshrrev_b32 %[t2], 8, %[id]\n\t"                                                                            \
+        "v_mov_b32 v37, 0x1000000\n\t"                                                                               \
+        "ds_add_rtn_u32 v36, v39, v37 offset:12\n\t"   /* take a slot number */                                \
+        "v_lshrrev_b32 v38, 8, %[id]\n\t"                                                                            \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-        "v_lshrrev_b32 %[t0], 24, %[t0]\n\t"                                                                           \
-        "v_cmp_gt_u32 vcc, 5, %[t0]\n\t"                                                                               \
+        "v_lshrrev_b32 v36, 24, v36\n\t"                                                                           \
+        "v_cmp_gt_u32 vcc, 5, v36\n\t"                                                                               \
         "s_and_b64 exec, exec, vcc\n\t"                        /* lanes whose number is a real slot */                 \
         "s_cbranch_execz 3f\n\t"                                                                                       \
-        "v_mad_u32_u24 %[t0], %[t0], 3, %[addr]\n\t"           /* byte address of the slot */                          \
-        "ds_write_b8 %[t0], %[id]\n\t"                                                                                 \
-        "ds_write_b8 %[t0], %[t2] offset:1\n\t"                                                                        \
-        "ds_write_b8_d16_hi %[t0], %[id] offset:2\n\t"                                                                 \
+        "v_mad_u32_u24 v36, v36, 3, v39\n\t"           /* byte address of the slot */                          \
+        "ds_write_b8 v36, %[id]\n\t"                                                                                 \
+        "ds_write_b8 v36, v38 offset:1\n\t"                                                                        \
+        "ds_write_b8_d16_hi v36, %[id] offset:2\n\t"                                                                 \
         "s_or_b64 %[fresh], %[fresh], exec\n\t"                                                                        \
         "s_andn2_b64 %[act], %[act], exec\n"                                                                           \
         "3:\n\t"                                                                                                       \
         "s_mov_b64 exec, %[act]\n\t"                           /* absent and unplaced: their bucket is full */         \
         "s_cbranch_execz 9f\n\t"                                                                                       \
-        "v_add_u32 %[addr], 16, %[addr]\n\t"                                                                           \
-        "v_cmp_eq_u32 vcc, %[end], %[addr]\n\t"                                                                        \
-        "v_cndmask_b32 %[addr], %[addr], %[basev], vcc\n\t"                                                            \
+        "v_add_u32 v39, 16, v39\n\t"                                                                           \
+        "v_cmp_eq_u32 vcc, %[end], v39\n\t"                                                                        \
+        "v_cndmask_b32 v39, v39, %[basev], vcc\n\t"                                                            \
         "s_branch 1b\n"                                                                                                \
         "4:\n\t"                                               /* ---- quotient form ---- */                           \
         "s_lshl_b32 %[mulc], %[nb], 4\n\t"                                                                             \
-        "v_mul_lo_u32 %[t0], %[t0], %[nb]\n\t"                 /* place inside the home bucket's range */              \
-        "v_lshrrev_b32 %[t0], %[shr], %[t0]\n\t"               /* < 2^12 */                                            \
-        "v_lshl_or_b32 %[t2], %[t0], 16, %[t0]\n"              /* the key in both halves, displacement 0 */            \
+        "v_mul_lo_u32 v36, v36, %[nb]\n\t"                 /* place inside the home bucket's range */              \
+        "v_lshrrev_b32 v36, %[shr], v36\n\t"               /* < 2^12 */                                            \
+        "v_lshl_or_b32 v38, v36, 16, v36\n"              /* the key in both halves, displacement 0 */            \
         "5:\n\t"                                                                                                       \
-        "ds_read_b128 v[60:63], %[addr]\n\t"                                                                           \
+        "ds_read_b128 v[60:63], v39\n\t"                                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-        "v_xor_b32 v56, v60, %[t2]\n\t"                                                                                \
-        "v_xor_b32 v57, v61, %[t2]\n\t"                                                                                \
-        "v_xor_b32 v58, v62, %[t2]\n\t"                                                                                \
-        "v_xor_b32 v59, v63, %[t2]\n\t"                                                                                \
+        "v_xor_b32 v56, v60, v38\n\t"                                                                                \
+        "v_xor_b32 v57, v61, v38\n\t"                                                                                \
+        "v_xor_b32 v58, v62, v38\n\t"                                                                                \
+        "v_xor_b32 v59, v63, v38\n\t"                                                                                \
         "v_pk_min_u16 v56, v56, v57\n\t"                                                                               \
         "v_pk_min_u16 v58, v58, v59\n\t"                                                                               \
-        "v_bfe_u32 %[t1], v63, 16, 12\n\t"                     /* slots handed out */                                  \
+        "v_bfe_u32 v37, v63, 16, 12\n\t"                     /* slots handed out */                                  \
         "v_pk_min_u16 v56, v56, v58\n\t"                                                                               \
         "v_mad_u32_u16 v56, v56, v56, 0 op_sel:[0,1,0,0]\n\t"  /* low half x high half: 0 <=> the key is in the bucket */ \
         "v_cmp_ne_u32 vcc, 0, v56\n\t"                                                                                 \
         "s_and_b64 exec, exec, vcc\n\t"                                                                                \
         "s_cbranch_execz 9f\n\t"                                                                                       \
         "s_mov_b64 %[act], exec\n\t"                                                                                   \
-        "v_cmp_gt_u32 vcc, 7, %[t1]\n\t"                                                                               \
+        "v_cmp_gt_u32 vcc, 7, v37\n\t"                                                                               \
         "s_and_b64 exec, exec, vcc\n\t"                                                                                \
         "s_cbranch_execz 6f\n\t"                                                                                       \
-        "v_mov_b32 %[t1], 0x10000\n\t"                                                                                 \
-        "ds_add_rtn_u32 %[t0], %[addr], %[t1] offset:12\n\t"                                                           \
+        "v_mov_b32 v37, 0x10000\n\t"                                                                                 \
+        "ds_add_rtn_u32 v36, v39, v37 offset:12\n\t"                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-        "v_bfe_u32 %[t0], %[t0], 16, 12\n\t"                                                                           \
-        "v_cmp_gt_u32 vcc, 7, %[t0]\n\t"                                                                               \
+        "v_bfe_u32 v36, v36, 16, 12\n\t"                                                                           \
+        "v_cmp_gt_u32 vcc, 7, v36\n\t"                                                                               \
         "s_and_b64 exec, exec, vcc\n\t"                                                                                \
         "s_cbranch_execz 6f\n\t"                                                                                       \
-        "v_lshl_add_u32 %[t0], %[t0], 1, %[addr]\n\t"                                                                  \
-        "ds_write_b16 %[t0], %[t2]\n\t"                                                                                \
+        "v_lshl_add_u32 v36, v36, 1, v39\n\t"                                                                  \
+        "ds_write_b16 v36, v38\n\t"                                                                                \
         "s_or_b64 %[fresh], %[fresh], exec\n\t"                                                                        \
         "s_andn2_b64 %[act], %[act], exec\n"                                                                           \
         "6:\n\t"                                                                                                       \
         "s_mov_b64 exec, %[act]\n\t"                                                                                   \
         "s_cbranch_execz 9f\n\t"                                                                                       \
-        "v_and_b32 %[t0], 7, %[t2]\n\t"                        /* next probe: 1 .. 8 buckets on, by the key's low bits */ \
-        "v_lshl_add_u32 %[t0], %[t0], 4, 16\n\t"               /* (no runs of full buckets shared by neighbouring homes) */ \
-        "v_add_u32 %[addr], %[addr], %[t0]\n\t"                                                                        \
+        "v_and_b32 v36, 7, v38\n\t"                        /* next probe: 1 .. 8 buckets on, by the key's low bits */ \
+        "v_lshl_add_u32 v36, v36, 4, 16\n\t"               /* (no runs of full buckets shared by neighbouring homes) */ \
+        "v_add_u32 v39, v39, v36\n\t"                                                                        \
         "s_bfe_u32 vcc_lo, %[shr], 0x10010\n\t"                /* 13 remainder bits: the probe number sits one bit higher */ \
         "s_lshl_b32 vcc_lo, 0x10001000, vcc_lo\n\t"                                                                    \
-        "v_add_u32 %[t2], vcc_lo, %[t2]\n\t"                   /* one probe further from home */                       \
-        "v_cmp_le_u32 vcc, %[end], %[addr]\n\t"                                                                        \
-        "v_subrev_u32 %[t0], %[mulc], %[addr]\n\t"             /* (%[mulc] holds the table's bytes by now) */          \
-        "v_cndmask_b32 %[addr], %[addr], %[t0], vcc\n\t"                                                               \
-        "v_cmp_gt_u32 vcc, %[shr], %[t2]\n\t"                  /* displacement still in range (below %[shr] >> 28) */  \
+        "v_add_u32 v38, vcc_lo, v38\n\t"                   /* one probe further from home */                       \
+        "v_cmp_le_u32 vcc, %[end], v39\n\t"                                                                        \
+        "v_subrev_u32 v36, %[mulc], v39\n\t"             /* (%[mulc] holds the table's bytes by now) */          \
+        "v_cndmask_b32 v39, v39, v36, vcc\n\t"                                                               \
+        "s_and_b32 vcc_lo, %[shr], 0xF0000000\n\t"           /* the probe-number field alone (ctl's low bits hold shifts and flags) */ \
+        "v_cmp_gt_u32 vcc, vcc_lo, v38\n\t"                  /* probe number still in range (below %[shr] >> 28) */  \
         "s_andn2_b64 %[act], exec, vcc\n\t"                    /* lanes out of range: reported in the odd bits of %[fresh] */ \
         "s_lshl_b64 %[act], %[act], 1\n\t"                                                                             \
         "s_or_b64 %[fresh], %[fresh], %[act]\n\t"                                                                      \
         "s_and_b64 exec, exec, vcc\n\t"                                                                                \
         "s_cbranch_execnz 5b\n"                                                                                        \
-        "9:\n\t"                                                                                                       \
-        "s_mov_b64 exec, %[sv]\n\t"
+        "9:\n\t"
 
 // METRIC 0: L2Metric::Dist, the lane holds 64 contiguous bytes of the row (roff = row + half * 64, loads at 0 / 16 / 32 / 48).
 // METRIC 1: Angular::Dist, the lane holds the even (odd) 16-byte pieces (roff = row + half * 16, loads at 0 / 32 / 64 / 96):
 // its eight running sums are independent chains, the even lane runs sums 0..3, the odd lane sums 4..7, and the fold
 // m_j = c_{j+4} + c_j happens once, in the odd lane (dot_pair_from_regs).
-template <int METRIC = 0, typename QP>
+//
+// The lane's 16 query floats (the pieces that face its four row loads).  QLDS = false: all in registers (`qh`).
+// QLDS = true (round 4: the ef <= 128 instances): none stays in registers; the pieces are re-read every hop from the
+// wavefront's LDS copy of the query (`qaddr` = its byte address + this lane's piece offset; the pieces sit at the row
+// loads' offsets) into the block's own temporaries -- v[36:39], free once the visited-set protocol is done, and v[56:63]
+// -- right behind the row loads, i.e. in their shadow (>= 500 cycles); the fourth piece follows into v[36:39] as soon as
+// step 0 has consumed the first.  The walk then holds 16 registers less across the hop, which is what lets these
+// instances fit 64 registers (8 wavefronts per SIMD) without a spill.
+#define GBNNS_L2_DIST_ASM(Q0A, Q0B, Q1A, Q1B, Q2A, Q2B, Q3A, Q3B, W1, W2, W3)                                                     \
+        "s_waitcnt vmcnt(3)\n\t"                               /* loads return in order: square each step as it lands */ \
+        "v_pk_add_f32 v[40:41], v[40:41], " Q0A " neg_lo:[0,1] neg_hi:[0,1]\n\t"                                        \
+        "v_pk_add_f32 v[42:43], v[42:43], " Q0B " neg_lo:[0,1] neg_hi:[0,1]\n\t"                                        \
+        "v_pk_mul_f32 v[40:41], v[40:41], v[40:41]\n\t"                                                                \
+        "v_pk_mul_f32 v[42:43], v[42:43], v[42:43]\n\t"                                                                \
+        W1                                                                                                             \
+        "v_pk_add_f32 v[44:45], v[44:45], " Q1A " neg_lo:[0,1] neg_hi:[0,1]\n\t"                                        \
+        "v_pk_add_f32 v[46:47], v[46:47], " Q1B " neg_lo:[0,1] neg_hi:[0,1]\n\t"                                        \
+        "v_pk_mul_f32 v[44:45], v[44:45], v[44:45]\n\t"                                                                \
+        "v_pk_mul_f32 v[46:47], v[46:47], v[46:47]\n\t"                                                                \
+        W2                                                                                                             \
+        "v_pk_add_f32 v[48:49], v[48:49], " Q2A " neg_lo:[0,1] neg_hi:[0,1]\n\t"                                        \
+        "v_pk_add_f32 v[50:51], v[50:51], " Q2B " neg_lo:[0,1] neg_hi:[0,1]\n\t"                                        \
+        "v_pk_mul_f32 v[48:49], v[48:49], v[48:49]\n\t"                                                                \
+        "v_pk_mul_f32 v[50:51], v[50:51], v[50:51]\n\t"                                                                \
+        W3                                                                                                             \
+        "v_pk_add_f32 v[52:53], v[52:53], " Q3A " neg_lo:[0,1] neg_hi:[0,1]\n\t"                                        \
+        "v_pk_add_f32 v[54:55], v[54:55], " Q3B " neg_lo:[0,1] neg_hi:[0,1]\n\t"                                        \
+        "v_pk_mul_f32 v[52:53], v[52:53], v[52:53]\n\t"                                                                \
+        "v_pk_mul_f32 v[54:55], v[54:55], v[54:55]\n\t"                                                                \
+        "v_pk_add_f32 v[60:61], v[40:41], v[44:45]\n\t"      /* even lane: steps 0..3 */                               \
+        "v_pk_add_f32 v[62:63], v[42:43], v[46:47]\n\t"                                                                \
+        "v_pk_add_f32 v[60:61], v[60:61], v[48:49]\n\t"                                                                \
+        "v_pk_add_f32 v[62:63], v[62:63], v[50:51]\n\t"                                                                \
+        "v_pk_add_f32 v[60:61], v[60:61], v[52:53]\n\t"                                                                \
+        "v_pk_add_f32 v[62:63], v[62:63], v[54:55]\n\t"                                                                \
+        "s_nop 1\n\t"                                                                                                  \
+        "v_mov_b32_dpp v56, v60 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"                                    \
+        "v_mov_b32_dpp v57, v61 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"                                    \
+        "v_mov_b32_dpp v58, v62 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"                                    \
+        "v_mov_b32_dpp v59, v63 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"                                    \
+        "v_pk_add_f32 v[56:57], v[56:57], v[40:41]\n\t"      /* odd lane: steps 4..7 on top */                         \
+        "v_pk_add_f32 v[58:59], v[58:59], v[42:43]\n\t"                                                                \
+        "v_pk_add_f32 v[56:57], v[56:57], v[44:45]\n\t"                                                                \
+        "v_pk_add_f32 v[58:59], v[58:59], v[46:47]\n\t"                                                                \
+        "v_pk_add_f32 v[56:57], v[56:57], v[48:49]\n\t"                                                                \
+        "v_pk_add_f32 v[58:59], v[58:59], v[50:51]\n\t"                                                                \
+        "v_pk_add_f32 v[56:57], v[56:57], v[52:53]\n\t"                                                                \
+        "v_pk_add_f32 v[58:59], v[58:59], v[54:55]\n\t"                                                                \
+        "v_add_f32 %[key], v56, v57\n\t"                                                                               \
+        "v_add_f32 %[key], %[key], v58\n\t"                                                                            \
+        "v_add_f32 %[key], %[key], v59\n\t"                                                                            \
+        "v_or_b32 %[key], 0x80000000, %[key]"                  /* fkey of a non-negative float */
+
+// (dot_pair_from_regs) products, then four running sums from +0 in load order
+#define GBNNS_DOT_DIST_ASM(Q0A, Q0B, Q1A, Q1B, Q2A, Q2B, Q3A, Q3B, W1, W2, W3)                                                    \
+        "s_waitcnt vmcnt(3)\n\t"                                                                                       \
+        "v_pk_mul_f32 v[40:41], v[40:41], " Q0A "\n\t"                                                                 \
+        "v_pk_mul_f32 v[42:43], v[42:43], " Q0B "\n\t"                                                                 \
+        W1                                                                                                             \
+        "v_pk_mul_f32 v[44:45], v[44:45], " Q1A "\n\t"                                                                 \
+        "v_pk_mul_f32 v[46:47], v[46:47], " Q1B "\n\t"                                                                 \
+        W2                                                                                                             \
+        "v_pk_mul_f32 v[48:49], v[48:49], " Q2A "\n\t"                                                                 \
+        "v_pk_mul_f32 v[50:51], v[50:51], " Q2B "\n\t"                                                                 \
+        W3                                                                                                             \
+        "v_pk_mul_f32 v[52:53], v[52:53], " Q3A "\n\t"                                                                 \
+        "v_pk_mul_f32 v[54:55], v[54:55], " Q3B "\n\t"                                                                 \
+        "v_mov_b32 v56, 0\n\t"                                 /* (the query pieces in v[56:63] are dead by now) */    \
+        "v_mov_b32 v57, 0\n\t"                                                                                         \
+        "v_pk_add_f32 v[60:61], v[56:57], v[40:41]\n\t"      /* 0 + p: a product of -0 must not make the sum -0 */     \
+        "v_pk_add_f32 v[62:63], v[56:57], v[42:43]\n\t"                                                                \
+        "v_pk_add_f32 v[60:61], v[60:61], v[44:45]\n\t"                                                                \
+        "v_pk_add_f32 v[62:63], v[62:63], v[46:47]\n\t"                                                                \
+        "v_pk_add_f32 v[60:61], v[60:61], v[48:49]\n\t"                                                                \
+        "v_pk_add_f32 v[62:63], v[62:63], v[50:51]\n\t"                                                                \
+        "v_pk_add_f32 v[60:61], v[60:61], v[52:53]\n\t"                                                                \
+        "v_pk_add_f32 v[62:63], v[62:63], v[54:55]\n\t"                                                                \
+        "s_nop 1\n\t"                                                                                                  \
+        "v_mov_b32_dpp v56, v60 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"   /* the even lane's sums 0..3 */   \
+        "v_mov_b32_dpp v57, v61 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"                                    \
+        "v_mov_b32_dpp v58, v62 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"                                    \
+        "v_mov_b32_dpp v59, v63 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"                                    \
+        "v_pk_add_f32 v[56:57], v[60:61], v[56:57]\n\t"      /* odd lane: m_j = c_{j+4} + c_j */                       \
+        "v_pk_add_f32 v[58:59], v[62:63], v[58:59]\n\t"                                                                \
+        "v_add_f32 %[key], v56, v57\n\t"                       /* (m0 + m1) + (m2 + m3) */                             \
+        "v_add_f32 v36, v58, v59\n\t"                                                                                  \
+        "v_add_f32 %[key], %[key], v36\n\t"                                                                            \
+        "v_xor_b32 %[key], 0x80000000, %[key]\n\t"             /* Angular::Dist = -(x . y) */                          \
+        "v_add_f32 %[key], 0, %[key]\n\t"                      /* fkey: -0 -> +0, */                                   \
+        "v_ashrrev_i32 v36, 31, %[key]\n\t"                    /* then flip all bits of a negative value, the sign bit of a positive one */ \
+        "v_or_b32 v36, 0x80000000, v36\n\t"                                                                            \
+        "v_xor_b32 %[key], %[key], v36"
+
+// The four row loads of a lane, two layouts:
+//  * SPEC (rounds 1-3; since round 4 only the instances for ef > 64): requested for every valid slot BEFORE the visited
+//    test, which then runs in their shadow -- shortest hop, but the rows of already-visited ids are fetched for nothing
+//    (15 % of the tested ids at ef = 64, two thirds at ef >= 180).
+//  * tested first (round 4, the ef <= 64 instances): requested AFTER the test, for the new ids only (lanes 2i / 2i+1 of
+//    a pair whose even lane claimed its id, or ran out of probe range and goes to the stash).  With 32 wavefronts per
+//    CU resident the longer hop is hidden and the saved row traffic shows: SIFT-like ef = 64 0.335 -> 0.322 ms, 29.3 ->
+//    31.0 M queries/s in flight; at ef = 128 / 180 / 300 (fewer wavefronts per CU: latency chains) it loses 7 - 12 %,
+//    hence the split.  No new id at all: the distance section is skipped.
+#define GBNNS_LOADS_SPEC(O1, O2, O3)                                    \
+        "global_load_dwordx4 v[40:43], %[roff], %[db]\n\t"              \
+        "global_load_dwordx4 v[44:47], %[roff], %[db] offset:" O1 "\n\t" \
+        "global_load_dwordx4 v[48:51], %[roff], %[db] offset:" O2 "\n\t" \
+        "global_load_dwordx4 v[52:55], %[roff], %[db] offset:" O3 "\n\t"
+#define GBNNS_LOADS_TESTED(O1, O2, O3)                                                                                 \
+        "s_lshr_b64 %[act], %[fresh], 1\n\t"                  /* out-of-range reports sit in the odd bits */           \
+        "s_or_b64 exec, %[act], %[fresh]\n\t"                                                                          \
+        "s_and_b32 exec_lo, exec_lo, 0x55555555\n\t"          /* even lanes with a new id */                           \
+        "s_and_b32 exec_hi, exec_hi, 0x55555555\n\t"                                                                   \
+        "s_lshl_b64 %[act], exec, 1\n\t"                                                                               \
+        "s_or_b64 exec, exec, %[act]\n\t"                     /* ... and their odd partners */                         \
+        "s_cbranch_execz 8f\n\t"                                                                                       \
+        GBNNS_LOADS_SPEC(O1, O2, O3)                                                                                   \
+        "s_mov_b64 exec, %[sv]\n\t"
+#define GBNNS_HOT_END "\n8:\n\ts_mov_b64 exec, %[sv]"
+
+#define GBNNS_HOT_CLOBBERS                                                                                              \
+    "vcc", "scc", "memory", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",  \
+        "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
+
+template <int METRIC = 0, bool QLDS = false, bool SPEC = !QLDS, typename QP>
 __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t roff, uint32_t nb, uint64_t valid, uint32_t lds_base,
-                                               uint32_t nbuckets, QP qh, uint64_t& claimed, uint32_t shr, uint64_t& overflowed) {
+                                               uint32_t nbuckets, QP qh, uint32_t qaddr, uint64_t& claimed, uint32_t shr, uint64_t& overflowed) {
     const uint32_t end = lds_base + (nbuckets << 4);
-    uint32_t basev = lds_base, addr, t0, t1, t2, key, mulc;
+    uint32_t basev = lds_base, key, mulc;
     uint64_t fresh, act, sv;
-    f32x2 ra0, rb0, ra1, rb1, ra2, rb2, ra3, rb3;  // row halves, then their squared differences
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 r0, r1, r2, r3;
 #define GBNNS_Q(T) [qa##T] "v"(f32x2{qh[T].x, qh[T].y}), [qb##T] "v"(f32x2{qh[T].z, qh[T].w})
-    if constexpr (METRIC == 0) {
+#define GBNNS_HOT_OUT [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [mulc] "=&s"(mulc), [key] "=&v"(key)
+#define GBNNS_HOT_IN [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [shr] "s"(shr), [nb] "s"(nbuckets), \
+                     [roff] "v"(roff), [db] "s"(db_base)
+    static_assert(QLDS != SPEC, "built forms: query in registers + speculative row loads, or query in LDS + rows of the new ids only");
+    if constexpr (METRIC == 0 && !QLDS) {
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[valid]\n\t"
-        "global_load_dwordx4 v[40:43], %[roff], %[db]\n\t"
-        "global_load_dwordx4 v[44:47], %[roff], %[db] offset:16\n\t"
-        "global_load_dwordx4 v[48:51], %[roff], %[db] offset:32\n\t"
-        "global_load_dwordx4 v[52:55], %[roff], %[db] offset:48\n\t"
+        GBNNS_LOADS_SPEC("16", "32", "48")
         GBNNS_VS_ASM
-        // ---- pair distance (l2_pair_from_regs), all lanes
-        "s_waitcnt vmcnt(3)\n\t"                               // loads return in order: square each step as it lands
-        "v_pk_add_f32 v[40:41], v[40:41], %[qa0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[42:43], v[42:43], %[qb0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_mul_f32 v[40:41], v[40:41], v[40:41]\n\t"
-        "v_pk_mul_f32 v[42:43], v[42:43], v[42:43]\n\t"
-        "s_waitcnt vmcnt(2)\n\t"
-        "v_pk_add_f32 v[44:45], v[44:45], %[qa1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[46:47], v[46:47], %[qb1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_mul_f32 v[44:45], v[44:45], v[44:45]\n\t"
-        "v_pk_mul_f32 v[46:47], v[46:47], v[46:47]\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        "v_pk_add_f32 v[48:49], v[48:49], %[qa2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[50:51], v[50:51], %[qb2] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_mul_f32 v[48:49], v[48:49], v[48:49]\n\t"
-        "v_pk_mul_f32 v[50:51], v[50:51], v[50:51]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_pk_add_f32 v[52:53], v[52:53], %[qa3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_add_f32 v[54:55], v[54:55], %[qb3] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-        "v_pk_mul_f32 v[52:53], v[52:53], v[52:53]\n\t"
-        "v_pk_mul_f32 v[54:55], v[54:55], v[54:55]\n\t"
-        "v_pk_add_f32 v[60:61], v[40:41], v[44:45]\n\t"      // even lane: steps 0..3
-        "v_pk_add_f32 v[62:63], v[42:43], v[46:47]\n\t"
-        "v_pk_add_f32 v[60:61], v[60:61], v[48:49]\n\t"
-        "v_pk_add_f32 v[62:63], v[62:63], v[50:51]\n\t"
-        "v_pk_add_f32 v[60:61], v[60:61], v[52:53]\n\t"
-        "v_pk_add_f32 v[62:63], v[62:63], v[54:55]\n\t"
-        "s_nop 1\n\t"
-        "v_mov_b32_dpp v56, v60 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v57, v61 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v58, v62 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v59, v63 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_pk_add_f32 v[56:57], v[56:57], v[40:41]\n\t"      // odd lane: steps 4..7 on top
-        "v_pk_add_f32 v[58:59], v[58:59], v[42:43]\n\t"
-        "v_pk_add_f32 v[56:57], v[56:57], v[44:45]\n\t"
-        "v_pk_add_f32 v[58:59], v[58:59], v[46:47]\n\t"
-        "v_pk_add_f32 v[56:57], v[56:57], v[48:49]\n\t"
-        "v_pk_add_f32 v[58:59], v[58:59], v[50:51]\n\t"
-        "v_pk_add_f32 v[56:57], v[56:57], v[52:53]\n\t"
-        "v_pk_add_f32 v[58:59], v[58:59], v[54:55]\n\t"
-        "v_add_f32 %[key], v56, v57\n\t"
-        "v_add_f32 %[key], %[key], v58\n\t"
-        "v_add_f32 %[key], %[key], v59\n\t"
-        "v_or_b32 %[key], 0x80000000, %[key]"                  // fkey of a non-negative float
-        : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [mulc] "=&s"(mulc), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
-          [addr] "=&v"(addr), [key] "=&v"(key)
-        : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [shr] "s"(shr),
-          [nb] "s"(nbuckets), [roff] "v"(roff), [db] "s"(db_base), GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
-        : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",
-          "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+        "s_mov_b64 exec, %[sv]\n\t"
+        GBNNS_L2_DIST_ASM("%[qa0]", "%[qb0]", "%[qa1]", "%[qb1]", "%[qa2]", "%[qb2]", "%[qa3]", "%[qb3]", "s_waitcnt vmcnt(2)\n\t", "s_waitcnt vmcnt(1)\n\t",
+                          "s_waitcnt vmcnt(0)\n\t")
+        : GBNNS_HOT_OUT
+        : GBNNS_HOT_IN, GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
+        : GBNNS_HOT_CLOBBERS);
+    } else if constexpr (METRIC == 0) {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[valid]\n\t"
+        GBNNS_VS_ASM
+        GBNNS_LOADS_TESTED("16", "32", "48")
+        "ds_read_b128 v[36:39], %[qaddr]\n\t"                // the query pieces that face row loads 0 .. 2 (all lanes);
+        "ds_read_b128 v[56:59], %[qaddr] offset:16\n\t"      // piece 3 follows into v[36:39] once step 0 has used piece 0
+        "ds_read_b128 v[60:63], %[qaddr] offset:32\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        GBNNS_L2_DIST_ASM("v[36:37]", "v[38:39]", "v[56:57]", "v[58:59]", "v[60:61]", "v[62:63]", "v[36:37]", "v[38:39]",
+                          "ds_read_b128 v[36:39], %[qaddr] offset:48\n\ts_waitcnt vmcnt(2) lgkmcnt(2)\n\t",
+                          "s_waitcnt vmcnt(1) lgkmcnt(1)\n\t", "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t")
+        GBNNS_HOT_END
+        : GBNNS_HOT_OUT
+        : GBNNS_HOT_IN, [qaddr] "v"(qaddr)
+        : GBNNS_HOT_CLOBBERS);
+    } else if constexpr (!QLDS) {
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[valid]\n\t"
+        GBNNS_LOADS_SPEC("32", "64", "96")
+        GBNNS_VS_ASM
+        "s_mov_b64 exec, %[sv]\n\t"
+        GBNNS_DOT_DIST_ASM("%[qa0]", "%[qb0]", "%[qa1]", "%[qb1]", "%[qa2]", "%[qb2]", "%[qa3]", "%[qb3]", "s_waitcnt vmcnt(2)\n\t", "s_waitcnt vmcnt(1)\n\t",
+                           "s_waitcnt vmcnt(0)\n\t")
+        : GBNNS_HOT_OUT
+        : GBNNS_HOT_IN, GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
+        : GBNNS_HOT_CLOBBERS);
     } else {
     asm volatile(
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[valid]\n\t"
-        "global_load_dwordx4 v[40:43], %[roff], %[db]\n\t"
-        "global_load_dwordx4 v[44:47], %[roff], %[db] offset:32\n\t"
-        "global_load_dwordx4 v[48:51], %[roff], %[db] offset:64\n\t"
-        "global_load_dwordx4 v[52:55], %[roff], %[db] offset:96\n\t"
         GBNNS_VS_ASM
-        // ---- pair distance (dot_pair_from_regs), all lanes: products, then four running sums from +0 in load order
-        "v_mov_b32 v56, 0\n\t"
-        "v_mov_b32 v57, 0\n\t"
-        "s_waitcnt vmcnt(3)\n\t"
-        "v_pk_mul_f32 v[40:41], v[40:41], %[qa0]\n\t"
-        "v_pk_mul_f32 v[42:43], v[42:43], %[qb0]\n\t"
-        "v_pk_add_f32 v[60:61], v[56:57], v[40:41]\n\t"      // 0 + p: a product of -0 must not make the sum -0
-        "v_pk_add_f32 v[62:63], v[56:57], v[42:43]\n\t"
-        "s_waitcnt vmcnt(2)\n\t"
-        "v_pk_mul_f32 v[44:45], v[44:45], %[qa1]\n\t"
-        "v_pk_mul_f32 v[46:47], v[46:47], %[qb1]\n\t"
-        "v_pk_add_f32 v[60:61], v[60:61], v[44:45]\n\t"
-        "v_pk_add_f32 v[62:63], v[62:63], v[46:47]\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        "v_pk_mul_f32 v[48:49], v[48:49], %[qa2]\n\t"
-        "v_pk_mul_f32 v[50:51], v[50:51], %[qb2]\n\t"
-        "v_pk_add_f32 v[60:61], v[60:61], v[48:49]\n\t"
-        "v_pk_add_f32 v[62:63], v[62:63], v[50:51]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_pk_mul_f32 v[52:53], v[52:53], %[qa3]\n\t"
-        "v_pk_mul_f32 v[54:55], v[54:55], %[qb3]\n\t"
-        "v_pk_add_f32 v[60:61], v[60:61], v[52:53]\n\t"
-        "v_pk_add_f32 v[62:63], v[62:63], v[54:55]\n\t"
-        "s_nop 1\n\t"
-        "v_mov_b32_dpp v56, v60 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"   // the even lane's sums 0..3
-        "v_mov_b32_dpp v57, v61 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v58, v62 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v59, v63 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_pk_add_f32 v[56:57], v[60:61], v[56:57]\n\t"      // odd lane: m_j = c_{j+4} + c_j
-        "v_pk_add_f32 v[58:59], v[62:63], v[58:59]\n\t"
-        "v_add_f32 %[key], v56, v57\n\t"                       // (m0 + m1) + (m2 + m3)
-        "v_add_f32 %[t0], v58, v59\n\t"
-        "v_add_f32 %[key], %[key], %[t0]\n\t"
-        "v_xor_b32 %[key], 0x80000000, %[key]\n\t"             // Angular::Dist = -(x . y)
-        "v_add_f32 %[key], 0, %[key]\n\t"                      // fkey: -0 -> +0,
-        "v_ashrrev_i32 %[t0], 31, %[key]\n\t"                  // then flip all bits of a negative value, the sign bit of a positive one
-        "v_or_b32 %[t0], 0x80000000, %[t0]\n\t"
-        "v_xor_b32 %[key], %[key], %[t0]"
-        : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [mulc] "=&s"(mulc), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
-          [addr] "=&v"(addr), [key] "=&v"(key)
-        : [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [shr] "s"(shr),
-          [nb] "s"(nbuckets), [roff] "v"(roff), [db] "s"(db_base), GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
-        : "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52",
-          "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+        GBNNS_LOADS_TESTED("32", "64", "96")
+        "ds_read_b128 v[36:39], %[qaddr]\n\t"
+        "ds_read_b128 v[56:59], %[qaddr] offset:32\n\t"
+        "ds_read_b128 v[60:63], %[qaddr] offset:64\n\t"
+        "s_waitcnt lgkmcnt(2)\n\t"
+        GBNNS_DOT_DIST_ASM("v[36:37]", "v[38:39]", "v[56:57]", "v[58:59]", "v[60:61]", "v[62:63]", "v[36:37]", "v[38:39]",
+                           "ds_read_b128 v[36:39], %[qaddr] offset:96\n\ts_waitcnt vmcnt(2) lgkmcnt(2)\n\t",
+                           "s_waitcnt vmcnt(1) lgkmcnt(1)\n\t", "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t")
+        GBNNS_HOT_END
+        : GBNNS_HOT_OUT
+        : GBNNS_HOT_IN, [qaddr] "v"(qaddr)
+        : GBNNS_HOT_CLOBBERS);
     }
 #undef GBNNS_Q
+#undef GBNNS_HOT_OUT
+#undef GBNNS_HOT_IN
     claimed = fresh & 0x5555555555555555ull;
     overflowed = fresh & 0xAAAAAAAAAAAAAAAAull;
     return key;
@@ -3064,11 +3167,15 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     const int lane = lane_id();
     const uint32_t slot = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;  // lane = 2 * adjacency slot + row half
     const int ef = p.ef;
-    // LDS: [tie list 128 B][merge buffer 528 B; its head stages the query until it is in registers][visited set]
+    // R = 1 (QLDS): the query stays in LDS and hot_expand re-reads a lane's four pieces every hop -- 64 registers, 8 wavefronts
+    // per SIMD; rows requested after the visited test.  R = 2: the query in registers, speculative row loads (rounds 1-3 layout).
+    constexpr bool QLDS = R == 1;
+    // LDS: [tie list 128 B][merge buffer 528 B (R = 2: 1 040 B; its head stages the query until it is in registers)]
+    //      [QLDS: the query, 128 B][visited set]
     uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
     uint64_t* stage = tie + kRegTieCap;
-    float* qf = reinterpret_cast<float*>(stage);
-    uint32_t* hash = reinterpret_cast<uint32_t*>(stage + reg_stage_slots(R));
+    float* qf = reinterpret_cast<float*>(QLDS ? stage + reg_stage_slots(R) : stage);
+    uint32_t* hash = reinterpret_cast<uint32_t*>(stage + reg_stage_slots(R)) + (QLDS ? 32 : 0);
     const float4* qs = reinterpret_cast<const float4*>(qf);
     const uint32_t cap = p.hash_cap;
     const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
@@ -3081,9 +3188,15 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     else packed_table_init(hash, nbuckets, 0u, lane);
     if (lane < 32) qf[lane] = p.q[(size_t)qi * p.qstride + lane];
     wave_sync();
-    RowRegs<4> qreg;  // this lane's half of the query: 64 contiguous bytes (L2) / the even or odd 16-byte pieces (dot)
+    // this lane's half of the query: 64 contiguous bytes (L2) / the even or odd 16-byte pieces (dot): the LDS byte address
+    // of its four pieces for hot_expand
+    RowRegs<4> qreg;  // (R = 2: the pieces in registers)
+    if constexpr (!QLDS) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) qreg.v[t] = METRIC == 0 ? qs[4 * half + t] : qs[2 * t + half];
+        for (int t = 0; t < 4; ++t) qreg.v[t] = METRIC == 0 ? qs[4 * half + t] : qs[2 * t + half];
+    }
+    const uint32_t qaddr = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(qf)) +
+                           half * (METRIC == 0 ? 64u : 16u);
 
     RegList<R> L;
     L.clear();
@@ -3225,7 +3338,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
             edges += __popcll(mv & 0x5555555555555555ull);
             // ---- gather (speculative: before the visited test), visited test, distances -----------
             uint64_t mclaimed, movf;
-            const uint32_t kd = hot_expand<METRIC>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, mclaimed, vs_shr, movf);
+            const uint32_t kd = hot_expand<METRIC, QLDS>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, qaddr, mclaimed, vs_shr, movf);
             if (__builtin_expect(movf != 0, 0)) {  // a probe sequence ran out (quotient form): the stash takes the id
                 // (the two-pass instances are at their scalar-register budget -- tests/test_isa_contract.py -- and hand over)
                 if constexpr (WIDE) return false;
@@ -3393,7 +3506,7 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
             STAMP(t3)
             STAMP_ADD(2, t2, t3)
             uint64_t mclaimed, movf;
-            const uint32_t kd = hot_expand<METRIC>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, mclaimed, vs_shr, movf);
+            const uint32_t kd = hot_expand<METRIC, false>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, 0u, mclaimed, vs_shr, movf);
             if (__builtin_expect(movf != 0, 0)) {  // a probe sequence ran out (quotient form): the stash takes the id
                 // (the two-pass instances are at their scalar-register budget -- tests/test_isa_contract.py -- and hand over)
                 if constexpr (WIDE) return false;
@@ -3466,7 +3579,7 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
     B.finish(p, qi, hops, dist_calc, edges, hash_bytes, lane);  // (re-rank query staged in the dead visited-set area)
 }
 
-__global__ __launch_bounds__(64) void walk_hot2_kernel(WalkParams p) {  // 64 < ef <= 128: two list registers per lane
+__global__ __launch_bounds__(64, 7) void walk_hot2_kernel(WalkParams p) {  // 64 < ef <= 128: two list registers per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<2>(p, walk_query_of(p, blockIdx.x), smem);
 }
@@ -3476,18 +3589,20 @@ __global__ __launch_bounds__(64) void walk_hot_big_kernel(WalkParams p) {  // 12
     walk_hot_big(p, walk_query_of(p, blockIdx.x), smem);
 }
 
-__global__ __launch_bounds__(64) void walk_hot_kernel(WalkParams p) {
+// (second launch bound = wavefronts per SIMD the register allocation must leave room for: 8 = 64 registers, which the hop needs
+// anyway since round 4 -- hot_expand, QLDS; the bound only keeps the prologue's entry distance from taking more)
+__global__ __launch_bounds__(64, 8) void walk_hot_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<1>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
 // the same three for adjacency rows of 33 .. 64 slots (two expansion passes per hop)
-__global__ __launch_bounds__(64) void walk_hotw_kernel(WalkParams p) {
+__global__ __launch_bounds__(64, 8) void walk_hotw_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<1, true>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
-__global__ __launch_bounds__(64) void walk_hotw2_kernel(WalkParams p) {
+__global__ __launch_bounds__(64, 7) void walk_hotw2_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<2, true>(p, walk_query_of(p, blockIdx.x), smem);
 }
@@ -3499,7 +3614,7 @@ __global__ __launch_bounds__(64) void walk_hotw_big_kernel(WalkParams p) {
 
 // ... and the negative-dot metric (Angular::Dist) on the same shapes (round 3): R = 1 / 2 list registers, or the two-list form
 template <int R, bool WIDE>
-__global__ __launch_bounds__(64) void walk_hot_dot_kernel(WalkParams p) {
+__global__ __launch_bounds__(64, R == 1 ? 8 : 7) void walk_hot_dot_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<R, WIDE, 1>(p, walk_query_of(p, blockIdx.x), smem);
 }
@@ -4388,7 +4503,7 @@ bool walk_uses_hot(const WalkParams& p, int metric) {
 // hot kernel stages the query inside the merge buffer (it lives in registers once the walk starts).
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list) {
     if (hot)  // tie list + merge buffer of 1 / 2 list registers; ef > 128: + the base list and the flush's flag bytes (walk_hot_big)
-        return ef <= 64 ? (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8
+        return ef <= 64 ? (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + 128   // (+ the query, re-read every hop)
                         : (ef <= kHot2MaxEf ? (size_t)kRegTieCap * 8 + (size_t)(64 * 2 + 2) * 8 : big_list_fixed_bytes(ef));
     if (ef <= kRegListMaxEf && !lds_list) {  // tie list + merge buffer (ranks 0..ef of the 1 / 2 / 4-register list) + query
         if (ef > kHot2MaxEf) return big_list_fixed_bytes(ef) + (size_t)dstride * 4;  // walk_reg_big_one

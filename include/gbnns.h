@@ -214,7 +214,8 @@ int gbnns_index_wait(gbnns_index* index, uint32_t keep);
  * counts straight from the kernels (no copies out), and may be used with GBNNS_FLAG_DEFER_JOIN.  The drop-in's
  * perform*Test functions pin the query / answer vectors before their timed region (the reference builds its
  * VisitedListPool there, search_function.h:333) and release them after it.  Pinning an already page-locked buffer
- * and releasing one that was not pinned here are no-ops. */
+ * and releasing one that was not pinned here are no-ops.  Registrations are made in whole pages and never overlap:
+ * small buffers that share a page share its registration (counted), which is released with its last user. */
 int gbnns_host_pin(void* ptr, size_t bytes);
 int gbnns_host_unpin(void* ptr);
 
@@ -252,6 +253,11 @@ typedef struct {
 } gbnns_profile;
 
 int gbnns_profile_enable(gbnns_index* index, int on);
+/* Diagnostic knobs of the process (tests, A/B runs); results never depend on them.  "quotient": 0 keeps the walk_hot*
+ * kernels' visited set in its packed form (default 1: the denser quotient form where it fits; initial value from the
+ * environment variable GBNNS_QUOTIENT).  "vs_disp": probe number at which a probe sequence of the quotient form gives
+ * up and the id goes to the stash / the query is handed over, 1 .. 15 (default 15; <= 0 restores it; GBNNS_DEBUG_VS_DISP). */
+int gbnns_debug_knob(const char* name, int value);
 int gbnns_profile_read(gbnns_index* index, gbnns_profile* out, int reset);
 
 /* hnswlikeGD (support_func.h:521-575, need_const_degree = false) + addReverseEdgesForGD

@@ -464,8 +464,8 @@ def test_deferred_join_pipeline(g, orc):
 def test_bench_two_ranks_rehearsal():
     """`python bench.py --gpus 2` as the driver calls it (no external launcher): the process starts its two workers
     itself before touching the GPU.  GBNNS_BENCH_REHEARSAL=1 puts both ranks on cuda:0 with gloo for the collective --
-    the N > 1 control flow (sharded queries, deferred joins, all-gather per step, max over ranks) on a one-GPU box;
-    not a measurement."""
+    the N > 1 control flow (sharded queries, deferred joins, all-gather per step, max over ranks, and the `capi_multi`
+    section: gbnns_multi_* from a child process of rank 0) on a one-GPU box; not a measurement."""
     import json
     import os
     import subprocess
@@ -484,6 +484,11 @@ def test_bench_two_ranks_rehearsal():
         assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["steps"] == 3 and r["gather_self_check"] is True
         assert r["value"] > 0 and r["roofline"]["frac"] > 0
         assert r["scaling"] == ("strong" if extra else "weak")
+        # the C ABI's own multi-replica path, driven by a child of rank 0 while the ranks are parked (rehearsal: the host
+        # form, both replicas on the one GPU): same answers as the ranks'
+        cm = r["capi_multi"]
+        assert "failed" not in cm, cm
+        assert cm["ranks"] == 2 and cm["queries_per_s"] > 0 and cm["ids_identical_to_rank_results"] is True, cm
 
 
 def test_multi_replicas_equal_single_handle(g, orc):
@@ -535,9 +540,10 @@ def test_multi_replicas_equal_single_handle(g, orc):
     one.close()
 
 
-def test_full_size_properties(g):
-    """SIFT1M-shaped workload at full size (n = 1e6, 10k queries, 128->32, ef = 64): too big for
-    the oracle to enumerate in seconds, so checked through size-independent properties --
+def test_full_size_properties(g, orc):
+    """SIFT1M-shaped workload at full size (n = 1e6, 10k queries, 128->32, ef = 64 and the recall-gate beam 36): the
+    first 2 000 queries against the compiled reference (oracle.Ref; the restatement where it is absent) -- ids, hops,
+    dist_calc, as search_function.h:348-385 produces them -- and the whole batch through size-independent properties:
     determinism, candidate lists sorted worst->best with exact recomputed distances, answer is
     the argmin of exact original-space distances over its candidate list, shard invariance."""
     import torch
@@ -574,6 +580,21 @@ def test_full_size_properties(g):
     # recall of the synthetic workload is what bench.py reports against
     rec = (r1["ids"].long() == ds.gt).float().mean().item()
     assert rec > 0.9, rec
+    # the reference itself on a sample of the same batch (every BASELINE.json beam of this shape that bench.py quotes)
+    impl = orc_mod.Ref() if orc_mod.have_ref() else orc
+    base, dbl = ds.base.cpu().numpy(), ds.db_low.cpu().numpy()
+    net = tuple(t.cpu().numpy() for t in ds.net)
+    if hasattr(impl, "prepare"):
+        impl.prepare(base)
+    ns = 2000
+    qh = q[:ns].cpu().numpy()
+    for ef in (64, 36, 128):
+        s = impl.search_batch(orc_mod.MODE_NET, qh, base, ds.graph_off, ds.graph_nbr, ef, db_low=dbl, net=net, threads=8)
+        r = ix.search(q, ef, want=("hops", "dist_calc"))
+        torch.cuda.synchronize()
+        assert np.array_equal(r["ids"][:ns].cpu().numpy().astype(np.int64), s["ids"].astype(np.int64)), ef
+        assert np.array_equal(r["hops"][:ns].cpu().numpy(), s["hops"]), ef
+        assert np.array_equal(r["dist_calc"][:ns].cpu().numpy() + ef, s["dist_calc"]), ef
     ix.close()
 
 
@@ -1198,11 +1219,18 @@ def test_two_list_kernels_by_name(g, orc):
         ix.close()
 
 
-def test_visited_set_forms_of_the_hot_kernels(g, orc, monkeypatch):
+def _knobs(g, quotient=1, vs_disp=15):
+    """The process-wide diagnostic knobs of the library (include/gbnns.h, gbnns_debug_knob), back to their defaults unless named."""
+    lib = g.load_library()
+    assert lib.gbnns_debug_knob(b"quotient", quotient) == 0
+    assert lib.gbnns_debug_knob(b"vs_disp", vs_disp) == 0
+
+
+def test_visited_set_forms_of_the_hot_kernels(g, orc):
     """The walk_hot* first pass keeps its visited set either as five 24-bit ids or -- when the table has at least
     2^(W-12) buckets, n <= 2^W -- as seven 16-bit quotient entries per 16-byte bucket (GBNNS_VS_ASM).  Both forms
-    (GBNNS_QUOTIENT=0 forces the first), automatic and explicit capacities, both metrics, one- and two-pass adjacency
-    rows, and the quotient form with probe sequences cut short (GBNNS_DEBUG_VS_DISP: queries are handed over to the
+    (gbnns_debug_knob("quotient", 0) forces the first), automatic and explicit capacities, both metrics, one- and two-pass adjacency
+    rows, and the quotient form with probe sequences cut short (knob "vs_disp": queries are handed over to the
     retry pass and the general kernel): ids, pop order, distance bits, hops and dist_calc equal the oracle's."""
     for si, (metric, deg) in enumerate(((0, 30), (1, 30), (0, 60))):
         c, off, nbr, db_low, ent = _oracle_case(orc, 7400 + si, 30000, 700, 64, 32, 64, deg=(2, deg))
@@ -1213,12 +1241,9 @@ def test_visited_set_forms_of_the_hot_kernels(g, orc, monkeypatch):
             s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net,
                                  entries=ent, metric=metric, threads=8)
             maxdc = int(w["dist_calc"].max())
-            for env, cap in (({}, 0), ({"GBNNS_QUOTIENT": "0"}, 0), ({}, maxdc + maxdc // 8 + 64), ({}, max(128, maxdc // 2)),
-                             ({"GBNNS_DEBUG_VS_DISP": "1"}, 0), ({"GBNNS_DEBUG_VS_DISP": "2"}, maxdc + maxdc // 8 + 64)):
-                for k in ("GBNNS_QUOTIENT", "GBNNS_DEBUG_VS_DISP"):
-                    monkeypatch.delenv(k, raising=False)
-                for k, v in env.items():
-                    monkeypatch.setenv(k, v)
+            for env, cap in (({}, 0), ({"quotient": 0}, 0), ({}, maxdc + maxdc // 8 + 64), ({}, max(128, maxdc // 2)),
+                             ({"vs_disp": 1}, 0), ({"vs_disp": 2}, maxdc + maxdc // 8 + 64)):
+                _knobs(g, **env)
                 for rep in range(2):  # (the second call runs with the capacity the first one's statistics ask for)
                     r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), hash_capacity=cap)
                     key = (metric, deg, ef, tuple(env.items()), cap, rep)
@@ -1227,8 +1252,39 @@ def test_visited_set_forms_of_the_hot_kernels(g, orc, monkeypatch):
                     assert np.array_equal(r["hops"], w["hops"]), key
                     assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
                     assert np.array_equal(r["ids"], s["ids"]), key
-        for k in ("GBNNS_QUOTIENT", "GBNNS_DEBUG_VS_DISP"):
-            monkeypatch.delenv(k, raising=False)
+        _knobs(g)
+        ix.close()
+
+
+def test_quotient_form_thirteen_remainder_bits(g, orc):
+    """Tables of fewer than 2^(W-12) buckets keep thirteen remainder bits and a 3-bit probe number (GBNNS_VS_ASM, bit 16 of
+    the control word).  Round 3 compared the WHOLE control word with the key when it tested the probe number: a key of
+    remainder 0 at probe 7 stayed below it, kept probing with a wrapped probe field and could report a false "visited"
+    (round-3 ADVICE).  n = 1.5 * 2^20 (W = 21), tables of 270 .. 500 buckets filled to their limit, 3 000 queries x ~10^3
+    ids (1 key in 8 192 has remainder 0): cand / hops / dist_calc equal the oracle's, with the product's probe limit and
+    with shorter ones (knob "vs_disp": stash and hand-over paths)."""
+    n, d, nq, deg = 3 << 19, 32, 3000, 10
+    rng = np.random.Generator(np.random.PCG64(20261005))
+    base = rng.random((n, d), dtype=np.float32)
+    queries = rng.random((nq, d), dtype=np.float32)
+    nbr = rng.integers(0, n, size=(n, deg), dtype=np.int64).astype(np.uint32).reshape(-1)
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(deg)
+    ent = rng.integers(0, n, size=nq).astype(np.uint32)
+    ix = g.Index(base, off, nbr)
+    try:
+        for ef in (24, 64):
+            w = orc.walk(queries, base, off, nbr, ef, k=ef, entries=ent, threads=8)
+            maxdc = int(w["dist_calc"].max())
+            for cap, disp in ((max(1900, maxdc + maxdc // 14 + 8), 15), (max(1900, maxdc + maxdc // 8), 15), (0, 15), (max(1900, maxdc + maxdc // 14 + 8), 3)):
+                assert cap < 3584  # (fewer than 2^(21-12) buckets of seven entries: the 13-bit form)
+                _knobs(g, vs_disp=disp)
+                r = ix.search(queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand"), hash_capacity=cap)
+                key = (ef, cap, disp)
+                assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
+                assert np.array_equal(r["hops"], w["hops"]), key
+                assert np.array_equal(r["cand"], w["ids"]), key
+    finally:
+        _knobs(g)
         ix.close()
 
 

@@ -84,9 +84,8 @@ def test_projection_kernels_fma_only_in_div_sqrt_expansion(kernels):
             continue
         n_fma = sum(1 for i in insts if FUSED.match(i))
         if n_fma:
-            # NORM = last template argument true (mlp_layer*_kernel<RELU, NORM>, mlp_narrow_kernel<RELU, NORM>); the
-            # one-launch kernel (mlp_fused_kernel) always normalises
-            assert re.search(r"Lb[01]ELb1E", name) or "mlp_fused" in name, \
+            # NORM = last template argument true (mlp_layer*_kernel<RELU, NORM>, mlp_narrow_kernel<RELU, NORM>)
+            assert re.search(r"Lb[01]ELb1E", name), \
                 "fma in a projection kernel without the normalise step: " + name
             assert n_fma < 64, (name, n_fma)  # a div + a sqrt expansion, not a dot-product loop
 
@@ -105,7 +104,9 @@ def test_hot_kernel_gather_does_not_wait_for_the_prefetch(kernels):
                    and insts[i + 1].startswith("global_load_dwordx4 v[44:47]") and "offset:16" in insts[i + 1]]
         assert gathers, name
         for gi in gathers:
-            back = [j for j in range(max(0, gi - 60), gi) if re.match(r"global_load_dword\s", insts[j])]
+            # (the ef <= 64 instances test the visited set between the prefetch and the gather since round 4: up to two
+            # bucket forms of ~50 instructions each)
+            back = [j for j in range(max(0, gi - 200), gi) if re.match(r"global_load_dword\s", insts[j])]
             assert back, "no adjacency prefetch in front of the gather in " + name
             between = insts[back[-1] + 1:gi]
             assert not any(re.match(r"s_waitcnt vmcnt\(0\)", s) for s in between), \
@@ -116,10 +117,13 @@ READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
 def test_hot_kernel_register_budgets(tmp_path):
-    """The hand-laid-out walk kernels claim fixed VGPRs (v40 .. v63; kernels.hip, hot_expand) beside the compiler's own; their
-    occupancy -- 28 wavefronts per CU at ef = 64 -- rests on the allocation staying within 72 registers (7 wavefronts per
-    SIMD of 512) and on nothing spilling.  A compiler update that pushed them over would cost a wavefront per SIMD
-    silently; this test reads the kernel descriptors' metadata of the shipped code objects and fails instead."""
+    """The hand-laid-out walk kernels claim fixed VGPRs (v36 .. v63; kernels.hip, hot_expand) beside the compiler's own.
+    Their occupancy rests on BOTH register files (measured on the hardware, tools/ubench/occupancy_census.hip: a
+    wavefront's scalar registers are handed out as ceil16(sgpr_count) + 16 of 800 per SIMD, so <= 80 -> 8 wavefronts per
+    SIMD, <= 96 -> 7, above -> 6; vector registers: <= 64 -> 8, <= 72 -> 7, <= 80 -> 6, <= 96 -> 5) and on nothing
+    spilling.  Rounds 1-3 shipped these kernels at 106 scalar registers -- an inline-asm clobber of s98 / s99 -- i.e. at
+    6 wavefronts per SIMD whatever the vector-register count said.  This test reads the kernel descriptors' metadata
+    of the shipped code objects and fails when an instance leaves its class."""
     if not os.path.exists(READELF) or not os.path.exists(OBJDUMP):
         pytest.skip("ROCm llvm tools not found")
     lib = shutil.copy(LIB, tmp_path)
@@ -136,17 +140,18 @@ def test_hot_kernel_register_budgets(tmp_path):
             meta[name.group(1)] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
                                    for k in ("vgpr_count", "sgpr_count", "private_segment_fixed_size", "vgpr_spill_count")
                                    if re.search(r"\.%s:\s+(\d+)" % k, block)}
-    # (substring of the mangled name, VGPR ceiling): waves per SIMD = floor(512 / ceil8(vgprs))
-    budgets = [("15walk_hot_kernelE", 72), ("16walk_hot2_kernelE", 72), ("19walk_hot_big_kernelE", 84),
+    # (substring of the mangled name, VGPR ceiling, SGPR ceiling)
+    budgets = [("15walk_hot_kernelE", 64, 80), ("16walk_hot2_kernelE", 72, 96), ("19walk_hot_big_kernelE", 96, 112),
                # the instances for adjacency rows of 33 .. 64 slots (second expansion pass)
-               ("16walk_hotw_kernelE", 72), ("17walk_hotw2_kernelE", 72), ("20walk_hotw_big_kernelE", 88),
+               ("16walk_hotw_kernelE", 64, 80), ("17walk_hotw2_kernelE", 72, 96), ("20walk_hotw_big_kernelE", 96, 112),
                # the negative-dot metric on the same shapes
-               ("19walk_hot_dot_kernelI", 72), ("23walk_hot_dot_big_kernelI", 88)]
-    for sub, cap in budgets:
+               ("19walk_hot_dot_kernelILi1E", 64, 80), ("19walk_hot_dot_kernelILi2E", 72, 96), ("23walk_hot_dot_big_kernelI", 96, 112)]
+    for sub, cap, scap in budgets:
         hits = {k: v for k, v in meta.items() if sub in k}
         assert hits, sub
         for k, v in hits.items():
             assert v["vgpr_count"] <= cap, (k, v)
+            assert v["sgpr_count"] <= scap, (k, v)
             assert v["private_segment_fixed_size"] == 0 and v.get("vgpr_spill_count", 0) == 0, (k, v)
     # no bit-exact distance kernel may spill to scratch at all (a spill in a latency chain is a hidden HBM round trip),
     # and the generic two-list / bitmap walks stay within 3 wavefronts per SIMD (<= 168 registers)
