@@ -109,7 +109,8 @@ def load_library():
                                   C.c_void_p]
     lib.gbnns_rerank.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-    lib.gbnns_debug_knob.argtypes = [C.c_char_p, C.c_int]
+    if hasattr(lib, "gbnns_debug_knob"):  # (absent from the rounds 1-3 libraries that tools/ab4.sh may put in place of this one)
+        lib.gbnns_debug_knob.argtypes = [C.c_char_p, C.c_int]
     lib.gbnns_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.gbnns_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile), C.c_int]
     lib.gbnns_build_graph_gd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,

@@ -187,20 +187,66 @@ struct gbnns_index {
 
 namespace {
 
+// Host -> device copy of a caller's (pageable) array through the library's own page-locked staging buffer, in pieces.
+// A plain hipMemcpy from pageable memory lets the runtime page-lock the caller's pages on the fly and remember the
+// mapping; a caller that frees such an array and gets the same addresses back from its allocator for another one (numpy,
+// std::vector) then has the next copy fault on the stale mapping now and then (round 4: "an illegal memory access" inside
+// the first upload of gbnns_index_create, about one full test-suite run in three; never in a short run).  One-time
+// uploads of an index do not miss the extra pass over host memory.
+int h2d_staged(void* dst, const void* src, size_t bytes) {
+    static std::mutex mu;
+    static void* stage = nullptr;
+    constexpr size_t kPiece = 8u << 20;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!stage) HIP_TRY(hipHostMalloc(&stage, 2 * kPiece, hipHostMallocDefault));
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    HIP_TRY(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+    int rc = GBNNS_OK;
+    size_t done = 0;
+    for (int i = 0; done < bytes && rc == GBNNS_OK; ++i, done += kPiece) {
+        const size_t nb = std::min(kPiece, bytes - done);
+        char* half = static_cast<char*>(stage) + (size_t)(i & 1) * kPiece;
+        hipError_t e = i >= 2 ? hipEventSynchronize(ev[i & 1]) : hipSuccess;  // the piece that used this half has left it
+        if (e == hipSuccess) {
+            std::memcpy(half, static_cast<const char*>(src) + done, nb);
+            e = hipMemcpyAsync(static_cast<char*>(dst) + done, half, nb, hipMemcpyHostToDevice, nullptr);
+        }
+        if (e == hipSuccess) e = hipEventRecord(ev[i & 1], nullptr);
+        if (e != hipSuccess) rc = fail(GBNNS_ERR_HIP, "staged upload: %s", hipGetErrorString(e));
+    }
+    if (rc == GBNNS_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(GBNNS_ERR_HIP, "staged upload: %s", hipGetErrorString(hipGetLastError()));
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    return rc;
+}
+
 int upload(DevBuf& dst, const void* src, size_t rows, size_t row_floats, size_t pad_floats,
            int mem_kind) {
     // copies a [rows x row_floats] f32 matrix into a zero-padded [rows x pad_floats] device matrix
     const size_t bytes = rows * pad_floats * sizeof(float);
     int rc = dst.ensure(bytes ? bytes : 4);
     if (rc) return rc;
-    const hipMemcpyKind kind = mem_kind == GBNNS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (pad_floats == row_floats) {
-        HIP_TRY(hipMemcpy(dst.p, src, bytes, kind));
-    } else {
-        HIP_TRY(hipMemset(dst.p, 0, bytes));
-        HIP_TRY(hipMemcpy2D(dst.p, pad_floats * 4, src, row_floats * 4, row_floats * 4, rows, kind));
+    if (mem_kind == GBNNS_MEM_DEVICE) {
+        if (pad_floats == row_floats) {
+            HIP_TRY(hipMemcpy(dst.p, src, bytes, hipMemcpyDeviceToDevice));
+        } else {
+            HIP_TRY(hipMemset(dst.p, 0, bytes));
+            HIP_TRY(hipMemcpy2D(dst.p, pad_floats * 4, src, row_floats * 4, row_floats * 4, rows, hipMemcpyDeviceToDevice));
+        }
+        return GBNNS_OK;
     }
-    return GBNNS_OK;
+    if (pad_floats == row_floats) return h2d_staged(dst.p, src, bytes);
+    // padded rows: the rows are packed into a temporary device matrix first, then spread on the device
+    DevBuf packed;
+    if ((rc = packed.ensure(rows * row_floats * 4 ? rows * row_floats * 4 : 4))) return rc;
+    rc = h2d_staged(packed.p, src, rows * row_floats * 4);
+    hipError_t e = rc ? hipSuccess : hipMemset(dst.p, 0, bytes);
+    if (!rc && e == hipSuccess) e = hipMemcpy2D(dst.p, pad_floats * 4, packed.p, row_floats * 4, row_floats * 4, rows, hipMemcpyDeviceToDevice);
+    if (!rc && e == hipSuccess) e = hipDeviceSynchronize();
+    packed.release();
+    if (!rc && e != hipSuccess) rc = fail(GBNNS_ERR_HIP, "padded upload: %s", hipGetErrorString(e));
+    return rc;
 }
 
 // [dout x (din+1)] rows = [W | b]  ->  W [dout x wstride] (zero padded) followed by bias [dout]
@@ -266,7 +312,10 @@ int build_ell(const uint64_t* off, const uint32_t* nbr, uint64_t n, std::vector<
 constexpr size_t kMaxLds = 160 * 1024;
 // LDS is handed out in granules of 1 280 bytes (measured, tools/ubench/occupancy_census.hip: one-wavefront workgroups of
 // 5 120 B -> 32 per CU, 5 121 .. 6 400 B -> 25, 6 401 .. 7 680 B -> 21): a wavefront's share is a multiple of it.
-constexpr size_t kLdsGran = 1280;
+#ifndef GBNNS_LDS_GRAN
+#define GBNNS_LDS_GRAN 1280
+#endif
+constexpr size_t kLdsGran = GBNNS_LDS_GRAN;
 
 // Diagnostic knobs (gbnns_debug_knob; the environment gives their initial values, read once when the library loads):
 // "quotient" 0 = never the quotient form of the visited set (GBNNS_QUOTIENT); "vs_disp" = probe number at which a probe
@@ -277,6 +326,8 @@ int knob_env(const char* name, int dflt) {
 }
 std::atomic<int> g_knob_quotient{knob_env("GBNNS_QUOTIENT", 1)};
 std::atomic<int> g_knob_vs_disp{knob_env("GBNNS_DEBUG_VS_DISP", 15)};
+// "max_waves" = most first-pass wavefronts per CU the LDS shares are cut for (GBNNS_MAX_WAVES; 0 = the per-kernel defaults)
+std::atomic<int> g_knob_max_waves{knob_env("GBNNS_MAX_WAVES", 0)};
 
 // A handle's workspace (projected queries, candidate lists, hand-over lists, control words) is shared by its
 // calls and ordered by stream order.  When a call names another stream than the last one that left work in
@@ -411,8 +462,8 @@ int gbnns_build_graph_gd_device(int device, const uint64_t* knn_offsets, const u
         if ((rc = nbr_dev.ensure(std::max<uint64_t>(total, 1) * 4))) return rc;
         if ((rc = adj_dev.ensure((size_t)n * cap * 4))) return rc;
         if ((rc = deg_dev.ensure((size_t)n * 4))) return rc;
-        HIP_TRY(hipMemcpy(off_dev.p, knn_offsets, (n + 1) * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(nbr_dev.p, knn_nbrs, total * 4, hipMemcpyHostToDevice));
+        if (int rc2 = h2d_staged(off_dev.p, knn_offsets, (n + 1) * 8)) return rc2;
+        if (int rc2 = h2d_staged(nbr_dev.p, knn_nbrs, total * 4)) return rc2;
         GdParams p{};
         p.ds = ds_dev.as<float>(); p.dstride = dpad; p.dim = d; p.n = (uint32_t)n; p.M = M;
         p.knn_off = off_dev.as<uint64_t>(); p.knn_nbr = nbr_dev.as<uint32_t>();
@@ -491,8 +542,7 @@ int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out) {
         rc = build_ell(desc->graph_offsets, desc->graph_nbrs, ix->n, ell, ix->ell_stride);
         if (!rc) rc = ix->ell.ensure(ell.size() * 4);
         if (!rc) {
-            hipError_t e = hipMemcpy(ix->ell.p, ell.data(), ell.size() * 4, hipMemcpyHostToDevice);
-            if (e != hipSuccess) rc = fail(GBNNS_ERR_HIP, "adjacency upload: %s", hipGetErrorString(e));
+            rc = h2d_staged(ix->ell.p, ell.data(), ell.size() * 4);
         }
     }
 
@@ -565,7 +615,7 @@ int gbnns_index_set_aux_graph(gbnns_index* ix, const uint64_t* offsets, const ui
     int rc = build_ell(offsets, nbrs, ix->n, ell, ix->aux_stride);
     if (rc) return rc;
     if ((rc = ix->aux_ell.ensure(ell.size() * 4))) return rc;
-    HIP_TRY(hipMemcpy(ix->aux_ell.p, ell.data(), ell.size() * 4, hipMemcpyHostToDevice));
+    if (int rc2 = h2d_staged(ix->aux_ell.p, ell.data(), ell.size() * 4)) return rc2;
     ix->has_aux = true;
     return GBNNS_OK;
 }
@@ -688,6 +738,7 @@ int gbnns_debug_knob(const char* name, int value) {
     if (!name) return fail(GBNNS_ERR_INVALID, "gbnns_debug_knob: null name");
     if (!std::strcmp(name, "quotient")) g_knob_quotient.store(value, std::memory_order_relaxed);
     else if (!std::strcmp(name, "vs_disp")) g_knob_vs_disp.store(value <= 0 ? 15 : value, std::memory_order_relaxed);
+    else if (!std::strcmp(name, "max_waves")) g_knob_max_waves.store(std::max(0, std::min(32, value)), std::memory_order_relaxed);
     else return fail(GBNNS_ERR_INVALID, "gbnns_debug_knob: unknown knob '%s'", name);
     return GBNNS_OK;
 }
@@ -1076,18 +1127,22 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     uint32_t cap;
     int form = packed ? 1 : 0;
     const bool auto_cap = a->hash_capacity == 0;
+    // (most wavefronts per CU worth cutting the LDS for: the register files' limit of the first-pass kernel -- 32 for the
+    // one-register hot instances, 28 / 24 / 20 for the others -- or the diagnostic knob)
+    const int knob_waves = g_knob_max_waves.load(std::memory_order_relaxed);
+    const size_t wave_cap = knob_waves > 0 ? (size_t)knob_waves : 32;
     // visited-set capacity for `need` entries in the given form, and the wavefronts per CU it leaves (0: no fit)
     auto size_table = [&](int f, uint32_t need, size_t& slots) -> uint32_t {
         const uint32_t floor_entries = f == 2 ? quotient_min : 0u, extra = f == 2 ? 7u * kStashBuckets : 0u;  // (the stash's four "buckets" hold no slots)
         need = std::max(need + extra, floor_entries);
         const size_t gran = kLdsGran;
         const size_t want = (lds_fixed + walk_hash_bytes(need + 4, f) + gran - 1) / gran * gran;
-        slots = std::min<size_t>(32, kMaxLds / want);
+        slots = std::min<size_t>(wave_cap, kMaxLds / want);
         if (slots == 0) return need;  // does not fit LDS at all: the general kernel takes the batch
         // One more wavefront per CU when it costs only part of the margin: `need` keeps 1/16 of headroom over the
         // largest walk seen; a share that still leaves 1/32 is taken (a later, longer walk is handed over once and
         // raises the requirement for good -- it never shrinks).
-        if (slots < 32 && ix->maxdc_for_ef.count(skey)) {
+        if (slots < wave_cap && ix->maxdc_for_ef.count(skey)) {
             const uint32_t m = ix->maxdc_for_ef[skey];
             const uint32_t need_min = std::max((m + m / 32 + 64) / 15 * 16 + 16 + extra, floor_entries);
             const size_t share1 = kMaxLds / (slots + 1) / gran * gran;

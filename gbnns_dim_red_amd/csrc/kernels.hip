@@ -507,22 +507,10 @@ __device__ __forceinline__ float dpp_from_odd(float x) {  // even lane <- its od
 // streams its candidates' rows at (bytes in flight) / latency: 200 rows of 960 floats (GIST, ef = 200) take it 0.095 ms
 // with 8 loads in flight and 0.070 ms with 24 (rocprofv3, one-query launches).  The generic wide-row walk kernels and
 // the stand-alone kernel have the registers for 24 (same operations, same order).
-// A 16-byte piece of an original-space row.  Each candidate row is read once per query and the table (n x d floats: 512 MB
-// for SIFT1M, 3.8 GB for GIST1M) is far larger than the 256 MB Infinity Cache, whose lines the WALKED tables (db_low +
-// adjacency: 256 MB at n = 10^6) want: the re-rank's rows are requested non-temporal (`nt`), so that they stream past
-// the caches instead of evicting the rows every other wavefront's next hops will ask for.  GBNNS_RERANK_TEMPORAL: plain loads.
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4_t ld_row16(const float4* p) {
-#ifdef GBNNS_RERANK_TEMPORAL
-    return *reinterpret_cast<const f32x4_t*>(p);
-#else
-    return __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
-#endif
-}
-
 template <int METRIC, int DEEP = 8, typename IdAt>
 __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi, int cnt, float* qf, int lane, IdAt id_at) {
     const uint32_t half = (uint32_t)lane & 1u, slot = (uint32_t)lane >> 1;
+    const float4* qs = reinterpret_cast<const float4*>(qf);
     for (uint32_t i = lane; i < a.dstride; i += 64)
         qf[i] = (i < a.dim) ? a.q[(size_t)qi * a.qstride + i] : 0.f;
     wave_sync();
@@ -533,21 +521,15 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
         const bool valid = r < cnt;
         uint32_t id = id_at(valid ? r : base);  // lanes beyond the list redo the first row (discarded)
         id = id < a.n ? id : 0u;                // (never dereference an id outside the table)
-        // (the table's address is laundered per chunk: left visible, the compiler keeps db + half * 16 and two or three
-        // displaced copies of it in vector-register pairs across the chunks -- loop-invariant, and what pushed the
-        // 64-register walk kernels that re-rank at the end of their walk into scratch)
-        const float* dbp = a.db;
-        uint32_t hoff = half * 4u;  // (floats)
-        asm volatile("" : "+s"(dbp), "+v"(hoff));
-        const float4* row = reinterpret_cast<const float4*>(dbp + ((size_t)id * a.dstride + hoff));
-        const float4* qh = reinterpret_cast<const float4*>(qf + hoff);
+        const float4* row = reinterpret_cast<const float4*>(a.db + (size_t)id * a.dstride) + half;
+        const float4* qh = qs + half;
         if constexpr (METRIC == 1) {
             float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;  // this lane's four of the eight running sums
             uint32_t k = 0;
             for (; k + 8 <= pairs; k += 8) {
-                f32x4_t rv[8];
+                float4 rv[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) rv[j] = ld_row16(row + 2 * (k + j));
+                for (int j = 0; j < 8; ++j) rv[j] = row[2 * (k + j)];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float4 qv = qh[2 * (k + j)];
@@ -555,7 +537,7 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
                 }
             }
             for (; k < pairs; ++k) {
-                const f32x4_t rv = ld_row16(row + 2 * k);
+                const float4 rv = row[2 * k];
                 const float4 qv = qh[2 * k];
                 c0 = c0 + rv.x * qv.x; c1 = c1 + rv.y * qv.y; c2 = c2 + rv.z * qv.z; c3 = c3 + rv.w * qv.w;
             }
@@ -572,9 +554,9 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
         uint32_t k = 0;
         if constexpr (DEEP > 8) {
             for (; k + DEEP <= pairs; k += DEEP) {
-                f32x4_t rv[DEEP];
+                float4 rv[DEEP];
 #pragma unroll
-                for (int j = 0; j < DEEP; ++j) rv[j] = ld_row16(row + 2 * (k + j));
+                for (int j = 0; j < DEEP; ++j) rv[j] = row[2 * (k + j)];
 #pragma unroll
                 for (int j = 0; j < DEEP; ++j) {
                     const float4 qv = qh[2 * (k + j)];
@@ -589,9 +571,9 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
             }
         }
         for (; k + 8 <= pairs; k += 8) {  // eight 16-B loads in flight per lane
-            f32x4_t rv[8];
+            float4 rv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rv[j] = ld_row16(row + 2 * (k + j));
+            for (int j = 0; j < 8; ++j) rv[j] = row[2 * (k + j)];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float4 qv = qh[2 * (k + j)];
@@ -605,9 +587,9 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
             }
         }
         for (; k + 4 <= pairs; k += 4) {
-            f32x4_t rv[4];
+            float4 rv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) rv[j] = ld_row16(row + 2 * (k + j));
+            for (int j = 0; j < 4; ++j) rv[j] = row[2 * (k + j)];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float4 qv = qh[2 * (k + j)];
@@ -621,7 +603,7 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
             }
         }
         for (; k < pairs; ++k) {
-            const f32x4_t rv = ld_row16(row + 2 * k);
+            const float4 rv = row[2 * k];
             const float4 qv = qh[2 * k];
             float e;
             e = rv.x - qv.x; const float p0 = e * e;
@@ -1097,6 +1079,21 @@ __device__ __forceinline__ uint64_t clear_bit64(uint64_t m, int bit) {  // wave-
     return m;
 }
 
+// Layout of the one-register hot instances (ef <= 64), A/B switches: GBNNS_HOT1_QLDS = the query is re-read from LDS every
+// hop (64 vector registers: 8 wavefronts per SIMD) instead of living in 16 registers (72: 7 per SIMD); GBNNS_HOT1_SPEC = the
+// rows are requested before the visited test (speculatively, for every valid slot) instead of after it (new ids only).
+#ifndef GBNNS_HOT1_QLDS
+#define GBNNS_HOT1_QLDS 1
+#endif
+#ifndef GBNNS_HOT1_SPEC
+#define GBNNS_HOT1_SPEC 0
+#endif
+// GBNNS_HOT1_PF2_IN_MERGE = 1: the second prefetch's closest survivor comes out of the merge's rank loop (one scalar minimum per
+// survivor) instead of a DPP butterfly in front of the merge -- 20 instructions per hop less, and the prefetch ~60
+// instructions later: measured 1 - 2 % SLOWER on the SIFT / GloVe shapes at ef = 36 / 64 (profiles/r04_ab.txt), so off.
+#ifndef GBNNS_HOT1_PF2_IN_MERGE
+#define GBNNS_HOT1_PF2_IN_MERGE 0
+#endif
 constexpr int kRegTieCap = 16;       // tie list of the register kernel (LDS, 128 B)
 constexpr int kRegListMaxEf = 1024;  // largest ef served by the register-list / two-list kernels (beyond: result list as one sorted LDS array)
 
@@ -1403,10 +1400,24 @@ __device__ __forceinline__ bool reg_offer(uint32_t dl, uint32_t nlo, RegList<R>&
 // its moment >= the final worst distance, so it lies outside the top-ef by (dist, id) unless it
 // TIES the final worst distance -- and an accepted element is only ever displaced by smaller keys.
 // On such a tie (returns false, list untouched) the caller falls back to the sequential offers.
+#ifdef GBNNS_MERGE_S98
+#define GBNNS_MERGE_SLO "s98"
+#define GBNNS_MERGE_SHI "s99"
+#define GBNNS_MERGE_SPAIR "s[98:99]"
+#else
+#define GBNNS_MERGE_SLO "s46"
+#define GBNNS_MERGE_SHI "s47"
+#define GBNNS_MERGE_SPAIR "s[46:47]"
+#endif
 constexpr int kRegStageSlots = 66;   // merge scatter buffer: ranks 0..ef (ef <= 64), padded to 16 B
 
-__device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk, uint32_t nb, RegList<1>& L, int& size,
-                                          uint32_t& worst, int& tsize, uint64_t* stage, int ef, int lane) {
+// WANT_MIN: the loop also keeps the smallest survivor distance key (one scalar instruction per survivor) and hands it to
+// `after_ranks(dmin)` right behind the loop -- the hot instance requests its second prefetch there (round 4; before, a
+// 25-instruction DPP butterfly in front of the merge found that minimum, every hop, in a kernel that is bound by the
+// CU's instruction issue).
+template <bool WANT_MIN, typename AfterRanks>
+__device__ __forceinline__ bool reg_merge_cb(uint64_t m, bool is_surv, uint32_t dk, uint32_t nb, RegList<1>& L, int& size,
+                                             uint32_t& worst, int& tsize, uint64_t* stage, int ef, int lane, AfterRanks&& after_ranks) {
     const int ns = __popcll(m);
     const uint64_t key = ((uint64_t)L.hi[0] << 32) | L.lo[0];
     const uint32_t slo = nb << 1;
@@ -1419,30 +1430,38 @@ __device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk,
     // it (rank), and the number of entries below survivor `sl` -- the zero bits of the compare mask,
     // because lanes that hold no entry hold all-ones or evicted keys, both greater than any survivor --
     // is dropped into lane `sl` (below).  Keys are distinct (a survivor was never visited).
-    uint32_t shift, rank, below, sl_, t_;
+    uint32_t shift, rank, below, sl_, t_, smin = 0xFFFFFFFFu;
     uint64_t ma, mb, mm = m;
-    asm volatile(
-        "v_mov_b32 %[shift], 0\n\t"
-        "v_mov_b32 %[rank], 0\n\t"
-        "v_mov_b32 %[below], 0\n"
-        "1:\n\t"
-        "s_ff1_i32_b64 %[sl], %[mm]\n\t"
-        "v_readlane_b32 s47, %[dk], %[sl]\n\t"
-        "v_readlane_b32 s46, %[slo], %[sl]\n\t"
-        "s_bitset0_b64 %[mm], %[sl]\n\t"
-        "s_mov_b32 m0, %[sl]\n\t"
-        "v_cmp_gt_u64_e64 %[ma], %[key], s[46:47]\n\t"
-        "v_cmp_gt_u64_e64 %[mb], %[skey], s[46:47]\n\t"
-        "s_bcnt0_i32_b64 %[t], %[ma]\n\t"
-        "v_addc_co_u32_e64 %[shift], vcc, 0, %[shift], %[ma]\n\t"
-        "v_addc_co_u32_e64 %[rank], vcc, 0, %[rank], %[mb]\n\t"
-        "v_writelane_b32 %[below], %[t], m0\n\t"
-        "s_cmp_lg_u64 %[mm], 0\n\t"
-        "s_cbranch_scc1 1b"
-        : [shift] "=&v"(shift), [rank] "=&v"(rank), [below] "=&v"(below), [sl] "=&s"(sl_), [t] "=&s"(t_), [ma] "=&s"(ma),
-          [mb] "=&s"(mb), [mm] "+s"(mm)
-        : [dk] "v"(dk), [slo] "v"(slo), [key] "v"(key), [skey] "v"(skey)
-        : "vcc", "scc", "m0", "s46", "s47");
+#define GBNNS_RANK_LOOP(MIN_STEP)                                                                                       \
+    asm volatile(                                                                                                      \
+        "v_mov_b32 %[shift], 0\n\t"                                                                                    \
+        "v_mov_b32 %[rank], 0\n\t"                                                                                     \
+        "v_mov_b32 %[below], 0\n"                                                                                      \
+        "1:\n\t"                                                                                                       \
+        "s_ff1_i32_b64 %[sl], %[mm]\n\t"                                                                               \
+        "v_readlane_b32 " GBNNS_MERGE_SHI ", %[dk], %[sl]\n\t"                                                                         \
+        "v_readlane_b32 " GBNNS_MERGE_SLO ", %[slo], %[sl]\n\t"                                                                        \
+        "s_bitset0_b64 %[mm], %[sl]\n\t"                                                                               \
+        "s_mov_b32 m0, %[sl]\n\t"                                                                                      \
+        "v_cmp_gt_u64_e64 %[ma], %[key], " GBNNS_MERGE_SPAIR "\n\t"                                                                 \
+        "v_cmp_gt_u64_e64 %[mb], %[skey], " GBNNS_MERGE_SPAIR "\n\t" MIN_STEP                                                       \
+        "s_bcnt0_i32_b64 %[t], %[ma]\n\t"                                                                              \
+        "v_addc_co_u32_e64 %[shift], vcc, 0, %[shift], %[ma]\n\t"                                                      \
+        "v_addc_co_u32_e64 %[rank], vcc, 0, %[rank], %[mb]\n\t"                                                        \
+        "v_writelane_b32 %[below], %[t], m0\n\t"                                                                       \
+        "s_cmp_lg_u64 %[mm], 0\n\t"                                                                                    \
+        "s_cbranch_scc1 1b"                                                                                            \
+        : [shift] "=&v"(shift), [rank] "=&v"(rank), [below] "=&v"(below), [sl] "=&s"(sl_), [t] "=&s"(t_), [ma] "=&s"(ma), \
+          [mb] "=&s"(mb), [mm] "+s"(mm), [smin] "+s"(smin)                                                              \
+        : [dk] "v"(dk), [slo] "v"(slo), [key] "v"(key), [skey] "v"(skey)                                                \
+        : "vcc", "scc", "m0", GBNNS_MERGE_SLO, GBNNS_MERGE_SHI)
+    if constexpr (WANT_MIN) {
+        GBNNS_RANK_LOOP("s_min_u32 %[smin], %[smin], " GBNNS_MERGE_SHI "\n\t");
+        after_ranks(smin);
+    } else {
+        GBNNS_RANK_LOOP("");
+    }
+#undef GBNNS_RANK_LOOP
     const int dst_e = lane + (int)shift, dst_s = (int)(rank + below);
     const int total = size + ns;
     const int new_size = total < ef ? total : ef;
@@ -1464,6 +1483,11 @@ __device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk,
     size = new_size;
     worst = nw;
     return true;
+}
+
+__device__ __forceinline__ bool reg_merge(uint64_t m, bool is_surv, uint32_t dk, uint32_t nb, RegList<1>& L, int& size,
+                                          uint32_t& worst, int& tsize, uint64_t* stage, int ef, int lane) {
+    return reg_merge_cb<false>(m, is_surv, dk, nb, L, size, worst, tsize, stage, ef, lane, [](uint32_t) {});
 }
 
 // The same batch merge for lists of R = 2 / 4 registers per lane (64 < ef <= 256): entry of rank i lives in
@@ -2839,112 +2863,112 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
 // few queries over every time).  A probe sequence longer than fifteen buckets gives up: the lane is reported and its id
 // goes to the stash (stash_claim).  Tables of 2^(W-13) .. 2^(W-12) buckets keep thirteen remainder bits and a 3-bit
 // probe number (seven probes; bit 16 of %[shr]).
-#define GBNNS_VS_ASM                                                                                                   \
+#define GBNNS_VS_ASM(T0, T1, T2, ADDR)                                                                                                   \
         "s_bfe_u32 %[mulc], %[shr], 0x50008\n\t"               /* 32 - W (0 in the packed form) */                     \
         "s_lshl_b32 %[mulc], 0x9E3779B1, %[mulc]\n\t"                                                                  \
-        "v_mul_lo_u32 v36, %[id], %[mulc]\n\t"                                                                       \
+        "v_mul_lo_u32 " T0 ", %[id], %[mulc]\n\t"                                                                       \
         "s_and_b32 exec_lo, exec_lo, 0x55555555\n\t"                                                                   \
         "s_and_b32 exec_hi, exec_hi, 0x55555555\n\t"                                                                   \
         "s_mov_b64 %[fresh], 0\n\t"                                                                                    \
         "s_cmp_lg_u32 %[shr], 0\n\t"                                                                                   \
-        "v_mul_hi_u32 v37, v36, %[nb]\n\t"                                                                         \
-        "v_lshl_add_u32 v39, v37, 4, %[basev]\n\t"                                                               \
+        "v_mul_hi_u32 " T1 ", " T0 ", %[nb]\n\t"                                                                         \
+        "v_lshl_add_u32 " ADDR ", " T1 ", 4, %[basev]\n\t"                                                               \
         "s_cbranch_scc1 4f\n"                                                                                          \
         "1:\n\t"                                                                                                       \
-        "ds_read_b128 v[60:63], v39\n\t"                                                                           \
+        "ds_read_b128 v[60:63], " ADDR "\n\t"                                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
         "v_bfe_u32 v56, v60, 0, 24\n\t"                        /* slot 0 */                                            \
         "v_alignbit_b32 v57, v61, v60, 24\n\t"                 /* slot 1 (bits 24..47) in the low 24 bits */           \
         "v_alignbit_b32 v58, v62, v61, 16\n\t"                 /* slot 2 (bits 48..71) */                              \
         "v_lshrrev_b32 v59, 8, v62\n\t"                        /* slot 3 (bits 72..95) */                              \
-        "v_bfe_u32 v37, v63, 0, 24\n\t"                      /* slot 4 (bits 96..119) */                             \
+        "v_bfe_u32 " T1 ", v63, 0, 24\n\t"                      /* slot 4 (bits 96..119) */                             \
         "v_bfe_u32 v57, v57, 0, 24\n\t"                                                                                \
         "v_bfe_u32 v58, v58, 0, 24\n\t"                                                                                \
         "v_xor_b32 v56, v56, %[id]\n\t"                                                                                \
         "v_xor_b32 v57, v57, %[id]\n\t"                                                                                \
         "v_xor_b32 v58, v58, %[id]\n\t"                                                                                \
         "v_xor_b32 v59, v59, %[id]\n\t"                                                                                \
-        "v_xor_b32 v37, v37, %[id]\n\t"                                                                            \
+        "v_xor_b32 " T1 ", " T1 ", %[id]\n\t"                                                                            \
         "v_min3_u32 v56, v56, v57, v58\n\t"                                                                            \
-        "v_min3_u32 v56, v56, v59, v37\n\t"                  /* 0 <=> id is in the bucket */                         \
-        "v_lshrrev_b32 v37, 24, v63\n\t"                     /* slots handed out */                                  \
+        "v_min3_u32 v56, v56, v59, " T1 "\n\t"                  /* 0 <=> id is in the bucket */                         \
+        "v_lshrrev_b32 " T1 ", 24, v63\n\t"                     /* slots handed out */                                  \
         "v_cmp_ne_u32 vcc, 0, v56\n\t"                                                                                 \
         "s_and_b64 exec, exec, vcc\n\t"                        /* lanes that found their id are done */                \
         "s_cbranch_execz 9f\n\t"                                                                                       \
         "s_mov_b64 %[act], exec\n\t"                                                                                   \
-        "v_cmp_gt_u32 vcc, 5, v37\n\t"                                                                               \
+        "v_cmp_gt_u32 vcc, 5, " T1 "\n\t"                                                                               \
         "s_and_b64 exec, exec, vcc\n\t"                        /* the bucket had room when it was read */              \
         "s_cbranch_execz 3f\n\t"                                                                                       \
-        "v_mov_b32 v37, 0x1000000\n\t"                                                                               \
-        "ds_add_rtn_u32 v36, v39, v37 offset:12\n\t"   /* take a slot number */                                \
-        "v_lshrrev_b32 v38, 8, %[id]\n\t"                                                                            \
+        "v_mov_b32 " T1 ", 0x1000000\n\t"                                                                               \
+        "ds_add_rtn_u32 " T0 ", " ADDR ", " T1 " offset:12\n\t"   /* take a slot number */                                \
+        "v_lshrrev_b32 " T2 ", 8, %[id]\n\t"                                                                            \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-        "v_lshrrev_b32 v36, 24, v36\n\t"                                                                           \
-        "v_cmp_gt_u32 vcc, 5, v36\n\t"                                                                               \
+        "v_lshrrev_b32 " T0 ", 24, " T0 "\n\t"                                                                           \
+        "v_cmp_gt_u32 vcc, 5, " T0 "\n\t"                                                                               \
         "s_and_b64 exec, exec, vcc\n\t"                        /* lanes whose number is a real slot */                 \
         "s_cbranch_execz 3f\n\t"                                                                                       \
-        "v_mad_u32_u24 v36, v36, 3, v39\n\t"           /* byte address of the slot */                          \
-        "ds_write_b8 v36, %[id]\n\t"                                                                                 \
-        "ds_write_b8 v36, v38 offset:1\n\t"                                                                        \
-        "ds_write_b8_d16_hi v36, %[id] offset:2\n\t"                                                                 \
+        "v_mad_u32_u24 " T0 ", " T0 ", 3, " ADDR "\n\t"           /* byte address of the slot */                          \
+        "ds_write_b8 " T0 ", %[id]\n\t"                                                                                 \
+        "ds_write_b8 " T0 ", " T2 " offset:1\n\t"                                                                        \
+        "ds_write_b8_d16_hi " T0 ", %[id] offset:2\n\t"                                                                 \
         "s_or_b64 %[fresh], %[fresh], exec\n\t"                                                                        \
         "s_andn2_b64 %[act], %[act], exec\n"                                                                           \
         "3:\n\t"                                                                                                       \
         "s_mov_b64 exec, %[act]\n\t"                           /* absent and unplaced: their bucket is full */         \
         "s_cbranch_execz 9f\n\t"                                                                                       \
-        "v_add_u32 v39, 16, v39\n\t"                                                                           \
-        "v_cmp_eq_u32 vcc, %[end], v39\n\t"                                                                        \
-        "v_cndmask_b32 v39, v39, %[basev], vcc\n\t"                                                            \
+        "v_add_u32 " ADDR ", 16, " ADDR "\n\t"                                                                           \
+        "v_cmp_eq_u32 vcc, %[end], " ADDR "\n\t"                                                                        \
+        "v_cndmask_b32 " ADDR ", " ADDR ", %[basev], vcc\n\t"                                                            \
         "s_branch 1b\n"                                                                                                \
         "4:\n\t"                                               /* ---- quotient form ---- */                           \
         "s_lshl_b32 %[mulc], %[nb], 4\n\t"                                                                             \
-        "v_mul_lo_u32 v36, v36, %[nb]\n\t"                 /* place inside the home bucket's range */              \
-        "v_lshrrev_b32 v36, %[shr], v36\n\t"               /* < 2^12 */                                            \
-        "v_lshl_or_b32 v38, v36, 16, v36\n"              /* the key in both halves, displacement 0 */            \
+        "v_mul_lo_u32 " T0 ", " T0 ", %[nb]\n\t"                 /* place inside the home bucket's range */              \
+        "v_lshrrev_b32 " T0 ", %[shr], " T0 "\n\t"               /* < 2^12 */                                            \
+        "v_lshl_or_b32 " T2 ", " T0 ", 16, " T0 "\n"              /* the key in both halves, displacement 0 */            \
         "5:\n\t"                                                                                                       \
-        "ds_read_b128 v[60:63], v39\n\t"                                                                           \
+        "ds_read_b128 v[60:63], " ADDR "\n\t"                                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-        "v_xor_b32 v56, v60, v38\n\t"                                                                                \
-        "v_xor_b32 v57, v61, v38\n\t"                                                                                \
-        "v_xor_b32 v58, v62, v38\n\t"                                                                                \
-        "v_xor_b32 v59, v63, v38\n\t"                                                                                \
+        "v_xor_b32 v56, v60, " T2 "\n\t"                                                                                \
+        "v_xor_b32 v57, v61, " T2 "\n\t"                                                                                \
+        "v_xor_b32 v58, v62, " T2 "\n\t"                                                                                \
+        "v_xor_b32 v59, v63, " T2 "\n\t"                                                                                \
         "v_pk_min_u16 v56, v56, v57\n\t"                                                                               \
         "v_pk_min_u16 v58, v58, v59\n\t"                                                                               \
-        "v_bfe_u32 v37, v63, 16, 12\n\t"                     /* slots handed out */                                  \
+        "v_bfe_u32 " T1 ", v63, 16, 12\n\t"                     /* slots handed out */                                  \
         "v_pk_min_u16 v56, v56, v58\n\t"                                                                               \
         "v_mad_u32_u16 v56, v56, v56, 0 op_sel:[0,1,0,0]\n\t"  /* low half x high half: 0 <=> the key is in the bucket */ \
         "v_cmp_ne_u32 vcc, 0, v56\n\t"                                                                                 \
         "s_and_b64 exec, exec, vcc\n\t"                                                                                \
         "s_cbranch_execz 9f\n\t"                                                                                       \
         "s_mov_b64 %[act], exec\n\t"                                                                                   \
-        "v_cmp_gt_u32 vcc, 7, v37\n\t"                                                                               \
+        "v_cmp_gt_u32 vcc, 7, " T1 "\n\t"                                                                               \
         "s_and_b64 exec, exec, vcc\n\t"                                                                                \
         "s_cbranch_execz 6f\n\t"                                                                                       \
-        "v_mov_b32 v37, 0x10000\n\t"                                                                                 \
-        "ds_add_rtn_u32 v36, v39, v37 offset:12\n\t"                                                           \
+        "v_mov_b32 " T1 ", 0x10000\n\t"                                                                                 \
+        "ds_add_rtn_u32 " T0 ", " ADDR ", " T1 " offset:12\n\t"                                                           \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
-        "v_bfe_u32 v36, v36, 16, 12\n\t"                                                                           \
-        "v_cmp_gt_u32 vcc, 7, v36\n\t"                                                                               \
+        "v_bfe_u32 " T0 ", " T0 ", 16, 12\n\t"                                                                           \
+        "v_cmp_gt_u32 vcc, 7, " T0 "\n\t"                                                                               \
         "s_and_b64 exec, exec, vcc\n\t"                                                                                \
         "s_cbranch_execz 6f\n\t"                                                                                       \
-        "v_lshl_add_u32 v36, v36, 1, v39\n\t"                                                                  \
-        "ds_write_b16 v36, v38\n\t"                                                                                \
+        "v_lshl_add_u32 " T0 ", " T0 ", 1, " ADDR "\n\t"                                                                  \
+        "ds_write_b16 " T0 ", " T2 "\n\t"                                                                                \
         "s_or_b64 %[fresh], %[fresh], exec\n\t"                                                                        \
         "s_andn2_b64 %[act], %[act], exec\n"                                                                           \
         "6:\n\t"                                                                                                       \
         "s_mov_b64 exec, %[act]\n\t"                                                                                   \
         "s_cbranch_execz 9f\n\t"                                                                                       \
-        "v_and_b32 v36, 7, v38\n\t"                        /* next probe: 1 .. 8 buckets on, by the key's low bits */ \
-        "v_lshl_add_u32 v36, v36, 4, 16\n\t"               /* (no runs of full buckets shared by neighbouring homes) */ \
-        "v_add_u32 v39, v39, v36\n\t"                                                                        \
+        "v_and_b32 " T0 ", 7, " T2 "\n\t"                        /* next probe: 1 .. 8 buckets on, by the key's low bits */ \
+        "v_lshl_add_u32 " T0 ", " T0 ", 4, 16\n\t"               /* (no runs of full buckets shared by neighbouring homes) */ \
+        "v_add_u32 " ADDR ", " ADDR ", " T0 "\n\t"                                                                        \
         "s_bfe_u32 vcc_lo, %[shr], 0x10010\n\t"                /* 13 remainder bits: the probe number sits one bit higher */ \
         "s_lshl_b32 vcc_lo, 0x10001000, vcc_lo\n\t"                                                                    \
-        "v_add_u32 v38, vcc_lo, v38\n\t"                   /* one probe further from home */                       \
-        "v_cmp_le_u32 vcc, %[end], v39\n\t"                                                                        \
-        "v_subrev_u32 v36, %[mulc], v39\n\t"             /* (%[mulc] holds the table's bytes by now) */          \
-        "v_cndmask_b32 v39, v39, v36, vcc\n\t"                                                               \
+        "v_add_u32 " T2 ", vcc_lo, " T2 "\n\t"                   /* one probe further from home */                       \
+        "v_cmp_le_u32 vcc, %[end], " ADDR "\n\t"                                                                        \
+        "v_subrev_u32 " T0 ", %[mulc], " ADDR "\n\t"             /* (%[mulc] holds the table's bytes by now) */          \
+        "v_cndmask_b32 " ADDR ", " ADDR ", " T0 ", vcc\n\t"                                                               \
         "s_and_b32 vcc_lo, %[shr], 0xF0000000\n\t"           /* the probe-number field alone (ctl's low bits hold shifts and flags) */ \
-        "v_cmp_gt_u32 vcc, vcc_lo, v38\n\t"                  /* probe number still in range (below %[shr] >> 28) */  \
+        "v_cmp_gt_u32 vcc, vcc_lo, " T2 "\n\t"                  /* probe number still in range (below %[shr] >> 28) */  \
         "s_andn2_b64 %[act], exec, vcc\n\t"                    /* lanes out of range: reported in the odd bits of %[fresh] */ \
         "s_lshl_b64 %[act], %[act], 1\n\t"                                                                             \
         "s_or_b64 %[fresh], %[fresh], %[act]\n\t"                                                                      \
@@ -3041,13 +3065,13 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
         "v_pk_add_f32 v[56:57], v[60:61], v[56:57]\n\t"      /* odd lane: m_j = c_{j+4} + c_j */                       \
         "v_pk_add_f32 v[58:59], v[62:63], v[58:59]\n\t"                                                                \
         "v_add_f32 %[key], v56, v57\n\t"                       /* (m0 + m1) + (m2 + m3) */                             \
-        "v_add_f32 v36, v58, v59\n\t"                                                                                  \
-        "v_add_f32 %[key], %[key], v36\n\t"                                                                            \
+        "v_add_f32 v60, v58, v59\n\t"                        /* (v[60:63] are free again) */                       \
+        "v_add_f32 %[key], %[key], v60\n\t"                                                                            \
         "v_xor_b32 %[key], 0x80000000, %[key]\n\t"             /* Angular::Dist = -(x . y) */                          \
         "v_add_f32 %[key], 0, %[key]\n\t"                      /* fkey: -0 -> +0, */                                   \
-        "v_ashrrev_i32 v36, 31, %[key]\n\t"                    /* then flip all bits of a negative value, the sign bit of a positive one */ \
-        "v_or_b32 v36, 0x80000000, v36\n\t"                                                                            \
-        "v_xor_b32 %[key], %[key], v36"
+        "v_ashrrev_i32 v60, 31, %[key]\n\t"                    /* then flip all bits of a negative value, the sign bit of a positive one */ \
+        "v_or_b32 v60, 0x80000000, v60\n\t"                                                                            \
+        "v_xor_b32 %[key], %[key], v60"
 
 // The four row loads of a lane, two layouts:
 //  * SPEC (rounds 1-3; since round 4 only the instances for ef > 64): requested for every valid slot BEFORE the visited
@@ -3075,9 +3099,9 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
         "s_mov_b64 exec, %[sv]\n\t"
 #define GBNNS_HOT_END "\n8:\n\ts_mov_b64 exec, %[sv]"
 
-#define GBNNS_HOT_CLOBBERS                                                                                              \
-    "vcc", "scc", "memory", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",  \
-        "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
+#define GBNNS_HOT_CLOBBERS_40                                                                                           \
+    "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54",  \
+        "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
 
 template <int METRIC = 0, bool QLDS = false, bool SPEC = !QLDS, typename QP>
 __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t roff, uint32_t nb, uint64_t valid, uint32_t lds_base,
@@ -3089,66 +3113,68 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
 #define GBNNS_HOT_OUT [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [mulc] "=&s"(mulc), [key] "=&v"(key)
 #define GBNNS_HOT_IN [id] "v"(nb), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [shr] "s"(shr), [nb] "s"(nbuckets), \
                      [roff] "v"(roff), [db] "s"(db_base)
-    static_assert(QLDS != SPEC, "built forms: query in registers + speculative row loads, or query in LDS + rows of the new ids only");
-    if constexpr (METRIC == 0 && !QLDS) {
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, %[valid]\n\t"
-        GBNNS_LOADS_SPEC("16", "32", "48")
-        GBNNS_VS_ASM
-        "s_mov_b64 exec, %[sv]\n\t"
-        GBNNS_L2_DIST_ASM("%[qa0]", "%[qb0]", "%[qa1]", "%[qb1]", "%[qa2]", "%[qb2]", "%[qa3]", "%[qb3]", "s_waitcnt vmcnt(2)\n\t", "s_waitcnt vmcnt(1)\n\t",
-                          "s_waitcnt vmcnt(0)\n\t")
-        : GBNNS_HOT_OUT
-        : GBNNS_HOT_IN, GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
-        : GBNNS_HOT_CLOBBERS);
-    } else if constexpr (METRIC == 0) {
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, %[valid]\n\t"
-        GBNNS_VS_ASM
-        GBNNS_LOADS_TESTED("16", "32", "48")
-        "ds_read_b128 v[36:39], %[qaddr]\n\t"                // the query pieces that face row loads 0 .. 2 (all lanes);
-        "ds_read_b128 v[56:59], %[qaddr] offset:16\n\t"      // piece 3 follows into v[36:39] once step 0 has used piece 0
-        "ds_read_b128 v[60:63], %[qaddr] offset:32\n\t"
-        "s_waitcnt lgkmcnt(2)\n\t"
-        GBNNS_L2_DIST_ASM("v[36:37]", "v[38:39]", "v[56:57]", "v[58:59]", "v[60:61]", "v[62:63]", "v[36:37]", "v[38:39]",
-                          "ds_read_b128 v[36:39], %[qaddr] offset:48\n\ts_waitcnt vmcnt(2) lgkmcnt(2)\n\t",
-                          "s_waitcnt vmcnt(1) lgkmcnt(1)\n\t", "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t")
-        GBNNS_HOT_END
-        : GBNNS_HOT_OUT
-        : GBNNS_HOT_IN, [qaddr] "v"(qaddr)
-        : GBNNS_HOT_CLOBBERS);
-    } else if constexpr (!QLDS) {
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, %[valid]\n\t"
-        GBNNS_LOADS_SPEC("32", "64", "96")
-        GBNNS_VS_ASM
-        "s_mov_b64 exec, %[sv]\n\t"
-        GBNNS_DOT_DIST_ASM("%[qa0]", "%[qb0]", "%[qa1]", "%[qb1]", "%[qa2]", "%[qb2]", "%[qa3]", "%[qb3]", "s_waitcnt vmcnt(2)\n\t", "s_waitcnt vmcnt(1)\n\t",
-                           "s_waitcnt vmcnt(0)\n\t")
-        : GBNNS_HOT_OUT
-        : GBNNS_HOT_IN, GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
-        : GBNNS_HOT_CLOBBERS);
+    // one statement per (metric, query source, load placement); the pieces are the macros above
+// (query in registers: the visited-set block's four temporaries are the compiler's to place, as in rounds 1-3; query in
+// LDS: they are v[36:39], which the query pieces take over afterwards)
+#define GBNNS_HOT_IN_QREG GBNNS_HOT_IN, GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
+#define GBNNS_HOT_IN_QLDS GBNNS_HOT_IN, [qaddr] "v"(qaddr)
+#define GBNNS_HOT_OUT_QREG GBNNS_HOT_OUT, [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [addr] "=&v"(addr)
+#define GBNNS_HOT_OUT_QLDS GBNNS_HOT_OUT
+#define GBNNS_VS_QREG GBNNS_VS_ASM("%[t0]", "%[t1]", "%[t2]", "%[addr]")
+#define GBNNS_VS_QLDS GBNNS_VS_ASM("v36", "v37", "v38", "v39")
+#define GBNNS_CLOB_QREG GBNNS_HOT_CLOBBERS_40
+#define GBNNS_CLOB_QLDS "v36", "v37", "v38", "v39", GBNNS_HOT_CLOBBERS_40
+#define GBNNS_HOT_STMT(LOADS_BEFORE, VS, AFTER_VS, DIST, OUTS, OPS, CLOB)                      \
+    asm volatile("s_mov_b64 %[sv], exec\n\t"                                                   \
+                 "s_mov_b64 exec, %[valid]\n\t" LOADS_BEFORE VS AFTER_VS DIST GBNNS_HOT_END      \
+                 : OUTS                                                                        \
+                 : OPS                                                                         \
+                 : CLOB)
+#define GBNNS_RESTORE_EXEC "s_mov_b64 exec, %[sv]\n\t"
+#define GBNNS_L2_QREG                                                                                                          \
+    GBNNS_L2_DIST_ASM("%[qa0]", "%[qb0]", "%[qa1]", "%[qb1]", "%[qa2]", "%[qb2]", "%[qa3]", "%[qb3]", "s_waitcnt vmcnt(2)\n\t", \
+                      "s_waitcnt vmcnt(1)\n\t", "s_waitcnt vmcnt(0)\n\t")
+#define GBNNS_L2_QLDS                                                                                                          \
+    "ds_read_b128 v[36:39], %[qaddr]\n\t"             /* the query pieces that face row loads 0 .. 2 (all lanes); */          \
+    "ds_read_b128 v[56:59], %[qaddr] offset:16\n\t"   /* piece 3 follows into v[36:39] once step 0 has used piece 0 */        \
+    "ds_read_b128 v[60:63], %[qaddr] offset:32\n\t"                                                                           \
+    "s_waitcnt lgkmcnt(2)\n\t"                                                                                                \
+    GBNNS_L2_DIST_ASM("v[36:37]", "v[38:39]", "v[56:57]", "v[58:59]", "v[60:61]", "v[62:63]", "v[36:37]", "v[38:39]",          \
+                      "ds_read_b128 v[36:39], %[qaddr] offset:48\n\ts_waitcnt vmcnt(2) lgkmcnt(2)\n\t",                        \
+                      "s_waitcnt vmcnt(1) lgkmcnt(1)\n\t", "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t")
+#define GBNNS_DOT_QREG                                                                                                          \
+    GBNNS_DOT_DIST_ASM("%[qa0]", "%[qb0]", "%[qa1]", "%[qb1]", "%[qa2]", "%[qb2]", "%[qa3]", "%[qb3]", "s_waitcnt vmcnt(2)\n\t", \
+                       "s_waitcnt vmcnt(1)\n\t", "s_waitcnt vmcnt(0)\n\t")
+#define GBNNS_DOT_QLDS                                                                                                         \
+    "ds_read_b128 v[36:39], %[qaddr]\n\t"                                                                                     \
+    "ds_read_b128 v[56:59], %[qaddr] offset:32\n\t"                                                                           \
+    "ds_read_b128 v[60:63], %[qaddr] offset:64\n\t"                                                                           \
+    "s_waitcnt lgkmcnt(2)\n\t"                                                                                                \
+    GBNNS_DOT_DIST_ASM("v[36:37]", "v[38:39]", "v[56:57]", "v[58:59]", "v[60:61]", "v[62:63]", "v[36:37]", "v[38:39]",         \
+                       "ds_read_b128 v[36:39], %[qaddr] offset:96\n\ts_waitcnt vmcnt(2) lgkmcnt(2)\n\t",                       \
+                       "s_waitcnt vmcnt(1) lgkmcnt(1)\n\t", "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t")
+    uint32_t t0, t1, t2, addr;  // (query-in-registers forms)
+    (void)t0; (void)t1; (void)t2; (void)addr;
+    if constexpr (METRIC == 0) {
+        if constexpr (!QLDS && SPEC) GBNNS_HOT_STMT(GBNNS_LOADS_SPEC("16", "32", "48"), GBNNS_VS_QREG, GBNNS_RESTORE_EXEC, GBNNS_L2_QREG, GBNNS_HOT_OUT_QREG, GBNNS_HOT_IN_QREG, GBNNS_CLOB_QREG);
+        else if constexpr (!QLDS) GBNNS_HOT_STMT("", GBNNS_VS_QREG, GBNNS_LOADS_TESTED("16", "32", "48"), GBNNS_L2_QREG, GBNNS_HOT_OUT_QREG, GBNNS_HOT_IN_QREG, GBNNS_CLOB_QREG);
+        else if constexpr (SPEC) GBNNS_HOT_STMT(GBNNS_LOADS_SPEC("16", "32", "48"), GBNNS_VS_QLDS, GBNNS_RESTORE_EXEC, GBNNS_L2_QLDS, GBNNS_HOT_OUT_QLDS, GBNNS_HOT_IN_QLDS, GBNNS_CLOB_QLDS);
+        else GBNNS_HOT_STMT("", GBNNS_VS_QLDS, GBNNS_LOADS_TESTED("16", "32", "48"), GBNNS_L2_QLDS, GBNNS_HOT_OUT_QLDS, GBNNS_HOT_IN_QLDS, GBNNS_CLOB_QLDS);
     } else {
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, %[valid]\n\t"
-        GBNNS_VS_ASM
-        GBNNS_LOADS_TESTED("32", "64", "96")
-        "ds_read_b128 v[36:39], %[qaddr]\n\t"
-        "ds_read_b128 v[56:59], %[qaddr] offset:32\n\t"
-        "ds_read_b128 v[60:63], %[qaddr] offset:64\n\t"
-        "s_waitcnt lgkmcnt(2)\n\t"
-        GBNNS_DOT_DIST_ASM("v[36:37]", "v[38:39]", "v[56:57]", "v[58:59]", "v[60:61]", "v[62:63]", "v[36:37]", "v[38:39]",
-                           "ds_read_b128 v[36:39], %[qaddr] offset:96\n\ts_waitcnt vmcnt(2) lgkmcnt(2)\n\t",
-                           "s_waitcnt vmcnt(1) lgkmcnt(1)\n\t", "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t")
-        GBNNS_HOT_END
-        : GBNNS_HOT_OUT
-        : GBNNS_HOT_IN, [qaddr] "v"(qaddr)
-        : GBNNS_HOT_CLOBBERS);
+        if constexpr (!QLDS && SPEC) GBNNS_HOT_STMT(GBNNS_LOADS_SPEC("32", "64", "96"), GBNNS_VS_QREG, GBNNS_RESTORE_EXEC, GBNNS_DOT_QREG, GBNNS_HOT_OUT_QREG, GBNNS_HOT_IN_QREG, GBNNS_CLOB_QREG);
+        else if constexpr (!QLDS) GBNNS_HOT_STMT("", GBNNS_VS_QREG, GBNNS_LOADS_TESTED("32", "64", "96"), GBNNS_DOT_QREG, GBNNS_HOT_OUT_QREG, GBNNS_HOT_IN_QREG, GBNNS_CLOB_QREG);
+        else if constexpr (SPEC) GBNNS_HOT_STMT(GBNNS_LOADS_SPEC("32", "64", "96"), GBNNS_VS_QLDS, GBNNS_RESTORE_EXEC, GBNNS_DOT_QLDS, GBNNS_HOT_OUT_QLDS, GBNNS_HOT_IN_QLDS, GBNNS_CLOB_QLDS);
+        else GBNNS_HOT_STMT("", GBNNS_VS_QLDS, GBNNS_LOADS_TESTED("32", "64", "96"), GBNNS_DOT_QLDS, GBNNS_HOT_OUT_QLDS, GBNNS_HOT_IN_QLDS, GBNNS_CLOB_QLDS);
     }
+#undef GBNNS_HOT_STMT
+#undef GBNNS_HOT_IN_QREG
+#undef GBNNS_HOT_IN_QLDS
+#undef GBNNS_CLOB_QLDS
+#undef GBNNS_CLOB_QREG
+#undef GBNNS_VS_QLDS
+#undef GBNNS_VS_QREG
+#undef GBNNS_HOT_OUT_QLDS
+#undef GBNNS_HOT_OUT_QREG
 #undef GBNNS_Q
 #undef GBNNS_HOT_OUT
 #undef GBNNS_HOT_IN
@@ -3169,7 +3195,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     const int ef = p.ef;
     // R = 1 (QLDS): the query stays in LDS and hot_expand re-reads a lane's four pieces every hop -- 64 registers, 8 wavefronts
     // per SIMD; rows requested after the visited test.  R = 2: the query in registers, speculative row loads (rounds 1-3 layout).
-    constexpr bool QLDS = R == 1;
+    constexpr bool QLDS = R == 1 && GBNNS_HOT1_QLDS, SPEC = R == 1 ? GBNNS_HOT1_SPEC != 0 : true;
     // LDS: [tie list 128 B][merge buffer 528 B (R = 2: 1 040 B; its head stages the query until it is in registers)]
     //      [QLDS: the query, 128 B][visited set]
     uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
@@ -3338,7 +3364,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
             edges += __popcll(mv & 0x5555555555555555ull);
             // ---- gather (speculative: before the visited test), visited test, distances -----------
             uint64_t mclaimed, movf;
-            const uint32_t kd = hot_expand<METRIC, QLDS>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, qaddr, mclaimed, vs_shr, movf);
+            const uint32_t kd = hot_expand<METRIC, QLDS, SPEC>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, qaddr, mclaimed, vs_shr, movf);
             if (__builtin_expect(movf != 0, 0)) {  // a probe sequence ran out (quotient form): the stash takes the id
                 // (the two-pass instances are at their scalar-register budget -- tests/test_isa_contract.py -- and hand over)
                 if constexpr (WIDE) return false;
@@ -3351,31 +3377,40 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
             // ---- survivors into the result list: batch merge, or one by one (reference order) --------
             if (m != 0) {
                 // Prefetch 2: a survivor closer than the runner-up will be the next node (it becomes the
-                // closest unexpanded entry); request its adjacency row now, before the merge and the next
+                // closest unexpanded entry); request its adjacency row now, before the merge's scatter and the next
                 // selection, instead of after them.  Only when it is unique (ties go the slow way).
-                {
+                auto prefetch2 = [&](const uint32_t dmin, const uint64_t me) {  // me = survivors at distance dmin
+                    if (dmin < h2 && me != 0 && (me & (me - 1)) == 0) {
+                        pf2_node = readlane_u32(nb, __ffsll((unsigned long long)me) - 1);
+                        pf2_val = *reinterpret_cast<const uint32_t*>(ell_base + pf2_node * ell_row_bytes + slot_off);
+                        if constexpr (WIDE) {
+                            pf2_valw = *reinterpret_cast<const uint32_t*>(ell_base + pf2_node * ell_row_bytes + slotw_off);
+                            h2 = dmin;  // the second pass overrides the prediction only with something closer still
+                        }
+                    }
+                };
+                bool merged = false;
+                if constexpr (R == 1 && GBNNS_HOT1_PF2_IN_MERGE) {
+                    // (the closest survivor comes out of the merge's rank loop -- one scalar minimum per survivor -- or, for
+                    // a lone survivor, out of its lane)
+                    if ((m & (m - 1)) != 0) {
+                        merged = reg_merge_cb<true>(m, __builtin_amdgcn_inverse_ballot_w64(m), dk, nb, L, size, worst, tsize, stage, ef, lane,
+                                                    [&](const uint32_t dmin) { if (dmin < h2) prefetch2(dmin, __ballot(dk == dmin) & m); });
+                    } else {
+                        prefetch2(readlane_u32(dk, __ffsll((unsigned long long)m) - 1), m);
+                    }
+                } else {
                     uint32_t x = dk;  // all-ones outside the new ids; survivors are below `worst`
                     x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));   // quad_perm 1,0,3,2
                     x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));   // quad_perm 2,3,0,1
                     x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));  // row_half_mirror
                     x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));  // row_mirror
                     const uint32_t dmin = min(min(readlane_u32(x, 0), readlane_u32(x, 16)), min(readlane_u32(x, 32), readlane_u32(x, 48)));
-                    if (dmin < h2) {
-                        const uint64_t me = __ballot(dk == dmin) & m;
-                        if (me != 0 && (me & (me - 1)) == 0) {
-                            pf2_node = readlane_u32(nb, __ffsll((unsigned long long)me) - 1);
-                            pf2_val = *reinterpret_cast<const uint32_t*>(ell_base + pf2_node * ell_row_bytes + slot_off);
-                            if constexpr (WIDE) {
-                                pf2_valw = *reinterpret_cast<const uint32_t*>(ell_base + pf2_node * ell_row_bytes + slotw_off);
-                                h2 = dmin;  // the second pass overrides the prediction only with something closer still
-                            }
-                        }
+                    if (dmin < h2) prefetch2(dmin, __ballot(dk == dmin) & m);
+                    if ((m & (m - 1)) != 0) {
+                        if constexpr (R == 1) merged = reg_merge(m, __builtin_amdgcn_inverse_ballot_w64(m), dk, nb, L, size, worst, tsize, stage, ef, lane);
+                        else merged = reg_merge_multi<R>(m, __builtin_amdgcn_inverse_ballot_w64(m), dk, nb, L, size, worst, tsize, stage, ef, lane);
                     }
-                }
-                bool merged = false;
-                if ((m & (m - 1)) != 0) {
-                    if constexpr (R == 1) merged = reg_merge(m, __builtin_amdgcn_inverse_ballot_w64(m), dk, nb, L, size, worst, tsize, stage, ef, lane);
-                    else merged = reg_merge_multi<R>(m, __builtin_amdgcn_inverse_ballot_w64(m), dk, nb, L, size, worst, tsize, stage, ef, lane);
                 }
                 if (!merged) {
                     do {
@@ -3506,7 +3541,7 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
             STAMP(t3)
             STAMP_ADD(2, t2, t3)
             uint64_t mclaimed, movf;
-            const uint32_t kd = hot_expand<METRIC, false>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, 0u, mclaimed, vs_shr, movf);
+            const uint32_t kd = hot_expand<METRIC, false, true>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, 0u, mclaimed, vs_shr, movf);
             if (__builtin_expect(movf != 0, 0)) {  // a probe sequence ran out (quotient form): the stash takes the id
                 // (the two-pass instances are at their scalar-register budget -- tests/test_isa_contract.py -- and hand over)
                 if constexpr (WIDE) return false;
@@ -3579,7 +3614,7 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
     B.finish(p, qi, hops, dist_calc, edges, hash_bytes, lane);  // (re-rank query staged in the dead visited-set area)
 }
 
-__global__ __launch_bounds__(64, 7) void walk_hot2_kernel(WalkParams p) {  // 64 < ef <= 128: two list registers per lane
+__global__ __launch_bounds__(64) void walk_hot2_kernel(WalkParams p) {  // 64 < ef <= 128: two list registers per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<2>(p, walk_query_of(p, blockIdx.x), smem);
 }
@@ -3591,18 +3626,18 @@ __global__ __launch_bounds__(64) void walk_hot_big_kernel(WalkParams p) {  // 12
 
 // (second launch bound = wavefronts per SIMD the register allocation must leave room for: 8 = 64 registers, which the hop needs
 // anyway since round 4 -- hot_expand, QLDS; the bound only keeps the prologue's entry distance from taking more)
-__global__ __launch_bounds__(64, 8) void walk_hot_kernel(WalkParams p) {
+__global__ __launch_bounds__(64, GBNNS_HOT1_QLDS ? 8 : 7) void walk_hot_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<1>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
 // the same three for adjacency rows of 33 .. 64 slots (two expansion passes per hop)
-__global__ __launch_bounds__(64, 8) void walk_hotw_kernel(WalkParams p) {
+__global__ __launch_bounds__(64, GBNNS_HOT1_QLDS ? 8 : 7) void walk_hotw_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<1, true>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
-__global__ __launch_bounds__(64, 7) void walk_hotw2_kernel(WalkParams p) {
+__global__ __launch_bounds__(64) void walk_hotw2_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<2, true>(p, walk_query_of(p, blockIdx.x), smem);
 }
@@ -3614,7 +3649,7 @@ __global__ __launch_bounds__(64) void walk_hotw_big_kernel(WalkParams p) {
 
 // ... and the negative-dot metric (Angular::Dist) on the same shapes (round 3): R = 1 / 2 list registers, or the two-list form
 template <int R, bool WIDE>
-__global__ __launch_bounds__(64, R == 1 ? 8 : 7) void walk_hot_dot_kernel(WalkParams p) {
+__global__ __launch_bounds__(64, R == 1 && GBNNS_HOT1_QLDS ? 8 : 1) void walk_hot_dot_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<R, WIDE, 1>(p, walk_query_of(p, blockIdx.x), smem);
 }
@@ -4503,7 +4538,7 @@ bool walk_uses_hot(const WalkParams& p, int metric) {
 // hot kernel stages the query inside the merge buffer (it lives in registers once the walk starts).
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list) {
     if (hot)  // tie list + merge buffer of 1 / 2 list registers; ef > 128: + the base list and the flush's flag bytes (walk_hot_big)
-        return ef <= 64 ? (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + 128   // (+ the query, re-read every hop)
+        return ef <= 64 ? (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (GBNNS_HOT1_QLDS ? 128 : 0)   // (+ the query, re-read every hop)
                         : (ef <= kHot2MaxEf ? (size_t)kRegTieCap * 8 + (size_t)(64 * 2 + 2) * 8 : big_list_fixed_bytes(ef));
     if (ef <= kRegListMaxEf && !lds_list) {  // tie list + merge buffer (ranks 0..ef of the 1 / 2 / 4-register list) + query
         if (ef > kHot2MaxEf) return big_list_fixed_bytes(ef) + (size_t)dstride * 4;  // walk_reg_big_one

@@ -122,7 +122,8 @@ def test_hot_kernel_register_budgets(tmp_path):
     wavefront's scalar registers are handed out as ceil16(sgpr_count) + 16 of 800 per SIMD, so <= 80 -> 8 wavefronts per
     SIMD, <= 96 -> 7, above -> 6; vector registers: <= 64 -> 8, <= 72 -> 7, <= 80 -> 6, <= 96 -> 5) and on nothing
     spilling.  Rounds 1-3 shipped these kernels at 106 scalar registers -- an inline-asm clobber of s98 / s99 -- i.e. at
-    6 wavefronts per SIMD whatever the vector-register count said.  This test reads the kernel descriptors' metadata
+    6 wavefronts per SIMD whatever the vector-register count said.  Only the one-register instances (ef <= 64) are held
+    to the 8-wavefront class: the others are bounded by their LDS share (<= 22 wavefronts per CU) well before.  This test reads the kernel descriptors' metadata
     of the shipped code objects and fails when an instance leaves its class."""
     if not os.path.exists(READELF) or not os.path.exists(OBJDUMP):
         pytest.skip("ROCm llvm tools not found")
@@ -141,11 +142,11 @@ def test_hot_kernel_register_budgets(tmp_path):
                                    for k in ("vgpr_count", "sgpr_count", "private_segment_fixed_size", "vgpr_spill_count")
                                    if re.search(r"\.%s:\s+(\d+)" % k, block)}
     # (substring of the mangled name, VGPR ceiling, SGPR ceiling)
-    budgets = [("15walk_hot_kernelE", 64, 80), ("16walk_hot2_kernelE", 72, 96), ("19walk_hot_big_kernelE", 96, 112),
+    budgets = [("15walk_hot_kernelE", 64, 80), ("16walk_hot2_kernelE", 72, 112), ("19walk_hot_big_kernelE", 96, 112),
                # the instances for adjacency rows of 33 .. 64 slots (second expansion pass)
-               ("16walk_hotw_kernelE", 64, 80), ("17walk_hotw2_kernelE", 72, 96), ("20walk_hotw_big_kernelE", 96, 112),
+               ("16walk_hotw_kernelE", 64, 80), ("17walk_hotw2_kernelE", 72, 112), ("20walk_hotw_big_kernelE", 96, 112),
                # the negative-dot metric on the same shapes
-               ("19walk_hot_dot_kernelILi1E", 64, 80), ("19walk_hot_dot_kernelILi2E", 72, 96), ("23walk_hot_dot_big_kernelI", 96, 112)]
+               ("19walk_hot_dot_kernelILi1E", 64, 80), ("19walk_hot_dot_kernelILi2E", 72, 112), ("23walk_hot_dot_big_kernelI", 96, 112)]
     for sub, cap, scap in budgets:
         hits = {k: v for k, v in meta.items() if sub in k}
         assert hits, sub

@@ -16,12 +16,12 @@ pass() {  # name counters...   (at most two counters per hardware block and pass
   echo "pass $name rc=$?" >> $OUT/passes.txt
 }
 pass a TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum GRBM_GUI_ACTIVE
-pass b TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum
-pass c TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_TAG_STALL_sum
-pass d TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCC_BUSY_sum TCC_CYCLE_sum
-pass e TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum
-pass f TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum
-pass g TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES
+pass b TD_TD_BUSY_sum TD_TC_STALL_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCC_REQ_sum TCC_TAG_STALL_sum
+pass c TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_HIT_sum TCC_MISS_sum
+pass d SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LEVEL_WAVES
+pass e SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_INSTS SQ_ACTIVE_INST_MISC
+pass f SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_FLAT
+pass g SQ_IFETCH SQ_IFETCH_LEVEL SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_BUSY_CYCLES SQC_DCACHE_BUSY_CYCLES SQ_INST_LEVEL_VMEM
 python3 tools/digest_profile.py $OUT --last 10 --config $CFG --tag $TAG > $OUT/summary.txt 2> $OUT/digest.err
 grep -E "^== counters|^walk_" $OUT/summary.txt
 cat $OUT/passes.txt

@@ -1,7 +1,7 @@
 // Micro-benchmark (diagnostic): throughput of random 128-byte row gathers from a table, by how the
 // lanes of a wavefront share a row.  LPR lanes per row (1 = one lane streams its whole row with 8
 // 16-B loads, 2 = pair, 4 = quad, 8 = octet: one 16-B load per lane), ROWS rows per iteration.
-// One wavefront per workgroup, 20 wavefronts per CU resident (LDS-limited like the walk kernel).
+// One wavefront per workgroup, 20 wavefronts per CU resident by default (LDS-limited like the walk kernel; argv[2]).
 // Build: hipcc --offload-arch=gfx950 -O3 -o gather_cost gather_cost.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -35,10 +35,12 @@ __global__ __launch_bounds__(64) void gather(const float4* __restrict__ tab, uin
     if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x + smem[0];
 }
 
+static size_t g_lds = 8 * 1024;  // 20 wavefronts per CU (argv[2]: LDS bytes per wavefront; 5120 -> 32 per CU, 6400 -> 25)
+
 template <int LPR, int ROWS>
 void run(const float4* tab, uint32_t nrows, float* out, const char* name) {
     const int iters = 200, grid = 256 * 40;
-    const size_t lds = 8 * 1024;  // 20 wavefronts per CU
+    const size_t lds = g_lds;
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     hipLaunchKernelGGL((gather<LPR, ROWS>), dim3(grid), dim3(64), lds, 0, tab, nrows, 20, out);
@@ -56,12 +58,14 @@ void run(const float4* tab, uint32_t nrows, float* out, const char* name) {
 
 int main(int argc, char** argv) {
     const size_t mb = argc > 1 ? atoi(argv[1]) : 128;
+    if (argc > 2) g_lds = (size_t)atoi(argv[2]);
     const uint32_t nrows = (uint32_t)(mb * 1024 * 1024 / 128);
     float4* tab; float* out;
     hipMalloc(&tab, (size_t)nrows * 128);
     hipMalloc(&out, 64);
     hipMemset(tab, 0, (size_t)nrows * 128);
-    printf("table %zu MB (%u rows of 128 B)\n", mb, nrows);
+    printf("table %zu MB (%u rows of 128 B), %zu B of LDS per wavefront = %zu wavefronts per CU\n", mb, nrows, g_lds,
+           (size_t)(163840 / ((g_lds + 1279) / 1280 * 1280)) > 32 ? (size_t)32 : (size_t)(163840 / ((g_lds + 1279) / 1280 * 1280)));
     run<1, 16>(tab, nrows, out, "lane per row");
     run<2, 16>(tab, nrows, out, "pair per row");
     run<4, 16>(tab, nrows, out, "quad per row");
