@@ -3628,6 +3628,9 @@ __global__ __launch_bounds__(64) void walk_hot_big_kernel(WalkParams p) {  // 12
 // anyway since round 4 -- hot_expand, QLDS; the bound only keeps the prologue's entry distance from taking more)
 __global__ __launch_bounds__(64, GBNNS_HOT1_QLDS ? 8 : 7) void walk_hot_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef GBNNS_HOT1_CAP6  // experiment: 97+ scalar registers = 6 wavefronts per SIMD, leaving 128 vector registers per SIMD to other kernels
+    asm volatile("" ::: "s96");
+#endif
     walk_hot_one<1>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
@@ -4060,8 +4063,13 @@ __global__ __launch_bounds__(256) void mlp_layer_kernel(LayerParams p) {
 // Same tile and arithmetic as mlp_layer_kernel, for 16-B aligned operands (xstride % 4 == 0):
 // 16-B global loads, and the next k-chunk is fetched into registers while the current one is
 // being consumed from LDS (the generic kernel exposes one global round trip per chunk).
+// (second launch bound: 1 = as many registers as the tile wants -- 162; 4 = at most 128, so that a block fits beside six 64-register
+// walk wavefronts per SIMD: the A/B switch of the round-4 pipeline experiment, profiles/r04_ab.txt)
+#ifndef GBNNS_MLP_WAVES
+#define GBNNS_MLP_WAVES 1
+#endif
 template <bool RELU, bool NORM = false>
-__global__ __launch_bounds__(256) void mlp_layer_vec_kernel(LayerParams p) {
+__global__ __launch_bounds__(256, GBNNS_MLP_WAVES) void mlp_layer_vec_kernel(LayerParams p) {
     __shared__ __attribute__((aligned(16))) float xs[kTQ * kLd];
     __shared__ __attribute__((aligned(16))) float ws[kTO * kLd];
     const int t = threadIdx.x;
