@@ -328,6 +328,8 @@ std::atomic<int> g_knob_quotient{knob_env("GBNNS_QUOTIENT", 1)};
 std::atomic<int> g_knob_vs_disp{knob_env("GBNNS_DEBUG_VS_DISP", 15)};
 // "max_waves" = most first-pass wavefronts per CU the LDS shares are cut for (GBNNS_MAX_WAVES; 0 = the per-kernel defaults)
 std::atomic<int> g_knob_max_waves{knob_env("GBNNS_MAX_WAVES", 0)};
+// "knn_filter" 0 = gbnns_exact_knn without the matrix-core filter (GBNNS_KNN_FILTER; tests compare the two paths)
+std::atomic<int> g_knob_knn_filter{knob_env("GBNNS_KNN_FILTER", 1)};
 
 // A handle's workspace (projected queries, candidate lists, hand-over lists, control words) is shared by its
 // calls and ordered by stream order.  When a call names another stream than the last one that left work in
@@ -407,7 +409,66 @@ int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* quer
     if ((rc = heap.ensure(p.heap_stride * (size_t)k * 8))) return rc;
     p.heap = heap.as<uint64_t>();
     HIP_TRY(hipMemsetAsync(p.heap, 0xFF, p.heap_stride * (size_t)k * 8, s));
-    HIP_TRY(launch_knn_scan(p, metric, s));
+    // Matrix-core filter in front of the exact distances (knn.hip): the L2 metric on rows of whole 16-byte steps, sets
+    // large enough to amortise its passes.  Same output, byte for byte (tests/test_gpu_parity.py); "knn_filter" 0 = off.
+    const int knob_filter = g_knob_knn_filter.load(std::memory_order_relaxed);  // 0 = never, 1 = by size, 2 = whenever the shape allows (tests)
+    const bool filter = metric == GBNNS_METRIC_L2 && d % 4 == 0 && d <= 128 && k <= 512 && n > (uint64_t)4 * k &&
+                        (knob_filter == 2 || (knob_filter == 1 && n >= (1u << 17) && nq >= 2048));
+    if (filter) {
+        const uint32_t dp = (d + 15u) & ~15u;
+        const uint32_t cap = (uint32_t)std::max(256, 4 * k + 64);
+        // rows per filtered chunk: 4 MB of packed rows at d = 32 (small sets, tests: a sixteenth of the set)
+        const uint32_t chunk = (uint32_t)std::min<uint64_t>(1u << 15, std::max<uint64_t>(64, (n / 16 + 63) & ~(uint64_t)63));
+        const uint64_t first = std::min<uint64_t>(n, std::max<uint64_t>(chunk, 4ull * (uint64_t)k));  // scanned exactly: fills the heaps
+        DevBuf bpack, bnorm, qpack, qnorm, rhs, cand, count, flag;
+        struct Release2 {
+            DevBuf* b[8];
+            ~Release2() { for (DevBuf* x : b) x->release(); }
+        } release2{{&bpack, &bnorm, &qpack, &qnorm, &rhs, &cand, &count, &flag}};
+        if ((rc = bpack.ensure((size_t)n * dp * 4))) return rc;       // 2 dp bf16 per row
+        if ((rc = bnorm.ensure((size_t)n * 4))) return rc;
+        if ((rc = qpack.ensure((size_t)nq * dp * 4))) return rc;
+        if ((rc = qnorm.ensure((size_t)nq * 4))) return rc;
+        if ((rc = rhs.ensure((size_t)nq * 4))) return rc;
+        if ((rc = cand.ensure((size_t)nq * cap * 4))) return rc;
+        if ((rc = count.ensure((size_t)nq * 4))) return rc;
+        if ((rc = flag.ensure(4))) return rc;
+        HIP_TRY(launch_knn_pack(p.base, d, d, n, bpack.as<uint16_t>(), bnorm.as<float>(), s));
+        HIP_TRY(launch_knn_pack(p.q, d, d, nq, qpack.as<uint16_t>(), qnorm.as<float>(), s));
+        KnnParams ps = p;          // the first rows: the exact scan, heaps kept
+        ps.n = first; ps.row0 = 0; ps.keep_heap = 1;
+        HIP_TRY(launch_knn_scan(ps, metric, s));
+        HIP_TRY(launch_knn_thresholds(p.heap, p.heap_stride, k, qnorm.as<float>(), nq, rhs.as<float>(), s));
+        uint32_t h_flag = 0;
+        for (uint64_t r0 = first; r0 < n; r0 += chunk) {
+            const uint32_t rows = (uint32_t)std::min<uint64_t>(chunk, n - r0);
+            HIP_TRY(hipMemsetAsync(count.p, 0, (size_t)nq * 4, s));
+            HIP_TRY(hipMemsetAsync(flag.p, 0, 4, s));
+            KnnFilterParams f{};
+            f.qpack = qpack.as<uint16_t>(); f.bpack = bpack.as<uint16_t>() + (size_t)r0 * dp * 2; f.bnorm = bnorm.as<float>() + r0;
+            f.rhs = rhs.as<float>(); f.nq = nq; f.dp = dp; f.rows = rows; f.row0 = (uint32_t)r0; f.cap = cap;
+            f.cand = cand.as<uint32_t>(); f.count = count.as<uint32_t>(); f.overflow = flag.as<uint32_t>();
+            HIP_TRY(launch_knn_filter(f, s));
+            HIP_TRY(hipMemcpyAsync(&h_flag, flag.p, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (h_flag) {
+                // some query kept more rows of this chunk than its list holds (adversarial order of the rows, or thresholds
+                // not yet tight): the chunk is scanned exactly for everyone instead -- same heaps, nothing offered twice
+                KnnParams pc = p;
+                pc.base = p.base + (size_t)r0 * d; pc.n = rows; pc.row0 = r0; pc.keep_heap = 1;
+                HIP_TRY(launch_knn_scan(pc, metric, s));
+                HIP_TRY(launch_knn_thresholds(p.heap, p.heap_stride, k, qnorm.as<float>(), nq, rhs.as<float>(), s));
+            } else {
+                KnnRescoreParams rp{};
+                rp.k = p; rp.cand = cand.as<uint32_t>(); rp.count = count.as<uint32_t>(); rp.cap = cap;
+                rp.qnorm = qnorm.as<float>(); rp.rhs = rhs.as<float>();
+                HIP_TRY(launch_knn_rescore(rp, s));
+            }
+        }
+        HIP_TRY(launch_knn_finalize(p, s));
+    } else {
+        HIP_TRY(launch_knn_scan(p, metric, s));
+    }
     if (host) {
         HIP_TRY(hipMemcpyAsync(out_ids, p.out_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
         if (out_dist) HIP_TRY(hipMemcpyAsync(out_dist, p.out_dist, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
@@ -739,6 +800,7 @@ int gbnns_debug_knob(const char* name, int value) {
     if (!std::strcmp(name, "quotient")) g_knob_quotient.store(value, std::memory_order_relaxed);
     else if (!std::strcmp(name, "vs_disp")) g_knob_vs_disp.store(value <= 0 ? 15 : value, std::memory_order_relaxed);
     else if (!std::strcmp(name, "max_waves")) g_knob_max_waves.store(std::max(0, std::min(32, value)), std::memory_order_relaxed);
+    else if (!std::strcmp(name, "knn_filter")) g_knob_knn_filter.store(value, std::memory_order_relaxed);
     else return fail(GBNNS_ERR_INVALID, "gbnns_debug_knob: unknown knob '%s'", name);
     return GBNNS_OK;
 }

@@ -158,8 +158,43 @@ struct KnnParams {
     size_t heap_stride;      // >= nq
     uint32_t* out_ids;       // [nq x k] ascending (distance, id); 0xFFFFFFFF where fewer than k rows exist
     float* out_dist;         // optional [nq x k]
+    uint64_t row0;           // id of `base` row 0 (scans of a slice of the base set; 0 = the whole set)
+    int32_t keep_heap;       // 1: leave the heaps as they are (no sort, no outputs): more rows follow
 };
 hipError_t launch_knn_scan(const KnnParams& p, int metric, hipStream_t s);
+
+// Matrix-core filter in front of the exact scan (knn.hip, round 4; L2 metric, d % 4 == 0, d <= 128).
+// Rows packed for v_mfma_f32_32x32x16_bf16: per row, per group of 8 dims, 8 bf16 "hi" parts then 8 bf16 "lo" parts
+// (x = hi + lo + r, |r| <= 2^-16 |x|), dims zero-padded to a multiple of 16; and the row's squared norm.
+hipError_t launch_knn_pack(const float* x, uint32_t stride, uint32_t dim, uint64_t rows, uint16_t* packed, float* norms, hipStream_t s);
+struct KnnFilterParams {
+    const uint16_t* qpack;   // [nq x 2 dp] packed queries
+    const uint16_t* bpack;   // [rows x 2 dp] packed base rows of this chunk
+    const float* bnorm;      // [rows] squared norms of the chunk's rows
+    const float* rhs;        // [nq] 0.5 ((1 - c) |q|^2 - T_q): a row passes when  q.x - 0.5 (1 - c) |x|^2 >= rhs  (-inf: everything passes)
+    uint32_t nq, dp;         // dp = padded dimension (multiple of 16)
+    uint32_t rows;           // rows of the chunk
+    uint32_t row0;           // id of the chunk's first row
+    uint32_t cap;            // candidate slots per query
+    uint32_t* cand;          // [nq x cap] ids that passed
+    uint32_t* count;         // [nq] how many passed (may exceed cap: then *overflow is set and the chunk is scanned exactly)
+    uint32_t* overflow;      // [1]
+};
+hipError_t launch_knn_filter(const KnnFilterParams& p, hipStream_t s);
+// thresholds from the heaps: rhs[q] = 0.5 ((1 - c) |q|^2 - d_k(q)), -inf while the heap is not full
+hipError_t launch_knn_thresholds(const uint64_t* heap, size_t heap_stride, int k, const float* qnorm, uint32_t nq, float* rhs, hipStream_t s);
+// exact distances (the reference's arithmetic) of the candidates, offered to the heaps; then the new thresholds
+struct KnnRescoreParams {
+    KnnParams k;             // base = the WHOLE base set, heap, q, ...
+    const uint32_t* cand;
+    const uint32_t* count;
+    uint32_t cap;
+    const float* qnorm;
+    float* rhs;
+};
+hipError_t launch_knn_rescore(const KnnRescoreParams& p, hipStream_t s);
+hipError_t launch_knn_finalize(const KnnParams& p, hipStream_t s);   // heap sort + outputs
+constexpr float kKnnFilterSlack = 1.0f / 4096.0f;  // c: |approximate - reference distance| <= c (|q|^2 + |x|^2) with room to spare (knn.hip)
 
 // GD pruning of a kNN graph, one node per wavefront (support_func.h:521-563).  deg[i] = 0xFFFFFFFF marks a node
 // left to the host (equal distances in its list, list longer than 1024, id out of range).

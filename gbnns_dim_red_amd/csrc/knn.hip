@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_scan_kernel(KnnParams p) {
     for (int a = 0; a < QPT; ++a) {
         qi[a] = (blockIdx.x * QPT + a) * kKnnThreads + t;
         live[a] = qi[a] < p.nq;
-        root[a] = ~0ull;  // the heap starts filled with all-ones keys
+        root[a] = live[a] ? p.heap[qi[a]] : ~0ull;  // (all-ones in a fresh heap; an earlier slice's root otherwise)
         const float* qp = p.q + (size_t)(live[a] ? qi[a] : 0u) * p.qstride;
 #pragma unroll
         for (int c = 0; c < S; ++c) {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_scan_kernel(KnnParams p) {
                     dist[a] = -((m01.x + m01.y) + (m23.x + m23.y));                     // :160-162
                 }
             }
-            const uint64_t row = base0 + r;
+            const uint64_t row = p.row0 + base0 + r;
 #pragma unroll
             for (int a = 0; a < QPT; ++a) {
                 const uint64_t key = ((uint64_t)knn_fkey(dist[a]) << 32) | (uint32_t)row;
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_scan_kernel(KnnParams p) {
         }
     }
 
+    if (p.keep_heap) return;
     // heap sort in place (ascending), then the outputs; every lane runs the same trip counts
 #pragma unroll
     for (int a = 0; a < QPT; ++a) {
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(kKnnThreads) void knn_scan_wide_kernel(KnnParams p)
     const uint32_t qi = blockIdx.x * kKnnThreads + t;
     const bool live = qi < p.nq;
     const float* qp = p.q + (size_t)(live ? qi : 0u) * p.qstride;
-    uint64_t root = ~0ull;
+    uint64_t root = live ? p.heap[qi] : ~0ull;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     for (uint64_t base0 = 0; base0 < p.n; base0 += R) {
@@ -289,14 +290,14 @@ __global__ __launch_bounds__(kKnnThreads) void knn_scan_wide_kernel(KnnParams p)
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint64_t row = base0 + r;
+            const uint64_t row = p.row0 + base0 + r;
             const uint64_t key = ((uint64_t)knn_fkey(dist[r]) << 32) | (uint32_t)row;
             const bool self = p.self_offset >= 0 && row == (uint64_t)qi + (uint64_t)p.self_offset;
-            if (live && row < p.n && !self && key < root)
+            if (live && base0 + r < p.n && !self && key < root)
                 root = heap_replace_root(p.heap + qi, p.heap_stride, p.k, key);
         }
     }
-    if (!live) return;
+    if (!live || p.keep_heap) return;
     uint64_t* h = p.heap + qi;
     const size_t st = p.heap_stride;
     for (int m = p.k - 1; m > 0; --m) {  // heap sort in place (ascending)
@@ -350,11 +351,270 @@ hipError_t launch_knn_m(const KnnParams& p, hipStream_t s) {
     return hipErrorInvalidValue;  // d > 10240: refused by gbnns_exact_knn (d <= 8192) before it gets here
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Matrix-core filter (round 4).  The kNN lists that feed the graph builder are the one stage of this path where
+// the reference has no arithmetic of its own to match: they come from faiss / torch.mm (dim_red/support_func.py:20-74,
+// 374-384).  What gbnns_exact_knn promises is the k smallest (L2Metric::Dist, id) pairs -- so an approximate distance
+// with a KNOWN error bound may decide which rows are worth an exact distance, as long as no row that belongs to the
+// answer can be dropped:
+//   a(q, x) = |q|^2 + |x|^2 - 2 q.x  with q.x on the matrix cores (v_mfma_f32_32x32x16_bf16, every float split into
+//   bf16 hi + lo: q.x ~ qh.xh + qh.xl + ql.xh), |a - Dist| <= eps(q, x) := c (|q|^2 + |x|^2), c = 2^-12 (bound below);
+//   a row is kept when a <= T_q + eps, T_q = the query's current exact k-th distance (its heap's root).  A dropped row has
+//   Dist >= a - eps > T_q >= the final k-th distance: it is not among the k smallest (distance, id) pairs, ties included.
+//   Kept rows get their exact distance in the reference's order (knn_rescore_kernel) and are offered to the same heap
+//   as before: the heap ends up holding the same k keys as the full scan's, whatever the order of the offers.
+// Error bound: x = xh + xl + r with |xl| <= 2^-8 |x|, |r| <= 2^-16 |x| (two round-to-nearest bf16 steps); the three
+// products kept are exact in f32, the three dropped ones sum to <= 3 * 2^-16 |q_k x_k| per dimension; f32 accumulation of
+// 3 d products <= 3 d 2^-24 sum |q_k x_k|; sum |q_k x_k| <= |q||x| <= (|q|^2 + |x|^2) / 2.  For d <= 128 the dot
+// product is off by <= 3.8e-5 (|q|^2 + |x|^2), a by twice that plus the norms' own rounding (d 2^-24 each) plus the
+// reference distance's rounding against the real value (<= (d / 4 + 3) 2^-23 Dist): < 9e-5 (|q|^2 + |x|^2) in all --
+// c = 2^-12 = 2.44e-4 leaves a factor 2.7.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint16_t bf16_rne(float x) {  // round to nearest even (finite inputs)
+    const uint32_t u = __float_as_uint(x);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float bf16_val(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// one thread per (row, group of 8 dims): writes the 8 hi and 8 lo parts (32 contiguous bytes); thread of group 0 also the norm
+__global__ __launch_bounds__(256) void knn_pack_kernel(const float* x, uint32_t stride, uint32_t dim, uint64_t rows, uint32_t groups,
+                                                       uint16_t* packed, float* norms) {
+    const uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t row = e / groups;
+    const uint32_t g = (uint32_t)(e % groups);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * stride;
+    uint16_t hi[8], lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t dcol = g * 8u + j;
+        const float v = dcol < dim ? xr[dcol] : 0.f;
+        hi[j] = bf16_rne(v);
+        lo[j] = bf16_rne(v - bf16_val(hi[j]));
+    }
+    uint4 a, b;
+    a.x = hi[0] | (uint32_t)hi[1] << 16; a.y = hi[2] | (uint32_t)hi[3] << 16; a.z = hi[4] | (uint32_t)hi[5] << 16; a.w = hi[6] | (uint32_t)hi[7] << 16;
+    b.x = lo[0] | (uint32_t)lo[1] << 16; b.y = lo[2] | (uint32_t)lo[3] << 16; b.z = lo[4] | (uint32_t)lo[5] << 16; b.w = lo[6] | (uint32_t)lo[7] << 16;
+    uint4* out = reinterpret_cast<uint4*>(packed + ((size_t)row * groups + g) * 16);
+    out[0] = a;
+    out[1] = b;
+    if (g == 0) {
+        float n2 = 0.f;
+        for (uint32_t c = 0; c < dim; ++c) n2 += xr[c] * xr[c];
+        norms[row] = n2;
+    }
+}
+
+// A workgroup = 4 wavefronts x QB blocks of 32 queries (operand A, in registers for the whole launch); blockIdx.y picks
+// a slab of the chunk's rows, walked in blocks of 32 (operand B straight from global memory: a 32 K-row chunk of packed
+// rows is 4 MB at d = 32, L2 / Infinity-Cache resident while every workgroup sweeps it).  Accumulators start at
+// -0.5 (1 - c) |x|^2 of the lane's row (the lane's column of the 32 x 32 tile), so a kept pair is one compare:
+// acc >= rhs[query].
+template <int KSTEPS, int QB>
+__global__ __launch_bounds__(256) void knn_filter_kernel(KnnFilterParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r = lane & 31, h = lane >> 5;
+    const uint32_t q0 = (blockIdx.x * 4u + wave) * (QB * 32u);
+    if (q0 >= p.nq) return;
+    const uint32_t groups = p.dp >> 3;  // 8-dim groups per row = 2 KSTEPS
+    // A fragments: query q0 + 32 b + r, k = 16 s + 8 h .. + 7 -> group 2 s + h: hi at halfword 16 (2 s + h), lo 8 further
+    bf16x8 qh[QB][KSTEPS], ql[QB][KSTEPS];
+    float rhs[QB][16];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const uint32_t qi = q0 + 32u * b + r;
+        const bool ok = qi < p.nq;
+        const uint16_t* qp = p.qpack + (size_t)(ok ? qi : 0u) * groups * 16;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const uint4* src = reinterpret_cast<const uint4*>(qp + (size_t)(2 * s + h) * 16);
+            uint4 a = src[0], c = src[1];
+            if (!ok) { a = make_uint4(0, 0, 0, 0); c = a; }
+            qh[b][s] = __builtin_bit_cast(bf16x8, a);
+            ql[b][s] = __builtin_bit_cast(bf16x8, c);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {  // this lane's 16 rows of the tile: queries (v & 3) + 8 (v >> 2) + 4 h
+            const uint32_t qv = q0 + 32u * b + (uint32_t)((v & 3) + 8 * (v >> 2)) + 4u * h;
+            rhs[b][v] = qv < p.nq ? p.rhs[qv] : __builtin_inff();
+        }
+    }
+    const uint32_t blocks = (p.rows + 31u) >> 5;
+    const uint32_t per = (blocks + gridDim.y - 1) / gridDim.y;
+    const uint32_t b_lo = blockIdx.y * per, b_hi = min(blocks, b_lo + per);
+    const float scale = -0.5f * (1.0f - kKnnFilterSlack);
+    for (uint32_t rb = b_lo; rb < b_hi; ++rb) {
+        const uint32_t j = rb * 32u + r;  // this lane's row of the chunk (column of the tile)
+        const bool jok = j < p.rows;
+        const uint16_t* bp = p.bpack + (size_t)(jok ? j : 0u) * groups * 16;
+        bf16x8 xh[KSTEPS], xl[KSTEPS];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const uint4* src = reinterpret_cast<const uint4*>(bp + (size_t)(2 * s + h) * 16);
+            xh[s] = __builtin_bit_cast(bf16x8, src[0]);
+            xl[s] = __builtin_bit_cast(bf16x8, src[1]);
+        }
+        const float init = jok ? scale * p.bnorm[j] : -__builtin_inff();  // (a row beyond the chunk never passes)
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            f32x16 acc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[v] = init;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[b][s], xh[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[b][s], xl[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[b][s], xh[s], acc, 0, 0, 0);
+            }
+            bool any = false;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) any |= acc[v] >= rhs[b][v];
+            if (__builtin_expect(__ballot(any) != 0ull, 0)) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    if (acc[v] >= rhs[b][v]) {
+                        const uint32_t qv = q0 + 32u * b + (uint32_t)((v & 3) + 8 * (v >> 2)) + 4u * h;
+                        const uint32_t pos = atomicAdd(&p.count[qv], 1u);
+                        if (pos < p.cap) p.cand[(size_t)qv * p.cap + pos] = p.row0 + j;
+                        else *p.overflow = 1u;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void knn_thresholds_kernel(const uint64_t* heap, int k, const float* qnorm, uint32_t nq, float* rhs) {
+    const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
+    if (qi >= nq) return;
+    const uint64_t root = heap[qi];
+    // heap not full yet (an all-ones key at the root): every row passes
+    rhs[qi] = root == ~0ull ? -__builtin_inff()
+                            : 0.5f * ((1.0f - kKnnFilterSlack) * qnorm[qi] - knn_fkey_inv((uint32_t)(root >> 32)));
+    (void)k;
+}
+
+// One thread per query: the exact distance (L2Metric::Dist, support_func.h:107-128, the scan kernels' operations and order)
+// of every candidate the filter kept, offered to the query's heap; then the query's new threshold.  d <= 128, query in
+// registers, candidate rows straight from global memory.
+template <int S>
+__global__ __launch_bounds__(128) void knn_rescore_kernel(KnnRescoreParams p) {
+    const KnnParams& kp = p.k;
+    const uint32_t qi = blockIdx.x * 128u + threadIdx.x;
+    if (qi >= kp.nq) return;
+    const uint32_t steps = kp.dim >> 2;
+    const float* qp = kp.q + (size_t)qi * kp.qstride;
+    float4 q[S];
+#pragma unroll
+    for (int c = 0; c < S; ++c)
+        q[c] = (uint32_t)c < steps ? make_float4(qp[4 * c], qp[4 * c + 1], qp[4 * c + 2], qp[4 * c + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    uint64_t root = kp.heap[qi];
+    const uint32_t cnt = min(p.count[qi], p.cap);
+    for (uint32_t e = 0; e < cnt; ++e) {
+        const uint32_t row = p.cand[(size_t)qi * p.cap + e];
+        const float* bp = kp.base + (size_t)row * kp.bstride;
+        f32x2 s01{0.f, 0.f}, s23{0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < S; ++c) {
+            if ((uint32_t)c < steps) {
+                const f32x2 b01{bp[4 * c], bp[4 * c + 1]}, b23{bp[4 * c + 2], bp[4 * c + 3]};
+                const f32x2 e01 = b01 - f32x2{q[c].x, q[c].y};
+                const f32x2 e23 = b23 - f32x2{q[c].z, q[c].w};
+                s01 = s01 + e01 * e01;
+                s23 = s23 + e23 * e23;
+            }
+        }
+        const float dist = ((s01.x + s01.y) + s23.x) + s23.y;
+        const uint64_t key = ((uint64_t)knn_fkey(dist) << 32) | row;
+        const bool self = kp.self_offset >= 0 && (uint64_t)row == (uint64_t)qi + (uint64_t)kp.self_offset;
+        if (!self && key < root) root = heap_replace_root(kp.heap + qi, kp.heap_stride, kp.k, key);
+    }
+    p.rhs[qi] = root == ~0ull ? -__builtin_inff()
+                              : 0.5f * ((1.0f - kKnnFilterSlack) * p.qnorm[qi] - knn_fkey_inv((uint32_t)(root >> 32)));
+}
+
+__global__ __launch_bounds__(128) void knn_finalize_kernel(KnnParams p) {
+    const uint32_t qi = blockIdx.x * 128u + threadIdx.x;
+    if (qi >= p.nq) return;
+    uint64_t* h = p.heap + qi;
+    const size_t st = p.heap_stride;
+    for (int m = p.k - 1; m > 0; --m) {  // heap sort in place (ascending)
+        const uint64_t last = h[(size_t)m * st];
+        h[(size_t)m * st] = h[0];
+        heap_replace_root(h, st, m, last);
+    }
+    for (int e = 0; e < p.k; ++e) {
+        const uint64_t kv = h[(size_t)e * st];
+        p.out_ids[(size_t)qi * p.k + e] = (uint32_t)kv;
+        if (p.out_dist)
+            p.out_dist[(size_t)qi * p.k + e] = (kv == ~0ull) ? __builtin_inff() : knn_fkey_inv((uint32_t)(kv >> 32));
+    }
+}
+
+template <int KSTEPS, int QB>
+hipError_t launch_knn_filter_t(const KnnFilterParams& p, hipStream_t s) {
+    const unsigned gx = (p.nq + QB * 128u - 1) / (QB * 128u);
+    const unsigned blocks = (p.rows + 31u) >> 5;
+    unsigned gy = gx >= 1024u ? 1u : (1024u + gx - 1) / gx;   // enough workgroups for 256 CUs x 4 SIMDs
+    if (gy > blocks) gy = blocks;
+    if (gy < 1u) gy = 1u;
+    hipLaunchKernelGGL((knn_filter_kernel<KSTEPS, QB>), dim3(gx, gy), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
 }  // namespace
 
 hipError_t launch_knn_scan(const KnnParams& p, int metric, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
     return metric == 1 ? launch_knn_m<1>(p, s) : launch_knn_m<0>(p, s);
+}
+
+hipError_t launch_knn_pack(const float* x, uint32_t stride, uint32_t dim, uint64_t rows, uint16_t* packed, float* norms, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    const uint32_t groups = ((dim + 15u) & ~15u) >> 3;
+    const uint64_t threads = rows * groups;
+    hipLaunchKernelGGL(knn_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, stride, dim, rows, groups, packed, norms);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_filter(const KnnFilterParams& p, hipStream_t s) {
+    if (p.nq == 0 || p.rows == 0) return hipSuccess;
+    switch (p.dp >> 4) {   // K steps of 16; query blocks per wavefront by what the operands leave of the register file
+        case 1: return launch_knn_filter_t<1, 4>(p, s);
+        case 2: return launch_knn_filter_t<2, 4>(p, s);
+        case 3: return launch_knn_filter_t<3, 2>(p, s);
+        case 4: return launch_knn_filter_t<4, 2>(p, s);
+        case 5: return launch_knn_filter_t<5, 1>(p, s);
+        case 6: return launch_knn_filter_t<6, 1>(p, s);
+        case 7: return launch_knn_filter_t<7, 1>(p, s);
+        case 8: return launch_knn_filter_t<8, 1>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_knn_thresholds(const uint64_t* heap, size_t heap_stride, int k, const float* qnorm, uint32_t nq, float* rhs, hipStream_t s) {
+    (void)heap_stride;
+    if (nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(knn_thresholds_kernel, dim3((nq + 255u) / 256u), dim3(256), 0, s, heap, k, qnorm, nq, rhs);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_rescore(const KnnRescoreParams& p, hipStream_t s) {
+    if (p.k.nq == 0) return hipSuccess;
+    const dim3 grid((p.k.nq + 127u) / 128u), block(128);
+    if (p.k.dim <= 32) hipLaunchKernelGGL(knn_rescore_kernel<8>, grid, block, 0, s, p);
+    else if (p.k.dim <= 64) hipLaunchKernelGGL(knn_rescore_kernel<16>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(knn_rescore_kernel<32>, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_finalize(const KnnParams& p, hipStream_t s) {
+    if (p.nq == 0) return hipSuccess;
+    hipLaunchKernelGGL(knn_finalize_kernel, dim3((p.nq + 127u) / 128u), dim3(128), 0, s, p);
+    return hipGetLastError();
 }
 
 }  // namespace gbnns

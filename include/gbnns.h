@@ -256,7 +256,10 @@ int gbnns_profile_enable(gbnns_index* index, int on);
 /* Diagnostic knobs of the process (tests, A/B runs); results never depend on them.  "quotient": 0 keeps the walk_hot*
  * kernels' visited set in its packed form (default 1: the denser quotient form where it fits; initial value from the
  * environment variable GBNNS_QUOTIENT).  "vs_disp": probe number at which a probe sequence of the quotient form gives
- * up and the id goes to the stash / the query is handed over, 1 .. 15 (default 15; <= 0 restores it; GBNNS_DEBUG_VS_DISP). */
+ * up and the id goes to the stash / the query is handed over, 1 .. 15 (default 15; <= 0 restores it; GBNNS_DEBUG_VS_DISP).
+ * "max_waves": most first-pass wavefronts per CU the LDS shares are cut for (0 = default; GBNNS_MAX_WAVES).
+ * "knn_filter": gbnns_exact_knn's matrix-core filter -- 0 never, 1 by size (default), 2 whenever the shape allows
+ * (GBNNS_KNN_FILTER). */
 int gbnns_debug_knob(const char* name, int value);
 int gbnns_profile_read(gbnns_index* index, gbnns_profile* out, int reset);
 
@@ -287,6 +290,9 @@ int gbnns_build_graph_gd_device(int device, const uint64_t* knn_offsets, const u
  * pair order, ties towards the lower id; 0xFFFFFFFF / +inf where fewer than k rows qualify.
  * self_offset >= 0 says query i IS base row i + self_offset and must not be reported as its own neighbour
  * (kNN graph of a set over itself, possibly computed in slices of queries); -1 turns that off.
+ * Large L2 problems (d % 4 == 0, d <= 128, n >= 2^17, n_q >= 2048, k <= 512) go through a matrix-core filter first
+ * (v_mfma_f32_32x32x16_bf16 on hi / lo bf16 halves, error-bounded) and only the rows it cannot rule out get their exact
+ * distance: same output, byte for byte, several times faster.
  * d <= 8192 (d > 128 runs a kernel that streams the query through in chunks); GBNNS_METRIC_NEG_DOT needs
  * d % 8 == 0 (else GBNNS_ERR_UNSUPPORTED).  Buffers are all host or all
  * device (mem_kind); the work runs on `stream` and the call returns when it has finished (a k x n_q x 8-byte

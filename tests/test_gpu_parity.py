@@ -886,6 +886,65 @@ def test_auxiliary_graph_vs_oracle_all_kernels(g, orc):
         ix.close()
 
 
+def test_exact_knn_matrix_core_filter_is_byte_identical(g, orc):
+    """gbnns_exact_knn's matrix-core filter (knn.hip: v_mfma_f32_32x32x16_bf16 on bf16 hi / lo halves with a proven error
+    bound, then the reference-order distance for the rows it keeps): ids AND distance bit patterns equal the plain exact
+    scan's -- on golden-style clustered data of every K-step width (d = 16 .. 128, d % 16 != 0 too), a lattice where
+    every distance ties thousands of times (ties at the k-th distance must all survive the filter), data far from the
+    origin (|x|^2 >> distances: the bound grows with the norms), a set over itself in slices with self exclusion, rows
+    sorted so that every chunk beats the thresholds (candidate lists overflow: the exact fallback), k = 1 .. 200, and
+    3 * 10^5 x 32 random rows (the size the filter is on for by default).  Small cases force it (knob "knn_filter" = 2)."""
+    lib = g.load_library()
+
+    def both(base, q, k, **kw):
+        assert lib.gbnns_debug_knob(b"knn_filter", 0) == 0
+        i0, d0 = g.exact_knn(base, q, k, want_dist=True, **kw)
+        assert lib.gbnns_debug_knob(b"knn_filter", 2) == 0
+        i1, d1 = g.exact_knn(base, q, k, want_dist=True, **kw)
+        assert lib.gbnns_debug_knob(b"knn_filter", 1) == 0
+        assert np.array_equal(i0, i1)
+        assert np.array_equal(gu.bits(d0), gu.bits(d1))
+        return i0, d0
+
+    try:
+        rng = np.random.Generator(np.random.PCG64(20261006))
+        for d, n, nq, k in ((16, 5000, 700, 10), (32, 9000, 1500, 48), (40, 4000, 300, 7), (64, 6000, 500, 33), (96, 5000, 400, 20),
+                            (100, 3000, 260, 5), (128, 4000, 300, 64), (32, 20000, 300, 200), (32, 3000, 100, 1)):
+            c = datagen.Case("kf", 5000 + d + k, n, nq, d, 4, 8)
+            ids, dist = both(c.base, c.queries, k)
+            oi, od = orc.exact_knn(c.base, c.queries[:64], k, 0, threads=8)
+            assert np.array_equal(ids[:64], oi) and np.array_equal(gu.bits(dist[:64]), gu.bits(od)), (d, k)
+        # lattice: coordinates in {0, 1, 2}, every vector three times -> masses of equal distances at every rank
+        lat = rng.integers(0, 3, size=(4000, 32)).astype(np.float32)
+        lat = np.concatenate([lat, lat, lat])
+        both(lat, lat[:500].copy(), 40)
+        both(lat, lat[:600].copy(), 40, self_offset=0)
+        # far from the origin: the bound is relative to the norms, the distances are not
+        far = (rng.standard_normal((8000, 32)) * 0.01 + 100.0).astype(np.float32)
+        both(far, far[:400].copy(), 25, self_offset=0)
+        # rows sorted by distance to the (clustered) queries, farthest first: every chunk is full of candidates
+        q = (rng.standard_normal((256, 32)) * 0.05).astype(np.float32)
+        rows = rng.standard_normal((12000, 32)).astype(np.float32)
+        rows = rows[np.argsort(-(rows ** 2).sum(1))]
+        both(rows, q, 30)
+        # a set over itself in two slices of queries
+        c = datagen.Case("kf", 5999, 7000, 8, 32, 4, 8)
+        a, _ = both(c.base, c.base[:3000].copy(), 24, self_offset=0)
+        b, _ = both(c.base, c.base[3000:].copy(), 24, self_offset=3000)
+        want, _ = orc.exact_knn(c.base, c.base, 24, 0, self_offset=0, threads=8)
+        assert np.array_equal(np.concatenate([a, b]), want)
+        # the default path at a size where it is on by itself
+        big = rng.standard_normal((300_000, 32)).astype(np.float32)
+        big /= np.linalg.norm(big, axis=1, keepdims=True)
+        assert lib.gbnns_debug_knob(b"knn_filter", 0) == 0
+        i0, d0 = g.exact_knn(big, big[:4096].copy(), 48, want_dist=True, self_offset=0)
+        assert lib.gbnns_debug_knob(b"knn_filter", 1) == 0
+        i1, d1 = g.exact_knn(big, big[:4096].copy(), 48, want_dist=True, self_offset=0)
+        assert np.array_equal(i0, i1) and np.array_equal(gu.bits(d0), gu.bits(d1))
+    finally:
+        lib.gbnns_debug_knob(b"knn_filter", 1)
+
+
 def test_exact_knn_vs_get_truth_and_oracle(g, orc):
     """gbnns_exact_knn: k = 1 equals the compiled reference's getTruth (tests/golden/knn_toy.npz), k > 1 equals the
     brute-force restatement -- ids and distance bit patterns; d % 4 != 0, tie-heavy data, both metrics, a set

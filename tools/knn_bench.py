@@ -15,17 +15,25 @@ ds = synth.make_dataset(device="cuda:0", cache_dir=os.environ.get("GBNNS_CACHE",
 x = ds.db_low.contiguous()
 torch.cuda.synchronize()
 slice_q = int(sys.argv[3]) if len(sys.argv) > 3 else n
-t0 = time.perf_counter()
-out = []
-for s0 in range(0, n, slice_q):
-    out.append(g.exact_knn(x, x[s0:s0 + slice_q], k, self_offset=s0))
-    print("  slice", s0, "done at %.2fs" % (time.perf_counter() - t0), flush=True)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-ids = torch.cat(out)
+lib = g.load_library()
 pairs = n * (n - 1)
-print("gbnns_exact_knn: n=%d d=32 k=%d  %.2f s  = %.2f T distance evaluations/s (%.1f TFLOP/s of ordered f32 sub/mul/add)"
-      % (n, k, dt, pairs / dt / 1e12, pairs * 32 * 3 / dt / 1e12))
+results = {}
+for knob, what in ((1, "matrix-core filter + exact distances of the kept rows"), (0, "exact scan of every row (rounds 1-3)")):
+    lib.gbnns_debug_knob(b"knn_filter", knob)
+    g.exact_knn(x[:200000].contiguous(), x[:4096].contiguous(), k, self_offset=0)  # (code objects loaded, allocator warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = []
+    for s0 in range(0, n, slice_q):
+        out.append(g.exact_knn(x, x[s0:s0 + slice_q], k, self_offset=s0))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    results[knob] = torch.cat(out)
+    print("gbnns_exact_knn, %s: n=%d d=32 k=%d  %.3f s  = %.2f T pairs/s (%.1f TFLOP/s-equivalent of ordered f32 sub/mul/add; the filter's "
+          "matrix-core work: %.1f TFLOP/s bf16)" % (what, n, k, dt, pairs / dt / 1e12, pairs * 32 * 3 / dt / 1e12, pairs * 32 * 2 * 3 / dt / 1e12), flush=True)
+lib.gbnns_debug_knob(b"knn_filter", 1)
+print("filter path byte-identical to the exact scan:", bool((results[0] == results[1]).all().item()))
+ids = results[1]
 t0 = time.perf_counter()
 ref = synth.knn_exact(x, k)
 torch.cuda.synchronize()
