@@ -417,22 +417,26 @@ int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* quer
     if (filter) {
         const uint32_t dp = (d + 15u) & ~15u;
         const uint32_t cap = (uint32_t)std::max(256, 4 * k + 64);
-        // rows per filtered chunk: 4 MB of packed rows at d = 32 (small sets, tests: a sixteenth of the set)
-        const uint32_t chunk = (uint32_t)std::min<uint64_t>(1u << 15, std::max<uint64_t>(64, (n / 16 + 63) & ~(uint64_t)63));
-        const uint64_t first = std::min<uint64_t>(n, std::max<uint64_t>(chunk, 4ull * (uint64_t)k));  // scanned exactly: fills the heaps
+        // The first rows are scanned exactly (they fill the heaps: thresholds exist afterwards); then filtered chunks, each
+        // at most as long as everything before it -- a query is then expected to keep about k rows of a chunk, whatever
+        // the chunk -- and at most 32 K rows (4 MB of packed rows at d = 32: L2 / Infinity-Cache resident while swept).
+        // Chunks start on multiples of 64 rows (the filter reads the norms in aligned groups of four).
+        const uint64_t max_chunk = std::min<uint64_t>(1u << 15, std::max<uint64_t>(64, (n / 16 + 63) & ~(uint64_t)63));  // (small sets, tests: a sixteenth)
+        const uint64_t first = std::min<uint64_t>(n, (std::max<uint64_t>(std::min<uint64_t>(max_chunk, 8192), 4ull * (uint64_t)k) + 63) & ~(uint64_t)63);
         DevBuf bpack, bnorm, qpack, qnorm, rhs, cand, count, flag;
         struct Release2 {
             DevBuf* b[8];
             ~Release2() { for (DevBuf* x : b) x->release(); }
         } release2{{&bpack, &bnorm, &qpack, &qnorm, &rhs, &cand, &count, &flag}};
         if ((rc = bpack.ensure((size_t)n * dp * 4))) return rc;       // 2 dp bf16 per row
-        if ((rc = bnorm.ensure((size_t)n * 4))) return rc;
+        if ((rc = bnorm.ensure(((size_t)n + 64) * 4))) return rc;  // (+inf behind the last row: the filter reads whole blocks of 32)
         if ((rc = qpack.ensure((size_t)nq * dp * 4))) return rc;
         if ((rc = qnorm.ensure((size_t)nq * 4))) return rc;
         if ((rc = rhs.ensure((size_t)nq * 4))) return rc;
         if ((rc = cand.ensure((size_t)nq * cap * 4))) return rc;
         if ((rc = count.ensure((size_t)nq * 4))) return rc;
         if ((rc = flag.ensure(4))) return rc;
+        HIP_TRY(launch_fill_u32(bnorm.as<uint32_t>() + n, 0x7F800000u, 64, s));
         HIP_TRY(launch_knn_pack(p.base, d, d, n, bpack.as<uint16_t>(), bnorm.as<float>(), s));
         HIP_TRY(launch_knn_pack(p.q, d, d, nq, qpack.as<uint16_t>(), qnorm.as<float>(), s));
         KnnParams ps = p;          // the first rows: the exact scan, heaps kept
@@ -440,7 +444,8 @@ int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* quer
         HIP_TRY(launch_knn_scan(ps, metric, s));
         HIP_TRY(launch_knn_thresholds(p.heap, p.heap_stride, k, qnorm.as<float>(), nq, rhs.as<float>(), s));
         uint32_t h_flag = 0;
-        for (uint64_t r0 = first; r0 < n; r0 += chunk) {
+        for (uint64_t r0 = first, chunk = 0; r0 < n; r0 += chunk) {
+            chunk = std::min<uint64_t>(max_chunk, r0);
             const uint32_t rows = (uint32_t)std::min<uint64_t>(chunk, n - r0);
             HIP_TRY(hipMemsetAsync(count.p, 0, (size_t)nq * 4, s));
             HIP_TRY(hipMemsetAsync(flag.p, 0, 4, s));

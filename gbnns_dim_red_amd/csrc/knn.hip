@@ -409,11 +409,13 @@ __global__ __launch_bounds__(256) void knn_pack_kernel(const float* x, uint32_t 
     }
 }
 
-// A workgroup = 4 wavefronts x QB blocks of 32 queries (operand A, in registers for the whole launch); blockIdx.y picks
-// a slab of the chunk's rows, walked in blocks of 32 (operand B straight from global memory: a 32 K-row chunk of packed
-// rows is 4 MB at d = 32, L2 / Infinity-Cache resident while every workgroup sweeps it).  Accumulators start at
-// -0.5 (1 - c) |x|^2 of the lane's row (the lane's column of the 32 x 32 tile), so a kept pair is one compare:
-// acc >= rhs[query].
+// A workgroup = 4 wavefronts x QB blocks of 32 queries (operand B of the product, in registers for the whole launch: the
+// lane's column of every 32 x 32 tile is ITS query, so one threshold per lane and block); blockIdx.y picks a slab of the
+// chunk's rows, walked in blocks of 32 (operand A straight from global memory, the next block's fragments requested
+// before the current block's products: a 32 K-row chunk of packed rows is 4 MB at d = 32, L2 / Infinity-Cache resident
+// while every workgroup sweeps it).  The accumulators start at -0.5 (1 - c) |x|^2 of their rows (16 rows of the block
+// per lane: four float4 loads of the norms), so a kept pair is  max over the lane's 16 rows >= rhs[query]  -- eight
+// v_max3 and one compare per tile beside its six matrix instructions.
 template <int KSTEPS, int QB>
 __global__ __launch_bounds__(256) void knn_filter_kernel(KnnFilterParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -421,9 +423,9 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(KnnFilterParams p) {
     const uint32_t q0 = (blockIdx.x * 4u + wave) * (QB * 32u);
     if (q0 >= p.nq) return;
     const uint32_t groups = p.dp >> 3;  // 8-dim groups per row = 2 KSTEPS
-    // A fragments: query q0 + 32 b + r, k = 16 s + 8 h .. + 7 -> group 2 s + h: hi at halfword 16 (2 s + h), lo 8 further
+    // B fragments: query q0 + 32 b + r, k = 16 s + 8 h .. + 7 -> group 2 s + h: hi at halfword 16 (2 s + h), lo 8 further
     bf16x8 qh[QB][KSTEPS], ql[QB][KSTEPS];
-    float rhs[QB][16];
+    float rhs[QB];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         const uint32_t qi = q0 + 32u * b + r;
@@ -432,52 +434,83 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(KnnFilterParams p) {
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             const uint4* src = reinterpret_cast<const uint4*>(qp + (size_t)(2 * s + h) * 16);
-            uint4 a = src[0], c = src[1];
-            if (!ok) { a = make_uint4(0, 0, 0, 0); c = a; }
-            qh[b][s] = __builtin_bit_cast(bf16x8, a);
-            ql[b][s] = __builtin_bit_cast(bf16x8, c);
+            qh[b][s] = __builtin_bit_cast(bf16x8, src[0]);
+            ql[b][s] = __builtin_bit_cast(bf16x8, src[1]);
         }
+        rhs[b] = ok ? p.rhs[qi] : __builtin_inff();  // (a query beyond the batch keeps nothing)
+    }
+    // (every compiler-issued load is used here, once: its waits then sit in this prologue and not inside the sweep)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {  // this lane's 16 rows of the tile: queries (v & 3) + 8 (v >> 2) + 4 h
-            const uint32_t qv = q0 + 32u * b + (uint32_t)((v & 3) + 8 * (v >> 2)) + 4u * h;
-            rhs[b][v] = qv < p.nq ? p.rhs[qv] : __builtin_inff();
-        }
+    for (int b = 0; b < QB; ++b) {
+        asm volatile("" ::"v"(rhs[b]));
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(qh[b][s]), "v"(ql[b][s]));
     }
     const uint32_t blocks = (p.rows + 31u) >> 5;
     const uint32_t per = (blocks + gridDim.y - 1) / gridDim.y;
     const uint32_t b_lo = blockIdx.y * per, b_hi = min(blocks, b_lo + per);
+    if (b_lo >= b_hi) return;
     const float scale = -0.5f * (1.0f - kKnnFilterSlack);
-    for (uint32_t rb = b_lo; rb < b_hi; ++rb) {
-        const uint32_t j = rb * 32u + r;  // this lane's row of the chunk (column of the tile)
-        const bool jok = j < p.rows;
-        const uint16_t* bp = p.bpack + (size_t)(jok ? j : 0u) * groups * 16;
+    // Fragments and norms of one block of 32 rows (rows beyond the chunk read row 0), requested by hand-written loads: the
+    // compiler's own bookkeeping put a full wait (vmcnt(0)) BEHIND the next block's requests -- no overlap at all --
+    // whatever the order in the source; these requests are invisible to it, and `landed` below is the one wait, placed in
+    // front of the next requests.  (No branch here: the norms' array is readable 64 entries beyond the set and +inf
+    // there, and the chunk starts on a multiple of 64 rows; a row of the NEXT chunk that slips through the test is
+    // refused where the hits are stored.)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    auto request_block = [&](uint32_t rb, u32x4 (&xh)[KSTEPS], u32x4 (&xl)[KSTEPS], f32x4v (&nx)[4]) {
+        const uint32_t j = rb * 32u + r;
+        const uint16_t* bp = p.bpack + ((size_t)(j < p.rows ? j : 0u) * groups + h) * 16;
+        const float* np = p.bnorm + rb * 32u + 4u * h;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {  // group 2 s + h: 64 bytes per K step further on
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xh[s]) : "v"(bp + 32 * s));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(xl[s]) : "v"(bp + 32 * s));
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)  // accumulator registers 4 g .. 4 g + 3 = rows 8 g + 4 h + 0 .. 3 of the block
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nx[g]) : "v"(np + 8 * g));
+    };
+    auto landed = [&](u32x4 (&xh)[KSTEPS], u32x4 (&xl)[KSTEPS], f32x4v (&nx)[4]) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx[0]));
+#pragma unroll
+        for (int g = 1; g < 4; ++g) asm volatile("" : "+v"(nx[g]));
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(xh[s]), "+v"(xl[s]));
+    };
+    // the products and the test of one block of rows against the QB query blocks
+    auto sweep_block = [&](uint32_t rb, const u32x4 (&xhr)[KSTEPS], const u32x4 (&xlr)[KSTEPS], const f32x4v (&nx)[4]) {
         bf16x8 xh[KSTEPS], xl[KSTEPS];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            const uint4* src = reinterpret_cast<const uint4*>(bp + (size_t)(2 * s + h) * 16);
-            xh[s] = __builtin_bit_cast(bf16x8, src[0]);
-            xl[s] = __builtin_bit_cast(bf16x8, src[1]);
+        for (int s = 0; s < KSTEPS; ++s) { xh[s] = __builtin_bit_cast(bf16x8, xhr[s]); xl[s] = __builtin_bit_cast(bf16x8, xlr[s]); }
+        f32x16 cinit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            cinit[4 * g + 0] = scale * nx[g].x; cinit[4 * g + 1] = scale * nx[g].y;
+            cinit[4 * g + 2] = scale * nx[g].z; cinit[4 * g + 3] = scale * nx[g].w;
         }
-        const float init = jok ? scale * p.bnorm[j] : -__builtin_inff();  // (a row beyond the chunk never passes)
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
-            f32x16 acc;
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[0], qh[b][0], cinit, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[0], qh[b][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[0], ql[b][0], acc, 0, 0, 0);
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[v] = init;
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[b][s], xh[s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qh[b][s], xl[s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ql[b][s], xh[s], acc, 0, 0, 0);
+            for (int s = 1; s < KSTEPS; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[s], qh[b][s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[s], qh[b][s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[s], ql[b][s], acc, 0, 0, 0);
             }
-            bool any = false;
+            float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
-            for (int v = 0; v < 16; ++v) any |= acc[v] >= rhs[b][v];
-            if (__builtin_expect(__ballot(any) != 0ull, 0)) {
+            for (int v = 3; v < 15; v += 2) m = fmaxf(fmaxf(m, acc[v]), acc[v + 1]);
+            m = fmaxf(m, acc[15]);
+            if (__builtin_expect(__ballot(m >= rhs[b]) != 0ull, 0)) {
+                const uint32_t qv = q0 + 32u * b + r;   // (rhs = +inf beyond the batch: never here with qv >= nq)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    if (acc[v] >= rhs[b][v]) {
-                        const uint32_t qv = q0 + 32u * b + (uint32_t)((v & 3) + 8 * (v >> 2)) + 4u * h;
+                    const uint32_t j = rb * 32u + (uint32_t)((v & 3) + 8 * (v >> 2)) + 4u * h;
+                    if (acc[v] >= rhs[b] && j < p.rows) {  // (a threshold of -inf -- heap not full yet -- lets -inf through too)
                         const uint32_t pos = atomicAdd(&p.count[qv], 1u);
                         if (pos < p.cap) p.cand[(size_t)qv * p.cap + pos] = p.row0 + j;
                         else *p.overflow = 1u;
@@ -485,6 +518,20 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(KnnFilterParams p) {
                 }
             }
         }
+    };
+    // two register sets in turn: wait for the set at hand, request the next block into the other one, sweep
+    u32x4 xh0[KSTEPS], xl0[KSTEPS], xh1[KSTEPS], xl1[KSTEPS];
+    f32x4v nx0[4], nx1[4];
+    request_block(b_lo, xh0, xl0, nx0);
+    for (uint32_t rb = b_lo;;) {
+        landed(xh0, xl0, nx0);
+        if (rb + 1u < b_hi) request_block(rb + 1u, xh1, xl1, nx1);
+        sweep_block(rb, xh0, xl0, nx0);
+        if (++rb >= b_hi) break;
+        landed(xh1, xl1, nx1);
+        if (rb + 1u < b_hi) request_block(rb + 1u, xh0, xl0, nx0);
+        sweep_block(rb, xh1, xl1, nx1);
+        if (++rb >= b_hi) break;
     }
 }
 
