@@ -730,7 +730,7 @@ def other_configs(args, t_start):
     while the wall-clock budget lasts, DEEP10M-shaped at full size (n = 10^7, ONE 1 M-query batch).  Per configuration:
     the same figures as the headline line's (in-flight value, serial rate, first-pass kernel, its time, algorithmic
     bytes, roofline fraction, recall) and the answers of a 1 000-query sample compared with the compiled reference."""
-    plan = [("gist", 20, 150), ("glove", 20, 120), ("glove-dot", 20, 90), ("deep", 3, 330)]
+    plan = [("gist", 20, 150), ("glove", 20, 120), ("glove-dot", 20, 90), ("deep", 3, 300)]
     out = {}
     for name, steps, need_s in plan:
         left = args.budget_s - (time.time() - t_start)
