@@ -1091,7 +1091,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
                                      (size_t)ix->d_low * 4, nq, kind, s));
         }
     }
-    // Deep batches are walked in locality order (kernels.hip, walk_query_of): a counting sort on the sign bits of the
+    // Deep batches are walked in locality order (walk_common.h, walk_query_of): a counting sort on the sign bits of the
     // first 12 walked-space coordinates, three small launches.  Wavefronts resident together then walk neighbouring
     // regions and find each other's rows in the caches: -8 % kernel time on a 4 M-node index, -3 % on 1 M -- which the
     // sort's launches would eat on a 10 000-query batch, so only from GBNNS_ORDER_MIN queries on (default 32 768).
@@ -1182,14 +1182,14 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     const bool hot = walk_uses_hot(w, ix->metric);
     const bool packed = walk_uses_packed(w);
     const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride, hot, walk_uses_lds_list(w));
-    // The hot first pass may keep its visited set in the quotient form (kernels.hip, GBNNS_VS_ASM: seven 16-bit entries
+    // The hot first pass may keep its visited set in the quotient form (walk_hot.hip, GBNNS_VS_ASM: seven 16-bit entries
     // per bucket instead of five 24-bit ids): ids are told apart inside a home bucket by W - floor(log2 buckets) <= 13
     // bits (n <= 2^W), so the table needs at least 2^(W-13) buckets.
     uint32_t idbits = 1;
     while (idbits < 32 && (1ull << idbits) < ix->n) ++idbits;
     const bool quotient_on = g_knob_quotient.load(std::memory_order_relaxed) != 0;  // tuning / A-B runs, tests: gbnns_debug_knob
     const bool vs_ok = walk_knows_quotient(w, ix->metric);
-    constexpr uint32_t kStashBuckets = 4;  // (kernels.hip: the table's last four "buckets" are the stash)
+    constexpr uint32_t kStashBuckets = 4;  // (walk_common.h: the table's last four "buckets" are the stash)
     const uint32_t quotient_min = 7u * ((idbits > 13 ? 1u << (idbits - 13) : 1u) + kStashBuckets + 8u);  // entries (>= 8 real buckets: probe steps of up to 8)
     uint32_t cap;
     int form = packed ? 1 : 0;

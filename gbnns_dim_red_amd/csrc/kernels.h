@@ -1,5 +1,5 @@
 // kernels.h -- launch interface between the C-ABI host layer (api.cpp) and the gfx950 kernels
-// (kernels.hip).  Plain structs of device pointers and sizes; no HIP types besides hipStream_t.
+// (the .hip units beside it: walk_hot, walk_l2 / walk_dot / walk_wide, walk_bitmap, walk_general, rerank, mlp, gd_order, knn).  Plain structs of device pointers and sizes; no HIP types besides hipStream_t.
 #pragma once
 
 #include <hip/hip_runtime.h>

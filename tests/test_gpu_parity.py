@@ -1430,6 +1430,25 @@ def test_serving_loop_cpp(tmp_path):
         assert "mismatches 0 host_mismatches 0 pageable_mismatches 0" in p.stdout
 
 
+def test_serving_loop_multi_cpp(tmp_path):
+    """tests/cpp/serving_loop_multi.cpp: gbnns_multi_* from the host language itself -- two and three replicas on the one
+    GPU of the test box (`devices = 0,0` / `0,0,0`: own handle, host thread and stream each), host batches through
+    gbnns_multi_search_ex with every replica writing its block straight into the caller's arrays: ids, hops and
+    dist_calc equal ONE gbnns_search_ex call over the whole batch; uneven blocks included.  (On a box with several
+    GPUs the same program also runs the device-block form with its RCCL all-gather: `serving_loop_multi 0,1 ...`.)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "gbnns_dim_red_amd", "lib")
+    exe = str(tmp_path / "serving_loop_multi")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-o", exe,
+                           os.path.join(root, "tests", "cpp", "serving_loop_multi.cpp"), "-L" + libdir, "-lgbnns_hip", "-Wl,-rpath," + libdir])
+    for args in (("0,0", "20000", "64", "32", "64", "3001", "4", "32"), ("0,0,0", "5000", "40", "32", "64", "700", "2", "100")):
+        p = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "mismatches 0 count_mismatches 0 device_form_mismatches -1" in p.stdout, p.stdout
+
+
 def test_host_batches_in_flight(g, orc):
     """GBNNS_MEM_HOST + GBNNS_FLAG_DEFER_JOIN with page-locked buffers (pinned torch CPU tensors through the binding):
     five distinct batches rotating over three buffer sets, gbnns_index_wait(depth - 1) after every call; ids, hops and

@@ -117,7 +117,7 @@ READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
 def test_hot_kernel_register_budgets(tmp_path):
-    """The hand-laid-out walk kernels claim fixed VGPRs (v36 .. v63; kernels.hip, hot_expand) beside the compiler's own.
+    """The hand-laid-out walk kernels claim fixed VGPRs (v36 .. v63; csrc/walk_hot.hip, hot_expand) beside the compiler's own.
     Their occupancy rests on BOTH register files (measured on the hardware, tools/ubench/occupancy_census.hip: a
     wavefront's scalar registers are handed out as ceil16(sgpr_count) + 16 of 800 per SIMD, so <= 80 -> 8 wavefronts per
     SIMD, <= 96 -> 7, above -> 6; vector registers: <= 64 -> 8, <= 72 -> 7, <= 80 -> 6, <= 96 -> 5) and on nothing
