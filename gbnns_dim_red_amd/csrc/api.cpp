@@ -328,6 +328,9 @@ std::atomic<int> g_knob_quotient{knob_env("GBNNS_QUOTIENT", 1)};
 std::atomic<int> g_knob_vs_disp{knob_env("GBNNS_DEBUG_VS_DISP", 15)};
 // "max_waves" = most first-pass wavefronts per CU the LDS shares are cut for (GBNNS_MAX_WAVES; 0 = the per-kernel defaults)
 std::atomic<int> g_knob_max_waves{knob_env("GBNNS_MAX_WAVES", 0)};
+// "spec_min_nq" = smallest batch whose ef <= 64 first pass requests the rows before the visited test (walk_hot_spec_kernel;
+// GBNNS_SPEC_MIN_NQ; 0 = never)
+std::atomic<int> g_knob_spec_min_nq{knob_env("GBNNS_SPEC_MIN_NQ", 32768)};
 // "knn_filter" 0 = gbnns_exact_knn without the matrix-core filter (GBNNS_KNN_FILTER; tests compare the two paths)
 std::atomic<int> g_knob_knn_filter{knob_env("GBNNS_KNN_FILTER", 1)};
 
@@ -805,6 +808,7 @@ int gbnns_debug_knob(const char* name, int value) {
     if (!std::strcmp(name, "quotient")) g_knob_quotient.store(value, std::memory_order_relaxed);
     else if (!std::strcmp(name, "vs_disp")) g_knob_vs_disp.store(value <= 0 ? 15 : value, std::memory_order_relaxed);
     else if (!std::strcmp(name, "max_waves")) g_knob_max_waves.store(std::max(0, std::min(32, value)), std::memory_order_relaxed);
+    else if (!std::strcmp(name, "spec_min_nq")) g_knob_spec_min_nq.store(std::max(0, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_filter")) g_knob_knn_filter.store(value, std::memory_order_relaxed);
     else return fail(GBNNS_ERR_INVALID, "gbnns_debug_knob: unknown knob '%s'", name);
     return GBNNS_OK;
@@ -1248,6 +1252,10 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     }
     cap = walk_hash_entries(walk_hash_bytes(cap, form), form);  // whole buckets
     w.vs_shr = 0;
+    {
+        const int spec_min = g_knob_spec_min_nq.load(std::memory_order_relaxed);
+        w.spec_rows = (spec_min > 0 && nq >= (uint32_t)spec_min) ? 1 : 0;
+    }
     if (form == 2) {
         const uint32_t buckets = cap / 7u > kStashBuckets ? cap / 7u - kStashBuckets : 0u;
         uint32_t lg = 0;

@@ -459,14 +459,14 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
 // multi-register lists.
 // WIDE: adjacency rows of 33 .. 64 slots (the level-0 lists of hnswlib M = 18 / 20 graphs, prepare_graph.cpp's M = 30):
 // the same hop with a second expansion pass over slots 32 .. 63 when the node has that many neighbours.
-template <int R, bool WIDE = false, int METRIC = 0>
+template <int R, bool WIDE = false, int METRIC = 0, bool SPEC1 = GBNNS_HOT1_SPEC != 0>
 __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, unsigned char* smem) {
     const int lane = lane_id();
     const uint32_t slot = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;  // lane = 2 * adjacency slot + row half
     const int ef = p.ef;
     // R = 1 (QLDS): the query stays in LDS and hot_expand re-reads a lane's four pieces every hop -- 64 registers, 8 wavefronts
     // per SIMD; rows requested after the visited test.  R = 2: the query in registers, speculative row loads (rounds 1-3 layout).
-    constexpr bool QLDS = R == 1 && GBNNS_HOT1_QLDS, SPEC = R == 1 ? GBNNS_HOT1_SPEC != 0 : true;
+    constexpr bool QLDS = R == 1 && GBNNS_HOT1_QLDS, SPEC = R == 1 ? SPEC1 : true;
     // LDS: [tie list 128 B][merge buffer 528 B (R = 2: 1 040 B; its head stages the query until it is in registers)]
     //      [QLDS: the query, 128 B][visited set]
     uint64_t* tie = reinterpret_cast<uint64_t*>(smem);
@@ -905,6 +905,14 @@ __global__ __launch_bounds__(64, GBNNS_HOT1_QLDS ? 8 : 7) void walk_hot_kernel(W
     walk_hot_one<1>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
+// ... with the rows requested BEFORE the visited test (the rounds 1-3 order): launches of many rounds of wavefronts -- the
+// DEEP10M-shaped 1 M-query batch in locality order -- are 6 % faster this way (21.7 against 23.1 ms: the hop is one LDS round
+// trip shorter and the extra rows mostly hit the L2), the 10 000-query launch 1 - 2 % slower (profiles/r04_ab.txt)
+__global__ __launch_bounds__(64, GBNNS_HOT1_QLDS ? 8 : 7) void walk_hot_spec_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_hot_one<1, false, 0, true>(p, walk_query_of(p, blockIdx.x), smem);
+}
+
 // the same three for adjacency rows of 33 .. 64 slots (two expansion passes per hop)
 __global__ __launch_bounds__(64, GBNNS_HOT1_QLDS ? 8 : 7) void walk_hotw_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -941,6 +949,7 @@ hipError_t launch_walk_hot(const WalkParams& p, int metric, hipStream_t s) {
     const bool wide = p.ell_stride > 32u;  // adjacency rows of 33 .. 64 slots: the two-pass instances
     if (p.ef <= 64) {
         if (metric == 1) return wide ? launch_walk_k(walk_hot_dot_kernel<1, true>, p, false, lds, s) : launch_walk_k(walk_hot_dot_kernel<1, false>, p, false, lds, s);
+        if (!wide && p.spec_rows && !GBNNS_HOT1_SPEC) return launch_walk_k(walk_hot_spec_kernel, p, false, lds, s);
         return wide ? launch_walk_k(walk_hotw_kernel, p, false, lds, s) : launch_walk_k(walk_hot_kernel, p, false, lds, s);
     }
     if (p.ef <= kHot2MaxEf) {

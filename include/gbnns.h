@@ -258,6 +258,8 @@ int gbnns_profile_enable(gbnns_index* index, int on);
  * environment variable GBNNS_QUOTIENT).  "vs_disp": probe number at which a probe sequence of the quotient form gives
  * up and the id goes to the stash / the query is handed over, 1 .. 15 (default 15; <= 0 restores it; GBNNS_DEBUG_VS_DISP).
  * "max_waves": most first-pass wavefronts per CU the LDS shares are cut for (0 = default; GBNNS_MAX_WAVES).
+ * "spec_min_nq": smallest batch whose ef <= 64 first pass requests a hop's rows before its visited test
+ * (walk_hot_spec_kernel; default 32 768, 0 = never; GBNNS_SPEC_MIN_NQ).
  * "knn_filter": gbnns_exact_knn's matrix-core filter -- 0 never, 1 by size (default), 2 whenever the shape allows
  * (GBNNS_KNN_FILTER). */
 int gbnns_debug_knob(const char* name, int value);

@@ -1237,7 +1237,10 @@ def test_two_list_kernels_by_name(g, orc):
     dot metric, pair form for 256-byte rows, one lane per row for 192-byte rows, the HBM-bitmap variants, and the
     two-register kernels below the crossover."""
     shapes = [  # d, d_low, d_hidden, metric, max degree, [(ef, flags, expected kernel-name prefix)]
-        (64, 32, 64, 0, 30, [(100, 0, "walk_hot2_kernel"), (200, 0, "walk_hot_big_kernel"), (1024, 0, "walk_hot_big_kernel"),
+        (64, 32, 64, 0, 30, [(8, 0, "walk_hot_kernel"), (64, 0, "walk_hot_kernel"),
+                             # (big batches request a hop's rows before its visited test: knob "spec_min_nq")
+                             (8, "spec", "walk_hot_spec_kernel"), (64, "spec", "walk_hot_spec_kernel"),
+                             (100, 0, "walk_hot2_kernel"), (200, 0, "walk_hot_big_kernel"), (1024, 0, "walk_hot_big_kernel"),
                              (300, "bitmap", "walk_bitmap_big_kernel<0, 8,")]),
         (64, 32, 64, 1, 30, [(8, 0, "walk_hot_dot_kernel<1, false>"), (64, 0, "walk_hot_dot_kernel<1, false>"),
                              (100, 0, "walk_hot_dot_kernel<2, false>"), (200, 0, "walk_hot_dot_big_kernel<false>"),
@@ -1262,6 +1265,7 @@ def test_two_list_kernels_by_name(g, orc):
         ix.profile_enable(True)
         for ef, fl, kname in cases:
             flags = g.FLAG_BITMAP_PASS if fl == "bitmap" else 0
+            _knobs(g, spec_min_nq=1 if fl == "spec" else 32768)
             w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, metric=metric, threads=8)
             s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net,
                                  entries=ent, metric=metric, threads=8)
@@ -1275,14 +1279,16 @@ def test_two_list_kernels_by_name(g, orc):
             assert np.array_equal(r["ids"], s["ids"]), key
             launched = ix.profile_read(reset=True)["walk_kernel"]
             assert launched.startswith(kname), (key, launched)
+        _knobs(g)
         ix.close()
 
 
-def _knobs(g, quotient=1, vs_disp=15):
+def _knobs(g, quotient=1, vs_disp=15, spec_min_nq=32768):
     """The process-wide diagnostic knobs of the library (include/gbnns.h, gbnns_debug_knob), back to their defaults unless named."""
     lib = g.load_library()
     assert lib.gbnns_debug_knob(b"quotient", quotient) == 0
     assert lib.gbnns_debug_knob(b"vs_disp", vs_disp) == 0
+    assert lib.gbnns_debug_knob(b"spec_min_nq", spec_min_nq) == 0
 
 
 def test_visited_set_forms_of_the_hot_kernels(g, orc):
@@ -1301,7 +1307,9 @@ def test_visited_set_forms_of_the_hot_kernels(g, orc):
                                  entries=ent, metric=metric, threads=8)
             maxdc = int(w["dist_calc"].max())
             for env, cap in (({}, 0), ({"quotient": 0}, 0), ({}, maxdc + maxdc // 8 + 64), ({}, max(128, maxdc // 2)),
-                             ({"vs_disp": 1}, 0), ({"vs_disp": 2}, maxdc + maxdc // 8 + 64)):
+                             ({"vs_disp": 1}, 0), ({"vs_disp": 2}, maxdc + maxdc // 8 + 64),
+                             # the big-batch instance of the ef <= 64 kernel (rows requested before the visited test)
+                             ({"spec_min_nq": 1}, 0), ({"spec_min_nq": 1, "quotient": 0}, 0), ({"spec_min_nq": 1, "vs_disp": 1}, 0)):
                 _knobs(g, **env)
                 for rep in range(2):  # (the second call runs with the capacity the first one's statistics ask for)
                     r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), hash_capacity=cap)

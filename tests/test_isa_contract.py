@@ -142,7 +142,7 @@ def test_hot_kernel_register_budgets(tmp_path):
                                    for k in ("vgpr_count", "sgpr_count", "private_segment_fixed_size", "vgpr_spill_count")
                                    if re.search(r"\.%s:\s+(\d+)" % k, block)}
     # (substring of the mangled name, VGPR ceiling, SGPR ceiling)
-    budgets = [("15walk_hot_kernelE", 64, 80), ("16walk_hot2_kernelE", 72, 112), ("19walk_hot_big_kernelE", 96, 112),
+    budgets = [("15walk_hot_kernelE", 64, 80), ("20walk_hot_spec_kernelE", 64, 80), ("16walk_hot2_kernelE", 72, 112), ("19walk_hot_big_kernelE", 96, 112),
                # the instances for adjacency rows of 33 .. 64 slots (second expansion pass)
                ("16walk_hotw_kernelE", 64, 80), ("17walk_hotw2_kernelE", 72, 112), ("20walk_hotw_big_kernelE", 96, 112),
                # the negative-dot metric on the same shapes
