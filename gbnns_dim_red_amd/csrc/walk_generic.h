@@ -540,62 +540,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
 // ef <= 64 whatever ef is (the R-register lists spent 28 % of a hop selecting and 30 % inserting at ef = 300).
 // LDS: [BigList: big_list_fixed_bytes(ef)][query: dstride floats][visited set | (BITMAP) re-rank scratch].
 // ONE_PASS: adjacency rows of one pass (the host checks ell_stride), no auxiliary graph -- the hop is straight-line code.
-// Rows one hop ahead (AHEAD instances): the register set the requests land in.  It is named in the asm text only -- never an
-// operand: the compiler would copy an operand's registers around while the loads are still in flight -- and lies above
-// the vector-register budget of the kernel (amdgpu_num_vgpr(128) on walk_reg_big_ahead_kernel: the compiler treats v128
-// and up as reserved, the kernel descriptor counts them through the clobber lists).
-#define GBNNS_AHEAD_CLOBBERS_6 "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", \
-    "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151"
-#define GBNNS_AHEAD_CLOBBERS_8 GBNNS_AHEAD_CLOBBERS_6, "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159"
-template <int H>
-__device__ __forceinline__ void ahead_issue(uint32_t off, const float* db) {  // H loads of 16 bytes per lane, in order
-    static_assert(H == 6 || H == 8, "192- or 256-byte rows in the pair form");
-    if constexpr (H == 8)
-        asm volatile("global_load_dwordx4 v[128:131], %0, %1\n\t"
-                     "global_load_dwordx4 v[132:135], %0, %1 offset:16\n\t"
-                     "global_load_dwordx4 v[136:139], %0, %1 offset:32\n\t"
-                     "global_load_dwordx4 v[140:143], %0, %1 offset:48\n\t"
-                     "global_load_dwordx4 v[144:147], %0, %1 offset:64\n\t"
-                     "global_load_dwordx4 v[148:151], %0, %1 offset:80\n\t"
-                     "global_load_dwordx4 v[152:155], %0, %1 offset:96\n\t"
-                     "global_load_dwordx4 v[156:159], %0, %1 offset:112"
-                     :: "v"(off), "s"(db) : "memory", GBNNS_AHEAD_CLOBBERS_8);
-    else
-        asm volatile("global_load_dwordx4 v[128:131], %0, %1\n\t"
-                     "global_load_dwordx4 v[132:135], %0, %1 offset:16\n\t"
-                     "global_load_dwordx4 v[136:139], %0, %1 offset:32\n\t"
-                     "global_load_dwordx4 v[140:143], %0, %1 offset:48\n\t"
-                     "global_load_dwordx4 v[144:147], %0, %1 offset:64\n\t"
-                     "global_load_dwordx4 v[148:151], %0, %1 offset:80"
-                     :: "v"(off), "s"(db) : "memory", GBNNS_AHEAD_CLOBBERS_6);
-}
-// waits until at most YOUNGER vector-memory operations issued after the requests are outstanding (loads return in order), then
-// copies the set into the compiler's row registers
-template <int H, int YOUNGER>
-__device__ __forceinline__ void ahead_take(RowRegs<H>& r) {
-    f32x2 a[2 * H];
-    if constexpr (H == 8)
-        asm volatile("s_waitcnt vmcnt(%16)\n\t"
-                     "v_mov_b64 %0, v[128:129]\n\tv_mov_b64 %1, v[130:131]\n\tv_mov_b64 %2, v[132:133]\n\tv_mov_b64 %3, v[134:135]\n\t"
-                     "v_mov_b64 %4, v[136:137]\n\tv_mov_b64 %5, v[138:139]\n\tv_mov_b64 %6, v[140:141]\n\tv_mov_b64 %7, v[142:143]\n\t"
-                     "v_mov_b64 %8, v[144:145]\n\tv_mov_b64 %9, v[146:147]\n\tv_mov_b64 %10, v[148:149]\n\tv_mov_b64 %11, v[150:151]\n\t"
-                     "v_mov_b64 %12, v[152:153]\n\tv_mov_b64 %13, v[154:155]\n\tv_mov_b64 %14, v[156:157]\n\tv_mov_b64 %15, v[158:159]"
-                     : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]), "=v"(a[4]), "=v"(a[5]), "=v"(a[6]), "=v"(a[7]), "=v"(a[8]),
-                       "=v"(a[9]), "=v"(a[10]), "=v"(a[11]), "=v"(a[12]), "=v"(a[13]), "=v"(a[14]), "=v"(a[15])
-                     : "n"(YOUNGER) : "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(%12)\n\t"
-                     "v_mov_b64 %0, v[128:129]\n\tv_mov_b64 %1, v[130:131]\n\tv_mov_b64 %2, v[132:133]\n\tv_mov_b64 %3, v[134:135]\n\t"
-                     "v_mov_b64 %4, v[136:137]\n\tv_mov_b64 %5, v[138:139]\n\tv_mov_b64 %6, v[140:141]\n\tv_mov_b64 %7, v[142:143]\n\t"
-                     "v_mov_b64 %8, v[144:145]\n\tv_mov_b64 %9, v[146:147]\n\tv_mov_b64 %10, v[148:149]\n\tv_mov_b64 %11, v[150:151]"
-                     : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]), "=v"(a[4]), "=v"(a[5]), "=v"(a[6]), "=v"(a[7]), "=v"(a[8]),
-                       "=v"(a[9]), "=v"(a[10]), "=v"(a[11])
-                     : "n"(YOUNGER) : "memory");
-#pragma unroll
-    for (int t = 0; t < H; ++t) r.v[t] = make_float4(a[2 * t].x, a[2 * t].y, a[2 * t + 1].x, a[2 * t + 1].y);
-}
-
-template <int METRIC, int STEPS, bool OFF32, bool AUX = false, bool BITMAP = false, bool ONE_PASS = false, bool AHEAD = false>
+template <int METRIC, int STEPS, bool OFF32, bool AUX = false, bool BITMAP = false, bool ONE_PASS = false>
 __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                                  uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
     constexpr bool kEarlyLoad = (STEPS > 0);
@@ -608,7 +553,6 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
     const int lane = lane_id();
 #ifdef GBNNS_STAMPS  // diagnostic build: cycles per segment of the hop (tools/stamps.py)
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned st_pf1 = 0;  // hops whose node was the runner-up prediction
     STAMP(t_begin)
     unsigned long long t_prev = t_begin;
 #endif
@@ -683,16 +627,6 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
 
     int status = 0;  // 0 = walking, 1 = finished, 2 = handed over
     uint32_t pf_node = kInvalidId, pf_val = kInvalidId;
-    // Rows one hop ahead (round 4; AHEAD = the one-pass pair-form instances over 192- / 256-byte rows, e.g. the GIST-shaped first pass): the runner-up of a hop's
-    // selection is the next hop's node three times in four (measured: 0.70 - 0.79 of the hops at ef 140 .. 300), and
-    // its adjacency row -- prefetched at the top of the hop -- has arrived by the time the hop's survivors are inserted.
-    // Its neighbours' rows are requested THERE, behind the inserts, into a second register set (ahead_issue / ahead_take); when the next selection
-    // does pick that node its hop starts with the rows (nearly) in registers instead of waiting a memory round trip
-    // behind latch + selection + adjacency.  A hop whose closest survivor beats the runner-up skips the request (that
-    // survivor is the next node).  Nothing but the moment of the loads changes: same rows, same arithmetic.
-    constexpr bool kSpecNext = AHEAD;
-    static_assert(!AHEAD || (kEarlyLoad && kPair && !kAlt && ONE_PASS && !AUX && !BITMAP && OFF32 && (kQSteps == 6 || kQSteps == 8)), "AHEAD: one-pass pair-form L2 instances");
-    uint32_t spec_node = kInvalidId;
     while (true) {
         uint32_t node, pred, h2;
         STAMP(t0)
@@ -704,30 +638,16 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
         const uint32_t* row = reinterpret_cast<const uint32_t*>(
             row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), node, p.ell_stride));
         uint32_t nb0;
-#ifdef GBNNS_STAMPS
-        if (node == pf_node) st_pf1 += 1;
-#endif
         if (node == pf_node) nb0 = pf_val;
-        else {
-            nb0 = (slot < p.ell_stride) ? row[slot] : kInvalidId;
-            // (AHEAD: the wait for this load must stay inside the branch -- a hop that found its row prefetched must not
-            // wait for the row requests in flight)
-            if constexpr (kSpecNext) asm volatile("" : "+v"(nb0));
-        }
+        else nb0 = (slot < p.ell_stride) ? row[slot] : kInvalidId;
         const uint64_t mv0 = __ballot(nb0 != kInvalidId);  // consumed BEFORE the prefetch is issued
         STAMP(t2)
         STAMP_ADD(1, t1, t2)
         pf_node = pred;
-        if constexpr (kSpecNext) {
-            // (AHEAD: the prefetch lands in v160 and is taken at the hop's end -- the compiler does not know of it and so never
-            // waits for it with the row requests in flight; every lane loads, lanes beyond the row read slot 0)
-            if (pred != kInvalidId)
-                asm volatile("global_load_dword v160, %0, %1" ::"v"((pred * p.ell_stride + (slot < p.ell_stride ? slot : 0u)) * 4u), "s"(p.ell) : "memory", "v160");
-        } else if (pred != kInvalidId)
+        if (pred != kInvalidId)
             pf_val = (slot < p.ell_stride) ? reinterpret_cast<const uint32_t*>(row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), pred, p.ell_stride))[slot] : kInvalidId;
 
         bool found = false;  // makeStep's flag (:34); only read when AUX
-        bool beaten = false;  // AHEAD: a survivor of this hop is closer than the runner-up
         for (int g = AUX ? ((uint32_t)hops < p.hops_bound ? 0 : 1) : 1; g < 2; ++g) {
         const bool is_aux = AUX && g == 0;
         if (AUX && g == 1 && found && p.llf) break;
@@ -761,11 +681,7 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                 constexpr bool kAllLanes = kPair || kQSteps >= 12;
                 const uint32_t nbl = kAllLanes ? (valid ? nb : 0u) : nb;
                 const bool ld = kAllLanes || valid;
-                if constexpr (kSpecNext) {
-                    // requested at the end of the previous hop (same ids: node == pf_node then), or now: every vector-memory
-                    // operation of these instances' hop is issued and awaited by hand (ahead_issue / ahead_take below)
-                    if (node != spec_node) ahead_issue<kQSteps>(nbl * kRowBytes + half * (kRowBytes / 2u), p.db);
-                } else if constexpr (OFF32) {
+                if constexpr (OFF32) {
                     roff = kPair ? nbl * kRowBytes + half * (kAlt ? 16u : kRowBytes / 2u) : nbl * (p.dstride * 4u);
                     const float* rp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff);
                     if constexpr (kAlt) { if (ld) load_row_alt(rr, rp); }
@@ -792,12 +708,6 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                 }
             } else if constexpr (packed) mclaimed = visited_claim_mask_packed(hash_lds, nbuckets, nb, mv & kSlotLanes);
             else mclaimed = visited_claim_mask(hash_lds, nbuckets, nb, mv & kSlotLanes);
-            if constexpr (kSpecNext) {
-                // rows requested a hop ago: the only younger vector-memory operation is this hop's adjacency prefetch, if there
-                // was one; rows requested above: they are the youngest
-                if (node == spec_node && pf_node != kInvalidId) ahead_take<kQSteps, 1>(rr);
-                else ahead_take<kQSteps, 0>(rr);
-            }
             const uint64_t mfresh = kPair ? (mclaimed << 1) : mclaimed;
             STAMP(t4)
             STAMP_ADD(3, t3, t4)
@@ -836,7 +746,6 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                     if (mb2 && !B.insert(mb2, dk, nb, lane)) { status = 2; break; }
                 }
             }
-            if constexpr (kSpecNext) beaten = m && __ballot(dk < h2);  // a survivor below the runner-up: the next node is not the predicted one
             STAMP(t6)
             STAMP_ADD(5, t5, t6)
 #ifdef GBNNS_STAMPS
@@ -846,21 +755,6 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
         if (status) break;
         }
         if (status) break;
-        if constexpr (kSpecNext) {
-            // the next hop's rows, if the runner-up is still the closest unexpanded entry; here, where every path of the hop
-            // passes, so that the adjacency prefetch is taken -- and awaited -- in front of the requests on all of them
-            spec_node = kInvalidId;
-            if (pf_node != kInvalidId) {
-                uint32_t pv;
-                asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v160" : "=v"(pv) :: "memory");
-                pf_val = slot < p.ell_stride ? pv : kInvalidId;
-                if (!beaten) {
-                    spec_node = pf_node;
-                    const uint32_t nbs = pf_val != kInvalidId ? pf_val : 0u;  // (empty slots read row 0, as in the pass)
-                    ahead_issue<kQSteps>(nbs * kRowBytes + half * (kRowBytes / 2u), p.db);
-                }
-            }
-        }
         hops += 1;
     }
 
@@ -875,7 +769,6 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
             atomicAdd(p.stamps + 24, (unsigned long long)B.st_nflush); atomicAdd(p.stamps + 25, (unsigned long long)B.st_nrefresh);
             atomicAdd(p.stamps + 26, (unsigned long long)B.st_nbase); atomicAdd(p.stamps + 27, (unsigned long long)B.st_nseq);
             atomicAdd(p.stamps + 28, (unsigned long long)B.st_ninsert); atomicAdd(p.stamps + 29, (unsigned long long)B.st_slow);
-            atomicAdd(p.stamps + 7, (unsigned long long)st_pf1);
         }
     }
 #endif
@@ -898,13 +791,6 @@ __global__ __launch_bounds__(64) void walk_reg_big_kernel(WalkParams p) {
     } else {
         walk_reg_big_one<METRIC, STEPS, OFF32, AUX, false, ONE_PASS>(p, walk_query_of(p, blockIdx.x), smem, p.ovf_count, p.ovf_list);
     }
-}
-
-// the first pass of a compact index over 192- / 256-byte rows with adjacency rows of one pass (the GIST shape): rows one hop ahead
-template <int STEPS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) void walk_reg_big_ahead_kernel(WalkParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    walk_reg_big_one<0, STEPS, true, false, false, true, true>(p, walk_query_of(p, blockIdx.x), smem, p.ovf_count, p.ovf_list);
 }
 
 template <int METRIC, int STEPS, bool OFF32, bool RETRY, int R, bool ONE_CHUNK = false, bool AUX = false>

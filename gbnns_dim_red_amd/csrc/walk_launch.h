@@ -22,12 +22,8 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, true>, p, false, lds, s);
         if (off32) {
             // the common shape (compact index, adjacency rows of one pass) gets the hop without the pass loop
-            if (!retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16) && METRIC == 0)) ? 32u : 64u)) {  // pair form: 32 slots per pass
-                if constexpr (GBNNS_SPEC_NEXT && METRIC == 0 && (STEPS == 12 || STEPS == 16)) {
-                    if (!p.stamps_on) return launch_walk_k(walk_reg_big_ahead_kernel<STEPS>, p, false, lds, s);
-                }
+            if (!retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16) && METRIC == 0)) ? 32u : 64u))  // pair form: 32 slots per pass
                 return launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, false, true>, p, false, lds, s);
-            }
             return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, true>, p, true, lds, s)
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false>, p, false, lds, s);
         }

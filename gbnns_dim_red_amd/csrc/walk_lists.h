@@ -43,9 +43,6 @@ __device__ __forceinline__ uint64_t clear_bit64(uint64_t m, int bit) {  // wave-
 // GBNNS_HOT1_PF2_IN_MERGE = 1: the second prefetch's closest survivor comes out of the merge's rank loop (one scalar minimum per
 // survivor) instead of a DPP butterfly in front of the merge -- 20 instructions per hop less, and the prefetch ~60
 // instructions later: measured 1 - 2 % SLOWER on the SIFT / GloVe shapes at ef = 36 / 64 (profiles/r04_ab.txt), so off.
-#ifndef GBNNS_SPEC_NEXT
-#define GBNNS_SPEC_NEXT 1  // generic one-pass two-list kernels: the predicted next node's rows are requested behind the inserts
-#endif
 #ifndef GBNNS_HOT1_PF2_IN_MERGE
 #define GBNNS_HOT1_PF2_IN_MERGE 0
 #endif
