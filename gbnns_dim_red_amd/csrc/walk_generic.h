@@ -553,6 +553,7 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
     const int lane = lane_id();
 #ifdef GBNNS_STAMPS  // diagnostic build: cycles per segment of the hop (tools/stamps.py)
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned st_pf1 = 0;  // hops whose node was the runner-up prediction
     STAMP(t_begin)
     unsigned long long t_prev = t_begin;
 #endif
@@ -638,6 +639,9 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
         const uint32_t* row = reinterpret_cast<const uint32_t*>(
             row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), node, p.ell_stride));
         uint32_t nb0;
+#ifdef GBNNS_STAMPS
+        if (node == pf_node) st_pf1 += 1;
+#endif
         if (node == pf_node) nb0 = pf_val;
         else nb0 = (slot < p.ell_stride) ? row[slot] : kInvalidId;
         const uint64_t mv0 = __ballot(nb0 != kInvalidId);  // consumed BEFORE the prefetch is issued
@@ -769,6 +773,7 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
             atomicAdd(p.stamps + 24, (unsigned long long)B.st_nflush); atomicAdd(p.stamps + 25, (unsigned long long)B.st_nrefresh);
             atomicAdd(p.stamps + 26, (unsigned long long)B.st_nbase); atomicAdd(p.stamps + 27, (unsigned long long)B.st_nseq);
             atomicAdd(p.stamps + 28, (unsigned long long)B.st_ninsert); atomicAdd(p.stamps + 29, (unsigned long long)B.st_slow);
+            atomicAdd(p.stamps + 7, (unsigned long long)st_pf1);
         }
     }
 #endif

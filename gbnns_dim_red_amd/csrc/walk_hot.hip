@@ -719,6 +719,7 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
     const int lane = lane_id();
 #ifdef GBNNS_STAMPS  // diagnostic build: cycles per segment of the hop (tools/stamps.py)
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned st_pf1 = 0, st_pf2 = 0;  // hops whose node was the runner-up prediction / the closest new survivor
     STAMP(t_begin)
     unsigned long long t_prev = t_begin;
 #endif
@@ -782,6 +783,10 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
 
         // ---- adjacency row of `node` (prefetched, or loaded now), then the prefetch for the next hop
         uint32_t nb, nbw = kInvalidId;
+#ifdef GBNNS_STAMPS
+        if (node == pf_node) st_pf1 += 1;
+        else if (node == pf2_node) st_pf2 += 1;
+#endif
         if (node == pf_node) {
             nb = pf_val;
             if constexpr (WIDE) nbw = pf_valw;
@@ -872,6 +877,7 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
             atomicAdd(p.stamps + 24, (unsigned long long)B.st_nflush); atomicAdd(p.stamps + 25, (unsigned long long)B.st_nrefresh);
             atomicAdd(p.stamps + 26, (unsigned long long)B.st_nbase); atomicAdd(p.stamps + 27, (unsigned long long)B.st_nseq);
             atomicAdd(p.stamps + 28, (unsigned long long)B.st_ninsert); atomicAdd(p.stamps + 29, (unsigned long long)B.st_slow);
+            atomicAdd(p.stamps + 7, (unsigned long long)st_pf1); atomicAdd(p.stamps + 31, (unsigned long long)st_pf2);
         }
     }
 #endif

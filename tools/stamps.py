@@ -38,6 +38,8 @@ for ef in (int(a) for a in (sys.argv[1:] or ["64"])):
     print("   survivors/hop histogram: " + "  ".join(f"{lab[i]}:{100.0*h[i]/max(sum(h[:8]),1):.1f}%" for i in range(8)))
     if buf[30]:
         print(f"   loop latch (insert end -> next select) {buf[30]/hops:.0f} cycles/hop")
+    if buf[7] or buf[31]:
+        print(f"   node = runner-up prediction (prefetch 1) {buf[7]/hops:.3f}/hop, = closest new survivor (prefetch 2) {buf[31]/hops:.3f}/hop")
     if any(buf[21:30]):
         print(f"   two-list structure: flush {buf[21]/hops:.0f} cycles/hop ({buf[24]/hops:.3f} flushes/hop, {buf[21]/max(buf[24],1):.0f} cycles each), "
               f"refresh_cache {buf[22]/hops:.0f} cycles/hop ({buf[25]/hops:.3f}/hop, {buf[22]/max(buf[25],1):.0f} each), eviction step {buf[23]/hops:.0f} cycles/hop "
