@@ -331,6 +331,9 @@ std::atomic<int> g_knob_max_waves{knob_env("GBNNS_MAX_WAVES", 0)};
 // "spec_min_nq" = smallest batch whose ef <= 64 first pass requests the rows before the visited test (walk_hot_spec_kernel;
 // GBNNS_SPEC_MIN_NQ; 0 = never)
 std::atomic<int> g_knob_spec_min_nq{knob_env("GBNNS_SPEC_MIN_NQ", 32768)};
+// "knn_pool_min_k" = shortest list gbnns_exact_knn keeps as an unordered pool (one wavefront per query and chunk) instead of a heap
+// (measured on 10^6 x 32: k = 48 0.327 against 0.333 s, k = 100 0.425 against 0.536 s, k = 1 000 2.4 against 7.6 s)
+std::atomic<int> g_knob_knn_pool_min_k{knob_env("GBNNS_KNN_POOL_MIN_K", 64)};
 // "knn_filter" 0 = gbnns_exact_knn without the matrix-core filter (GBNNS_KNN_FILTER; tests compare the two paths)
 std::atomic<int> g_knob_knn_filter{knob_env("GBNNS_KNN_FILTER", 1)};
 
@@ -415,9 +418,78 @@ int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* quer
     // Matrix-core filter in front of the exact distances (knn.hip): the L2 metric on rows of whole 16-byte steps, sets
     // large enough to amortise its passes.  Same output, byte for byte (tests/test_gpu_parity.py); "knn_filter" 0 = off.
     const int knob_filter = g_knob_knn_filter.load(std::memory_order_relaxed);  // 0 = never, 1 = by size, 2 = whenever the shape allows (tests)
-    const bool filter = metric == GBNNS_METRIC_L2 && d % 4 == 0 && d <= 128 && k <= 512 && n > (uint64_t)4 * k &&
-                        (knob_filter == 2 || (knob_filter == 1 && n >= (1u << 17) && nq >= 2048));
-    if (filter) {
+    const bool filter_shape = metric == GBNNS_METRIC_L2 && d % 4 == 0 && d <= 128 && n > (uint64_t)4 * k &&
+                              (knob_filter == 2 || (knob_filter == 1 && n >= (1u << 17) && nq >= 2048));
+    // long lists keep a query's keys as an unordered pool instead of a heap (knn.hip, knn_pool_update_kernel)
+    const bool pool_path = filter_shape && k >= g_knob_knn_pool_min_k.load(std::memory_order_relaxed) && k <= 4096;
+    const bool filter = filter_shape && k <= 512 && !pool_path;
+    if (pool_path) {
+        const uint32_t dp = (d + 15u) & ~15u;
+        const uint32_t cap = (uint32_t)(4 * k + 64);
+        const uint64_t rows_first = cap & ~63u;  // a chunk of at most `cap` rows cannot overflow a query's list: the first chunk (no thresholds yet) and the fallback
+        const uint64_t max_chunk = std::min<uint64_t>(1u << 15, std::max<uint64_t>(64, (n / 16 + 63) & ~(uint64_t)63));
+        // queries in slabs whose candidate lists take at most 4 GiB
+        const uint32_t slab = (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(1024, ((4ull << 30) / ((uint64_t)cap * 4)) & ~(uint64_t)127));
+        DevBuf bpack, bnorm, qpack, qnorm, rhs, cand, count, flag, pool, root;
+        struct Release3 {
+            DevBuf* b[10];
+            ~Release3() { for (DevBuf* x : b) x->release(); }
+        } release3{{&bpack, &bnorm, &qpack, &qnorm, &rhs, &cand, &count, &flag, &pool, &root}};
+        if ((rc = bpack.ensure((size_t)n * dp * 4))) return rc;
+        if ((rc = bnorm.ensure(((size_t)n + 64) * 4))) return rc;
+        if ((rc = qpack.ensure((size_t)slab * dp * 4))) return rc;
+        if ((rc = qnorm.ensure((size_t)slab * 4))) return rc;
+        if ((rc = rhs.ensure((size_t)slab * 4))) return rc;
+        if ((rc = cand.ensure((size_t)slab * cap * 4))) return rc;
+        if ((rc = count.ensure((size_t)slab * 4))) return rc;
+        if ((rc = flag.ensure(4))) return rc;
+        if ((rc = pool.ensure((size_t)slab * (size_t)k * 8))) return rc;
+        if ((rc = root.ensure((size_t)slab * 8))) return rc;
+        HIP_TRY(launch_fill_u32(bnorm.as<uint32_t>() + n, 0x7F800000u, 64, s));
+        HIP_TRY(launch_knn_pack(p.base, d, d, n, bpack.as<uint16_t>(), bnorm.as<float>(), s));
+        for (uint32_t q0 = 0; q0 < nq; q0 += slab) {
+            const uint32_t qn = std::min(slab, nq - q0);
+            KnnPoolParams pp{};
+            pp.k = p;
+            pp.k.q = p.q + (size_t)q0 * d; pp.k.nq = qn; pp.k.out_ids = p.out_ids + (size_t)q0 * k;
+            pp.k.out_dist = p.out_dist ? p.out_dist + (size_t)q0 * k : nullptr;
+            pp.k.self_offset = self_offset >= 0 ? self_offset + (int64_t)q0 : -1;
+            pp.pool = pool.as<uint64_t>(); pp.root = root.as<uint64_t>(); pp.cand = cand.as<uint32_t>(); pp.count = count.as<uint32_t>();
+            pp.cap = cap; pp.qnorm = qnorm.as<float>(); pp.rhs = rhs.as<float>();
+            HIP_TRY(launch_knn_pack(pp.k.q, d, d, qn, qpack.as<uint16_t>(), qnorm.as<float>(), s));
+            HIP_TRY(hipMemsetAsync(pool.p, 0xFF, (size_t)qn * (size_t)k * 8, s));
+            HIP_TRY(hipMemsetAsync(root.p, 0xFF, (size_t)qn * 8, s));
+            HIP_TRY(launch_fill_u32(rhs.as<uint32_t>(), 0xFF800000u, qn, s));  // -inf: every row passes
+            uint32_t h_flag = 0;
+            auto filter_rows = [&](uint64_t r0, uint32_t rows) -> int {
+                HIP_TRY(hipMemsetAsync(count.p, 0, (size_t)qn * 4, s));
+                HIP_TRY(hipMemsetAsync(flag.p, 0, 4, s));
+                KnnFilterParams f{};
+                f.qpack = qpack.as<uint16_t>(); f.bpack = bpack.as<uint16_t>() + (size_t)r0 * dp * 2; f.bnorm = bnorm.as<float>() + r0;
+                f.rhs = rhs.as<float>(); f.nq = qn; f.dp = dp; f.rows = rows; f.row0 = (uint32_t)r0; f.cap = cap;
+                f.cand = cand.as<uint32_t>(); f.count = count.as<uint32_t>(); f.overflow = flag.as<uint32_t>();
+                HIP_TRY(launch_knn_filter(f, s));
+                return GBNNS_OK;
+            };
+            for (uint64_t r0 = 0, chunk = 0; r0 < n; r0 += chunk) {
+                chunk = r0 == 0 ? std::min<uint64_t>(n, rows_first) : std::min<uint64_t>(max_chunk, r0);
+                const uint32_t rows = (uint32_t)std::min<uint64_t>(chunk, n - r0);
+                if ((rc = filter_rows(r0, rows))) return rc;
+                HIP_TRY(hipMemcpyAsync(&h_flag, flag.p, 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (!h_flag) {
+                    HIP_TRY(launch_knn_pool_update(pp, s));
+                    continue;
+                }
+                // some query kept more rows of this chunk than its list holds: the chunk again in pieces that cannot overflow
+                for (uint64_t r1 = r0; r1 < r0 + rows; r1 += rows_first) {
+                    if ((rc = filter_rows(r1, (uint32_t)std::min<uint64_t>(rows_first, r0 + rows - r1)))) return rc;
+                    HIP_TRY(launch_knn_pool_update(pp, s));
+                }
+            }
+            HIP_TRY(launch_knn_pool_finalize(pp, s));
+        }
+    } else if (filter) {
         const uint32_t dp = (d + 15u) & ~15u;
         const uint32_t cap = (uint32_t)std::max(256, 4 * k + 64);
         // The first rows are scanned exactly (they fill the heaps: thresholds exist afterwards); then filtered chunks, each
@@ -809,6 +881,7 @@ int gbnns_debug_knob(const char* name, int value) {
     else if (!std::strcmp(name, "vs_disp")) g_knob_vs_disp.store(value <= 0 ? 15 : value, std::memory_order_relaxed);
     else if (!std::strcmp(name, "max_waves")) g_knob_max_waves.store(std::max(0, std::min(32, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "spec_min_nq")) g_knob_spec_min_nq.store(std::max(0, value), std::memory_order_relaxed);
+    else if (!std::strcmp(name, "knn_pool_min_k")) g_knob_knn_pool_min_k.store(std::max(1, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_filter")) g_knob_knn_filter.store(value, std::memory_order_relaxed);
     else return fail(GBNNS_ERR_INVALID, "gbnns_debug_knob: unknown knob '%s'", name);
     return GBNNS_OK;

@@ -195,6 +195,19 @@ struct KnnRescoreParams {
 };
 hipError_t launch_knn_rescore(const KnnRescoreParams& p, hipStream_t s);
 hipError_t launch_knn_finalize(const KnnParams& p, hipStream_t s);   // heap sort + outputs
+// long lists (64 <= k <= 4 096): the k smallest keys of a query as an unordered pool, one wavefront per query and chunk (knn.hip)
+struct KnnPoolParams {
+    KnnParams k;             // base = the WHOLE base set, q, dims, self_offset, outputs (heap unused)
+    uint64_t* pool;          // [nq x k] keys, all-ones = no entry
+    uint64_t* root;          // [nq] largest key of the pool (all-ones while it is not full)
+    const uint32_t* cand;    // [nq x cap] rows the filter kept
+    const uint32_t* count;   // [nq]
+    uint32_t cap;
+    const float* qnorm;
+    float* rhs;              // [nq] the filter's thresholds, rewritten from `root`
+};
+hipError_t launch_knn_pool_update(const KnnPoolParams& p, hipStream_t s);
+hipError_t launch_knn_pool_finalize(const KnnPoolParams& p, hipStream_t s);   // ascending order + outputs
 constexpr float kKnnFilterSlack = 1.0f / 4096.0f;  // c: |approximate - reference distance| <= c (|q|^2 + |x|^2) with room to spare (knn.hip)
 
 // GD pruning of a kNN graph, one node per wavefront (support_func.h:521-563).  deg[i] = 0xFFFFFFFF marks a node

@@ -602,6 +602,178 @@ __global__ __launch_bounds__(128) void knn_finalize_kernel(KnnParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Long lists (k >= 64; the reference's graph builder reads 1 000-NN lists, dim_red/support_func.py:374-384 ->
+// prepare_graph.cpp:66).  A binary heap per query in global memory costs ~3 log2 k scattered accesses per entrant and a
+// query sees about k ln(n / k) entrants (7 000 at k = 1 000, n = 10^6): 20 TB of 64-byte lines for 10^6 queries, seven
+// seconds.  Here a query's current k smallest keys are an UNORDERED pool [k] in global memory and one wavefront serves
+// one query per chunk: it reads the pool into LDS (coalesced), computes the exact distances (the reference's operations
+// and order, one candidate per lane) of the rows the filter kept, appends the keys below the pool's largest, and when
+// the appended keys fill their buffer -- or the chunk ends -- keeps the k smallest of the union with a radix select on the
+// 64-bit (distance, id) keys: a 256-bin histogram per digit from the top, until the bin that holds the k-th key holds
+// nothing else.  Same set of keys as the heaps would hold, whatever the order; knn_pool_finalize_kernel sorts it.
+// ------------------------------------------------------------------------------------------
+constexpr int kPoolNew = 1024;  // appended keys per selection round
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, d);
+        v += lane >= d ? t : 0u;
+    }
+    return v;
+}
+
+// k-th smallest (1-based) of keys[0 .. M), M > k; afterwards keys[0 .. k) hold the k smallest (any order; all-ones keys
+// are "no entry" and may repeat, every other key is distinct).  Returns the largest of them.
+__device__ __forceinline__ uint64_t pool_select(uint64_t* keys, int k, int M, uint32_t* hist, int lane) {
+    uint64_t prefix = 0, mask = 0;
+    uint32_t need = (uint32_t)k;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (int j = lane; j < 256; j += 64) hist[j] = 0u;
+        __syncthreads();
+        for (int i = lane; i < M; i += 64) {
+            const uint64_t key = keys[i];
+            if ((key & mask) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        const uint32_t c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+        const uint32_t sum = c0 + c1 + c2 + c3;
+        const uint32_t incl = wave_incl_scan_u32(sum, lane), excl = incl - sum;
+        const bool has = excl < need && need <= incl;  // exactly one lane
+        const uint32_t r = need - excl;
+        uint32_t b = 3, below = c0 + c1 + c2, cb = c3;
+        if (r <= c0) { b = 0; below = 0; cb = c0; }
+        else if (r <= c0 + c1) { b = 1; below = c0; cb = c1; }
+        else if (r <= c0 + c1 + c2) { b = 2; below = c0 + c1; cb = c2; }
+        const int src = __ffsll((unsigned long long)__ballot(has)) - 1;
+        const uint32_t bin = (uint32_t)__shfl((int)(4u * (uint32_t)lane + b), src);
+        const uint32_t skipped = (uint32_t)__shfl((int)(excl + below), src);
+        const uint32_t in_bin = (uint32_t)__shfl((int)cb, src);
+        need -= skipped;
+        prefix |= (uint64_t)bin << shift;
+        mask |= 255ull << shift;
+        if (in_bin == 1u) break;
+    }
+    uint64_t tau = prefix;  // every digit fixed (only all-ones keys repeat), or: the one key under the prefix
+    if (mask != ~0ull) {
+        uint64_t found = 0;
+        for (int i = lane; i < M; i += 64) {
+            const uint64_t key = keys[i];
+            if ((key & mask) == prefix) found = key;
+        }
+        const int src = __ffsll((unsigned long long)__ballot(found != 0)) - 1;  // (a key is never 0: distance keys have a bit set)
+        tau = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(found >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)found, src);
+    }
+    int c = 0;  // keys below tau to the front, in place (a key moves to a position at or below its own)
+    for (int i0 = 0; i0 < M; i0 += 64) {
+        const int i = i0 + lane;
+        const uint64_t key = i < M ? keys[i] : ~0ull;
+        const bool keep = i < M && key < tau;
+        const uint64_t m = __ballot(keep);
+        const int pos = c + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        __syncthreads();
+        if (keep) keys[pos] = key;
+        c += __popcll(m);
+        __syncthreads();
+    }
+    for (int i = c + lane; i < k; i += 64) keys[i] = tau;  // the k-th itself (all-ones: every free place)
+    __syncthreads();
+    return tau;
+}
+
+template <int S>
+__global__ __launch_bounds__(64) void knn_pool_update_kernel(KnnPoolParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char knn_pool_smem[];
+    const KnnParams& kp = p.k;
+    const uint32_t qi = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int k = kp.k;
+    const uint32_t cnt = min(p.count[qi], p.cap);
+    if (cnt == 0) return;  // (threshold unchanged)
+    uint64_t* keys = reinterpret_cast<uint64_t*>(knn_pool_smem);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(keys + k + kPoolNew);
+    uint64_t* pool = p.pool + (size_t)qi * (size_t)k;
+    for (int i = lane; i < k; i += 64) keys[i] = pool[i];
+    uint64_t root = p.root[qi];
+    const uint32_t steps = kp.dim >> 2;
+    const float* qp = kp.q + (size_t)qi * kp.qstride;
+    float4 q[S];
+#pragma unroll
+    for (int c = 0; c < S; ++c)
+        q[c] = (uint32_t)c < steps ? make_float4(qp[4 * c], qp[4 * c + 1], qp[4 * c + 2], qp[4 * c + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    int nnew = 0;
+    for (uint32_t e0 = 0; e0 < cnt; e0 += 64) {
+        const uint32_t e = e0 + (uint32_t)lane;
+        const bool valid = e < cnt;
+        const uint32_t row = valid ? p.cand[(size_t)qi * p.cap + e] : 0u;
+        const float* bp = kp.base + (size_t)row * kp.bstride;
+        f32x2 s01{0.f, 0.f}, s23{0.f, 0.f};  // L2Metric::Dist, the scan kernels' operations and order
+#pragma unroll
+        for (int c = 0; c < S; ++c) {
+            if ((uint32_t)c < steps) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bp + 4 * c);
+                const f32x2 e01 = f32x2{b4.x, b4.y} - f32x2{q[c].x, q[c].y};
+                const f32x2 e23 = f32x2{b4.z, b4.w} - f32x2{q[c].z, q[c].w};
+                s01 = s01 + e01 * e01;
+                s23 = s23 + e23 * e23;
+            }
+        }
+        const float dist = ((s01.x + s01.y) + s23.x) + s23.y;
+        const uint64_t key = ((uint64_t)knn_fkey(dist) << 32) | row;
+        const bool self = kp.self_offset >= 0 && (uint64_t)row == (uint64_t)qi + (uint64_t)kp.self_offset;
+        const bool keep = valid && !self && key < root;
+        const uint64_t m = __ballot(keep);
+        if (keep) keys[k + nnew + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = key;
+        nnew += __popcll(m);
+        if (nnew > kPoolNew - 64) {
+            __syncthreads();
+            root = pool_select(keys, k, k + nnew, hist, lane);
+            nnew = 0;
+        }
+    }
+    __syncthreads();
+    if (nnew) root = pool_select(keys, k, k + nnew, hist, lane);
+    for (int i = lane; i < k; i += 64) pool[i] = keys[i];
+    if (lane == 0) {
+        p.root[qi] = root;
+        p.rhs[qi] = root == ~0ull ? -__builtin_inff()
+                                  : 0.5f * ((1.0f - kKnnFilterSlack) * p.qnorm[qi] - knn_fkey_inv((uint32_t)(root >> 32)));
+    }
+}
+
+// ascending (distance, id) order of a query's pool and the outputs: one wavefront per query, bitonic network in LDS
+__global__ __launch_bounds__(64) void knn_pool_finalize_kernel(KnnPoolParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char knn_pool_smem[];
+    const KnnParams& kp = p.k;
+    const uint32_t qi = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int k = kp.k;
+    int N = 64;
+    while (N < k) N <<= 1;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(knn_pool_smem);
+    const uint64_t* pool = p.pool + (size_t)qi * (size_t)k;
+    for (int i = lane; i < N; i += 64) keys[i] = i < k ? pool[i] : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= N; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = lane; t < (N >> 1); t += 64) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const bool up = (i & size) == 0;
+                const uint64_t a = keys[i], b = keys[j];
+                if ((a > b) == up) { keys[i] = b; keys[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = lane; e < k; e += 64) {
+        const uint64_t kv = keys[e];
+        kp.out_ids[(size_t)qi * k + e] = (uint32_t)kv;
+        if (kp.out_dist) kp.out_dist[(size_t)qi * k + e] = (kv == ~0ull) ? __builtin_inff() : knn_fkey_inv((uint32_t)(kv >> 32));
+    }
+}
+
 template <int KSTEPS, int QB>
 hipError_t launch_knn_filter_t(const KnnFilterParams& p, hipStream_t s) {
     const unsigned gx = (p.nq + QB * 128u - 1) / (QB * 128u);
@@ -655,6 +827,31 @@ hipError_t launch_knn_rescore(const KnnRescoreParams& p, hipStream_t s) {
     if (p.k.dim <= 32) hipLaunchKernelGGL(knn_rescore_kernel<8>, grid, block, 0, s, p);
     else if (p.k.dim <= 64) hipLaunchKernelGGL(knn_rescore_kernel<16>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(knn_rescore_kernel<32>, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_pool_update(const KnnPoolParams& p, hipStream_t s) {
+    if (p.k.nq == 0) return hipSuccess;
+    const size_t lds = ((size_t)p.k.k + kPoolNew) * 8 + 256 * 4;
+    const dim3 grid(p.k.nq), block(64);
+    auto go = [&](auto kernel) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, p);
+        return hipGetLastError();
+    };
+    if (p.k.dim <= 32) return go(knn_pool_update_kernel<8>);
+    if (p.k.dim <= 64) return go(knn_pool_update_kernel<16>);
+    return go(knn_pool_update_kernel<32>);
+}
+
+hipError_t launch_knn_pool_finalize(const KnnPoolParams& p, hipStream_t s) {
+    if (p.k.nq == 0) return hipSuccess;
+    size_t N = 64;
+    while (N < (size_t)p.k.k) N <<= 1;
+    hipLaunchKernelGGL(knn_pool_finalize_kernel, dim3(p.k.nq), dim3(64), N * 8, s, p);
     return hipGetLastError();
 }
 

@@ -945,6 +945,56 @@ def test_exact_knn_matrix_core_filter_is_byte_identical(g, orc):
         lib.gbnns_debug_knob(b"knn_filter", 1)
 
 
+def test_exact_knn_long_lists_pool_path_is_byte_identical(g, orc):
+    """Lists of 64 entries and more (the reference's graph builder reads 1 000-NN lists: dim_red/support_func.py:374-384 ->
+    prepare_graph.cpp:66) keep a query's k smallest keys as an unordered pool, one wavefront per query and chunk, with a radix
+    select on the (distance, id) keys (knn.hip, knn_pool_update_kernel / knn_pool_finalize_kernel) instead of a heap.  Same
+    ids and distance bits as the plain exact scan: k = 300 / 1 000 / 2 500 (a pool beyond one selection round, not a power of
+    two), short lists forced onto the pool path (knob "knn_pool_min_k"), the lattice of ties, rows sorted farthest first
+    (every chunk overflows the candidate lists: the piecewise fallback), self exclusion over query slices, and the oracle."""
+    lib = g.load_library()
+
+    def both(base, q, k, **kw):
+        assert lib.gbnns_debug_knob(b"knn_filter", 0) == 0
+        i0, d0 = g.exact_knn(base, q, k, want_dist=True, **kw)
+        assert lib.gbnns_debug_knob(b"knn_filter", 2) == 0
+        i1, d1 = g.exact_knn(base, q, k, want_dist=True, **kw)
+        assert lib.gbnns_debug_knob(b"knn_filter", 1) == 0
+        assert np.array_equal(i0, i1), k
+        assert np.array_equal(gu.bits(d0), gu.bits(d1)), k
+        return i0, d0
+
+    try:
+        rng = np.random.Generator(np.random.PCG64(20261007))
+        for d, n, nq, k in ((32, 20000, 300, 300), (32, 30000, 200, 1000), (64, 12000, 150, 2500), (96, 6000, 100, 400), (16, 9000, 130, 1029)):
+            c = datagen.Case("kp", 6000 + d + k, n, nq, d, 4, 8)
+            ids, dist = both(c.base, c.queries, k)
+            oi, od = orc.exact_knn(c.base, c.queries[:16], k, 0, threads=8)
+            assert np.array_equal(ids[:16], oi) and np.array_equal(gu.bits(dist[:16]), gu.bits(od)), (d, k)
+        # short lists on the pool path
+        assert lib.gbnns_debug_knob(b"knn_pool_min_k", 1) == 0
+        for d, n, nq, k in ((32, 9000, 700, 48), (40, 4000, 300, 7), (128, 4000, 200, 64), (32, 3000, 100, 1)):
+            c = datagen.Case("kp", 6100 + d + k, n, nq, d, 4, 8)
+            both(c.base, c.queries, k)
+        lat = rng.integers(0, 3, size=(4000, 32)).astype(np.float32)
+        lat = np.concatenate([lat, lat, lat])
+        both(lat, lat[:300].copy(), 40)
+        both(lat, lat[:300].copy(), 700, self_offset=0)
+        q = (rng.standard_normal((200, 32)) * 0.05).astype(np.float32)
+        rows = rng.standard_normal((12000, 32)).astype(np.float32)
+        rows = rows[np.argsort(-(rows ** 2).sum(1))]
+        both(rows, q, 30)
+        both(rows, q, 500)
+        c = datagen.Case("kp", 6999, 7000, 8, 32, 4, 8)
+        a, _ = both(c.base, c.base[:3000].copy(), 300, self_offset=0)
+        b, _ = both(c.base, c.base[3000:].copy(), 300, self_offset=3000)
+        want, _ = orc.exact_knn(c.base, c.base[2990:3010], 300, 0, self_offset=2990, threads=8)
+        assert np.array_equal(np.concatenate([a, b])[2990:3010], want)
+    finally:
+        lib.gbnns_debug_knob(b"knn_filter", 1)
+        lib.gbnns_debug_knob(b"knn_pool_min_k", 64)
+
+
 def test_exact_knn_vs_get_truth_and_oracle(g, orc):
     """gbnns_exact_knn: k = 1 equals the compiled reference's getTruth (tests/golden/knn_toy.npz), k > 1 equals the
     brute-force restatement -- ids and distance bit patterns; d % 4 != 0, tie-heavy data, both metrics, a set

@@ -18,7 +18,11 @@ slice_q = int(sys.argv[3]) if len(sys.argv) > 3 else n
 lib = g.load_library()
 pairs = n * (n - 1)
 results = {}
-for knob, what in ((1, "matrix-core filter + exact distances of the kept rows"), (0, "exact scan of every row (rounds 1-3)")):
+# KNN_FILTER_ONLY=1: time the filter path alone (k = 1000: the exact scan of every row takes minutes)
+paths = ((1, "matrix-core filter + exact distances of the kept rows"), (0, "exact scan of every row (rounds 1-3)"))
+if os.environ.get("KNN_FILTER_ONLY"):
+    paths = paths[:1]
+for knob, what in paths:
     lib.gbnns_debug_knob(b"knn_filter", knob)
     g.exact_knn(x[:200000].contiguous(), x[:4096].contiguous(), k, self_offset=0)  # (code objects loaded, allocator warm)
     torch.cuda.synchronize()
@@ -32,6 +36,8 @@ for knob, what in ((1, "matrix-core filter + exact distances of the kept rows"),
     print("gbnns_exact_knn, %s: n=%d d=32 k=%d  %.3f s  = %.2f T pairs/s (%.1f TFLOP/s-equivalent of ordered f32 sub/mul/add; the filter's "
           "matrix-core work: %.1f TFLOP/s bf16)" % (what, n, k, dt, pairs / dt / 1e12, pairs * 32 * 3 / dt / 1e12, pairs * 32 * 2 * 3 / dt / 1e12), flush=True)
 lib.gbnns_debug_knob(b"knn_filter", 1)
+if os.environ.get("KNN_FILTER_ONLY"):
+    sys.exit(0)
 print("filter path byte-identical to the exact scan:", bool((results[0] == results[1]).all().item()))
 ids = results[1]
 t0 = time.perf_counter()
