@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--batches", type=int, default=4, help="distinct query batches rotated through the timed loop")
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 20 for gist / glove*, 3 for deep)")
     ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--settle-ms", type=float, default=50.0,
+                    help="untimed stretch of the step loop in front of the warm-up steps (device clocks; 0 = none)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="sift")
     ap.add_argument("--ef", type=int, default=None, help="beam width of the timed steps (default: the configuration's)")
     ap.add_argument("--n", type=int, default=None, help="override the base-set size (quick looks)")
@@ -364,6 +366,24 @@ def main():
         ix.search(batches[j % nb], ef, want=(), hash_capacity=args.hash_capacity, flags=step_flags, defer_depth=depth)
         ix.join()
         torch.cuda.synchronize()
+    # ... and the device itself: the first ~10 ms of batches in flight after the set-up above run 10 % slower than the
+    # steady state (measured: 20 timed steps after 5 warm-up steps 28.4 M queries/s, after 100 warm-up steps 31.1 M, 200
+    # timed steps after 5: 31.4 M -- clocks / power state, not the pipeline's fill and drain).  An untimed stretch of the
+    # same loop, about 50 ms long (at most 500 steps; the same count on every rank), comes before the W warm-up steps.
+    ts = time.perf_counter()
+    for _ in range(4):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    nstep = 0
+    est = max((time.perf_counter() - ts) / 4, 1e-5)
+    n_settle = int(min(500, max(0, round(args.settle_ms * 1e-3 / est))))
+    if world > 1:
+        tn = torch.tensor([n_settle], dtype=torch.int64, device=dev)
+        dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+        n_settle = int(tn.item())
+    for _ in range(n_settle):
+        step()
     for _ in range(args.warmup):
         step()
     drain()
@@ -436,6 +456,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "settle_steps_before_warmup": n_settle + 4,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",

@@ -1,12 +1,18 @@
-"""Prints the last N dispatches of a rocprofv3 --kernel-trace CSV as a timeline: start (us, relative), duration, queue."""
-import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
+#!/usr/bin/env python3
+"""GPU box: kernel timeline of a rocprofv3 --kernel-trace directory (csv): start (us), duration (us), short kernel name of the last N dispatches.
+usage: timeline.py <dir> [N]"""
+import csv, glob, re, sys
+d = sys.argv[1]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+rows = []
+for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+    rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-rows = rows[-int(sys.argv[2]):]
+rows = rows[-n:]
 t0 = int(rows[0]["Start_Timestamp"])
+prev_end = t0
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0].split("::")[-1][:44]
-    st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print("%-46s start %9.1f  end %9.1f  dur %7.1f  q %s grid %s" % (name, (st - t0) / 1e3, (en - t0) / 1e3, (en - st) / 1e3,
-          r.get("Queue_Id", "?"), r.get("Grid_Size_X", r.get("Grid_Size", "?"))))
+    m = re.search(r"(walk_\w+|mlp_\w+|rerank_\w+|knn_\w+|\w+_kernel)", r["Kernel_Name"])
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    print("%10.1f  dur %8.1f  gap %7.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, m.group(1) if m else r["Kernel_Name"][:40]))
+    prev_end = max(prev_end, e)
