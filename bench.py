@@ -882,11 +882,13 @@ def ef_sweep(ix, ds, q, cfg, ef0, recalls, recall_of, nq, max_degree, rank, batc
         flight = None
         if batches and depth > 1:
             bufs = [{} for _ in range(depth)]
-            for i in range(2 * depth):
+            # (an untimed stretch of ~30 ms first, as in front of the headline's steps: the device's first milliseconds with
+            # batches in flight are 10 % slower than its steady state; then at least ~20 ms of timed steps)
+            for i in range(max(2 * depth, min(200, int(0.03 / dt) + 1))):
                 ix.search(batches[i % len(batches)], e, want=(), out=bufs[i % depth], flags=g.FLAG_DEFER_JOIN, defer_depth=depth)
             ix.join()
             torch.cuda.synchronize()
-            nrep = 4 * reps
+            nrep = max(4 * reps, min(200, int(0.02 / dt) + 1)) if nq <= 20_000 else 4 * reps
             t2 = time.perf_counter()
             for i in range(nrep):
                 ix.search(batches[i % len(batches)], e, want=(), out=bufs[i % depth], flags=g.FLAG_DEFER_JOIN, defer_depth=depth)

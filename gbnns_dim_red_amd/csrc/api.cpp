@@ -333,6 +333,8 @@ std::atomic<int> g_knob_max_waves{knob_env("GBNNS_MAX_WAVES", 0)};
 std::atomic<int> g_knob_spec_min_nq{knob_env("GBNNS_SPEC_MIN_NQ", 32768)};
 // "knn_pool_min_k" = shortest list gbnns_exact_knn keeps as an unordered pool (one wavefront per query and chunk) instead of a heap
 // (measured on 10^6 x 32: k = 48 0.327 against 0.333 s, k = 100 0.425 against 0.536 s, k = 1 000 2.4 against 7.6 s)
+// "knn_chunk" = most rows per filtered chunk (a multiple of 64)
+std::atomic<int> g_knob_knn_chunk{knob_env("GBNNS_KNN_CHUNK", 1 << 15)};
 std::atomic<int> g_knob_knn_pool_min_k{knob_env("GBNNS_KNN_POOL_MIN_K", 64)};
 // "knn_filter" 0 = gbnns_exact_knn without the matrix-core filter (GBNNS_KNN_FILTER; tests compare the two paths)
 std::atomic<int> g_knob_knn_filter{knob_env("GBNNS_KNN_FILTER", 1)};
@@ -427,7 +429,8 @@ int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* quer
         const uint32_t dp = (d + 15u) & ~15u;
         const uint32_t cap = (uint32_t)(4 * k + 64);
         const uint64_t rows_first = cap & ~63u;  // a chunk of at most `cap` rows cannot overflow a query's list: the first chunk (no thresholds yet) and the fallback
-        const uint64_t max_chunk = std::min<uint64_t>(1u << 15, std::max<uint64_t>(64, (n / 16 + 63) & ~(uint64_t)63));
+        // (chunks four times the heap path's: every chunk costs a query a pass over its whole pool; measured at k = 1 000: 32 K rows 1.98 s, 64 K 1.86 s, 128 K 1.89 s)
+        const uint64_t max_chunk = std::min<uint64_t>(4ull * (uint64_t)g_knob_knn_chunk.load(std::memory_order_relaxed), std::max<uint64_t>(64, (n / 16 + 63) & ~(uint64_t)63));
         // queries in slabs whose candidate lists take at most 4 GiB
         const uint32_t slab = (uint32_t)std::min<uint64_t>(nq, std::max<uint64_t>(1024, ((4ull << 30) / ((uint64_t)cap * 4)) & ~(uint64_t)127));
         DevBuf bpack, bnorm, qpack, qnorm, rhs, cand, count, flag, pool, root;
@@ -496,7 +499,7 @@ int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* quer
         // at most as long as everything before it -- a query is then expected to keep about k rows of a chunk, whatever
         // the chunk -- and at most 32 K rows (4 MB of packed rows at d = 32: L2 / Infinity-Cache resident while swept).
         // Chunks start on multiples of 64 rows (the filter reads the norms in aligned groups of four).
-        const uint64_t max_chunk = std::min<uint64_t>(1u << 15, std::max<uint64_t>(64, (n / 16 + 63) & ~(uint64_t)63));  // (small sets, tests: a sixteenth)
+        const uint64_t max_chunk = std::min<uint64_t>((uint64_t)g_knob_knn_chunk.load(std::memory_order_relaxed), std::max<uint64_t>(64, (n / 16 + 63) & ~(uint64_t)63));  // (small sets, tests: a sixteenth)
         const uint64_t first = std::min<uint64_t>(n, (std::max<uint64_t>(std::min<uint64_t>(max_chunk, 8192), 4ull * (uint64_t)k) + 63) & ~(uint64_t)63);
         DevBuf bpack, bnorm, qpack, qnorm, rhs, cand, count, flag;
         struct Release2 {
@@ -881,6 +884,7 @@ int gbnns_debug_knob(const char* name, int value) {
     else if (!std::strcmp(name, "vs_disp")) g_knob_vs_disp.store(value <= 0 ? 15 : value, std::memory_order_relaxed);
     else if (!std::strcmp(name, "max_waves")) g_knob_max_waves.store(std::max(0, std::min(32, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "spec_min_nq")) g_knob_spec_min_nq.store(std::max(0, value), std::memory_order_relaxed);
+    else if (!std::strcmp(name, "knn_chunk")) g_knob_knn_chunk.store(std::max(64, value & ~63), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_pool_min_k")) g_knob_knn_pool_min_k.store(std::max(1, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_filter")) g_knob_knn_filter.store(value, std::memory_order_relaxed);
     else return fail(GBNNS_ERR_INVALID, "gbnns_debug_knob: unknown knob '%s'", name);

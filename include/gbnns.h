@@ -260,6 +260,8 @@ int gbnns_profile_enable(gbnns_index* index, int on);
  * "max_waves": most first-pass wavefronts per CU the LDS shares are cut for (0 = default; GBNNS_MAX_WAVES).
  * "spec_min_nq": smallest batch whose ef <= 64 first pass requests a hop's rows before its visited test
  * (walk_hot_spec_kernel; default 32 768, 0 = never; GBNNS_SPEC_MIN_NQ).
+ * "knn_chunk": most base rows per filtered chunk of gbnns_exact_knn (default 32 768; the pool path takes four times that;
+ * GBNNS_KNN_CHUNK).
  * "knn_pool_min_k": shortest list gbnns_exact_knn's filter path keeps as an unordered pool with a radix select (one
  * wavefront per query) instead of a binary heap (default 64; GBNNS_KNN_POOL_MIN_K).
  * "knn_filter": gbnns_exact_knn's matrix-core filter -- 0 never, 1 by size (default), 2 whenever the shape allows
@@ -298,7 +300,7 @@ int gbnns_build_graph_gd_device(int device, const uint64_t* knn_offsets, const u
  * (v_mfma_f32_32x32x16_bf16 on hi / lo bf16 halves, error-bounded) and only the rows it cannot rule out get their exact
  * distance: same output, byte for byte, several times faster.  Lists of 64 entries and more are kept as
  * unordered pools with a radix select per chunk (one wavefront per query) instead of binary heaps: 1 000-NN lists of
- * 10^6 x 32 in 2.4 s (7.6 s).
+ * 10^6 x 32 in 1.4 s (7.6 s).
  * d <= 8192 (d > 128 runs a kernel that streams the query through in chunks); GBNNS_METRIC_NEG_DOT needs
  * d % 8 == 0 (else GBNNS_ERR_UNSUPPORTED).  Buffers are all host or all
  * device (mem_kind); the work runs on `stream` and the call returns when it has finished (a k x n_q x 8-byte
