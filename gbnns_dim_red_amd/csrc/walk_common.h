@@ -199,7 +199,7 @@ __device__ __forceinline__ bool visited_claim(uint32_t* hash, uint32_t nbuckets,
 // whose id was new.  `lds_base` = LDS byte address of the table.  A lane that loses the slot race
 // to another lane of the wavefront retries the following slots of the bucket straight away (the
 // occupant cannot be its own id: ids offered together are distinct) and only re-reads the bucket
-// when they run out.  e0..e3 need a contiguous register quad, hence the fixed v[92:95].
+// when they run out.  e0..e3 need a contiguous register quad, hence the fixed v[68:71].
 __device__ __forceinline__ uint64_t visited_claim_mask(uint32_t lds_base, uint32_t nbuckets, uint32_t id, uint64_t valid) {
     const uint32_t end = lds_base + (nbuckets << 4);
     const uint32_t mulc = 0x9E3779B1u;
@@ -214,19 +214,19 @@ __device__ __forceinline__ uint64_t visited_claim_mask(uint32_t lds_base, uint32
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[valid]\n"
         "1:\n\t"
-        "ds_read_b128 v[92:95], %[addr]\n\t"
+        "ds_read_b128 v[68:71], %[addr]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_xor_b32 %[t0], v92, %[id]\n\t"
-        "v_xor_b32 %[t1], v93, %[id]\n\t"
-        "v_xor_b32 %[t2], v94, %[id]\n\t"
+        "v_xor_b32 %[t0], v68, %[id]\n\t"
+        "v_xor_b32 %[t1], v69, %[id]\n\t"
+        "v_xor_b32 %[t2], v70, %[id]\n\t"
         "v_min3_u32 %[t0], %[t0], %[t1], %[t2]\n\t"
-        "v_xor_b32 %[t2], v95, %[id]\n\t"
-        "v_ashrrev_i32 v92, 31, v92\n\t"
-        "v_ashrrev_i32 v93, 31, v93\n\t"
-        "v_ashrrev_i32 v94, 31, v94\n\t"
+        "v_xor_b32 %[t2], v71, %[id]\n\t"
+        "v_ashrrev_i32 v68, 31, v68\n\t"
+        "v_ashrrev_i32 v69, 31, v69\n\t"
+        "v_ashrrev_i32 v70, 31, v70\n\t"
         "v_min_u32 %[t0], %[t0], %[t2]\n\t"          // 0 <=> id is in the bucket
-        "v_ashrrev_i32 %[t2], 31, v95\n\t"
-        "v_add3_u32 %[t1], v92, v93, v94\n\t"
+        "v_ashrrev_i32 %[t2], 31, v71\n\t"
+        "v_add3_u32 %[t1], v68, v69, v70\n\t"
         "v_cmp_ne_u32 vcc, 0, %[t0]\n\t"
         "v_add3_u32 %[t1], %[t1], %[t2], 4\n\t"       // occupied slots (they fill in order)
         "s_and_b64 exec, exec, vcc\n\t"                // lanes that found their id are done
@@ -259,7 +259,7 @@ __device__ __forceinline__ uint64_t visited_claim_mask(uint32_t lds_base, uint32
           [t2] "=&v"(t2), [addr] "=&v"(addr)
         : [id] "v"(id), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [neg1] "v"(neg1), [mulc] "s"(mulc),
           [nb] "s"(nbuckets)
-        : "vcc", "memory", "v92", "v93", "v94", "v95");
+        : "vcc", "memory", "v68", "v69", "v70", "v71");
     return fresh;
 }
 
@@ -283,24 +283,24 @@ __device__ __forceinline__ uint64_t visited_claim_mask_packed(uint32_t lds_base,
         "s_mov_b64 %[sv], exec\n\t"
         "s_mov_b64 exec, %[valid]\n"
         "1:\n\t"
-        "ds_read_b128 v[92:95], %[addr]\n\t"
+        "ds_read_b128 v[68:71], %[addr]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_bfe_u32 v88, v92, 0, 24\n\t"
-        "v_alignbit_b32 v89, v93, v92, 24\n\t"
-        "v_alignbit_b32 v90, v94, v93, 16\n\t"
-        "v_lshrrev_b32 v91, 8, v94\n\t"
-        "v_bfe_u32 %[t1], v95, 0, 24\n\t"
-        "v_bfe_u32 v89, v89, 0, 24\n\t"
-        "v_bfe_u32 v90, v90, 0, 24\n\t"
-        "v_xor_b32 v88, v88, %[id]\n\t"
-        "v_xor_b32 v89, v89, %[id]\n\t"
-        "v_xor_b32 v90, v90, %[id]\n\t"
-        "v_xor_b32 v91, v91, %[id]\n\t"
+        "v_bfe_u32 v64, v68, 0, 24\n\t"
+        "v_alignbit_b32 v65, v69, v68, 24\n\t"
+        "v_alignbit_b32 v66, v70, v69, 16\n\t"
+        "v_lshrrev_b32 v67, 8, v70\n\t"
+        "v_bfe_u32 %[t1], v71, 0, 24\n\t"
+        "v_bfe_u32 v65, v65, 0, 24\n\t"
+        "v_bfe_u32 v66, v66, 0, 24\n\t"
+        "v_xor_b32 v64, v64, %[id]\n\t"
+        "v_xor_b32 v65, v65, %[id]\n\t"
+        "v_xor_b32 v66, v66, %[id]\n\t"
+        "v_xor_b32 v67, v67, %[id]\n\t"
         "v_xor_b32 %[t1], %[t1], %[id]\n\t"
-        "v_min3_u32 v88, v88, v89, v90\n\t"
-        "v_min3_u32 v88, v88, v91, %[t1]\n\t"               // 0 <=> id is in the bucket
-        "v_lshrrev_b32 %[t1], 24, v95\n\t"                  // slots handed out
-        "v_cmp_ne_u32 vcc, 0, v88\n\t"
+        "v_min3_u32 v64, v64, v65, v66\n\t"
+        "v_min3_u32 v64, v64, v67, %[t1]\n\t"               // 0 <=> id is in the bucket
+        "v_lshrrev_b32 %[t1], 24, v71\n\t"                  // slots handed out
+        "v_cmp_ne_u32 vcc, 0, v64\n\t"
         "s_and_b64 exec, exec, vcc\n\t"
         "s_cbranch_execz 9f\n\t"
         "s_mov_b64 %[act], exec\n\t"
@@ -333,7 +333,7 @@ __device__ __forceinline__ uint64_t visited_claim_mask_packed(uint32_t lds_base,
           [t2] "=&v"(t2), [addr] "=&v"(addr)
         : [id] "v"(id), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [inc] "v"(inc), [mulc] "s"(mulc),
           [nb] "s"(nbuckets)
-        : "vcc", "memory", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+        : "vcc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
     return fresh;
 }
 
@@ -360,18 +360,18 @@ __device__ __forceinline__ uint64_t visited_claim_mask_quotient(uint32_t lds_bas
         "v_lshrrev_b32 %[t0], %[shr], %[t0]\n\t"
         "v_lshl_or_b32 %[t2], %[t0], 16, %[t0]\n"
         "5:\n\t"
-        "ds_read_b128 v[92:95], %[addr]\n\t"
+        "ds_read_b128 v[68:71], %[addr]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
-        "v_xor_b32 v88, v92, %[t2]\n\t"
-        "v_xor_b32 v89, v93, %[t2]\n\t"
-        "v_xor_b32 v90, v94, %[t2]\n\t"
-        "v_xor_b32 v91, v95, %[t2]\n\t"
-        "v_pk_min_u16 v88, v88, v89\n\t"
-        "v_pk_min_u16 v90, v90, v91\n\t"
-        "v_bfe_u32 %[t1], v95, 16, 12\n\t"
-        "v_pk_min_u16 v88, v88, v90\n\t"
-        "v_mad_u32_u16 v88, v88, v88, 0 op_sel:[0,1,0,0]\n\t"
-        "v_cmp_ne_u32 vcc, 0, v88\n\t"
+        "v_xor_b32 v64, v68, %[t2]\n\t"
+        "v_xor_b32 v65, v69, %[t2]\n\t"
+        "v_xor_b32 v66, v70, %[t2]\n\t"
+        "v_xor_b32 v67, v71, %[t2]\n\t"
+        "v_pk_min_u16 v64, v64, v65\n\t"
+        "v_pk_min_u16 v66, v66, v67\n\t"
+        "v_bfe_u32 %[t1], v71, 16, 12\n\t"
+        "v_pk_min_u16 v64, v64, v66\n\t"
+        "v_mad_u32_u16 v64, v64, v64, 0 op_sel:[0,1,0,0]\n\t"
+        "v_cmp_ne_u32 vcc, 0, v64\n\t"
         "s_and_b64 exec, exec, vcc\n\t"
         "s_cbranch_execz 9f\n\t"
         "s_mov_b64 %[act], exec\n\t"
@@ -412,7 +412,7 @@ __device__ __forceinline__ uint64_t visited_claim_mask_quotient(uint32_t lds_bas
         : [fresh] "=&s"(fresh), [act] "=&s"(act), [sv] "=&s"(sv), [ovf] "=&s"(ovf), [mulc] "=&s"(mulc), [t0] "=&v"(t0), [t1] "=&v"(t1),
           [t2] "=&v"(t2), [addr] "=&v"(addr)
         : [id] "v"(id), [valid] "s"(valid), [end] "s"(end), [basev] "v"(basev), [shr] "s"(ctl), [nb] "s"(nbuckets)
-        : "vcc", "scc", "memory", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+        : "vcc", "scc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
     overflowed = ovf;
     return fresh;
 }

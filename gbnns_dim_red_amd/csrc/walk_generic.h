@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void walk_bitmap_kernel(WalkParams p) {
 // AUX: the auxiliary-graph walk (search_function.h:73-89): a hop expands the node's auxiliary row first (while
 // hops < hops_bound), then -- unless llf and that step inserted something -- its main row.
 // BITMAP: visited set = one bit per node in HBM (`bitmap`, this wavefront's slot), see walk_bitmap_kernel.
-template <int METRIC, int STEPS, bool OFF32, int R, bool ONE_CHUNK = false, bool AUX = false, bool BITMAP = false>
+template <int METRIC, int STEPS, bool OFF32, int R, bool ONE_CHUNK = false, bool AUX = false, bool BITMAP = false, bool QLDS_W = false>
 __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                              uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
     static_assert(!(AUX && ONE_CHUNK), "auxiliary rows have their own length");
@@ -211,8 +211,12 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
 
     // the query stays in registers (every lane holds all of it): the occupancy scan shows the walk is
     // issue-bound from ~14 wavefronts/CU, so the registers cost nothing and each hop saves 8 LDS reads
-    RowRegs<kQSteps> qreg;
-    if constexpr (kEarlyLoad) {
+    // QLDS_W (walk_reg_wide_kernel: 192- / 256-byte rows, ef <= 64, one pass): the lane's query pieces are re-read from the
+    // wavefront's LDS copy every hop, in the shadow of the row loads -- 24 / 32 registers less across the hop
+    constexpr bool kWideQLds = QLDS_W;
+    static_assert(!QLDS_W || (kPair && (STEPS == 12 || STEPS == 16) && R == 1 && !BITMAP), "QLDS_W: pair-form L2 instances over wide rows");
+    RowRegs<kWideQLds ? 0 : kQSteps> qreg;
+    if constexpr (kEarlyLoad && !kWideQLds) {
 #pragma unroll
         for (int t = 0; t < kQSteps; ++t) qreg.v[t] = kAlt ? qs[2 * t + half] : qs[kQSteps * half + t];
     }
@@ -440,6 +444,11 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                     dk = fresh ? kd : 0xFFFFFFFFu;
                 } else if constexpr (kPair && STEPS == 8) {
                     const uint32_t kd = fkey_sumsq(l2_pair_from_regs(rr, qreg.v));  // all lanes; odd lanes hold distances
+                    dk = fresh ? kd : 0xFFFFFFFFu;
+                } else if constexpr (kPair && kWideQLds) {
+                    const float4* ql = qs + kQSteps * half;
+                    asm volatile("" : "+v"(ql));  // (not hoisted out of the hop loop)
+                    const uint32_t kd = fkey_sumsq(l2_pair_from_regs_wide<kQSteps>(rr, ql));
                     dk = fresh ? kd : 0xFFFFFFFFu;
                 } else if constexpr (kPair) {
                     const uint32_t kd = fkey_sumsq(l2_pair_from_regs_wide<kQSteps>(rr, qreg.v));
@@ -806,6 +815,14 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
     } else {
         walk_reg_one<METRIC, STEPS, OFF32, R, ONE_CHUNK, AUX>(p, walk_query_of(p, blockIdx.x), smem, p.ovf_count, p.ovf_list);
     }
+}
+
+// The reference's deep shape (96 -> 48: 192-byte rows) and 256-byte rows at ef <= 64, compact index, adjacency rows of one pass:
+// the generic hop with the query in LDS, held to GBNNS_WIDE_VGPRS vector registers (6 wavefronts per SIMD instead of 5).
+template <int STEPS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(GBNNS_WIDE_VGPRS))) void walk_reg_wide_kernel(WalkParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    walk_reg_one<0, STEPS, true, 1, true, false, false, true>(p, walk_query_of(p, blockIdx.x), smem, p.ovf_count, p.ovf_list);
 }
 
 // First pass with HBM visited bitmaps on register lists (128-byte rows, L2 or dot): persistent wavefronts.

@@ -39,8 +39,12 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
         if constexpr ((METRIC == 0 || METRIC == 1) && STEPS == 8) {
             if (!retry && walk_uses_hot(p, METRIC)) return launch_walk_hot(p, METRIC, s);  // (walk_hot.hip: the hand-laid-out hop)
         }
-        if (off32 && !retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16) && METRIC == 0)) ? 32u : 64u))  // pair form: 32 slots per pass
+        if (off32 && !retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16) && METRIC == 0)) ? 32u : 64u)) {  // pair form: 32 slots per pass
+            if constexpr (METRIC == 0 && (STEPS == 12 || STEPS == 16)) {
+                if (!p.stamps_on) return launch_walk_k(walk_reg_wide_kernel<STEPS>, p, false, lds, s);
+            }
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
+        }
     }
     if constexpr (R == 2 && (METRIC == 0 || METRIC == 1) && STEPS == 8) {
         // the hot shape, 64 < ef <= 128: two list registers (measured: 0.85 ms against 0.93 ms with the two-list structure)

@@ -43,6 +43,9 @@ __device__ __forceinline__ uint64_t clear_bit64(uint64_t m, int bit) {  // wave-
 // GBNNS_HOT1_PF2_IN_MERGE = 1: the second prefetch's closest survivor comes out of the merge's rank loop (one scalar minimum per
 // survivor) instead of a DPP butterfly in front of the merge -- 20 instructions per hop less, and the prefetch ~60
 // instructions later: measured 1 - 2 % SLOWER on the SIFT / GloVe shapes at ef = 36 / 64 (profiles/r04_ab.txt), so off.
+#ifndef GBNNS_WIDE_VGPRS
+#define GBNNS_WIDE_VGPRS 80  // walk_reg_wide_kernel's vector-register budget
+#endif
 #ifndef GBNNS_HOT1_PF2_IN_MERGE
 #define GBNNS_HOT1_PF2_IN_MERGE 0
 #endif
@@ -141,7 +144,7 @@ __device__ __forceinline__ float l2_from_regs8(const RowRegs<8>& r, QP qs) {
 // Why: a lane that streams a whole 128-B row alone costs the CU's vector-memory path one cache-line
 // access per 16-B load; two lanes per row halve that (tools/ubench/gather_cost.hip: 36 -> 51 G rows/s
 // at ~16 rows per instruction), and the walk was bound by exactly that path.
-// Uses v[88:95] as scratch (contiguous pairs are needed for the packed sums).
+// Uses v[64:71] as scratch (contiguous pairs are needed for the packed sums).
 #define GBNNS_P_SUB(T)                                                                  \
     "v_pk_add_f32 %[pa" #T "], %[a" #T "], %[qa" #T "] neg_lo:[0,1] neg_hi:[0,1]\n\t" \
     "v_pk_add_f32 %[pb" #T "], %[b" #T "], %[qb" #T "] neg_lo:[0,1] neg_hi:[0,1]\n\t"
@@ -149,8 +152,8 @@ __device__ __forceinline__ float l2_from_regs8(const RowRegs<8>& r, QP qs) {
     "v_pk_mul_f32 %[pa" #T "], %[pa" #T "], %[pa" #T "]\n\t" \
     "v_pk_mul_f32 %[pb" #T "], %[pb" #T "], %[pb" #T "]\n\t"
 #define GBNNS_P_ACC(T)                                         \
-    "v_pk_add_f32 v[88:89], v[88:89], %[pa" #T "]\n\t"      \
-    "v_pk_add_f32 v[90:91], v[90:91], %[pb" #T "]\n\t"
+    "v_pk_add_f32 v[64:65], v[64:65], %[pa" #T "]\n\t"      \
+    "v_pk_add_f32 v[66:67], v[66:67], %[pb" #T "]\n\t"
 template <typename QP>
 __device__ __forceinline__ float l2_pair_from_regs(const RowRegs<4>& r, QP qh) {
     f32x2 pa0, pb0, pa1, pb1, pa2, pb2, pa3, pb3;  // squared differences of this lane's four steps
@@ -159,25 +162,25 @@ __device__ __forceinline__ float l2_pair_from_regs(const RowRegs<4>& r, QP qh) {
     [a##T] "v"(f32x2{r.v[T].x, r.v[T].y}), [b##T] "v"(f32x2{r.v[T].z, r.v[T].w}),                \
     [qa##T] "v"(f32x2{qh[T].x, qh[T].y}), [qb##T] "v"(f32x2{qh[T].z, qh[T].w})
     asm(GBNNS_P_SUB(0) GBNNS_P_SUB(1) GBNNS_P_MUL(0) GBNNS_P_MUL(1) GBNNS_P_SUB(2) GBNNS_P_SUB(3) GBNNS_P_MUL(2) GBNNS_P_MUL(3)
-        "v_pk_add_f32 v[92:93], %[pa0], %[pa1]\n\t"      // even lane: steps 0..3 (0 + e*e == e*e)
-        "v_pk_add_f32 v[94:95], %[pb0], %[pb1]\n\t"
-        "v_pk_add_f32 v[92:93], v[92:93], %[pa2]\n\t"
-        "v_pk_add_f32 v[94:95], v[94:95], %[pb2]\n\t"
-        "v_pk_add_f32 v[92:93], v[92:93], %[pa3]\n\t"
-        "v_pk_add_f32 v[94:95], v[94:95], %[pb3]\n\t"
+        "v_pk_add_f32 v[68:69], %[pa0], %[pa1]\n\t"      // even lane: steps 0..3 (0 + e*e == e*e)
+        "v_pk_add_f32 v[70:71], %[pb0], %[pb1]\n\t"
+        "v_pk_add_f32 v[68:69], v[68:69], %[pa2]\n\t"
+        "v_pk_add_f32 v[70:71], v[70:71], %[pb2]\n\t"
+        "v_pk_add_f32 v[68:69], v[68:69], %[pa3]\n\t"
+        "v_pk_add_f32 v[70:71], v[70:71], %[pb3]\n\t"
         "s_nop 1\n\t"                                    // VALU write -> DPP read of the same register
-        "v_mov_b32_dpp v88, v92 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v89, v93 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v90, v94 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
-        "v_mov_b32_dpp v91, v95 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v64, v68 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v65, v69 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v66, v70 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp v67, v71 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
         GBNNS_P_ACC(0) GBNNS_P_ACC(1) GBNNS_P_ACC(2) GBNNS_P_ACC(3)   // odd lane: steps 4..7 on top
-        "v_add_f32 %[d], v88, v89\n\t"
-        "v_add_f32 %[d], %[d], v90\n\t"
-        "v_add_f32 %[d], %[d], v91"
+        "v_add_f32 %[d], v64, v65\n\t"
+        "v_add_f32 %[d], %[d], v66\n\t"
+        "v_add_f32 %[d], %[d], v67"
         : [d] "=&v"(d), [pa0] "=&v"(pa0), [pb0] "=&v"(pb0), [pa1] "=&v"(pa1), [pb1] "=&v"(pb1), [pa2] "=&v"(pa2),
           [pb2] "=&v"(pb2), [pa3] "=&v"(pa3), [pb3] "=&v"(pb3)
         : GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
-        : "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+        : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71");
 #undef GBNNS_Q
     return d;
 }

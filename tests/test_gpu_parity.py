@@ -1284,7 +1284,7 @@ def test_two_list_kernels_by_name(g, orc):
     """128 < ef <= 1024 runs on the two-list kernels (sorted base list in LDS + front list in a register) whatever the
     row length and metric; the library reports the first-pass kernel it launched (gbnns_profile.walk_kernel), so the
     test checks WHICH kernel produced the bit-exact answer: hot instance (L2, 128-byte rows), generic pair form for the
-    dot metric, pair form for 256-byte rows, one lane per row for 192-byte rows, the HBM-bitmap variants, and the
+    dot metric, pair form for 192- / 256-byte rows (ef <= 64: walk_reg_wide_kernel), the HBM-bitmap variants, and the
     two-register kernels below the crossover."""
     shapes = [  # d, d_low, d_hidden, metric, max degree, [(ef, flags, expected kernel-name prefix)]
         (64, 32, 64, 0, 30, [(8, 0, "walk_hot_kernel"), (64, 0, "walk_hot_kernel"),
@@ -1298,9 +1298,11 @@ def test_two_list_kernels_by_name(g, orc):
         (64, 32, 64, 1, 60, [(64, 0, "walk_hot_dot_kernel<1, true>"), (100, 0, "walk_hot_dot_kernel<2, true>"),
                              (300, 0, "walk_hot_dot_big_kernel<true>")]),
         (64, 32, 64, 1, 90, [(64, 0, "walk_reg_kernel<1, 8,"), (200, 0, "walk_reg_big_kernel<1, 8,")]),  # > 64 slots: generic
-        (128, 64, 128, 0, 30, [(64, 0, "walk_reg_kernel<0, 16,"), (200, 0, "walk_reg_big_kernel<0, 16,"),
+        (128, 64, 128, 0, 30, [(64, 0, "walk_reg_wide_kernel<16>"), (200, 0, "walk_reg_big_kernel<0, 16,"),
                                (1000, 0, "walk_reg_big_kernel<0, 16,"), (600, "bitmap", "walk_bitmap_big_kernel<0, 16,")]),
-        (96, 48, 64, 0, 30, [(200, 0, "walk_reg_big_kernel<0, 12,")]),
+        # (the reference's deep shape, 96 -> 48: ef <= 64 on the instance with the query in LDS, 6 wavefronts per SIMD)
+        (96, 48, 64, 0, 30, [(8, 0, "walk_reg_wide_kernel<12>"), (40, 0, "walk_reg_wide_kernel<12>"), (100, 0, "walk_reg_kernel<0, 12,"),
+                             (200, 0, "walk_reg_big_kernel<0, 12,")]),
         (64, 32, 64, 0, 70, [(300, 0, "walk_reg_big_kernel<0, 8,")]),  # adjacency rows of more than 64 slots: generic kernel
         # adjacency rows of 33 .. 64 slots (hnswlib M = 18 / 20 level-0 lists, prepare_graph.cpp's M = 30): the hot
         # instances with a second expansion pass

@@ -146,7 +146,9 @@ def test_hot_kernel_register_budgets(tmp_path):
                # the instances for adjacency rows of 33 .. 64 slots (second expansion pass)
                ("16walk_hotw_kernelE", 64, 80), ("17walk_hotw2_kernelE", 72, 112), ("20walk_hotw_big_kernelE", 96, 112),
                # the negative-dot metric on the same shapes
-               ("19walk_hot_dot_kernelILi1E", 64, 80), ("19walk_hot_dot_kernelILi2E", 72, 112), ("23walk_hot_dot_big_kernelI", 96, 112)]
+               ("19walk_hot_dot_kernelILi1E", 64, 80), ("19walk_hot_dot_kernelILi2E", 72, 112), ("23walk_hot_dot_big_kernelI", 96, 112),
+               # the generic hop over 192-byte rows at ef <= 64 (the reference's deep 96 -> 48 shape): query in LDS, 6 wavefronts per SIMD
+               ("20walk_reg_wide_kernelILi12E", 80, 96)]
     for sub, cap, scap in budgets:
         hits = {k: v for k, v in meta.items() if sub in k}
         assert hits, sub
