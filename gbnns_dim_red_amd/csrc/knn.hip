@@ -418,15 +418,10 @@ __global__ __launch_bounds__(256) void knn_pack_kernel(const float* x, uint32_t 
 // v_max3 and one compare per tile beside its six matrix instructions.
 template <int KSTEPS, int QB>
 __global__ __launch_bounds__(256) void knn_filter_kernel(KnnFilterParams p) {
-    // LDS: two tiles of 32 packed rows (row pitch = the row's 64 KSTEPS bytes + 16: a wavefront's 16-byte reads of 32
-    // different rows then spread over all banks) + their 32 norms each
-    constexpr uint32_t kRowBytes = 64u * KSTEPS, kPitch = kRowBytes + 16u, kTile = 32u * kPitch + 128u;
-    constexpr uint32_t kPieces = 32u * kRowBytes / 16u;   // 16-byte pieces of a tile's rows (128 KSTEPS)
-    constexpr uint32_t kPer = (kPieces + 255u) / 256u;    // ... per thread (KSTEPS = 1: half the threads load one)
-    __shared__ __attribute__((aligned(16))) unsigned char tiles[2 * kTile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t r = lane & 31, h = lane >> 5;
-    const uint32_t q0 = (blockIdx.x * 4u + wave) * (QB * 32u);  // (a wavefront beyond the batch stays for the barriers: rhs = +inf, no hits)
+    const uint32_t q0 = (blockIdx.x * 4u + wave) * (QB * 32u);
+    if (q0 >= p.nq) return;
     const uint32_t groups = p.dp >> 3;  // 8-dim groups per row = 2 KSTEPS
     // B fragments: query q0 + 32 b + r, k = 16 s + 8 h .. + 7 -> group 2 s + h: hi at halfword 16 (2 s + h), lo 8 further
     bf16x8 qh[QB][KSTEPS], ql[QB][KSTEPS];
@@ -444,58 +439,56 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(KnnFilterParams p) {
         }
         rhs[b] = ok ? p.rhs[qi] : __builtin_inff();  // (a query beyond the batch keeps nothing)
     }
+    // (every compiler-issued load is used here, once: its waits then sit in this prologue and not inside the sweep)
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        asm volatile("" ::"v"(rhs[b]));
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(qh[b][s]), "v"(ql[b][s]));
+    }
     const uint32_t blocks = (p.rows + 31u) >> 5;
     const uint32_t per = (blocks + gridDim.y - 1) / gridDim.y;
     const uint32_t b_lo = blockIdx.y * per, b_hi = min(blocks, b_lo + per);
-    if (b_lo >= b_hi) return;  // (the whole workgroup)
+    if (b_lo >= b_hi) return;
     const float scale = -0.5f * (1.0f - kKnnFilterSlack);
-    // A block of 32 rows goes global -> registers -> LDS ONCE per workgroup (round 4, second half: before, each of the four
-    // wavefronts fetched every block for itself -- the matrix pipe waited 1.8 us per block for the L2 and was busy 0.38 of
-    // its cycles): thread t carries pieces t, t + 256, ... of the block's 32 kRowBytes packed bytes (rows beyond the chunk
-    // read row 0; the chunk starts on a multiple of 64 rows and the norms' array is readable, +inf, 64 entries beyond the
-    // set), threads 0 .. 7 also the norms.  Requested at the top of an iteration, stored behind its products.
-    uint4 stage[kPer];
-    float4 nstage = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto request_block = [&](uint32_t rb) {
+    // Fragments and norms of one block of 32 rows (rows beyond the chunk read row 0), requested by hand-written loads: the
+    // compiler's own bookkeeping put a full wait (vmcnt(0)) BEHIND the next block's requests -- no overlap at all --
+    // whatever the order in the source; these requests are invisible to it, and `landed` below is the one wait, placed in
+    // front of the next requests.  (No branch here: the norms' array is readable 64 entries beyond the set and +inf
+    // there, and the chunk starts on a multiple of 64 rows; a row of the NEXT chunk that slips through the test is
+    // refused where the hits are stored.)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    auto request_block = [&](uint32_t rb, u32x4 (&xh)[KSTEPS], u32x4 (&xl)[KSTEPS], f32x4v (&nx)[4]) {
+        const uint32_t j = rb * 32u + r;
+        const uint16_t* bp = p.bpack + ((size_t)(j < p.rows ? j : 0u) * groups + h) * 16;
+        const float* np = p.bnorm + rb * 32u + 4u * h;
 #pragma unroll
-        for (uint32_t i = 0; i < kPer; ++i) {
-            const uint32_t piece = threadIdx.x + 256u * i;
-            if (kPieces % 256u == 0u || piece < kPieces) {
-                const uint32_t row = piece / (kRowBytes / 16u), off = piece % (kRowBytes / 16u);
-                const uint32_t j = rb * 32u + row;
-                stage[i] = *reinterpret_cast<const uint4*>(p.bpack + (size_t)(j < p.rows ? j : 0u) * groups * 16 + off * 8u);
-            }
+        for (int s = 0; s < KSTEPS; ++s) {  // group 2 s + h: 64 bytes per K step further on
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xh[s]) : "v"(bp + 32 * s));
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(xl[s]) : "v"(bp + 32 * s));
         }
-        if (threadIdx.x < 8u) nstage = *reinterpret_cast<const float4*>(p.bnorm + rb * 32u + 4u * threadIdx.x);
-    };
-    auto store_block = [&](uint32_t buf) {
-        unsigned char* t = tiles + buf * kTile;
 #pragma unroll
-        for (uint32_t i = 0; i < kPer; ++i) {
-            const uint32_t piece = threadIdx.x + 256u * i;
-            if (kPieces % 256u == 0u || piece < kPieces) {
-                const uint32_t row = piece / (kRowBytes / 16u), off = piece % (kRowBytes / 16u);
-                *reinterpret_cast<uint4*>(t + row * kPitch + off * 16u) = stage[i];
-            }
-        }
-        if (threadIdx.x < 8u) *reinterpret_cast<float4*>(t + 32u * kPitch + 16u * threadIdx.x) = nstage;
+        for (int g = 0; g < 4; ++g)  // accumulator registers 4 g .. 4 g + 3 = rows 8 g + 4 h + 0 .. 3 of the block
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nx[g]) : "v"(np + 8 * g));
     };
-    // the products and the test of one block of rows (LDS tile `buf`) against the QB query blocks
-    auto sweep_block = [&](uint32_t rb, uint32_t buf) {
-        const unsigned char* t = tiles + buf * kTile;
+    auto landed = [&](u32x4 (&xh)[KSTEPS], u32x4 (&xl)[KSTEPS], f32x4v (&nx)[4]) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nx[0]));
+#pragma unroll
+        for (int g = 1; g < 4; ++g) asm volatile("" : "+v"(nx[g]));
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) asm volatile("" : "+v"(xh[s]), "+v"(xl[s]));
+    };
+    // the products and the test of one block of rows against the QB query blocks
+    auto sweep_block = [&](uint32_t rb, const u32x4 (&xhr)[KSTEPS], const u32x4 (&xlr)[KSTEPS], const f32x4v (&nx)[4]) {
         bf16x8 xh[KSTEPS], xl[KSTEPS];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {  // row r, group 2 s + h: hi then lo
-            const uint4* src = reinterpret_cast<const uint4*>(t + r * kPitch + (2u * s + h) * 32u);
-            xh[s] = __builtin_bit_cast(bf16x8, src[0]);
-            xl[s] = __builtin_bit_cast(bf16x8, src[1]);
-        }
+        for (int s = 0; s < KSTEPS; ++s) { xh[s] = __builtin_bit_cast(bf16x8, xhr[s]); xl[s] = __builtin_bit_cast(bf16x8, xlr[s]); }
         f32x16 cinit;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // accumulator registers 4 g .. 4 g + 3 = rows 8 g + 4 h + 0 .. 3 of the block
-            const float4 nx = *reinterpret_cast<const float4*>(t + 32u * kPitch + (8u * g + 4u * h) * 4u);
-            cinit[4 * g + 0] = scale * nx.x; cinit[4 * g + 1] = scale * nx.y;
-            cinit[4 * g + 2] = scale * nx.z; cinit[4 * g + 3] = scale * nx.w;
+        for (int g = 0; g < 4; ++g) {
+            cinit[4 * g + 0] = scale * nx[g].x; cinit[4 * g + 1] = scale * nx[g].y;
+            cinit[4 * g + 2] = scale * nx[g].z; cinit[4 * g + 3] = scale * nx[g].w;
         }
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
@@ -536,16 +529,19 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(KnnFilterParams p) {
             }
         }
     };
-    request_block(b_lo);
-    store_block(0u);
-    __syncthreads();
-    for (uint32_t rb = b_lo; rb < b_hi; ++rb) {
-        const uint32_t buf = (rb - b_lo) & 1u;
-        const bool more = rb + 1u < b_hi;
-        if (more) request_block(rb + 1u);
-        sweep_block(rb, buf);
-        if (more) store_block(buf ^ 1u);
-        __syncthreads();  // tile buf ^ 1 complete; every wavefront is done with tile buf (rewritten next iteration)
+    // two register sets in turn: wait for the set at hand, request the next block into the other one, sweep
+    u32x4 xh0[KSTEPS], xl0[KSTEPS], xh1[KSTEPS], xl1[KSTEPS];
+    f32x4v nx0[4], nx1[4];
+    request_block(b_lo, xh0, xl0, nx0);
+    for (uint32_t rb = b_lo;;) {
+        landed(xh0, xl0, nx0);
+        if (rb + 1u < b_hi) request_block(rb + 1u, xh1, xl1, nx1);
+        sweep_block(rb, xh0, xl0, nx0);
+        if (++rb >= b_hi) break;
+        landed(xh1, xl1, nx1);
+        if (rb + 1u < b_hi) request_block(rb + 1u, xh0, xl0, nx0);
+        sweep_block(rb, xh1, xl1, nx1);
+        if (++rb >= b_hi) break;
     }
 }
 

@@ -25,6 +25,9 @@ def short(name):
     if "walk_reg_big_kernel" in name:  # walk_reg_big_kernel<METRIC, STEPS, OFF32, RETRY, AUX>
         args = name[name.find("<") + 1:name.rfind(">")].replace(" ", "").split(",")
         return "walk_reg_big_kernel" + ("/retry" if len(args) > 3 and args[3] in ("true", "1") else "")
+    for key in ("walk_hot_spec_kernel", "walk_reg_wide_kernel"):
+        if key in name:
+            return key + (name[name.find("<"):name.find(">") + 1].replace(" ", "") if "<" in name and "wide" in key else "")
     for key in ("walk_hot_dot_big_kernel", "walk_hot_dot_kernel", "walk_hotw_big_kernel", "walk_hotw2_kernel", "walk_hotw_kernel"):
         if key in name:  # the dot-metric and wide-row hot instances (template arguments kept: R, WIDE)
             return key + (name[name.find("<"):name.find(">") + 1].replace(" ", "") if "<" in name and "dot" in key else "")
