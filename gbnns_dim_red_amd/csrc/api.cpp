@@ -331,6 +331,8 @@ std::atomic<int> g_knob_max_waves{knob_env("GBNNS_MAX_WAVES", 0)};
 // "spec_min_nq" = smallest batch whose ef <= 64 first pass requests the rows before the visited test (walk_hot_spec_kernel;
 // GBNNS_SPEC_MIN_NQ; 0 = never)
 std::atomic<int> g_knob_spec_min_nq{knob_env("GBNNS_SPEC_MIN_NQ", 32768)};
+// "spec_any_form" = 1: ... whatever the form of the visited set (tests; default: only tables NOT in the quotient form)
+std::atomic<int> g_knob_spec_any_form{knob_env("GBNNS_SPEC_ANY_FORM", 0)};
 // "knn_pool_min_k" = shortest list gbnns_exact_knn keeps as an unordered pool (one wavefront per query and chunk) instead of a heap
 // (measured on 10^6 x 32: k = 48 0.327 against 0.333 s, k = 100 0.425 against 0.536 s, k = 1 000 2.4 against 7.6 s)
 // "knn_chunk" = most rows per filtered chunk (a multiple of 64)
@@ -883,6 +885,7 @@ int gbnns_debug_knob(const char* name, int value) {
     if (!std::strcmp(name, "quotient")) g_knob_quotient.store(value, std::memory_order_relaxed);
     else if (!std::strcmp(name, "vs_disp")) g_knob_vs_disp.store(value <= 0 ? 15 : value, std::memory_order_relaxed);
     else if (!std::strcmp(name, "max_waves")) g_knob_max_waves.store(std::max(0, std::min(32, value)), std::memory_order_relaxed);
+    else if (!std::strcmp(name, "spec_any_form")) g_knob_spec_any_form.store(value != 0, std::memory_order_relaxed);
     else if (!std::strcmp(name, "spec_min_nq")) g_knob_spec_min_nq.store(std::max(0, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_chunk")) g_knob_knn_chunk.store(std::max(64, value & ~63), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_pool_min_k")) g_knob_knn_pool_min_k.store(std::max(1, value), std::memory_order_relaxed);
@@ -1329,10 +1332,6 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     }
     cap = walk_hash_entries(walk_hash_bytes(cap, form), form);  // whole buckets
     w.vs_shr = 0;
-    {
-        const int spec_min = g_knob_spec_min_nq.load(std::memory_order_relaxed);
-        w.spec_rows = (spec_min > 0 && nq >= (uint32_t)spec_min) ? 1 : 0;
-    }
     if (form == 2) {
         const uint32_t buckets = cap / 7u > kStashBuckets ? cap / 7u - kStashBuckets : 0u;
         uint32_t lg = 0;
@@ -1348,6 +1347,13 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
             const bool r13 = idbits > lg + 12;
             w.vs_shr = (32u - idbits + lg) | (32u - idbits) << 8 | (r13 ? 1u << 16 | std::min(disp, 7u) << 29 : disp << 28);
         }
+    }
+    {
+        // Big batches over an index too large for the quotient form (DEEP10M: 24-bit ids) request a hop's rows before its
+        // visited test (walk_hot_spec_kernel: 21.6 against 23.1 ms per 1 M-query launch); with the quotient form testing
+        // first wins at every batch size (SIFT-shaped 65 536-query launch 0.90 against 0.79 of the peak).  DESIGN.md 5.1.
+        const int spec_min = g_knob_spec_min_nq.load(std::memory_order_relaxed);
+        w.spec_rows = (spec_min > 0 && nq >= (uint32_t)spec_min && (w.vs_shr == 0 || g_knob_spec_any_form.load(std::memory_order_relaxed))) ? 1 : 0;
     }
     w.hash_cap = cap;
     w.hash_limit = cap - cap / 16;

@@ -259,7 +259,8 @@ int gbnns_profile_enable(gbnns_index* index, int on);
  * up and the id goes to the stash / the query is handed over, 1 .. 15 (default 15; <= 0 restores it; GBNNS_DEBUG_VS_DISP).
  * "max_waves": most first-pass wavefronts per CU the LDS shares are cut for (0 = default; GBNNS_MAX_WAVES).
  * "spec_min_nq": smallest batch whose ef <= 64 first pass requests a hop's rows before its visited test
- * (walk_hot_spec_kernel; default 32 768, 0 = never; GBNNS_SPEC_MIN_NQ).
+ * (walk_hot_spec_kernel; default 32 768, 0 = never; GBNNS_SPEC_MIN_NQ) -- on indexes whose visited sets are not in the
+ * quotient form (more than 2^21 rows or so), unless "spec_any_form" is 1 (tests; GBNNS_SPEC_ANY_FORM).
  * "knn_chunk": most base rows per filtered chunk of gbnns_exact_knn (default 32 768; the pool path takes four times that;
  * GBNNS_KNN_CHUNK).
  * "knn_pool_min_k": shortest list gbnns_exact_knn's filter path keeps as an unordered pool with a radix select (one

@@ -1336,11 +1336,14 @@ def test_two_list_kernels_by_name(g, orc):
 
 
 def _knobs(g, quotient=1, vs_disp=15, spec_min_nq=32768):
-    """The process-wide diagnostic knobs of the library (include/gbnns.h, gbnns_debug_knob), back to their defaults unless named."""
+    """The process-wide diagnostic knobs of the library (include/gbnns.h, gbnns_debug_knob), back to their defaults unless named.
+    (A lowered spec_min_nq means "the speculative instance, whatever the table's form": by default only big batches on
+    indexes beyond the quotient form take it.)"""
     lib = g.load_library()
     assert lib.gbnns_debug_knob(b"quotient", quotient) == 0
     assert lib.gbnns_debug_knob(b"vs_disp", vs_disp) == 0
     assert lib.gbnns_debug_knob(b"spec_min_nq", spec_min_nq) == 0
+    assert lib.gbnns_debug_knob(b"spec_any_form", 1 if spec_min_nq != 32768 else 0) == 0
 
 
 def test_visited_set_forms_of_the_hot_kernels(g, orc):
