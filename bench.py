@@ -378,6 +378,8 @@ def main():
     nstep = 0
     est = max((time.perf_counter() - ts) / 4, 1e-5)
     n_settle = int(min(500, max(0, round(args.settle_ms * 1e-3 / est))))
+    if args.settle_ms > 0 and nq_rank <= 20_000:
+        n_settle = max(n_settle, 120)  # (the four steps of the estimate are themselves slow ones)
     if world > 1:
         tn = torch.tensor([n_settle], dtype=torch.int64, device=dev)
         dist.all_reduce(tn, op=dist.ReduceOp.MAX)
