@@ -335,6 +335,8 @@ std::atomic<int> g_knob_spec_min_nq{knob_env("GBNNS_SPEC_MIN_NQ", 32768)};
 std::atomic<int> g_knob_spec_any_form{knob_env("GBNNS_SPEC_ANY_FORM", 0)};
 // "knn_pool_min_k" = shortest list gbnns_exact_knn keeps as an unordered pool (one wavefront per query and chunk) instead of a heap
 // (measured on 10^6 x 32: k = 48 0.327 against 0.333 s, k = 100 0.425 against 0.536 s, k = 1 000 2.4 against 7.6 s)
+// "mlp_small" = smallest batch IN FLIGHT whose hidden projection layers run on the small-footprint kernel (0 = never)
+std::atomic<int> g_knob_mlp_small{knob_env("GBNNS_MLP_SMALL", 4096)};
 // "knn_chunk" = most rows per filtered chunk (a multiple of 64)
 std::atomic<int> g_knob_knn_chunk{knob_env("GBNNS_KNN_CHUNK", 1 << 15)};
 std::atomic<int> g_knob_knn_pool_min_k{knob_env("GBNNS_KNN_POOL_MIN_K", 64)};
@@ -799,13 +801,18 @@ namespace {
 
 // MLP over rows x [nx x xstride] (device) -> out [nx x dl_pad] (device); h1/h2 are scratch.
 int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint32_t nx, float* out,
-                hipStream_t s) {
+                hipStream_t s, bool in_flight = false) {
     // (a one-launch form of the whole net existed through round 3 -- csrc/project.hip, GBNNS_FUSED_MLP=1: 0.084 ms against
     // 0.071 ms for the three per-layer launches on the SIFT shape, off by default and untested; deleted in round 4)
     int rc = L.h1.ensure((size_t)nx * ix->d_hidden * 4);
     if (!rc) rc = L.h2.ensure((size_t)nx * ix->d_hidden * 4);
     if (rc) return rc;
     LayerParams p{};
+    // batches in flight whose walks fill the machine: the small-footprint kernel for the hidden layers (mlp.hip; sift-like
+    // +2.5 % at ef 64, +3.6 % at ef 36; a 1 000-query GIST batch -- one walk wavefront per SIMD, nothing to squeeze in
+    // beside -- and every batch that runs alone are faster on the big-tile kernel)
+    const int small_min = g_knob_mlp_small.load(std::memory_order_relaxed);
+    p.small_footprint = (in_flight && small_min > 0 && nx >= (uint32_t)small_min) ? 1 : 0;
     p.x = x; p.xstride = xstride; p.w = ix->w1; p.wstride = ix->ws1; p.bias = ix->b1;
     p.out = L.h1.as<float>(); p.ostride = ix->d_hidden; p.nq = nx; p.din = ix->d;
     p.dout = ix->d_hidden; p.relu = 1;
@@ -887,6 +894,7 @@ int gbnns_debug_knob(const char* name, int value) {
     else if (!std::strcmp(name, "max_waves")) g_knob_max_waves.store(std::max(0, std::min(32, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "spec_any_form")) g_knob_spec_any_form.store(value != 0, std::memory_order_relaxed);
     else if (!std::strcmp(name, "spec_min_nq")) g_knob_spec_min_nq.store(std::max(0, value), std::memory_order_relaxed);
+    else if (!std::strcmp(name, "mlp_small")) g_knob_mlp_small.store(std::max(0, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_chunk")) g_knob_knn_chunk.store(std::max(64, value & ~63), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_pool_min_k")) g_knob_knn_pool_min_k.store(std::max(1, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_filter")) g_knob_knn_filter.store(value, std::memory_order_relaxed);
@@ -1160,7 +1168,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         if ((rc = L.q_low.ensure((size_t)nq * ix->dl_pad * 4))) return rc;
         float* ql = L.q_low.as<float>();
         if (a->mode == GBNNS_MODE_NET) {
-            if ((rc = run_project(ix, L, q_dev, ix->d, nq, ql, s))) return rc;
+            if ((rc = run_project(ix, L, q_dev, ix->d, nq, ql, s, s == L.stream && L.stream != nullptr))) return rc;
             w.q = ql; w.qstride = ix->dl_pad;
         } else if (host) {
             HIP_TRY(hipMemcpyAsync(ql, a->queries_low, (size_t)nq * ix->d_low * 4, hipMemcpyHostToDevice, s));

@@ -138,6 +138,7 @@ struct LayerParams {
     uint32_t nq, din, dout;
     int32_t relu;
     int32_t normalize;       // 1: follow the layer by normalizeVector over its dout outputs (fused when dout <= 64)
+    int32_t small_footprint; // 1: hidden layers on the 60-register / 9 KB kernel (batches in flight: its blocks fit beside walk wavefronts)
 };
 hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s);
 // y [nq x stride]: y /= sqrt(L2(y, 0)) over dim (4-lane order, d%4 tail ignored in the norm),

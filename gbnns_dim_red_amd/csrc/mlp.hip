@@ -278,6 +278,110 @@ __global__ __launch_bounds__(256, GBNNS_MLP_WAVES) void mlp_layer_vec_kernel(Lay
     }
 }
 
+// Hidden layers of batches IN FLIGHT (round 4; LayerParams::small_footprint): lane = query, the wavefront's four neurons are
+// wave-uniform, so their weights come through SCALAR loads (s_load_dwordx8, read through the constant address space) and
+// are the scalar source of the packed multiplies; LDS only carries the x tile (64 queries x 32 k, one 32-byte read per
+// lane and k step).  60 vector registers and 9 KB of LDS per block instead of 162 and 14 KB: its blocks find room beside
+// the walk wavefronts of the batch before, which mlp_layer_vec_kernel's do not.  Alone it is the SLOWER
+// kernel (0.080 against 0.070 ms per 10 000 x 128 -> 256 -> 256 -> 32 projection: scalar loads that miss the 16 KB K$ take
+// long and cannot be pipelined inside a wavefront -- they return out of order, every wait is lgkmcnt(0); two queries per
+// lane made it 0.128 ms), so a batch that runs alone keeps the kernel above.  Same arithmetic: eight running sums per
+// (query, neuron) over k mod 8, the folds and the tail rules of the kernel above, bit for bit.
+// Block = 4 wavefronts = 64 queries x 16 neurons (wavefront w: neurons 4 w .. 4 w + 3 of the block's 16).
+constexpr int kSwQ = 64, kSwO = 16;
+template <bool RELU>
+__global__ __launch_bounds__(256) void mlp_layer_sw_kernel(LayerParams p) {
+    __shared__ __attribute__((aligned(16))) float xs[kSwQ * kLd];
+    const int t = threadIdx.x, lane = t & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t qbase = blockIdx.x * kSwQ;
+    const uint32_t obase = blockIdx.y * kSwO + 4u * wave;
+    const uint32_t kmain = (p.din >> 3) << 3;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // staging role: float4 number t and t + 256 of the 64 x 32 tile (row = number / 8)
+    const int r0 = t >> 3, r1 = r0 + 32, sc4 = (t & 7) * 4;
+    auto fetch = [&](uint32_t k0, float4& f0, float4& f1) {
+        const bool kin = k0 + sc4 < kmain;
+        f0 = (kin && qbase + r0 < p.nq) ? *reinterpret_cast<const float4*>(p.x + (size_t)(qbase + r0) * p.xstride + k0 + sc4) : zero4;
+        f1 = (kin && qbase + r1 < p.nq) ? *reinterpret_cast<const float4*>(p.x + (size_t)(qbase + r1) * p.xstride + k0 + sc4) : zero4;
+    };
+    // the wavefront's four weight rows (neurons beyond dout read the last row: their results are dropped)
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    cfloat_p wr[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const uint32_t og = obase + o < p.dout ? obase + o : p.dout - 1u;
+        wr[o] = (cfloat_p)(uintptr_t)(p.w + (size_t)og * p.wstride);
+    }
+    float acc[4][8];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[o][l] = 0.f;
+
+    float4 f0, f1;
+    fetch(0, f0, f1);
+    for (uint32_t k0 = 0; k0 < kmain; k0 += kKC) {
+        const uint32_t kc = (kmain - k0 < (uint32_t)kKC) ? (kmain - k0) : (uint32_t)kKC;
+        *reinterpret_cast<float4*>(&xs[r0 * kLd + sc4]) = f0;
+        *reinterpret_cast<float4*>(&xs[r1 * kLd + sc4]) = f1;
+        __syncthreads();
+        if (k0 + kKC < kmain) fetch(k0 + kKC, f0, f1);  // in flight during the compute below
+        for (uint32_t s = 0; s < kc; s += 8) {
+            const float4* xp = reinterpret_cast<const float4*>(&xs[lane * kLd + s]);
+            const float4 xa = xp[0], xb = xp[1];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                cfloat_p w = wr[o] + k0 + s;  // wave-uniform address: scalar loads
+                acc[o][0] = acc[o][0] + w[0] * xa.x;
+                acc[o][1] = acc[o][1] + w[1] * xa.y;
+                acc[o][2] = acc[o][2] + w[2] * xa.z;
+                acc[o][3] = acc[o][3] + w[3] * xa.w;
+                acc[o][4] = acc[o][4] + w[4] * xb.x;
+                acc[o][5] = acc[o][5] + w[5] * xb.y;
+                acc[o][6] = acc[o][6] + w[6] * xb.z;
+                acc[o][7] = acc[o][7] + w[7] * xb.w;
+            }
+        }
+        __syncthreads();
+    }
+
+    const uint32_t rem8 = p.din & 7;
+    const uint32_t qg = qbase + lane;
+    if (qg >= p.nq) return;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const uint32_t og = obase + o;
+        if (og >= p.dout) continue;
+        float m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = acc[o][j + 4] + acc[o][j];
+        uint32_t kk = kmain, rem = rem8;
+        const float* xr = p.x + (size_t)qg * p.xstride;
+        const float* wt = p.w + (size_t)og * p.wstride;
+        if (rem >= 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = m[j] + wt[kk + j] * xr[kk + j];
+            kk += 4;
+            rem -= 4;
+        }
+        if (rem > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xv = ((uint32_t)j < rem) ? xr[kk + j] : 0.f;
+                const float wv = ((uint32_t)j < rem) ? wt[kk + j] : 0.f;
+                m[j] = m[j] + wv * xv;
+            }
+        }
+        const float dist = -((m[0] + m[1]) + (m[2] + m[3]));  // Angular::Dist
+        float v = 0.f;
+        v = v - dist;               // support_func.h:627
+        v = v + p.bias[og];         // :628
+        if (RELU && v < 0.f) v = 0.f;  // :629-631
+        p.out[(size_t)qg * p.ostride + og] = v;
+    }
+}
+
 // Narrow layers (dout <= 32, din <= 256: the last projection layer): the chunked kernels above spend
 // their time waiting -- eight dependent chunk round trips for two microseconds of arithmetic.  Here a
 // block stages its whole x tile [32 queries x din] and W tile [32 neurons x din] in one go (all loads in
@@ -469,7 +573,11 @@ hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s) {
         else hipLaunchKernelGGL((mlp_layer_kernel<false, true>), grid, dim3(256), 0, s, p);
         return hipGetLastError();
     }
-    if (aligned) {
+    if (aligned && p.small_footprint && !p.normalize && p.dout >= 64u) {
+        const dim3 gsw((p.nq + kSwQ - 1) / kSwQ, (p.dout + kSwO - 1) / kSwO);
+        if (p.relu) hipLaunchKernelGGL((mlp_layer_sw_kernel<true>), gsw, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((mlp_layer_sw_kernel<false>), gsw, dim3(256), 0, s, p);
+    } else if (aligned) {
         if (p.relu) hipLaunchKernelGGL((mlp_layer_vec_kernel<true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((mlp_layer_vec_kernel<false>), grid, dim3(256), 0, s, p);
     } else {

@@ -407,6 +407,36 @@ def test_one_handle_on_alternating_streams(g, orc):
     ix.close()
 
 
+def test_projection_of_batches_in_flight_small_footprint_kernel(g, orc):
+    """Batches in flight of >= 4 096 queries run their hidden projection layers on mlp_layer_sw_kernel (weights through scalar
+    loads, 60 registers: its blocks fit beside the walk wavefronts of the batch before; csrc/mlp.hip).  Same arithmetic as
+    the big-tile kernel: q_low bit patterns and answers of deferred calls equal the oracle's for input widths with every
+    tail rule (d % 8 = 0 / 4, a hidden width that is no multiple of the block's 16 neurons), batch sizes that are no
+    multiple of the block's 64 queries, with the kernel forced onto small batches (knob "mlp_small") and at its default
+    threshold."""
+    import torch
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lib = g.load_library()
+    try:
+        for si, (d, dh, nq, small) in enumerate(((40, 64, 1000, 1), (44, 72, 777, 1), (132, 136, 300, 1), (64, 64, 4500, 4096))):
+            assert lib.gbnns_debug_knob(b"mlp_small", small) == 0
+            c, off, nbr, db_low, ent = _oracle_case(orc, 8700 + si, 8000, nq, d, 32, dh)
+            want_q = orc.project(c.net, c.queries)
+            sref = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, 48, db_low=db_low, net=c.net, entries=ent, threads=8)
+            ix = g.Index(t(c.base), off, nbr, db_low=t(db_low), net=tuple(t(x) for x in c.net))
+            q, e = t(c.queries), t(ent.astype(np.int32))
+            outs = [ix.search(q, 48, entry_ids=e, want=("q_low",), out={}, flags=g.FLAG_DEFER_JOIN, defer_depth=3) for _ in range(4)]
+            ix.join()
+            torch.cuda.synchronize()
+            for r in outs:
+                assert np.array_equal(gu.bits(r["q_low"].cpu().numpy()), gu.bits(want_q)), (d, dh, nq)
+                assert np.array_equal(r["ids"].cpu().numpy().view(np.uint32), sref["ids"]), (d, dh, nq)
+            ix.close()
+    finally:
+        lib.gbnns_debug_knob(b"mlp_small", 4096)
+
+
 def test_deferred_join_pipeline(g, orc):
     """GBNNS_FLAG_DEFER_JOIN (gbnns.h, "Batches in flight"): consecutive batches alternate between the handle's two
     internal streams and the caller's stream waits for batch i only at call i+1 / gbnns_index_join.  A pipelined run of
