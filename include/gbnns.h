@@ -262,7 +262,7 @@ int gbnns_profile_enable(gbnns_index* index, int on);
  * (walk_hot_spec_kernel; default 32 768, 0 = never; GBNNS_SPEC_MIN_NQ) -- on indexes whose visited sets are not in the
  * quotient form (more than 2^21 rows or so), unless "spec_any_form" is 1 (tests; GBNNS_SPEC_ANY_FORM).
  * "mlp_small": smallest batch in flight (GBNNS_FLAG_DEFER_JOIN) whose hidden projection layers run on the small-footprint
- * kernel (mlp_layer_sw_kernel; default 4 096, 0 = never; GBNNS_MLP_SMALL).
+ * kernel (mlp_layer_sw_kernel; default 4 096, up to 32 times that, 0 = never; GBNNS_MLP_SMALL).
  * "knn_chunk": most base rows per filtered chunk of gbnns_exact_knn (default 32 768; the pool path takes four times that;
  * GBNNS_KNN_CHUNK).
  * "knn_pool_min_k": shortest list gbnns_exact_knn's filter path keeps as an unordered pool with a radix select (one
