@@ -203,23 +203,26 @@ __device__ __forceinline__ float dpp_from_even(float x) {
 // the reference.  Same operations in the same order as one lane walking the whole row (support_func.h:107-128).
 template <int H, typename QP>
 __device__ __forceinline__ float l2_pair_from_regs_wide(const RowRegs<H>& r, QP qh) {
-    float4 e[H];
+    // (two-wide vector types: the compiler issues v_pk_add_f32 / v_pk_mul_f32, half the instructions of the scalar form --
+    // on a GIST-shaped batch the hop is one wavefront's instruction chain; same IEEE operations per component, no contraction)
+    f32x2 ea[H], eb[H];
 #pragma unroll
     for (int t = 0; t < H; ++t) {
         const float4 a = r.v[t], b = qh[t];
-        const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
-        e[t] = make_float4(dx * dx, dy * dy, dz * dz, dw * dw);
+        const f32x2 da = f32x2{a.x, a.y} - f32x2{b.x, b.y}, db = f32x2{a.z, a.w} - f32x2{b.z, b.w};
+        ea[t] = da * da;
+        eb[t] = db * db;
     }
-    float4 sa = e[0];
+    f32x2 sa = ea[0], sb = eb[0];
 #pragma unroll
-    for (int t = 1; t < H; ++t) sa = make_float4(sa.x + e[t].x, sa.y + e[t].y, sa.z + e[t].z, sa.w + e[t].w);
+    for (int t = 1; t < H; ++t) { sa = sa + ea[t]; sb = sb + eb[t]; }
     auto from_even = [](float v) {  // lanes 2i and 2i + 1 <- lane 2i   (quad_perm [0, 0, 2, 2])
         return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xA0, 0xf, 0xf, false));
     };
-    float4 sb = make_float4(from_even(sa.x), from_even(sa.y), from_even(sa.z), from_even(sa.w));
+    f32x2 ta = f32x2{from_even(sa.x), from_even(sa.y)}, tb = f32x2{from_even(sb.x), from_even(sb.y)};
 #pragma unroll
-    for (int t = 0; t < H; ++t) sb = make_float4(sb.x + e[t].x, sb.y + e[t].y, sb.z + e[t].z, sb.w + e[t].w);
-    return ((sb.x + sb.y) + sb.z) + sb.w;
+    for (int t = 0; t < H; ++t) { ta = ta + ea[t]; tb = tb + eb[t]; }
+    return ((ta.x + ta.y) + tb.x) + tb.y;
 }
 
 template <typename QP>
