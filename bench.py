@@ -840,7 +840,9 @@ def roofline_of(ds, res, prof, ef, nq, max_degree, cfg, rank, launches=1):
         "algorithmic_bytes_walk_part": round(walk_bytes),
         "algorithmic_bytes_rerank_part": round(rerank_bytes if fused else 0),
         "kernel_ms": round(walk_ms, 4),
-        "kernel_ms_mode": "serialised steps (one stream, kernels back to back), hipEvent pairs on the launch stream",
+        "kernel_ms_mode": "serialised steps (one stream, kernels back to back), hipEvent pairs on the launch stream; a launch that runs "
+                          "alone lets its last, partial round of wavefronts request rows before the visited test (library knob "
+                          "spec_tail; batches in flight -- `value` -- do not)",
     }
     if pmc and pmc.get("valu_insts"):
         # second roofline: vector-instruction issue.  One VALU instruction occupies its SIMD's issue port for 4

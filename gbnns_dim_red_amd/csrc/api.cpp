@@ -337,6 +337,9 @@ std::atomic<int> g_knob_spec_any_form{knob_env("GBNNS_SPEC_ANY_FORM", 0)};
 // (measured on 10^6 x 32: k = 48 0.327 against 0.333 s, k = 100 0.425 against 0.536 s, k = 1 000 2.4 against 7.6 s)
 // "mlp_small" = smallest batch IN FLIGHT whose hidden projection layers run on the small-footprint kernel (0 = never)
 std::atomic<int> g_knob_mlp_small{knob_env("GBNNS_MLP_SMALL", 4096)};
+// "spec_tail" = largest partial last round of a lone launch, in percent of the device's wavefront slots, whose wavefronts
+// request their rows before the visited test (0 = off)
+std::atomic<int> g_knob_spec_tail{knob_env("GBNNS_SPEC_TAIL", 50)};
 // "knn_chunk" = most rows per filtered chunk (a multiple of 64)
 std::atomic<int> g_knob_knn_chunk{knob_env("GBNNS_KNN_CHUNK", 1 << 15)};
 std::atomic<int> g_knob_knn_pool_min_k{knob_env("GBNNS_KNN_POOL_MIN_K", 64)};
@@ -897,6 +900,7 @@ int gbnns_debug_knob(const char* name, int value) {
     else if (!std::strcmp(name, "spec_any_form")) g_knob_spec_any_form.store(value != 0, std::memory_order_relaxed);
     else if (!std::strcmp(name, "spec_min_nq")) g_knob_spec_min_nq.store(std::max(0, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "mlp_small")) g_knob_mlp_small.store(std::max(0, value), std::memory_order_relaxed);
+    else if (!std::strcmp(name, "spec_tail")) g_knob_spec_tail.store(std::max(0, std::min(100, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_chunk")) g_knob_knn_chunk.store(std::max(64, value & ~63), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_pool_min_k")) g_knob_knn_pool_min_k.store(std::max(1, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_filter")) g_knob_knn_filter.store(value, std::memory_order_relaxed);
@@ -1364,6 +1368,16 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // first wins at every batch size (SIFT-shaped 65 536-query launch 0.90 against 0.79 of the peak).  DESIGN.md 5.1.
         const int spec_min = g_knob_spec_min_nq.load(std::memory_order_relaxed);
         w.spec_rows = (spec_min > 0 && nq >= (uint32_t)spec_min && (w.vs_shr == 0 || g_knob_spec_any_form.load(std::memory_order_relaxed))) ? 1 : 0;
+    }
+    {
+        // A launch's last round, when it is a partial one (10 000 queries on 8 192 wavefront slots: 1 808 of them), walks a
+        // draining machine: those wavefronts request their rows BEFORE the visited test (the shorter hop; the rows of
+        // already-visited ids cost nothing there) -- walk_hot_kernel 0.320 -> 0.307 ms, 0.68 -> 0.71 of the peak.  Only for a
+        // batch that runs alone: with batches in flight the neighbours fill that tail and the extra rows cost 2 - 4 %.
+        const uint32_t slots = 256u * 32u;  // wavefront slots of the device (ef <= 64 hot instances: 8 per SIMD)
+        const int knob = g_knob_spec_tail.load(std::memory_order_relaxed);
+        w.spec_from = 0xFFFFFFFFu;
+        if (sync_host && knob > 0 && nq > slots && nq % slots != 0 && nq % slots <= slots * (uint32_t)knob / 100u) w.spec_from = nq - nq % slots;
     }
     w.hash_cap = cap;
     w.hash_limit = cap - cap / 16;

@@ -368,15 +368,32 @@ __device__ __forceinline__ bool regN_select_slow(RegList<R>& L, int p1, int& tsi
         "s_cbranch_execz 8f\n\t"                                                                                       \
         GBNNS_LOADS_SPEC(O1, O2, O3)                                                                                   \
         "s_mov_b64 exec, %[sv]\n\t"
+// ... and both in one block, chosen by the wave-uniform %[spec] (WalkParams::spec_from: the wavefronts of a launch's last,
+// partial round request before the test -- they walk a draining machine, where the shorter hop wins and the rows of
+// already-visited ids cost nothing)
+#define GBNNS_LOADS_DYN_BEFORE(O1, O2, O3)      \
+        "s_cmp_eq_u32 %[spec], 0\n\t"           \
+        "s_cbranch_scc1 12f\n\t"                \
+        GBNNS_LOADS_SPEC(O1, O2, O3)            \
+        "12:\n\t"
+#define GBNNS_LOADS_DYN_AFTER(O1, O2, O3)       \
+        "s_cmp_lg_u32 %[spec], 0\n\t"           \
+        "s_cbranch_scc0 10f\n\t"                \
+        "s_mov_b64 exec, %[sv]\n\t"             \
+        "s_branch 11f\n"                        \
+        "10:\n\t"                               \
+        GBNNS_LOADS_TESTED(O1, O2, O3)          \
+        "11:\n\t"
 #define GBNNS_HOT_END "\n8:\n\ts_mov_b64 exec, %[sv]"
 
 #define GBNNS_HOT_CLOBBERS_40                                                                                           \
     "vcc", "scc", "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54",  \
         "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
 
-template <int METRIC = 0, bool QLDS = false, bool SPEC = !QLDS, typename QP>
+template <int METRIC = 0, bool QLDS = false, bool SPEC = !QLDS, bool DYN = false, typename QP>
 __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t roff, uint32_t nb, uint64_t valid, uint32_t lds_base,
-                                               uint32_t nbuckets, QP qh, uint32_t qaddr, uint64_t& claimed, uint32_t shr, uint64_t& overflowed) {
+                                               uint32_t nbuckets, QP qh, uint32_t qaddr, uint64_t& claimed, uint32_t shr, uint64_t& overflowed,
+                                               uint32_t spec = 0u) {
     const uint32_t end = lds_base + (nbuckets << 4);
     uint32_t basev = lds_base, key, mulc;
     uint64_t fresh, act, sv;
@@ -389,6 +406,7 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
 // LDS: they are v[36:39], which the query pieces take over afterwards)
 #define GBNNS_HOT_IN_QREG GBNNS_HOT_IN, GBNNS_Q(0), GBNNS_Q(1), GBNNS_Q(2), GBNNS_Q(3)
 #define GBNNS_HOT_IN_QLDS GBNNS_HOT_IN, [qaddr] "v"(qaddr)
+#define GBNNS_HOT_IN_QLDS_DYN GBNNS_HOT_IN_QLDS, [spec] "s"(spec)
 #define GBNNS_HOT_OUT_QREG GBNNS_HOT_OUT, [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [addr] "=&v"(addr)
 #define GBNNS_HOT_OUT_QLDS GBNNS_HOT_OUT
 #define GBNNS_VS_QREG GBNNS_VS_ASM("%[t0]", "%[t1]", "%[t2]", "%[addr]")
@@ -426,7 +444,11 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
                        "s_waitcnt vmcnt(1) lgkmcnt(1)\n\t", "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t")
     uint32_t t0, t1, t2, addr;  // (query-in-registers forms)
     (void)t0; (void)t1; (void)t2; (void)addr;
-    if constexpr (METRIC == 0) {
+    if constexpr (DYN) {  // (QLDS instances only)
+        static_assert(!DYN || QLDS, "the dynamic order exists for the query-in-LDS instances");
+        if constexpr (METRIC == 0) GBNNS_HOT_STMT(GBNNS_LOADS_DYN_BEFORE("16", "32", "48"), GBNNS_VS_QLDS, GBNNS_LOADS_DYN_AFTER("16", "32", "48"), GBNNS_L2_QLDS, GBNNS_HOT_OUT_QLDS, GBNNS_HOT_IN_QLDS_DYN, GBNNS_CLOB_QLDS);
+        else GBNNS_HOT_STMT(GBNNS_LOADS_DYN_BEFORE("32", "64", "96"), GBNNS_VS_QLDS, GBNNS_LOADS_DYN_AFTER("32", "64", "96"), GBNNS_DOT_QLDS, GBNNS_HOT_OUT_QLDS, GBNNS_HOT_IN_QLDS_DYN, GBNNS_CLOB_QLDS);
+    } else if constexpr (METRIC == 0) {
         if constexpr (!QLDS && SPEC) GBNNS_HOT_STMT(GBNNS_LOADS_SPEC("16", "32", "48"), GBNNS_VS_QREG, GBNNS_RESTORE_EXEC, GBNNS_L2_QREG, GBNNS_HOT_OUT_QREG, GBNNS_HOT_IN_QREG, GBNNS_CLOB_QREG);
         else if constexpr (!QLDS) GBNNS_HOT_STMT("", GBNNS_VS_QREG, GBNNS_LOADS_TESTED("16", "32", "48"), GBNNS_L2_QREG, GBNNS_HOT_OUT_QREG, GBNNS_HOT_IN_QREG, GBNNS_CLOB_QREG);
         else if constexpr (SPEC) GBNNS_HOT_STMT(GBNNS_LOADS_SPEC("16", "32", "48"), GBNNS_VS_QLDS, GBNNS_RESTORE_EXEC, GBNNS_L2_QLDS, GBNNS_HOT_OUT_QLDS, GBNNS_HOT_IN_QLDS, GBNNS_CLOB_QLDS);
@@ -440,6 +462,7 @@ __device__ __forceinline__ uint32_t hot_expand(const char* db_base, uint32_t rof
 #undef GBNNS_HOT_STMT
 #undef GBNNS_HOT_IN_QREG
 #undef GBNNS_HOT_IN_QLDS
+#undef GBNNS_HOT_IN_QLDS_DYN
 #undef GBNNS_CLOB_QLDS
 #undef GBNNS_CLOB_QREG
 #undef GBNNS_VS_QLDS
@@ -523,6 +546,7 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     const char* db_base = reinterpret_cast<const char*>(p.db);
     const uint32_t dc_limit = p.hash_limit >= 32u ? p.hash_limit - 32u : 0u;  // at most 32 new ids per pass
     bool handed_over = false;
+    const uint32_t spec_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x >= p.spec_from));  // wave-uniform
     uint32_t pf_node = kInvalidId, pf_val = kInvalidId;    // prefetch 1: the runner-up of the selection
     uint32_t pf2_node = kInvalidId, pf2_val = kInvalidId;  // prefetch 2: the closest new survivor (see below)
     uint32_t pf_valw = kInvalidId, pf2_valw = kInvalidId;  // WIDE: the rows' second halves
@@ -635,7 +659,8 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
             edges += __popcll(mv & 0x5555555555555555ull);
             // ---- gather (speculative: before the visited test), visited test, distances -----------
             uint64_t mclaimed, movf;
-            const uint32_t kd = hot_expand<METRIC, QLDS, SPEC>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, qaddr, mclaimed, vs_shr, movf);
+            // (R = 1, tested-first: the order is a run-time choice per wavefront, WalkParams::spec_from)
+            const uint32_t kd = hot_expand<METRIC, QLDS, SPEC, (QLDS && !SPEC)>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, qaddr, mclaimed, vs_shr, movf, spec_tail);
             if (__builtin_expect(movf != 0, 0)) {  // a probe sequence ran out (quotient form): the stash takes the id
                 // (the two-pass instances are at their scalar-register budget -- tests/test_isa_contract.py -- and hand over)
                 if constexpr (WIDE) return false;
