@@ -262,7 +262,8 @@ int gbnns_profile_enable(gbnns_index* index, int on);
  * (walk_hot_spec_kernel; default 32 768, 0 = never; GBNNS_SPEC_MIN_NQ) -- on indexes whose visited sets are not in the
  * quotient form (more than 2^21 rows or so), unless "spec_any_form" is 1 (tests; GBNNS_SPEC_ANY_FORM).
  * "spec_tail": a synchronous call whose last round of wavefronts fills at most this many percent of the device's 8 192
- * slots runs that round with the rows requested before the visited test (default 50, 0 = off; GBNNS_SPEC_TAIL).
+ * slots runs that round with the rows requested before the visited test, and a synchronous batch of at most 60 % of the
+ * slots runs so throughout (default 50, 0 = neither; GBNNS_SPEC_TAIL).
  * "mlp_small": smallest batch in flight (GBNNS_FLAG_DEFER_JOIN) whose hidden projection layers run on the small-footprint
  * kernel (mlp_layer_sw_kernel; default 4 096, up to 32 times that, 0 = never; GBNNS_MLP_SMALL).
  * "knn_chunk": most base rows per filtered chunk of gbnns_exact_knn (default 32 768; the pool path takes four times that;
