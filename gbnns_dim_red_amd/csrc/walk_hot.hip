@@ -5,6 +5,11 @@
 #include "launch_util.h"
 #include "walk_lists.h"
 
+// (A/B switch: wavefronts per SIMD the ef <= 64 instances are compiled for.  8 = at most 80 scalar registers, 13 of them spilled
+// to lanes of a vector register; 7 = 94, no spill: 0.313 against 0.306 ms alone, a tie with batches in flight)
+#ifndef GBNNS_HOT1_LB
+#define GBNNS_HOT1_LB (GBNNS_HOT1_QLDS ? 8 : 7)
+#endif
 namespace gbnns {
 
 namespace {
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(64) void walk_hot_big_kernel(WalkParams p) {  // 12
 
 // (second launch bound = wavefronts per SIMD the register allocation must leave room for: 8 = 64 registers, which the hop needs
 // anyway since round 4 -- hot_expand, QLDS; the bound only keeps the prologue's entry distance from taking more)
-__global__ __launch_bounds__(64, GBNNS_HOT1_QLDS ? 8 : 7) void walk_hot_kernel(WalkParams p) {
+__global__ __launch_bounds__(64, GBNNS_HOT1_LB) void walk_hot_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef GBNNS_HOT1_CAP6  // experiment: 97+ scalar registers = 6 wavefronts per SIMD, leaving 128 vector registers per SIMD to other kernels
     asm volatile("" ::: "s96");
@@ -939,13 +944,13 @@ __global__ __launch_bounds__(64, GBNNS_HOT1_QLDS ? 8 : 7) void walk_hot_kernel(W
 // ... with the rows requested BEFORE the visited test (the rounds 1-3 order): launches of many rounds of wavefronts -- the
 // DEEP10M-shaped 1 M-query batch in locality order -- are 6 % faster this way (21.7 against 23.1 ms: the hop is one LDS round
 // trip shorter and the extra rows mostly hit the L2), the 10 000-query launch 1 - 2 % slower (profiles/r04_ab.txt)
-__global__ __launch_bounds__(64, GBNNS_HOT1_QLDS ? 8 : 7) void walk_hot_spec_kernel(WalkParams p) {
+__global__ __launch_bounds__(64, GBNNS_HOT1_LB) void walk_hot_spec_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<1, false, 0, true>(p, walk_query_of(p, blockIdx.x), smem);
 }
 
 // the same three for adjacency rows of 33 .. 64 slots (two expansion passes per hop)
-__global__ __launch_bounds__(64, GBNNS_HOT1_QLDS ? 8 : 7) void walk_hotw_kernel(WalkParams p) {
+__global__ __launch_bounds__(64, GBNNS_HOT1_LB) void walk_hotw_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     walk_hot_one<1, true>(p, walk_query_of(p, blockIdx.x), smem);
 }
