@@ -637,6 +637,10 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
 
     int status = 0;  // 0 = walking, 1 = finished, 2 = handed over
     uint32_t pf_node = kInvalidId, pf_val = kInvalidId;
+    // prefetch 2 (as in walk_hot_big): a unique survivor closer than the runner-up IS the next node -- its adjacency row is
+    // requested before the insertion instead of after the next selection (one-pass instances; a quarter of the hops)
+    constexpr bool kPf2 = ONE_PASS && !AUX && !BITMAP;
+    uint32_t pf2_node = kInvalidId, pf2_val = kInvalidId;
     while (true) {
         uint32_t node, pred, h2;
         STAMP(t0)
@@ -652,7 +656,9 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
         if (node == pf_node) st_pf1 += 1;
 #endif
         if (node == pf_node) nb0 = pf_val;
+        else if (kPf2 && node == pf2_node) nb0 = pf2_val;
         else nb0 = (slot < p.ell_stride) ? row[slot] : kInvalidId;
+        pf2_node = kInvalidId;
         const uint64_t mv0 = __ballot(nb0 != kInvalidId);  // consumed BEFORE the prefetch is issued
         STAMP(t2)
         STAMP_ADD(1, t1, t2)
@@ -747,6 +753,23 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
             const uint64_t m = (B.l + B.f < ef) ? mfresh : __ballot(fresh && dk < B.worst);
             STAMP(t5)
             STAMP_ADD(4, t4, t5)
+            if constexpr (kPf2) {
+                if (m) {
+                    uint32_t x = dk;  // all-ones outside the new ids
+                    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));   // quad_perm 1,0,3,2
+                    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));   // quad_perm 2,3,0,1
+                    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));  // row_half_mirror
+                    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));  // row_mirror
+                    const uint32_t dmin = min(min(readlane_u32(x, 0), readlane_u32(x, 16)), min(readlane_u32(x, 32), readlane_u32(x, 48)));
+                    if (dmin < h2) {
+                        const uint64_t me = __ballot(dk == dmin) & m;
+                        if (me != 0 && (me & (me - 1)) == 0) {
+                            pf2_node = readlane_u32(nb, __ffsll((unsigned long long)me) - 1);
+                            pf2_val = (slot < p.ell_stride) ? reinterpret_cast<const uint32_t*>(row_ptr<OFF32>(reinterpret_cast<const float*>(p.ell), pf2_node, p.ell_stride))[slot] : kInvalidId;
+                        }
+                    }
+                }
+            }
             if (m) {
                 if (AUX) found = true;  // the first of them is inserted whatever happens to the others
                 // BigList::insert takes up to 32 survivors (its eviction step is one lane per split): the two halves of
