@@ -203,20 +203,27 @@ __global__ __launch_bounds__(256, GBNNS_MLP_WAVES) void mlp_layer_vec_kernel(Lay
         *reinterpret_cast<float4*>(&ws[(srow + 32) * kLd + sc4]) = fw1;
         __syncthreads();
         if (k0 + kKC < kmain) fetch(k0 + kKC, fx, fw0, fw1);  // in flight during the compute below
-        for (uint32_t s = 0; s < kc; s += 8) {
-            float4 xv[2][2], wv[4][2];
+        float4 xv[2][2], wv[4][2];
+        auto lds_step = [&](uint32_t s, float4 (&xo)[2][2], float4 (&wo)[4][2]) {
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const float4* xp = reinterpret_cast<const float4*>(&xs[(2 * tq + a) * kLd + s]);
-                xv[a][0] = xp[0];
-                xv[a][1] = xp[1];
+                xo[a][0] = xp[0];
+                xo[a][1] = xp[1];
             }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const float4* wp = reinterpret_cast<const float4*>(&ws[(to + 16 * b) * kLd + s]);
-                wv[b][0] = wp[0];
-                wv[b][1] = wp[1];
+                wo[b][0] = wp[0];
+                wo[b][1] = wp[1];
             }
+        };
+        lds_step(0, xv, wv);
+        for (uint32_t s = 0; s < kc; s += 8) {
+            // (the next step's operands are requested before this step's products: one LDS round trip less in the chain)
+            float4 xn[2][2], wn[4][2];
+            if (s + 8 < kc) lds_step(s + 8, xn, wn);
+            else lds_step(s, xn, wn);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -230,6 +237,10 @@ __global__ __launch_bounds__(256, GBNNS_MLP_WAVES) void mlp_layer_vec_kernel(Lay
                     acc[a][b][6] = acc[a][b][6] + wv[b][1].z * xv[a][1].z;
                     acc[a][b][7] = acc[a][b][7] + wv[b][1].w * xv[a][1].w;
                 }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) { xv[a][0] = xn[a][0]; xv[a][1] = xn[a][1]; }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { wv[b][0] = wn[b][0]; wv[b][1] = wn[b][1]; }
         }
         __syncthreads();
     }
