@@ -68,12 +68,13 @@ class Profile(C.Structure):
         ("struct_size", C.c_uint32), ("calls", C.c_uint32), ("project_ms", C.c_double),
         ("walk_ms", C.c_double), ("walk_general_ms", C.c_double), ("rerank_ms", C.c_double),
         ("total_ms", C.c_double), ("queries", C.c_uint64), ("general_queries", C.c_uint64),
-        ("walk_kernel", C.c_char * 96),
+        ("walk_kernel", C.c_char * 96), ("project_kernel", C.c_char * 32),
     ]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "struct_size"}
         d["walk_kernel"] = d["walk_kernel"].decode("ascii", "replace")
+        d["project_kernel"] = d["project_kernel"].decode("ascii", "replace")
         return d
 
 

@@ -161,6 +161,7 @@ struct gbnns_index {
     bool has_net = false;
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     uint32_t ws1 = 0, ws2 = 0, ws3 = 0;
+    int cus = 0;                    // compute units of the device (sizes the one-launch projection's query strips)
     // workspaces: lane 0 serves plain calls on the caller's stream; the batches of deferred calls rotate over
     // lanes 0 .. n_lanes-1, each on its own internal stream (see gbnns_search_ex)
     Lane lanes[kMaxLanes];
@@ -337,6 +338,8 @@ std::atomic<int> g_knob_spec_any_form{knob_env("GBNNS_SPEC_ANY_FORM", 0)};
 // (measured on 10^6 x 32: k = 48 0.327 against 0.333 s, k = 100 0.425 against 0.536 s, k = 1 000 2.4 against 7.6 s)
 // "mlp_small" = smallest batch IN FLIGHT whose hidden projection layers run on the small-footprint kernel (0 = never)
 std::atomic<int> g_knob_mlp_small{knob_env("GBNNS_MLP_SMALL", 4096)};
+// "mlp_net" 0 = never the one-launch projection (mlp_net.hip), 1 = for the shapes and batch sizes it serves (GBNNS_MLP_NET)
+std::atomic<int> g_knob_mlp_net{knob_env("GBNNS_MLP_NET", 1)};
 // "spec_tail" = largest partial last round of a lone launch, in percent of the device's wavefront slots, whose wavefronts
 // request their rows before the visited test (0 = off)
 std::atomic<int> g_knob_spec_tail{knob_env("GBNNS_SPEC_TAIL", 50)};
@@ -714,9 +717,11 @@ int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out) {
             p3 = l3.data();
         }
         if (!rc) {
-            ix->ws1 = round_up(d, 8);
-            ix->ws2 = round_up(dh, 8);
-            ix->ws3 = round_up(dh, 8);
+            // (rows padded with zeros to 16 floats: the one-launch projection reads whole 16-input blocks)
+            ix->ws1 = round_up(d, 16);
+            ix->ws2 = round_up(dh, 16);
+            ix->ws3 = round_up(dh, 16);
+            (void)hipDeviceGetAttribute(&ix->cus, hipDeviceAttributeMultiprocessorCount, ix->device);
             std::vector<float> packed;
             repack_layer(p1, d, dh, ix->ws1, packed);
             const size_t o2 = packed.size();
@@ -805,8 +810,23 @@ namespace {
 // MLP over rows x [nx x xstride] (device) -> out [nx x dl_pad] (device); h1/h2 are scratch.
 int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint32_t nx, float* out,
                 hipStream_t s, bool in_flight = false) {
-    // (a one-launch form of the whole net existed through round 3 -- csrc/project.hip, GBNNS_FUSED_MLP=1: 0.084 ms against
-    // 0.071 ms for the three per-layer launches on the SIFT shape, off by default and untested; deleted in round 4)
+    // the whole net in one launch where it serves (round 5, mlp_net.hip: 0.048 against 0.075 ms on the SIFT shape; the
+    // round-2 one-launch form -- csrc/project.hip, deleted in round 4 -- was slower than the three launches)
+    if (g_knob_mlp_net.load(std::memory_order_relaxed)) {
+        NetLaunch n{};
+        n.x = x; n.xstride = xstride; n.nq = nx; n.out = out; n.ostride = ix->dl_pad; n.cus = ix->cus;
+        n.w[0] = ix->w1; n.w[1] = ix->w2; n.w[2] = ix->w3;
+        n.wstride[0] = ix->ws1; n.wstride[1] = ix->ws2; n.wstride[2] = ix->ws3;
+        n.bias[0] = ix->b1; n.bias[1] = ix->b2; n.bias[2] = ix->b3;
+        n.din[0] = ix->d; n.din[1] = n.din[2] = ix->d_hidden;
+        n.dout[0] = n.dout[1] = ix->d_hidden; n.dout[2] = ix->d_low;
+        if (mlp_net_serves(n)) {
+            HIP_TRY(launch_mlp_net(n, s));
+            std::snprintf(ix->acc.project_kernel, sizeof(ix->acc.project_kernel), "mlp_net_kernel");
+            return GBNNS_OK;
+        }
+    }
+    std::snprintf(ix->acc.project_kernel, sizeof(ix->acc.project_kernel), "mlp_layer_kernels");
     int rc = L.h1.ensure((size_t)nx * ix->d_hidden * 4);
     if (!rc) rc = L.h2.ensure((size_t)nx * ix->d_hidden * 4);
     if (rc) return rc;
@@ -900,6 +920,7 @@ int gbnns_debug_knob(const char* name, int value) {
     else if (!std::strcmp(name, "spec_any_form")) g_knob_spec_any_form.store(value != 0, std::memory_order_relaxed);
     else if (!std::strcmp(name, "spec_min_nq")) g_knob_spec_min_nq.store(std::max(0, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "mlp_small")) g_knob_mlp_small.store(std::max(0, value), std::memory_order_relaxed);
+    else if (!std::strcmp(name, "mlp_net")) g_knob_mlp_net.store(value != 0, std::memory_order_relaxed);
     else if (!std::strcmp(name, "spec_tail")) g_knob_spec_tail.store(std::max(0, std::min(100, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_chunk")) g_knob_knn_chunk.store(std::max(64, value & ~63), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_pool_min_k")) g_knob_knn_pool_min_k.store(std::max(1, value), std::memory_order_relaxed);

@@ -143,6 +143,23 @@ struct LayerParams {
     int32_t small_footprint; // 1: hidden layers on the 60-register / 9 KB kernel (batches in flight: its blocks fit beside walk wavefronts)
 };
 hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s);
+// The whole three-layer net in one launch (mlp_net.hip): activations stay in LDS, one block per 16 .. 40 queries.  Same
+// arithmetic as three launch_mlp_layer calls (relu, relu, normalize), bit for bit.
+struct NetLaunch {
+    const float* x;          // [nq x xstride]
+    uint32_t xstride, nq;
+    const float* w[3];       // [dout x wstride], rows zero padded
+    uint32_t wstride[3];
+    const float* bias[3];
+    uint32_t din[3], dout[3];
+    float* out;              // [nq x ostride]; columns [dout[2], ostride) are written as zero
+    uint32_t ostride;
+    int32_t cus;             // compute units of the device (0: 256)
+    int32_t force_a;         // diagnostic: queries per lane group (2 .. 5; 0 = chosen by the launcher)
+    unsigned long long* stamps;  // diagnostic builds (-DGBNNS_NET_STAMPS): [blocks x 8] 100 MHz timestamps of the phase ends
+};
+bool mlp_net_serves(const NetLaunch& n);   // shape, alignment and batch size fit the one-launch kernel
+hipError_t launch_mlp_net(const NetLaunch& n, hipStream_t s);
 // y [nq x stride]: y /= sqrt(L2(y, 0)) over dim (4-lane order, d%4 tail ignored in the norm),
 // pad columns [dim, stride) are written as zero.
 hipError_t launch_normalize(float* y, uint32_t stride, uint32_t dim, uint32_t nq, hipStream_t s);

@@ -250,6 +250,7 @@ typedef struct {
     uint64_t queries;             /* queries processed */
     uint64_t general_queries;     /* of which were (re)run by the general kernel */
     char walk_kernel[96];         /* first-pass walk kernel of the last profiled call, template arguments included */
+    char project_kernel[32];      /* kernel family of the handle's last projection: "mlp_net_kernel" (one launch) or "mlp_layer_kernels" */
 } gbnns_profile;
 
 int gbnns_profile_enable(gbnns_index* index, int on);
@@ -266,6 +267,9 @@ int gbnns_profile_enable(gbnns_index* index, int on);
  * slots runs so throughout (default 50, 0 = neither; GBNNS_SPEC_TAIL).
  * "mlp_small": smallest batch in flight (GBNNS_FLAG_DEFER_JOIN) whose hidden projection layers run on the small-footprint
  * kernel (mlp_layer_sw_kernel; default 4 096, up to 32 times that, 0 = never; GBNNS_MLP_SMALL).
+ * "mlp_net": 1 (default) = batches of 2 048 queries and more whose net has d % 8 == 0 and d_hidden % 8 == 0 are projected
+ * by the one-launch kernel (mlp_net_kernel: the three layers of a strip of queries in one workgroup, activations in LDS),
+ * 0 = always the per-layer kernels; identical outputs either way (GBNNS_MLP_NET).
  * "knn_chunk": most base rows per filtered chunk of gbnns_exact_knn (default 32 768; the pool path takes four times that;
  * GBNNS_KNN_CHUNK).
  * "knn_pool_min_k": shortest list gbnns_exact_knn's filter path keeps as an unordered pool with a radix select (one

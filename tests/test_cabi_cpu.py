@@ -36,7 +36,7 @@ def test_struct_sizes_match_header(lib):
     # 8-byte aligned C layouts as declared in include/gbnns.h
     assert ctypes.sizeof(binding._IndexDesc) == 96
     assert ctypes.sizeof(binding._SearchArgs) == 136  # + n_entries, defer_depth
-    assert ctypes.sizeof(binding.Profile) == 160  # + walk_kernel[96]
+    assert ctypes.sizeof(binding.Profile) == 192  # + walk_kernel[96], project_kernel[32]
 
 
 def test_shard_bounds_arithmetic(lib):

@@ -437,6 +437,47 @@ def test_projection_of_batches_in_flight_small_footprint_kernel(g, orc):
         lib.gbnns_debug_knob(b"mlp_small", 4096)
 
 
+def test_projection_one_launch_kernel(g, orc):
+    """Batches of 2 048 queries and more whose net has d % 8 == 0 and d_hidden % 8 == 0 are projected by mlp_net_kernel
+    (csrc/mlp_net.hip: the three layers of a strip of queries in one workgroup, the eight running sums of an output split
+    over four lanes, folds by row swaps).  Same arithmetic as GetLowQueryFromNet (support_func.h:645-658): q_low bit patterns
+    and answers equal the oracle's -- for input / hidden widths that are and are not multiples of the 16- and 32-input
+    blocks the kernel reads (zero padded), d_low of 32, 48 and 64 (two and four neurons per lane group in the last layer,
+    a half-empty pass), batch sizes that are no multiple of a block's strip -- and equal the per-layer kernels' (knob
+    "mlp_net" 0) on the same handle; batches in flight take it too."""
+    import torch
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lib = g.load_library()
+    try:
+        for si, (d, dh, dl, nq) in enumerate(((128, 256, 32, 2500), (96, 128, 48, 2049), (200, 72, 32, 3001), (40, 264, 64, 2048),
+                                              (16, 8, 16, 2100))):
+            assert lib.gbnns_debug_knob(b"mlp_net", 1) == 0
+            c, off, nbr, db_low, ent = _oracle_case(orc, 9100 + si, 6000, nq, d, dl, dh)
+            want_q = orc.project(c.net, c.queries)
+            sref = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, 40, db_low=db_low, net=c.net, entries=ent, threads=8)
+            ix = g.Index(t(c.base), off, nbr, db_low=t(db_low), net=tuple(t(x) for x in c.net))
+            q, e = t(c.queries), t(ent.astype(np.int32))
+            r = ix.search(q, 40, entry_ids=e, want=("q_low",), out={})
+            torch.cuda.synchronize()
+            assert ix.profile_read(reset=False)["project_kernel"] == "mlp_net_kernel", (d, dh, dl)
+            assert np.array_equal(gu.bits(r["q_low"].cpu().numpy()), gu.bits(want_q)), (d, dh, dl, nq)
+            assert np.array_equal(r["ids"].cpu().numpy().view(np.uint32), sref["ids"]), (d, dh, dl, nq)
+            outs = [ix.search(q, 40, entry_ids=e, want=("q_low",), out={}, flags=g.FLAG_DEFER_JOIN, defer_depth=3) for _ in range(3)]
+            ix.join()
+            torch.cuda.synchronize()
+            for o in outs:
+                assert np.array_equal(gu.bits(o["q_low"].cpu().numpy()), gu.bits(want_q)), (d, dh, dl, nq)
+            assert lib.gbnns_debug_knob(b"mlp_net", 0) == 0
+            r0 = ix.search(q, 40, entry_ids=e, want=("q_low",), out={})
+            torch.cuda.synchronize()
+            assert ix.profile_read(reset=False)["project_kernel"] == "mlp_layer_kernels"
+            assert np.array_equal(gu.bits(r0["q_low"].cpu().numpy()), gu.bits(want_q)), (d, dh, dl, nq)
+            ix.close()
+    finally:
+        lib.gbnns_debug_knob(b"mlp_net", 1)
+
+
 def test_deferred_join_pipeline(g, orc):
     """GBNNS_FLAG_DEFER_JOIN (gbnns.h, "Batches in flight"): consecutive batches alternate between the handle's two
     internal streams and the caller's stream waits for batch i only at call i+1 / gbnns_index_join.  A pipelined run of
