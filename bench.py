@@ -563,6 +563,12 @@ def main():
             "answers_identical": bool((ru["ids"] == res["ids"]).all().item()),
         }
 
+    # ---- the multi-device path's exchange leg on the one GPU there is (gbnns_multi_*, csrc/multi.cpp): one replica, librccl
+    # loaded, a one-rank communicator, ncclAllGather of the single block per batch -- answers compared, the RCCL version
+    # recorded; never `value`
+    if extras and small:
+        result["rccl_single_rank"] = rccl_single_rank(g, ds, q, ef, metric_id, res["ids"], nq_rank)
+
     # ---- PCIe-inclusive rate (host buffers in, ids out: what the C++ drop-in times, and SURVEY 8d's
     # "one gbnns_search_batch incl. H2D of queries and D2H of ids"); never `value`
     if extras and small:
@@ -643,6 +649,27 @@ def main():
         ix.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def rccl_single_rank(g, ds, q, ef, metric_id, ref_ids, nq):
+    out = {"form": "gbnns_multi_create(devices = [0]) + gbnns_multi_rccl_single_rank + gbnns_multi_search_device: search, "
+                   "ncclAllGather on a one-rank communicator, unpadding copy"}
+    try:
+        mi = g.MultiIndex(ds.base.cpu().numpy(), ds.graph_off, ds.graph_nbr, db_low=ds.db_low.cpu().numpy(),
+                          net=tuple(t.cpu().numpy() for t in ds.net), metric=metric_id, devices=[0])
+        mi.rccl_single_rank(True)
+        outs = mi.search_device([q], ef, nq)
+        mi.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            outs = mi.search_device([q], ef, nq)
+        mi.synchronize()
+        out.update({"rccl_version": mi.rccl_version(), "ms_per_step": round((time.perf_counter() - t1) * 100, 4),
+                    "ids_identical_to_single_handle": bool(torch.equal(outs[0].view(ref_ids.dtype), ref_ids))})
+        mi.close()
+    except Exception as e:  # reported, never fatal
+        out["failed"] = str(e)[-300:]
+    return out
 
 
 def capi_multi_parent(args, argv, world, pieces, rehearsal):

@@ -32,6 +32,7 @@ SYMBOLS = [
     "gbnns_multi_create", "gbnns_multi_destroy", "gbnns_multi_size", "gbnns_multi_replica", "gbnns_multi_device_of",
     "gbnns_multi_stream", "gbnns_multi_set_aux_graph", "gbnns_shard_bounds", "gbnns_multi_search_ex",
     "gbnns_multi_search_device", "gbnns_multi_synchronize", "gbnns_multi_last_error",
+    "gbnns_multi_rccl_single_rank", "gbnns_multi_rccl_version",
 ]
 
 
@@ -137,6 +138,8 @@ def load_library():
     lib.gbnns_multi_search_ex.argtypes = [C.c_void_p, C.POINTER(_SearchArgs)]
     lib.gbnns_multi_search_device.argtypes = [C.c_void_p, C.POINTER(_SearchArgs), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gbnns_multi_synchronize.argtypes = [C.c_void_p]
+    lib.gbnns_multi_rccl_single_rank.argtypes = [C.c_void_p, C.c_int]
+    lib.gbnns_multi_rccl_version.argtypes = [C.c_void_p]
     lib.gbnns_shard_bounds.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.gbnns_shard_bounds.restype = None
     lib.gbnns_index_d_low.argtypes = [C.c_void_p]
@@ -352,6 +355,14 @@ class MultiIndex:
 
     def synchronize(self):
         _check_multi(self._lib.gbnns_multi_synchronize(self._h))
+
+    def rccl_single_rank(self, on=True):
+        """One replica: run the exchange leg all the same (one-rank communicator, ncclAllGather of the single block)."""
+        _check_multi(self._lib.gbnns_multi_rccl_single_rank(self._h, int(on)))
+
+    def rccl_version(self):
+        """ncclGetVersion() of the librccl this handle has loaded, 0 while it has not loaded one."""
+        return int(self._lib.gbnns_multi_rccl_version(self._h))
 
 
 class Index:

@@ -40,6 +40,7 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     bool load(std::string& why) {
         if (so) return true;
         // GBNNS_RCCL_LIB names the library instead of the usual places (also how the tests reach the failure path)
@@ -66,6 +67,7 @@ struct Rccl {
         GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        GetVersion = reinterpret_cast<decltype(GetVersion)>(sym("ncclGetVersion"));
         if (!CommInitAll || !CommDestroy || !AllGather || !GroupStart || !GroupEnd) {
             why = "librccl.so lacks an expected symbol";
             dlclose(so);
@@ -88,6 +90,7 @@ struct gbnns_multi {
     std::vector<uint32_t*> send, recv;  // per replica: [width] padded answers, [R x width] gathered
     size_t width = 0;
     uint32_t d = 0;
+    bool rccl_one = false;  // a single replica goes through the communicator too (gbnns_multi_rccl_single_rank)
 };
 
 namespace {
@@ -282,7 +285,8 @@ int gbnns_multi_search_device(gbnns_multi* m, const gbnns_search_args* tmpl, uin
     const int R = (int)m->replicas.size();
     const size_t width = (size_t)((n_q + (uint64_t)R - 1) / (uint64_t)R);
     // communicators and staging buffers (first use, or a larger batch)
-    if (R > 1 && m->comms.empty()) {
+    const bool exchange = R > 1 || m->rccl_one;  // (one replica: a plain copy, unless the exchange leg is asked for)
+    if (exchange && m->comms.empty()) {
         std::string why;
         if (!m->rccl.load(why)) return mfail(GBNNS_ERR_UNSUPPORTED, "RCCL unavailable: %s", why.c_str());
         m->comms.assign((size_t)R, nullptr);
@@ -330,7 +334,7 @@ int gbnns_multi_search_device(gbnns_multi* m, const gbnns_search_args* tmpl, uin
     });
     if (rc) return rc;
     // the path's one exchange step: all-gather of the answer ids (RCCL over xGMI; a plain copy for one replica)
-    if (R > 1) {
+    if (exchange) {
         ncclResult_t e = m->rccl.GroupStart();
         for (int r = 0; r < R && e == ncclSuccess; ++r)
             e = m->rccl.AllGather(m->send[(size_t)r], m->recv[(size_t)r], m->width, ncclUint32, m->comms[(size_t)r], m->streams[(size_t)r]);
@@ -341,7 +345,7 @@ int gbnns_multi_search_device(gbnns_multi* m, const gbnns_search_args* tmpl, uin
     // unpad: block s of the gathered [R x width] array -> rows shard_bounds(n_q, R, s) of out_ids_all[r]
     for (int r = 0; r < R; ++r) {
         if (hipSetDevice(m->devices[(size_t)r]) != hipSuccess) return mfail(GBNNS_ERR_HIP, "hipSetDevice failed");
-        const uint32_t* src = R > 1 ? m->recv[(size_t)r] : m->send[(size_t)r];
+        const uint32_t* src = exchange ? m->recv[(size_t)r] : m->send[(size_t)r];
         for (int s = 0; s < R; ++s) {
             uint64_t lo, hi;
             gbnns_shard_bounds(n_q, R, s, &lo, &hi);
@@ -371,6 +375,19 @@ int gbnns_internal_rccl_probe(void) {
     if (!r.load(why)) return mfail(GBNNS_ERR_UNSUPPORTED, "RCCL unavailable: %s", why.c_str());
     dlclose(r.so);
     return GBNNS_OK;
+}
+
+int gbnns_multi_rccl_single_rank(gbnns_multi* m, int on) {
+    if (!m) return mfail(GBNNS_ERR_INVALID, "null argument");
+    if (m->replicas.size() != 1) return mfail(GBNNS_ERR_INVALID, "gbnns_multi_rccl_single_rank: the handle has %zu replicas", m->replicas.size());
+    m->rccl_one = on != 0;
+    return GBNNS_OK;
+}
+
+int gbnns_multi_rccl_version(gbnns_multi* m) {
+    if (!m || !m->rccl.so || !m->rccl.GetVersion) return 0;
+    int v = 0;
+    return m->rccl.GetVersion(&v) == ncclSuccess ? v : 0;
 }
 
 void* gbnns_multi_stream(gbnns_multi* m, int32_t i) {

@@ -353,6 +353,12 @@ int gbnns_multi_search_device(gbnns_multi* multi, const gbnns_search_args* args,
                               const float* const* query_blocks, const uint32_t* const* entry_blocks,
                               uint32_t* const* out_ids_all);
 int gbnns_multi_synchronize(gbnns_multi* multi);
+/* A handle with ONE replica copies its answers instead of gathering them.  on != 0: it goes through the exchange leg as
+ * well -- librccl loaded, a one-rank communicator (ncclCommInitAll over its device), ncclAllGather of the single block --
+ * so that symbol resolution, stream order and the gather buffer's layout can be exercised on a one-GPU machine. */
+int gbnns_multi_rccl_single_rank(gbnns_multi* multi, int on);
+/* ncclGetVersion() of the librccl this handle has loaded (e.g. 22707), 0 while it has not loaded one. */
+int gbnns_multi_rccl_version(gbnns_multi* multi);
 const char* gbnns_multi_last_error(void);
 
 int gbnns_device_count(void);

@@ -602,6 +602,16 @@ def test_multi_replicas_equal_single_handle(g, orc):
     outs = m.search_device([qd], 64, c.nq, entry_blocks=[ed])
     m.synchronize()
     assert np.array_equal(outs[0].cpu().numpy().view(np.uint32), one.search(c.queries, 64, entry_ids=ent)["ids"])
+    assert m.rccl_version() == 0  # one replica: a copy, librccl not even loaded
+    # the exchange leg itself on the one GPU there is: librccl loaded, a ONE-RANK communicator (ncclCommInitAll), ncclAllGather
+    # of the single block on the replica's stream, the gathered buffer unpadded into the caller's array.  It must work here
+    # (a missing or unloadable librccl is a failure, not a skip).
+    m.rccl_single_rank(True)
+    for nq_part in (c.nq, 77, c.nq):   # (a smaller batch reuses the staging buffers of the larger one)
+        outs = m.search_device([qd[:nq_part].contiguous()], 64, nq_part, entry_blocks=[ed[:nq_part].contiguous()])
+        m.synchronize()
+        assert np.array_equal(outs[0].cpu().numpy().view(np.uint32), one.search(c.queries[:nq_part], 64, entry_ids=ent[:nq_part])["ids"])
+    assert m.rccl_version() >= 20000, m.rccl_version()
     m.close()
     m2 = g.MultiIndex(c.base, off, nbr, db_low=db_low, net=c.net, devices=[0, 0])
     lo, hi = m2.shard_bounds(c.nq, 0)
