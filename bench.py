@@ -563,6 +563,14 @@ def main():
             "answers_identical": bool((ru["ids"] == res["ids"]).all().item()),
         }
 
+    # ---- the throughput option (GBNNS_FLAG_MFMA_PROJECTION: the projection as v_mfma_f32_32x32x2_f32 GEMMs, NOT bit-exact):
+    # its projection time, the rate with batches in flight, how far q_low moves and how many of the batch's answers differ
+    # from the exact path's (which the cpu_baseline section compares with the reference); never `value`
+    if extras and small and cfg["name"] != "plain":
+        result["throughput_option"] = throughput_option(g, ix, q, ef, res, batches, depth if pipelined else 1, nq_rank)
+    if extras:
+        result["graph_prep"] = graph_prep_figures()
+
     # ---- the multi-device path's exchange leg on the one GPU there is (gbnns_multi_*, csrc/multi.cpp): one replica, librccl
     # loaded, a one-rank communicator, ncclAllGather of the single block per batch -- answers compared, the RCCL version
     # recorded; never `value`
@@ -651,9 +659,81 @@ def main():
         dist.destroy_process_group()
 
 
+def throughput_option(g, ix, q, ef, res_exact, batches, depth, nq):
+    out = {"flag": "GBNNS_FLAG_MFMA_PROJECTION", "kernel": "mlp_layer_mfma_kernel (v_mfma_f32_32x32x2_f32, 64 x 64 tiles through LDS) x 3 + "
+                   "normalize_kernel", "never_the_default": True}
+    try:
+        fl = g.FLAG_MFMA_PROJECTION
+        ex = ix.search(q, ef, want=("q_low",), flags=g.FLAG_SERIAL)
+        op = ix.search(q, ef, want=("q_low",), flags=fl | g.FLAG_SERIAL)
+        torch.cuda.synchronize()
+        out["max_abs_q_low_err"] = float((op["q_low"] - ex["q_low"]).abs().max().item())
+        out["id_mismatches_vs_exact_path"] = int((op["ids"] != res_exact["ids"]).sum().item())
+        out["id_mismatches_vs_reference"] = out["id_mismatches_vs_exact_path"]  # (the exact path's ids ARE the reference's: cpu_baseline.gpu_ids_identical)
+        out["batch"] = nq
+        for _ in range(3):
+            ix.search(q, ef, want=(), flags=fl | g.FLAG_SERIAL)
+        torch.cuda.synchronize()
+        ix.profile_read(reset=True)
+        ix.profile_enable(True)
+        for _ in range(10):
+            ix.search(q, ef, want=(), flags=fl | g.FLAG_SERIAL)
+        torch.cuda.synchronize()
+        p = ix.profile_read(reset=True)
+        ix.profile_enable(False)
+        out["project_ms"] = round(p["project_ms"] / max(p["calls"], 1), 4)
+        if depth > 1 and batches:
+            bufs = [{} for _ in range(depth)]
+            for i in range(60):
+                ix.search(batches[i % len(batches)], ef, want=(), out=bufs[i % depth], flags=fl | g.FLAG_DEFER_JOIN, defer_depth=depth)
+            ix.join()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(120):
+                ix.search(batches[i % len(batches)], ef, want=(), out=bufs[i % depth], flags=fl | g.FLAG_DEFER_JOIN, defer_depth=depth)
+            ix.join()
+            torch.cuda.synchronize()
+            out["value_in_flight"] = round(120 * nq / (time.perf_counter() - t1), 1)
+        # matrix-pipe utilisation of the layer kernel: SQ_VALU_MFMA_BUSY_CYCLES / (1 024 SIMDs x kernel cycles), from the
+        # committed counter pass of this command line (rocprofv3 cannot run inside this process)
+        mu = profile_figure("profiles/r05_mfma_option_summary.txt", r"mlp_layer_mfma_kernel matrix-pipe utilisation = [^\n]*= ([0-9.]+)")
+        out["mfma_util"] = mu
+        out["mfma_util_source"] = "profiles/r05_mfma_option_summary.txt" if mu is not None else None
+    except Exception as e:
+        out["failed"] = str(e)[-300:]
+    return out
+
+
+def profile_figure(path, pattern):
+    import re
+    try:
+        m = re.search(pattern, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), path)).read())
+        return float(m.group(1)) if m else None
+    except OSError:
+        return None
+
+
+def graph_prep_figures():
+    """Graph preparation (exact kNN with the matrix-core filter + GD pruning) is not part of a timed step; its
+    figures come from the committed builder-run profiles (tools/knn_bench.py, tools/gd_bench.py on the GPU box)."""
+    return {
+        "knn_s": profile_figure("profiles/r04_knn_summary.txt", r"matrix-core filter \+ exact distances of the kept rows: n=1000000 d=32 k=48\s+([0-9.]+) s"),
+        "knn_exact_scan_s": profile_figure("profiles/r04_knn_summary.txt", r"exact scan of every row \(rounds 1-3\): n=1000000 d=32 k=48\s+([0-9.]+) s"),
+        "knn_mfma_util": profile_figure("profiles/r04_knn_summary.txt", r"matrix-pipe utilisation = [^=]*= ([0-9.]+)"),
+        "gd_s": profile_figure("profiles/r05_graph_prep.txt", r"with the pruning on the device: ([0-9.]+) s"),
+        "workload": "48-NN lists of 10^6 x 32 rows (gbnns_exact_knn), then GD pruning M = 16 (gbnns_build_graph_gd_device)",
+        "source": "profiles/r04_knn_summary.txt, profiles/r05_graph_prep.txt (builder-run on the GPU box; not re-measured in this run)",
+    }
+
+
 def rccl_single_rank(g, ds, q, ef, metric_id, ref_ids, nq):
     out = {"form": "gbnns_multi_create(devices = [0]) + gbnns_multi_rccl_single_rank + gbnns_multi_search_device: search, "
                    "ncclAllGather on a one-rank communicator, unpadding copy"}
+    # (librccl greets on stdout when it initialises a communicator; this process's stdout carries the ONE json line: the
+    # greeting goes to stderr)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
     try:
         mi = g.MultiIndex(ds.base.cpu().numpy(), ds.graph_off, ds.graph_nbr, db_low=ds.db_low.cpu().numpy(),
                           net=tuple(t.cpu().numpy() for t in ds.net), metric=metric_id, devices=[0])
@@ -669,6 +749,10 @@ def rccl_single_rank(g, ds, q, ef, metric_id, ref_ids, nq):
         mi.close()
     except Exception as e:  # reported, never fatal
         out["failed"] = str(e)[-300:]
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
     return out
 
 

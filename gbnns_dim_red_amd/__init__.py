@@ -6,7 +6,7 @@ tests and by bench.py, and the build driver.  It never imports `oracle` and has 
 implementation of the search path: if the HIP library is missing, importing the binding raises.
 """
 from .binding import (  # noqa: F401
-    FLAG_AUX_GRAPH, FLAG_BITMAP_PASS, FLAG_LLF, FLAG_NO_FUSED_RERANK, FLAG_WIDE_INDEX, FLAG_SERIAL, FLAG_DEFER_JOIN, GbnnsError, Index, MultiIndex, METRIC_L2, METRIC_NEG_DOT, MODE_LOWQ, MODE_NET, MODE_PLAIN, build_graph_gd, build_graph_gd_device,
+    FLAG_AUX_GRAPH, FLAG_BITMAP_PASS, FLAG_LLF, FLAG_NO_FUSED_RERANK, FLAG_WIDE_INDEX, FLAG_SERIAL, FLAG_DEFER_JOIN, FLAG_MFMA_PROJECTION, GbnnsError, Index, MultiIndex, METRIC_L2, METRIC_NEG_DOT, MODE_LOWQ, MODE_NET, MODE_PLAIN, build_graph_gd, build_graph_gd_device,
     device_count, exact_knn, lib_path, load_library, version,
 )
 from .build import build_library  # noqa: F401

@@ -22,6 +22,7 @@ FLAG_WIDE_INDEX = 16
 FLAG_BITMAP_PASS = 32
 FLAG_SERIAL = 64
 FLAG_DEFER_JOIN = 128
+FLAG_MFMA_PROJECTION = 256
 
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [

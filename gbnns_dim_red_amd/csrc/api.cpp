@@ -809,10 +809,10 @@ namespace {
 
 // MLP over rows x [nx x xstride] (device) -> out [nx x dl_pad] (device); h1/h2 are scratch.
 int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint32_t nx, float* out,
-                hipStream_t s, bool in_flight = false) {
+                hipStream_t s, bool in_flight = false, bool mfma = false) {
     // the whole net in one launch where it serves (round 5, mlp_net.hip: 0.048 against 0.075 ms on the SIFT shape; the
     // round-2 one-launch form -- csrc/project.hip, deleted in round 4 -- was slower than the three launches)
-    if (g_knob_mlp_net.load(std::memory_order_relaxed)) {
+    if (!mfma && g_knob_mlp_net.load(std::memory_order_relaxed)) {
         NetLaunch n{};
         n.x = x; n.xstride = xstride; n.nq = nx; n.out = out; n.ostride = ix->dl_pad; n.cus = ix->cus;
         n.w[0] = ix->w1; n.w[1] = ix->w2; n.w[2] = ix->w3;
@@ -826,7 +826,7 @@ int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint
             return GBNNS_OK;
         }
     }
-    std::snprintf(ix->acc.project_kernel, sizeof(ix->acc.project_kernel), "mlp_layer_kernels");
+    std::snprintf(ix->acc.project_kernel, sizeof(ix->acc.project_kernel), mfma ? "mlp_layer_mfma_kernel" : "mlp_layer_kernels");
     int rc = L.h1.ensure((size_t)nx * ix->d_hidden * 4);
     if (!rc) rc = L.h2.ensure((size_t)nx * ix->d_hidden * 4);
     if (rc) return rc;
@@ -838,16 +838,17 @@ int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint
     // (... up to 32 times that: a 1 M-query DEEP batch is twenty rounds of the machine on its own, its projection is not
     // waiting for room, and the big-tile kernel's 12 % matter again: 43.1 against 41.5 M queries/s)
     p.small_footprint = (in_flight && small_min > 0 && nx >= (uint32_t)small_min && (uint64_t)nx <= 32ull * (uint64_t)small_min) ? 1 : 0;
+    auto layer = [&](const LayerParams& lp) { return mfma ? launch_mlp_layer_mfma(lp, s) : launch_mlp_layer(lp, s); };
     p.x = x; p.xstride = xstride; p.w = ix->w1; p.wstride = ix->ws1; p.bias = ix->b1;
     p.out = L.h1.as<float>(); p.ostride = ix->d_hidden; p.nq = nx; p.din = ix->d;
     p.dout = ix->d_hidden; p.relu = 1;
-    HIP_TRY(launch_mlp_layer(p, s));
+    HIP_TRY(layer(p));
     p.x = L.h1.as<float>(); p.xstride = ix->d_hidden; p.w = ix->w2; p.wstride = ix->ws2;
     p.bias = ix->b2; p.out = L.h2.as<float>(); p.din = ix->d_hidden;
-    HIP_TRY(launch_mlp_layer(p, s));
+    HIP_TRY(layer(p));
     p.x = L.h2.as<float>(); p.w = ix->w3; p.wstride = ix->ws3; p.bias = ix->b3; p.out = out;
     p.ostride = ix->dl_pad; p.dout = ix->d_low; p.relu = 0; p.normalize = 1;
-    HIP_TRY(launch_mlp_layer(p, s));
+    HIP_TRY(layer(p));
     return GBNNS_OK;
 }
 
@@ -1195,7 +1196,9 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         if ((rc = L.q_low.ensure((size_t)nq * ix->dl_pad * 4))) return rc;
         float* ql = L.q_low.as<float>();
         if (a->mode == GBNNS_MODE_NET) {
-            if ((rc = run_project(ix, L, q_dev, ix->d, nq, ql, s, s == L.stream && L.stream != nullptr))) return rc;
+            if ((rc = run_project(ix, L, q_dev, ix->d, nq, ql, s, s == L.stream && L.stream != nullptr,
+                                  (a->flags & GBNNS_FLAG_MFMA_PROJECTION) != 0)))
+                return rc;
             w.q = ql; w.qstride = ix->dl_pad;
         } else if (host) {
             HIP_TRY(hipMemcpyAsync(ql, a->queries_low, (size_t)nq * ix->d_low * 4, hipMemcpyHostToDevice, s));

@@ -143,6 +143,8 @@ struct LayerParams {
     int32_t small_footprint; // 1: hidden layers on the 60-register / 9 KB kernel (batches in flight: its blocks fit beside walk wavefronts)
 };
 hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s);
+// the throughput option (GBNNS_FLAG_MFMA_PROJECTION): the same layer as a v_mfma_f32_32x32x2_f32 GEMM -- NOT bit-exact
+hipError_t launch_mlp_layer_mfma(const LayerParams& p, hipStream_t s);
 // The whole three-layer net in one launch (mlp_net.hip): activations stay in LDS, one block per 16 .. 40 queries.  Same
 // arithmetic as three launch_mlp_layer calls (relu, relu, normalize), bit for bit.
 struct NetLaunch {

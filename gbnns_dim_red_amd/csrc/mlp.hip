@@ -529,6 +529,61 @@ __global__ __launch_bounds__(256) void mlp_narrow_kernel(LayerParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The THROUGHPUT OPTION (GBNNS_FLAG_MFMA_PROJECTION; never the default, never in the bench's `value`): a layer as a GEMM on
+// the matrix cores, v_mfma_f32_32x32x2_f32.  Its sums are ONE k-ordered fma chain per output (one rounding per product-and-
+// sum), not the reference's eight separately rounded running sums (support_func.h:131-163): outputs differ from the exact
+// kernels' in the last bits (<= a few 1e-7 on unit-norm q_low), and through the walk's compare-driven control flow a few
+// answers of a batch can differ -- the bench reports how many (throughput_option.id_mismatches_vs_reference).
+// Block = 4 wavefronts = 64 queries x 64 neurons (a 32 x 32 accumulator tile each), x / W tiles of 32 k-values through LDS
+// (rows padded to 33 floats: the 32 rows an operand read touches hit 32 banks).
+constexpr int kMQ = 64, kMO = 64, kMK = 32, kMLd = kMK + 1;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void mlp_layer_mfma_kernel(LayerParams p) {
+    __shared__ float xs[kMQ * kMLd];
+    __shared__ float ws[kMO * kMLd];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t qbase = blockIdx.x * kMQ, obase = blockIdx.y * kMO;
+    const int qoff = (wave & 1) * 32, ooff = (wave >> 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // staging role: rows t / 8 and t / 8 + 32 of each tile, floats 4 (t % 8) .. + 3 of the chunk
+    const int srow = t >> 3, sc4 = (t & 7) * 4;
+    for (uint32_t k0 = 0; k0 < p.din; k0 += kMK) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t r = srow + 32 * h, qg = qbase + r, og = obase + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t k = k0 + sc4 + i;
+                xs[r * kMLd + sc4 + i] = (qg < p.nq && k < p.din) ? p.x[(size_t)qg * p.xstride + k] : 0.f;
+                ws[r * kMLd + sc4 + i] = (og < p.dout && k < p.din) ? p.w[(size_t)og * p.wstride + k] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < kMK / 2; ++s2) {
+            const float a = xs[(qoff + (lane & 31)) * kMLd + 2 * s2 + (lane >> 5)];
+            const float b = ws[(ooff + (lane & 31)) * kMLd + 2 * s2 + (lane >> 5)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // accumulator register r of lane l: query row 8 (r / 4) + 4 (l / 32) + r % 4, neuron column l % 32
+    const uint32_t og = obase + ooff + (lane & 31);
+    const float bs = og < p.dout ? p.bias[og] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t qg = qbase + qoff + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+        float v = acc[r] + bs;
+        if (RELU && v < 0.f) v = 0.f;
+        if (qg < p.nq && og < p.dout) p.out[(size_t)qg * p.ostride + og] = v;
+    }
+}
+
 // support_func.h:636-642 normalizeVector: norm = sqrt(L2Metric.Dist(y, zeros)); y[i] /= norm.
 __global__ __launch_bounds__(256) void normalize_kernel(float* y, uint32_t stride, uint32_t dim,
                                                         uint32_t nq) {
@@ -601,6 +656,16 @@ hipError_t launch_mlp_layer(const LayerParams& p, hipStream_t s) {
         return launch_normalize(p.out, p.ostride, p.dout, p.nq, s);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_mlp_layer_mfma(const LayerParams& p, hipStream_t s) {
+    if (p.nq == 0 || p.dout == 0) return hipSuccess;
+    const dim3 grid((p.nq + kMQ - 1) / kMQ, (p.dout + kMO - 1) / kMO);
+    if (p.relu) hipLaunchKernelGGL((mlp_layer_mfma_kernel<true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((mlp_layer_mfma_kernel<false>), grid, dim3(256), 0, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !p.normalize) return e;
+    return launch_normalize(p.out, p.ostride, p.dout, p.nq, s);  // (the exact normalise step on the approximate outputs)
 }
 
 hipError_t launch_normalize(float* y, uint32_t stride, uint32_t dim, uint32_t nq, hipStream_t s) {

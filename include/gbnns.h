@@ -139,10 +139,13 @@ typedef struct {
     uint32_t defer_depth;      /* with GBNNS_FLAG_DEFER_JOIN: batches in flight, 2 .. 4 (0 = 3, the measured optimum) */
 } gbnns_search_args;
 
-/* (Flag bit 1 is retired.  Rounds 1-2 offered the projection on the matrix cores -- v_mfma_f32_32x32x2_f32, a k-ordered
- * fma chain, not bit-exact -- as an opt-in: 17 % matrix-pipe utilisation, 0.069 against 0.071 ms on the SIFT net, 0.154
- * against 0.160 ms on the GIST net, and nothing once batches are in flight, where the projection hides under the
- * previous batch's walk.  Removed in round 3; DESIGN.md section 5.3 has the counters.  The bit is ignored.) */
+/* The throughput option (opt-in; never a default, never what bench.py reports as `value`): the projection's three layers
+ * as GEMMs on the matrix cores (v_mfma_f32_32x32x2_f32, csrc/mlp.hip: mlp_layer_mfma_kernel).  An output is then ONE
+ * k-ordered fma chain instead of the reference's eight separately rounded running sums (support_func.h:131-163): q_low
+ * differs from the exact kernels' in its last bits (a few 1e-7), and a few answers of a batch may differ from the
+ * reference's -- bench.py states how many (throughput_option.id_mismatches_vs_reference).  (Rounds 1-2 had this option on
+ * flag bit 1; removed in round 3, rebuilt in round 5 on bit 8.) */
+#define GBNNS_FLAG_MFMA_PROJECTION 256u
 /* Diagnostic: keep the re-rank (getRealNearest, search_function.h:105-125) in its own kernel launch even
  * where the walk kernels could re-rank each query at the end of its walk.  Results are identical either
  * way; the flag exists for A/B measurements and for timing the two stages separately. */

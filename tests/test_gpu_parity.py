@@ -478,6 +478,35 @@ def test_projection_one_launch_kernel(g, orc):
         lib.gbnns_debug_knob(b"mlp_net", 1)
 
 
+def test_matrix_core_projection_option(g, orc):
+    """GBNNS_FLAG_MFMA_PROJECTION (gbnns.h): the projection as v_mfma_f32_32x32x2_f32 GEMMs -- the throughput option, NOT
+    bit-exact (one k-ordered fma chain per output instead of eight separately rounded running sums).  What is promised and
+    checked: it is opt-in (the same handle without the flag gives the exact bits), q_low stays within 2e-6 of the exact
+    projection on unit-norm outputs, and the answers of a batch differ from the exact path's for at most 0.5 % of the
+    queries (bench.py states the count on its own workload: throughput_option.id_mismatches_vs_reference)."""
+    import torch
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for si, (d, dh, dl, nq) in enumerate(((128, 256, 32, 3000), (100, 72, 48, 500))):
+        c, off, nbr, db_low, ent = _oracle_case(orc, 9300 + si, 8000, nq, d, dl, dh)
+        want_q = orc.project(c.net, c.queries)
+        ix = g.Index(t(c.base), off, nbr, db_low=t(db_low), net=tuple(t(x) for x in c.net))
+        q, e = t(c.queries), t(ent.astype(np.int32))
+        exact = ix.search(q, 48, entry_ids=e, want=("q_low",), out={})
+        opt = ix.search(q, 48, entry_ids=e, want=("q_low",), out={}, flags=g.FLAG_MFMA_PROJECTION)
+        torch.cuda.synchronize()
+        assert ix.profile_read(reset=False)["project_kernel"] == "mlp_layer_mfma_kernel"
+        assert np.array_equal(gu.bits(exact["q_low"].cpu().numpy()), gu.bits(want_q))
+        err = np.abs(opt["q_low"].cpu().numpy() - want_q).max()
+        assert 0 < err < 2e-6, err          # (> 0: the option really ran a different arithmetic)
+        diff = int((opt["ids"] != exact["ids"]).sum().item())
+        assert diff <= max(1, nq // 200), (diff, nq)
+        again = ix.search(q, 48, entry_ids=e, want=("q_low",), out={})
+        torch.cuda.synchronize()
+        assert np.array_equal(gu.bits(again["q_low"].cpu().numpy()), gu.bits(want_q))
+        ix.close()
+
+
 def test_deferred_join_pipeline(g, orc):
     """GBNNS_FLAG_DEFER_JOIN (gbnns.h, "Batches in flight"): consecutive batches alternate between the handle's two
     internal streams and the caller's stream waits for batch i only at call i+1 / gbnns_index_join.  A pipelined run of
