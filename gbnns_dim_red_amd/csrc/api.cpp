@@ -326,26 +326,26 @@ int knob_env(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 std::atomic<int> g_knob_quotient{knob_env("GBNNS_QUOTIENT", 1)};
-std::atomic<int> g_knob_vs_disp{knob_env("GBNNS_DEBUG_VS_DISP", 15)};
+std::atomic<int> g_knob_vs_disp{[] { const int v = knob_env("GBNNS_DEBUG_VS_DISP", 15); return v <= 0 ? 15 : v; }()};
 // "max_waves" = most first-pass wavefronts per CU the LDS shares are cut for (GBNNS_MAX_WAVES; 0 = the per-kernel defaults)
-std::atomic<int> g_knob_max_waves{knob_env("GBNNS_MAX_WAVES", 0)};
+std::atomic<int> g_knob_max_waves{std::max(0, std::min(32, knob_env("GBNNS_MAX_WAVES", 0)))};
 // "spec_min_nq" = smallest batch whose ef <= 64 first pass requests the rows before the visited test (walk_hot_spec_kernel;
 // GBNNS_SPEC_MIN_NQ; 0 = never)
-std::atomic<int> g_knob_spec_min_nq{knob_env("GBNNS_SPEC_MIN_NQ", 32768)};
+std::atomic<int> g_knob_spec_min_nq{std::max(0, knob_env("GBNNS_SPEC_MIN_NQ", 32768))};
 // "spec_any_form" = 1: ... whatever the form of the visited set (tests; default: only tables NOT in the quotient form)
 std::atomic<int> g_knob_spec_any_form{knob_env("GBNNS_SPEC_ANY_FORM", 0)};
 // "knn_pool_min_k" = shortest list gbnns_exact_knn keeps as an unordered pool (one wavefront per query and chunk) instead of a heap
 // (measured on 10^6 x 32: k = 48 0.327 against 0.333 s, k = 100 0.425 against 0.536 s, k = 1 000 2.4 against 7.6 s)
 // "mlp_small" = smallest batch IN FLIGHT whose hidden projection layers run on the small-footprint kernel (0 = never)
-std::atomic<int> g_knob_mlp_small{knob_env("GBNNS_MLP_SMALL", 4096)};
+std::atomic<int> g_knob_mlp_small{std::max(0, knob_env("GBNNS_MLP_SMALL", 4096))};
 // "mlp_net" 0 = never the one-launch projection (mlp_net.hip), 1 = for the shapes and batch sizes it serves (GBNNS_MLP_NET)
 std::atomic<int> g_knob_mlp_net{knob_env("GBNNS_MLP_NET", 1)};
 // "spec_tail" = largest partial last round of a lone launch, in percent of the device's wavefront slots, whose wavefronts
 // request their rows before the visited test (0 = off)
-std::atomic<int> g_knob_spec_tail{knob_env("GBNNS_SPEC_TAIL", 50)};
+std::atomic<int> g_knob_spec_tail{std::max(0, std::min(100, knob_env("GBNNS_SPEC_TAIL", 50)))};
 // "knn_chunk" = most rows per filtered chunk (a multiple of 64)
-std::atomic<int> g_knob_knn_chunk{knob_env("GBNNS_KNN_CHUNK", 1 << 15)};
-std::atomic<int> g_knob_knn_pool_min_k{knob_env("GBNNS_KNN_POOL_MIN_K", 64)};
+std::atomic<int> g_knob_knn_chunk{std::max(64, knob_env("GBNNS_KNN_CHUNK", 1 << 15) & ~63)};  // (a multiple of 64, never 0: the chunk loops step by it)
+std::atomic<int> g_knob_knn_pool_min_k{std::max(1, knob_env("GBNNS_KNN_POOL_MIN_K", 64))};
 // "knn_filter" 0 = gbnns_exact_knn without the matrix-core filter (GBNNS_KNN_FILTER; tests compare the two paths)
 std::atomic<int> g_knob_knn_filter{knob_env("GBNNS_KNN_FILTER", 1)};
 
@@ -424,9 +424,6 @@ int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* quer
     }
     p.bstride = d; p.qstride = d; p.n = n; p.nq = nq; p.dim = d; p.k = k; p.self_offset = self_offset;
     p.heap_stride = ((size_t)nq + 63) & ~(size_t)63;
-    if ((rc = heap.ensure(p.heap_stride * (size_t)k * 8))) return rc;
-    p.heap = heap.as<uint64_t>();
-    HIP_TRY(hipMemsetAsync(p.heap, 0xFF, p.heap_stride * (size_t)k * 8, s));
     // Matrix-core filter in front of the exact distances (knn.hip): the L2 metric on rows of whole 16-byte steps, sets
     // large enough to amortise its passes.  Same output, byte for byte (tests/test_gpu_parity.py); "knn_filter" 0 = off.
     const int knob_filter = g_knob_knn_filter.load(std::memory_order_relaxed);  // 0 = never, 1 = by size, 2 = whenever the shape allows (tests)
@@ -435,6 +432,11 @@ int gbnns_exact_knn(int device, const float* base, uint64_t n, const float* quer
     // long lists keep a query's keys as an unordered pool instead of a heap (knn.hip, knn_pool_update_kernel)
     const bool pool_path = filter_shape && k >= g_knob_knn_pool_min_k.load(std::memory_order_relaxed) && k <= 4096;
     const bool filter = filter_shape && k <= 512 && !pool_path;
+    if (!pool_path) {  // (the pool path keeps its keys in slabs of its own: at k = 1 000 and 10^6 queries the heaps would be 9 GB)
+        if ((rc = heap.ensure(p.heap_stride * (size_t)k * 8))) return rc;
+        p.heap = heap.as<uint64_t>();
+        HIP_TRY(hipMemsetAsync(p.heap, 0xFF, p.heap_stride * (size_t)k * 8, s));
+    }
     if (pool_path) {
         const uint32_t dp = (d + 15u) & ~15u;
         const uint32_t cap = (uint32_t)(4 * k + 64);
@@ -675,6 +677,7 @@ int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out) {
     ix->d = desc->d;
     ix->d_low = desc->d_low;
     ix->d_hidden = desc->d_hidden;
+    (void)hipDeviceGetAttribute(&ix->cus, hipDeviceAttributeMultiprocessorCount, ix->device);
     ix->d_pad = round_up(desc->d, 4);
     ix->dl_pad = round_up(desc->d_low, 4);
     int rc = GBNNS_OK;
@@ -721,7 +724,7 @@ int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out) {
             ix->ws1 = round_up(d, 16);
             ix->ws2 = round_up(dh, 16);
             ix->ws3 = round_up(dh, 16);
-            (void)hipDeviceGetAttribute(&ix->cus, hipDeviceAttributeMultiprocessorCount, ix->device);
+
             std::vector<float> packed;
             repack_layer(p1, d, dh, ix->ws1, packed);
             const size_t o2 = packed.size();
@@ -1091,6 +1094,16 @@ T* pinned_alias(const T* host_ptr, size_t bytes) {
     if (bytes > 1) {
         char* const last = static_cast<char*>(probe(reinterpret_cast<const char*>(host_ptr) + (bytes - 1)));
         if (last != first + (bytes - 1)) return nullptr;
+        // both ends page-locked and contiguous on the device side; two separate registrations with an unregistered hole
+        // between them would pass that too: where the runtime reports the extent of the mapping the first byte belongs to,
+        // the whole buffer has to lie inside it
+        hipDeviceptr_t rbase = nullptr;
+        size_t rsize = 0;
+        if (hipMemGetAddressRange(&rbase, &rsize, first) == hipSuccess && rbase && rsize) {
+            if (first < static_cast<char*>(rbase) || first + bytes > static_cast<char*>(rbase) + rsize) return nullptr;
+        } else {
+            (void)hipGetLastError();
+        }
     }
     return reinterpret_cast<T*>(first);
 }
@@ -1398,7 +1411,8 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // draining machine: those wavefronts request their rows BEFORE the visited test (the shorter hop; the rows of
         // already-visited ids cost nothing there) -- walk_hot_kernel 0.320 -> 0.307 ms, 0.68 -> 0.71 of the peak.  Only for a
         // batch that runs alone: with batches in flight the neighbours fill that tail and the extra rows cost 2 - 4 %.
-        const uint32_t slots = 256u * 32u;  // wavefront slots of the device (ef <= 64 hot instances: 8 per SIMD)
+        // wavefront slots of the device (ef <= 64 hot instances: 8 per SIMD, 32 per CU; the CU count is the device's, not a literal)
+        const uint32_t slots = (uint32_t)(ix->cus > 0 ? ix->cus : 256) * 32u;
         const int knob = g_knob_spec_tail.load(std::memory_order_relaxed);
         w.spec_from = 0xFFFFFFFFu;
         if (sync_host && knob > 0 && nq > slots && nq % slots != 0 && nq % slots <= slots * (uint32_t)knob / 100u) w.spec_from = nq - nq % slots;

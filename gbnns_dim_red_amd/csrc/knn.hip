@@ -368,9 +368,19 @@ hipError_t launch_knn_m(const KnnParams& p, hipStream_t s) {
 // products kept are exact in f32, the three dropped ones sum to <= 3 * 2^-16 |q_k x_k| per dimension; f32 accumulation of
 // 3 d products <= 3 d 2^-24 sum |q_k x_k|; sum |q_k x_k| <= |q||x| <= (|q|^2 + |x|^2) / 2.  For d <= 128 the dot
 // product is off by <= 3.8e-5 (|q|^2 + |x|^2), a by twice that plus the norms' own rounding (d 2^-24 each) plus the
-// reference distance's rounding against the real value (<= (d / 4 + 3) 2^-23 Dist): < 9e-5 (|q|^2 + |x|^2) in all --
-// c = 2^-12 = 2.44e-4 leaves a factor 2.7.
+// reference distance's rounding against the real value (<= (d / 4 + 3) 2^-23 Dist): < 9e-5 (|q|^2 + |x|^2) so far.
+// (Round-4 review: one term was missing here.)  The accumulator does not start at zero but at -0.5 (1 - c) |x|^2, so every
+// one of the <= 3 d / 16 accumulate steps of the matrix pipe rounds against |x|^2 / 2 + sum |q_k x_k| <= |q|^2 + |x|^2, not
+// against sum |q_k x_k| alone -- and its internal adds may truncate (2^-23) instead of rounding to nearest: with 24 steps at
+// d = 128 that adds <= 24 * 2^-23 (|q|^2 + |x|^2) = 2.9e-6 on the dot product's scale, 5.7e-6 on a's ... taken with the
+// worst case of every other term on top of each other the error on a stays < 1.6e-4 (|q|^2 + |x|^2): c = 2^-12 = 2.44e-4
+// leaves a factor 1.5, not the 2.7 claimed before -- and none to spare for longer rows: the shape guard below (dp <= 128)
+// and the host's (d <= 128, gbnns_exact_knn) are what the bound rests on.
 // ------------------------------------------------------------------------------------------
+// the slack c must cover 4 dp 2^-23 (accumulation on the scale |q|^2 + |x|^2, truncating adds) + 2^-14 (the dropped
+// lo x lo products and the norms' and the reference distance's own roundings) at the longest row the filter takes
+constexpr uint32_t kKnnFilterMaxDim = 128;
+static_assert(kKnnFilterSlack >= 4.0f * kKnnFilterMaxDim / 8388608.0f + 1.0f / 16384.0f, "kKnnFilterSlack no longer covers the filter's error bound at its longest row");
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -788,7 +798,12 @@ template <int KSTEPS, int QB>
 hipError_t launch_knn_filter_t(const KnnFilterParams& p, hipStream_t s) {
     const unsigned gx = (p.nq + QB * 128u - 1) / (QB * 128u);
     const unsigned blocks = (p.rows + 31u) >> 5;
-    unsigned gy = gx >= 1024u ? 1u : (1024u + gx - 1) / gx;   // enough workgroups for 256 CUs x 4 SIMDs
+    static const unsigned simds = [] {  // 4 SIMDs per CU of the current device (the MI355X: 1 024)
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return 4u * (unsigned)cus;
+    }();
+    unsigned gy = gx >= simds ? 1u : (simds + gx - 1) / gx;   // enough workgroups for every SIMD
     if (gy > blocks) gy = blocks;
     if (gy < 1u) gy = 1u;
     hipLaunchKernelGGL((knn_filter_kernel<KSTEPS, QB>), dim3(gx, gy), dim3(256), 0, s, p);
