@@ -1,4 +1,4 @@
-// kernels.h -- launch interface between the C-ABI host layer (api.cpp) and the gfx950 kernels
+// kernels.h -- launch interface between the C-ABI host layer (handle.cpp, lanes.cpp, search_core.cpp, sizing.cpp, graph_api.cpp, pin.cpp) and the gfx950 kernels
 // (the .hip units beside it: walk_hot, walk_l2 / walk_dot / walk_wide, walk_bitmap, walk_general, rerank, mlp, gd_order, knn).  Plain structs of device pointers and sizes; no HIP types besides hipStream_t.
 #pragma once
 
@@ -79,7 +79,7 @@ struct WalkParams {
     // (13 remainder bits ? 1 << 16 : 0) | limit << 28 (top four bits: a probe sequence gives up -- stash, hand-over -- when
     // its probe number reaches 15, or 7 << 1 with 13 remainder bits; less in test runs)
     uint32_t vs_shr;
-    int32_t spec_rows;       // ef <= 64 hot first pass: 1 = request the rows before the visited test (big launches, see api.cpp)
+    int32_t spec_rows;       // ef <= 64 hot first pass: 1 = request the rows before the visited test (big launches, see sizing.cpp)
     uint32_t spec_from;      // ... and in the tested-first instances, for the wavefronts from this work item on (the last, partial round
                              // of a launch walks a draining machine: the shorter hop wins there); 0xFFFFFFFF = none
     const uint32_t* order;   // optional [nq]: work item b of a first pass runs query order[b] (a permutation: locality order of a deep batch)

@@ -31,7 +31,7 @@ def short(name):
     for key in ("walk_hot_dot_big_kernel", "walk_hot_dot_kernel", "walk_hotw_big_kernel", "walk_hotw2_kernel", "walk_hotw_kernel"):
         if key in name:  # the dot-metric and wide-row hot instances (template arguments kept: R, WIDE)
             return key + (name[name.find("<"):name.find(">") + 1].replace(" ", "") if "<" in name and "dot" in key else "")
-    for key in ("walk_bitmap_big_kernel", "walk_hot_big_kernel", "walk_hot2_kernel", "mlp_fused_kernel", "walk_bitmap_reg_kernel", "walk_bitmap_kernel",
+    for key in ("walk_bitmap_big_kernel", "walk_hot_big_kernel", "walk_hot2_kernel", "mlp_net_kernel", "mlp_fused_kernel", "walk_bitmap_reg_kernel", "walk_bitmap_kernel",
                 "mlp_narrow_kernel", "gd_prune_kernel", "knn_scan_kernel"):
         if key in name:
             return key
