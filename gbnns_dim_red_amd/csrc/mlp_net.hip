@@ -151,6 +151,19 @@ __device__ __forceinline__ void net_row2(f2& c0, f2& c1, const float4& x, const 
 // step, query a's 16 bytes of the next step right after query a's products of this step (into the same registers); the weight
 // chunks (CK inputs of the wavefront's 2 B rows) run two ahead: chunk i + 2 is on its way from L2 while chunk i + 1 sits
 // staged in the wavefront's other LDS buffer.  Chunks and steps are numbered THROUGH the layer's passes.
+// Which 2 B-neuron slices of a layer a wavefront takes, in order: round robin.  (The vector pipe is arbitrated by age -- with two
+// slices each the four older wavefronts of a block are through a 256-neuron layer in 16 us, the younger in 25 -- but handing
+// the older ones three slices and the younger one made the older ones the slow ones: 25.2 / 17.4 us, 52.5 us per projection
+// against 48.5.  Measured and dropped, round 5.)
+template <int NW>
+__device__ __forceinline__ uint32_t net_slice(uint32_t wave, uint32_t k) { return k * NW + wave; }  // the k-th slice of `wave`
+template <int NW>
+__device__ __forceinline__ uint32_t net_slices(uint32_t wave, uint32_t total) {  // how many of `total` slices `wave` takes
+    uint32_t n = 0;
+    while (net_slice<NW>(wave, n) < total) ++n;
+    return n;
+}
+
 template <int NW, int B>
 struct NetW;
 template <int NW>
@@ -163,7 +176,7 @@ struct NetW {            // one layer's weights as a wavefront's stream of chunk
         : W(w), wstride(ws), k16(net_pad16(din)), dout(dout_), nch(net_padk(din, NetGeom<B>::CK) / NetGeom<B>::CK) {}
     __device__ __forceinline__ NetChunk<B> fetch(uint32_t i, int lane, int wave) const {  // chunk i of the stream
         const uint32_t ps = i / nch, c = i - ps * nch;
-        return net_fetch<B>(W, wstride, k16, dout, (ps * NW + (uint32_t)wave) * 2u * B, c * NetGeom<B>::CK, lane);
+        return net_fetch<B>(W, wstride, k16, dout, net_slice<NW>((uint32_t)wave, ps) * 2u * B, c * NetGeom<B>::CK, lane);
     }
 };
 
@@ -176,8 +189,15 @@ __device__ __forceinline__ void net_layer(const float* xs, uint32_t sx, const Ne
     static_assert(B == 2 || B == 4 || B == 8, "neurons per lane group");
     const uint32_t j = (uint32_t)lane >> 4, go = ((uint32_t)lane >> 3) & 1u, gq = (uint32_t)lane & 7u;
     const uint32_t dout = w.dout, nch = w.nch;
-    const uint32_t npass = (dout + NW * 2 * B - 1) / (NW * 2 * B);
+    const uint32_t npass = net_slices<NW>((uint32_t)wave, (dout + 2 * B - 1) / (2 * B));  // this wavefront's slices of 2 B neurons
     const uint32_t total = nch * npass;
+    if (npass == 0) {  // (a layer of fewer slices than wavefronts) nothing here but the next layer's first chunks
+        if constexpr (NB > 0) {
+            n0 = nw.fetch(0, lane, wave);
+            n1 = nw.fetch(1, lane, wave);
+        }
+        return;
+    }
     const float* xl = xs + gq * sx + 4 * j;
     const float* wl = wb + go * B * G::LDW + 4 * j;
     net_stage<B>(wb, g0, lane);
@@ -185,7 +205,7 @@ __device__ __forceinline__ void net_layer(const float* xs, uint32_t sx, const Ne
     constexpr int NBV = B >= 4 ? B / 4 : 1;  // distinct neurons among a lane's outputs: b = (4 gi + j) mod B
     float bsv[NBV];
     auto load_bias = [&](uint32_t ps) {
-        const uint32_t ob = (ps * NW + (uint32_t)wave) * 2u * B + go * B;
+        const uint32_t ob = net_slice<NW>((uint32_t)wave, ps) * 2u * B + go * B;
 #pragma unroll
         for (int tb = 0; tb < NBV; ++tb) {
             const uint32_t o = ob + (B >= 4 ? j + 4u * tb : j % B);
@@ -256,7 +276,7 @@ __device__ __forceinline__ void net_layer(const float* xs, uint32_t sx, const Ne
             }
         }
         // fold (support_func.h:159-161): m = c_{j+4} + c_j in the lane, then the rows' reduce-scatter; row j owns output 4 gi + j
-        const uint32_t obase = (ps * NW + (uint32_t)wave) * 2u * B;
+        const uint32_t obase = net_slice<NW>((uint32_t)wave, ps) * 2u * B;
         constexpr int N = A * B, NG = (N + 3) / 4;
         float res[NG];
 #pragma unroll
@@ -428,7 +448,11 @@ static size_t net_lds_bytes(const NetLaunch& n, int A, int nw, int bh, uint32_t*
 }
 
 bool mlp_net_serves(const NetLaunch& n) {
-    if (n.nq < 2048u) return false;                       // small batches: a block per 8 A queries leaves most CUs idle
+    // Batch sizes it wins at (tools/ubench/mlp_lab, one launch against the three per-layer launches): 2 048 queries 26.6 / 32.3 us,
+    // 10 000 49.6 / 76.0 (96 -> 128 -> 32: 20.4 / 37.0), 100 000 479 / 526 (96 -> 128: 187 / 193) -- but a 1 M-query batch of the
+    // small 96 -> 128 -> 32 net 2 205 / 1 843: one block per CU at a time leaves a block's staging, barriers and stores uncovered,
+    // which a hundred rounds of it pay a hundred times while the per-layer kernels' co-resident blocks cover each other's.
+    if (n.nq < 2048u || n.nq > 200000u) return false;
     for (int l = 0; l < 3; ++l) {
         if (n.din[l] % 8u || n.wstride[l] % 4u || n.wstride[l] < net_pad16(n.din[l]) || (reinterpret_cast<uintptr_t>(n.w[l]) & 15u))
             return false;
@@ -436,8 +460,10 @@ bool mlp_net_serves(const NetLaunch& n) {
     }
     if (n.xstride % 4u || (reinterpret_cast<uintptr_t>(n.x) & 15u)) return false;
     if (n.dout[2] > 128u) return false;
+    // (strips of at least 32 queries must fit: hidden layers of 512 and more leave room for 24 -- 256 -> 512 -> 512 -> 64 then
+    // takes 223 us against 215)
     uint32_t ba, bb;
-    return net_lds_bytes(n, 2, 8, 8, &ba, &bb) <= 160u * 1024u;
+    return net_lds_bytes(n, 4, 8, 8, &ba, &bb) <= 160u * 1024u;
 }
 
 template <int NW, int A, int BH, int B3>
