@@ -396,7 +396,17 @@ int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint
     // (... up to 32 times that: a 1 M-query DEEP batch is twenty rounds of the machine on its own, its projection is not
     // waiting for room, and the big-tile kernel's 12 % matter again: 43.1 against 41.5 M queries/s)
     p.small_footprint = (in_flight && small_min > 0 && nx >= (uint32_t)small_min && (uint64_t)nx <= 32ull * (uint64_t)small_min) ? 1 : 0;
-    auto layer = [&](const LayerParams& lp) { return mfma ? launch_mlp_layer_mfma(lp, s) : launch_mlp_layer(lp, s); };
+    // a layer that is one round of the machine for the slab kernel (small batches, the GIST shape's 1 000 x 960 -> 1 024 -> 1 024 -> 64:
+    // 117 against 153 us, the 64-neuron last layer alone 15 against 43) takes that; everything else the per-layer kernels of mlp.hip
+    bool slab_used = false;
+    auto layer = [&](const LayerParams& lp) {
+        if (mfma) return launch_mlp_layer_mfma(lp, s);
+        if (!lp.small_footprint && mlp_slab_wins(lp, ix->cus)) {
+            slab_used = true;
+            return launch_mlp_slab(lp, ix->cus, s);
+        }
+        return launch_mlp_layer(lp, s);
+    };
     p.x = x; p.xstride = xstride; p.w = ix->w1; p.wstride = ix->ws1; p.bias = ix->b1;
     p.out = L.h1.as<float>(); p.ostride = ix->d_hidden; p.nq = nx; p.din = ix->d;
     p.dout = ix->d_hidden; p.relu = 1;
@@ -407,6 +417,7 @@ int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint
     p.x = L.h2.as<float>(); p.w = ix->w3; p.wstride = ix->ws3; p.bias = ix->b3; p.out = out;
     p.ostride = ix->dl_pad; p.dout = ix->d_low; p.relu = 0; p.normalize = 1;
     HIP_TRY(layer(p));
+    if (slab_used) std::snprintf(ix->acc.project_kernel, sizeof(ix->acc.project_kernel), "mlp_slab_kernel");
     return GBNNS_OK;
 }
 

@@ -165,6 +165,11 @@ hipError_t launch_mlp_net(const NetLaunch& n, hipStream_t s);
 // y [nq x stride]: y /= sqrt(L2(y, 0)) over dim (4-lane order, d%4 tail ignored in the norm),
 // pad columns [dim, stride) are written as zero.
 hipError_t launch_normalize(float* y, uint32_t stride, uint32_t dim, uint32_t nq, hipStream_t s);
+// One wide layer of a small batch with the one-launch kernel's inner loop (mlp_net.hip, mlp_slab_kernel): 8 A queries x 128 neurons
+// per workgroup, inputs a slab of 256 at a time.
+bool mlp_slab_serves(const LayerParams& p);
+bool mlp_slab_wins(const LayerParams& p, int cus);  // ... and the layer is one round of the machine in its workgroup shape
+hipError_t launch_mlp_slab(const LayerParams& p, int cus, hipStream_t s, int force_a = 0);
 
 // Exact brute-force kNN scan (knn.hip): getTruth (support_func.h:270-290) generalised to k results per query.
 struct KnnParams {

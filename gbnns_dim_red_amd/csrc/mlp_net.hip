@@ -435,6 +435,194 @@ __global__ __launch_bounds__(NW * 64) void mlp_net_kernel(NetParams p) {
     NET_STAMP(6);
 }
 
+// ------------------------------------------------------------------------------------------
+// One LAYER with the same inner loop, for wide layers of small batches (the GIST shape: 1 000 queries through 960 -> 1 024 -> 1 024):
+// the one-launch kernel cannot hold such activations in LDS, and the per-layer kernel of mlp.hip runs them at two wavefronts per
+// SIMD with a compiler-scheduled loop.  A workgroup takes 8 A queries x 128 neurons (8 wavefronts x 16) through the whole k range;
+// the queries' inputs pass through LDS a SLAB of 256 at a time, two images used alternately: the next slab's floats are requested
+// into registers before the current slab's arithmetic and written behind it (one barrier per slab); accumulators stay in
+// registers across slabs.  Same arithmetic as net_layer, bit for bit.
+constexpr int kSlabK = 256;
+
+struct SlabParams {
+    LayerParams l;
+    uint32_t sg;  // floats between the gq groups of a slab image
+};
+
+template <int NW, int A, bool RELU, bool NORM>
+__global__ __launch_bounds__(NW * 64) void mlp_slab_kernel(SlabParams sp) {
+    extern __shared__ __attribute__((aligned(16))) float nsm[];
+    constexpr int B = 8, NT = NW * 64, Q = 8 * A;
+    constexpr int NBLK = kSlabK / 16;                 // 16-float blocks of a query's slab
+    constexpr int E = (Q * NBLK + NT - 1) / NT;       // ... of them per thread
+    using G = NetGeom<B>;
+    const LayerParams& p = sp.l;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const uint32_t isz = 8u * sp.sg;                  // floats of one image
+    float* wb = nsm + 2u * isz + (size_t)wave * (2 * G::BUF);
+    const uint32_t qbase = blockIdx.x * Q;
+    const uint32_t obase = (blockIdx.y * NW + (uint32_t)wave) * 2u * B;
+    const uint32_t j = (uint32_t)lane >> 4, go = ((uint32_t)lane >> 3) & 1u, gq = (uint32_t)lane & 7u;
+    const uint32_t k16 = net_pad16(p.din), kpad = net_padk(p.din, G::CK), total = kpad / G::CK;
+    auto fetch = [&](uint32_t i) { return net_fetch<B>(p.w, p.wstride, k16, p.dout, obase, i * G::CK, lane); };
+    // a thread's share of a slab: blocks e = t, t + NT, ... of the Q x NBLK grid, requested as four float4 each
+    float4 sv[E][4];
+    auto slab_request = [&](uint32_t k0) {
+#pragma unroll
+        for (int ei = 0; ei < E; ++ei) {
+            const uint32_t e = (uint32_t)t + (uint32_t)ei * NT, row = e / NBLK, blk = e % NBLK, qg = qbase + row;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const uint32_t k = k0 + 16u * blk + 4u * c4;
+                sv[ei][c4] = (e < (uint32_t)Q * NBLK && qg < p.nq && k < p.din)
+                                 ? *reinterpret_cast<const float4*>(p.x + (size_t)qg * p.xstride + k)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto slab_write = [&](float* img) {
+#pragma unroll
+        for (int ei = 0; ei < E; ++ei) {
+            const uint32_t e = (uint32_t)t + (uint32_t)ei * NT, row = e / NBLK, blk = e % NBLK;
+            if (e < (uint32_t)Q * NBLK) {
+                float4* d = reinterpret_cast<float4*>(img + net_xpos<A>(row, 16u * blk, sp.sg));
+                d[0] = make_float4(sv[ei][0].x, sv[ei][1].x, sv[ei][2].x, sv[ei][3].x);
+                d[1] = make_float4(sv[ei][0].y, sv[ei][1].y, sv[ei][2].y, sv[ei][3].y);
+                d[2] = make_float4(sv[ei][0].z, sv[ei][1].z, sv[ei][2].z, sv[ei][3].z);
+                d[3] = make_float4(sv[ei][0].w, sv[ei][1].w, sv[ei][2].w, sv[ei][3].w);
+            }
+        }
+    };
+    slab_request(0);
+    NetChunk<B> g = fetch(0);
+    net_stage<B>(wb, g, lane);
+    g = fetch(total > 1 ? 1 : 0);
+    float bsv[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const uint32_t o = obase + go * B + j + 4u * tb;
+        bsv[tb] = o < p.dout ? p.bias[o] : 0.f;
+    }
+    f2 acc[A][B];
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+        for (int b = 0; b < B; ++b) acc[a][b] = f2{0.f, 0.f};
+    const float* wl = wb + go * B * G::LDW + 4 * j;
+    float4 xv[A], wv[2][B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) wv[0][b] = *reinterpret_cast<const float4*>(wl + b * G::LDW);
+    slab_write(nsm);
+    __syncthreads();
+    uint32_t i = 0, par = 0;  // chunk of the layer; image in use
+    for (uint32_t k0 = 0; k0 < kpad; k0 += kSlabK, par ^= 1u) {
+        const uint32_t ks = kpad - k0 < (uint32_t)kSlabK ? kpad - k0 : (uint32_t)kSlabK;  // inputs of this slab (a multiple of CK)
+        const bool next_slab = k0 + kSlabK < kpad;
+        if (next_slab) slab_request(k0 + kSlabK);
+        const float* xl = nsm + par * isz + gq * sp.sg + 4 * j;
+#pragma unroll
+        for (int a = 0; a < A; ++a) xv[a] = *reinterpret_cast<const float4*>(xl + a * 16);
+        const uint32_t cps = ks / G::CK;
+#pragma clang loop unroll(disable)
+        for (uint32_t cs = 0; cs < cps; ++cs, ++i) {
+            net_stage<B>(wb + ((i + 1) & 1u) * G::BUF, g, lane);
+            g = fetch(i + 2 < total ? i + 2 : total - 1);
+            const float* wcur = wl + (i & 1u) * G::BUF;
+            const float* wnxt = wl + ((i + 1) & 1u) * G::BUF;
+            const float* xc = xl + cs * (G::NU * A * 16);
+            const bool more = cs + 1 < cps;  // (the slab's last step has no next step in this image)
+#pragma unroll
+            for (int u = 0; u < G::NU; ++u) {
+                const int cb = u & 1, nb = cb ^ 1;
+#pragma unroll
+                for (int b = 0; b < B; ++b)
+                    wv[nb][b] = u + 1 < G::NU ? *reinterpret_cast<const float4*>(wcur + b * G::LDW + 16 * (u + 1))
+                                              : *reinterpret_cast<const float4*>(wnxt + b * G::LDW);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+#pragma unroll
+                    for (int b = 0; b < B; b += 4)
+                        net_row4(acc[a][b], acc[a][b + 1], acc[a][b + 2], acc[a][b + 3], xv[a], wv[cb][b], wv[cb][b + 1], wv[cb][b + 2],
+                                 wv[cb][b + 3]);
+                    if (u + 1 < G::NU) xv[a] = *reinterpret_cast<const float4*>(xc + ((u + 1) * A + a) * 16);
+                    else if (more) xv[a] = *reinterpret_cast<const float4*>(xc + (G::NU * A + a) * 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (next_slab) {
+            slab_write(nsm + (par ^ 1u) * isz);  // (last read one slab ago: everyone has passed the barrier since)
+            __syncthreads();
+        }
+    }
+    // fold (support_func.h:159-161) by rows, then bias, ReLU (:627-631) and the store, once per output (as net_layer)
+    constexpr int N = A * B, NG = (N + 3) / 4;
+    float res[NG];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        float m[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = 4 * gi + r < N ? 4 * gi + r : 4 * gi;
+            m[r] = acc[idx / B][idx % B].y + acc[idx / B][idx % B].x;
+        }
+        res[gi] = net_fold32(net_fold16(m[0], m[1]), net_fold16(m[2], m[3]));
+    }
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const uint32_t idx = 4u * gi + j, a = idx / B, b = idx % B;
+        const uint32_t o = obase + go * B + b, qg = qbase + gq + 8u * a;
+        const float dist = -res[gi];                 // Angular::Dist
+        float v = 0.f;
+        v = v - dist;                                // support_func.h:627
+        v = v + bsv[gi % 2];                         // :628
+        if (RELU && v < 0.f) v = 0.f;                // :629-631
+        if constexpr (NORM) res[gi] = v;
+        else if (idx < (uint32_t)N && o < p.dout && qg < p.nq) p.out[(size_t)qg * p.ostride + o] = v;
+    }
+    if constexpr (NORM) {
+        // the workgroup owns every output of its queries (one block column): normalizeVector (support_func.h:636-642) here, as in
+        // mlp_net_kernel -- 8 threads per query; threads 0..3 run the four running sums of L2Metric::Dist(y, 0) (:107-128, d % 4 tail
+        // ignored), then every thread divides its share of the outputs
+        const uint32_t ldy = p.dout + 1u;
+        float* ybuf = nsm;                       // [Q][ldy] (the slab images are dead once everyone has left the k loop)
+        float* nsum = nsm + (size_t)Q * ldy;     // [Q][4]
+        __syncthreads();
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const uint32_t idx = 4u * gi + j, a = idx / B, b = idx % B;
+            const uint32_t o = obase + go * B + b, ql = gq + 8u * a;
+            if (idx < (uint32_t)N && o < p.dout) ybuf[ql * ldy + o] = res[gi];
+        }
+        __syncthreads();
+        const int part = t & 7;
+        for (int q = t >> 3; q < Q; q += NT / 8) {
+            if (part < 4) {
+                const float* y = ybuf + (size_t)q * ldy;
+                const uint32_t steps = p.dout >> 2;
+                float sc = 0.f;
+                for (uint32_t k = 0; k < steps; ++k) {
+                    const float e = y[4 * k + part] - 0.f;
+                    sc = sc + e * e;
+                }
+                nsum[q * 4 + part] = sc;
+            }
+        }
+        __syncthreads();
+        for (int q = t >> 3; q < Q; q += NT / 8) {
+            if (qbase + q >= p.nq) break;
+            const float* y = ybuf + (size_t)q * ldy;
+            float norm = ((nsum[q * 4 + 0] + nsum[q * 4 + 1]) + nsum[q * 4 + 2]) + nsum[q * 4 + 3];
+            norm = __builtin_sqrtf(norm);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+            float* r = p.out + (size_t)(qbase + q) * p.ostride;
+            for (uint32_t i = part; i < p.dout; i += 8) r[i] = __fdiv_rn(y[i], norm);
+            for (uint32_t i = p.dout + part; i < p.ostride; i += 8) r[i] = 0.f;
+        }
+    }
+}
+
 }  // namespace
 
 // LDS bytes of the one-launch projection for Q = 8 A queries per block, NW wavefronts, BH neurons per lane group in the hidden layers
@@ -518,6 +706,87 @@ hipError_t launch_mlp_net(const NetLaunch& n, hipStream_t s) {
     const uint32_t per = (n.dout[2] + 2u * nw - 1u) / (2u * nw);
     const int b3 = per <= 2 ? 2 : 4;
     return net_launch_a<8, 8>(p, bestA, b3, lds, s);
+}
+
+bool mlp_slab_serves(const LayerParams& p) {
+    return p.nq > 0 && p.dout > 0 && p.din % 8u == 0 && p.xstride % 4u == 0 && p.wstride % 4u == 0 && p.wstride >= net_pad16(p.din) &&
+           (reinterpret_cast<uintptr_t>(p.x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15u) == 0;
+}
+
+template <int NW, int A>
+static hipError_t slab_launch(const SlabParams& sp, unsigned gx, unsigned gy, size_t lds, bool norm, hipStream_t s) {
+    hipError_t e;
+    if constexpr (NW <= 4) {
+        if (norm) {  // (the last layer: no ReLU)
+            if ((e = set_lds(mlp_slab_kernel<NW, A, false, true>, lds)) != hipSuccess) return e;
+            hipLaunchKernelGGL((mlp_slab_kernel<NW, A, false, true>), dim3(gx, gy), dim3(NW * 64), lds, s, sp);
+            return hipGetLastError();
+        }
+    }
+    if (sp.l.relu) {
+        if ((e = set_lds(mlp_slab_kernel<NW, A, true, false>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((mlp_slab_kernel<NW, A, true, false>), dim3(gx, gy), dim3(NW * 64), lds, s, sp);
+    } else {
+        if ((e = set_lds(mlp_slab_kernel<NW, A, false, false>, lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((mlp_slab_kernel<NW, A, false, false>), dim3(gx, gy), dim3(NW * 64), lds, s, sp);
+    }
+    return hipGetLastError();
+}
+
+// Workgroup shape of the slab kernel for a layer: wide layers 8 wavefronts (128 neurons) x 16 .. 40 queries, layers of up to 64
+// neurons one wavefront per 16 neurons x 8 or 16 queries (a 1 000-query batch through 1 024 -> 64 is then 125 workgroups instead of
+// the 32 of the per-layer kernel's 32-query tiles: 42 us of a 154-us projection were that layer's).
+static void slab_shape(const LayerParams& p, int cus, int force_a, int& nw, int& bestA, uint64_t& blocks) {
+    const bool narrow = p.dout <= 64u;
+    nw = narrow ? (p.dout <= 32u ? 2 : 4) : 8;
+    const unsigned gy = (p.dout + 16u * nw - 1u) / (16u * nw);
+    bestA = narrow ? 1 : 2;
+    uint64_t best = ~0ull;
+    for (int A = narrow ? 2 : 5; A >= (narrow ? 1 : 2); --A) {  // the strip length that needs the fewest rounds of the machine x A
+        if (force_a && A != force_a) continue;
+        const uint64_t b = (uint64_t)((p.nq + 8u * A - 1u) / (8u * A)) * gy;
+        const uint64_t cost = ((b + cus - 1) / cus) * A;
+        if (cost < best) { best = cost; bestA = A; blocks = b; }
+    }
+}
+
+// (measured, tools/ubench/mlp_lab MLP_LAB_SLAB=1: it wins where the layer is one round of the machine -- 1 000 x 960 -> 1 024 50.7
+// against 59.2 us, 1 000 x 200 -> 256 9.0 / 11.0 -- and loses beyond: 4 000 x 1 024 -> 1 024 201 / 183, 10 000 x 512 -> 512 123 / 119)
+bool mlp_slab_wins(const LayerParams& p, int cus) {
+    if (!mlp_slab_serves(p)) return false;
+    if (cus <= 0) cus = 256;
+    int nw, a;
+    uint64_t blocks = 0;
+    slab_shape(p, cus, 0, nw, a, blocks);
+    return blocks <= (uint64_t)cus && p.din >= 64u;
+}
+
+hipError_t launch_mlp_slab(const LayerParams& p, int cus, hipStream_t s, int force_a) {
+    if (!mlp_slab_serves(p)) return hipErrorInvalidValue;
+    if (cus <= 0) cus = 256;
+    int nw, bestA;
+    uint64_t blocks = 0;
+    slab_shape(p, cus, force_a, nw, bestA, blocks);
+    SlabParams sp{};
+    sp.l = p;
+    sp.sg = net_gstride(kSlabK, bestA);
+    const size_t lds = ((size_t)2 * 8 * sp.sg + (size_t)nw * 2 * NetGeom<8>::BUF) * sizeof(float);
+    const unsigned gx = (p.nq + 8u * bestA - 1u) / (8u * bestA), gy = (p.dout + 16u * nw - 1u) / (16u * nw);
+    // normalizeVector inside the launch when a workgroup holds all the outputs of its queries (and the layer has no ReLU)
+    const bool norm = p.normalize && !p.relu && gy == 1 && nw <= 4;
+    hipError_t e = hipErrorInvalidValue;
+    switch (nw * 8 + bestA) {
+        case 8 * 8 + 2: e = slab_launch<8, 2>(sp, gx, gy, lds, norm, s); break;
+        case 8 * 8 + 3: e = slab_launch<8, 3>(sp, gx, gy, lds, norm, s); break;
+        case 8 * 8 + 4: e = slab_launch<8, 4>(sp, gx, gy, lds, norm, s); break;
+        case 8 * 8 + 5: e = slab_launch<8, 5>(sp, gx, gy, lds, norm, s); break;
+        case 4 * 8 + 1: e = slab_launch<4, 1>(sp, gx, gy, lds, norm, s); break;
+        case 4 * 8 + 2: e = slab_launch<4, 2>(sp, gx, gy, lds, norm, s); break;
+        case 2 * 8 + 1: e = slab_launch<2, 1>(sp, gx, gy, lds, norm, s); break;
+        case 2 * 8 + 2: e = slab_launch<2, 2>(sp, gx, gy, lds, norm, s); break;
+    }
+    if (e != hipSuccess || !p.normalize || norm) return e;
+    return launch_normalize(p.out, p.ostride, p.dout, p.nq, s);
 }
 
 }  // namespace gbnns

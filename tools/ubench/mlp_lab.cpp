@@ -261,6 +261,35 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("  %-40s %.2f us per projection\n", name, ms * 1000.f / reps);
     };
+    if (getenv("MLP_LAB_SLAB")) {  // layer by layer: mlp.hip's kernels against the slab kernel; bit comparison of the slab net
+        const int fa = getenv("MLP_LAB_SLAB_A") ? atoi(getenv("MLP_LAB_SLAB_A")) : 0;
+        auto layer_params = [&](int l, float* out_last) {
+            gbnns::LayerParams p{};
+            p.nq = nq; p.w = dw[l]; p.wstride = ws[l]; p.bias = db[l]; p.din = din[l]; p.dout = dout[l];
+            p.x = l == 0 ? dx : (l == 1 ? h1 : h2); p.xstride = din[l];
+            p.out = l == 0 ? h1 : (l == 1 ? h2 : out_last); p.ostride = l == 2 ? ostride : dh;
+            p.relu = l < 2; p.normalize = l == 2;
+            return p;
+        };
+        per_layer(0);
+        for (int l = 0; l < 3; ++l) {
+            char name[64];
+            snprintf(name, sizeof name, "layer %d, mlp.hip", l + 1);
+            timeit(name, [&] { CK(gbnns::launch_mlp_layer(layer_params(l, o_ref), s)); });
+            snprintf(name, sizeof name, "layer %d, slab kernel", l + 1);
+            timeit(name, [&] { CK(gbnns::launch_mlp_slab(layer_params(l, o_net), n.cus, s, fa)); });
+        }
+        per_layer(0);
+        for (int l = 0; l < 3; ++l) CK(gbnns::launch_mlp_slab(layer_params(l, o_net), n.cus, s, fa));
+        CK(hipStreamSynchronize(s));
+        std::vector<uint32_t> a((size_t)nq * ostride), b((size_t)nq * ostride);
+        CK(hipMemcpy(a.data(), o_ref, a.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(b.data(), o_net, b.size() * 4, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (size_t q = 0; q < nq; ++q)
+            for (uint32_t c = 0; c < dl; ++c) bad += a[q * ostride + c] != b[q * ostride + c];
+        printf("  slab net: outputs that differ in a bit: %zu of %zu\n", bad, (size_t)nq * dl);
+    }
     timeit("three launches (mlp.hip)", [&] { per_layer(0); });
     timeit("three launches, small-footprint hidden", [&] { per_layer(1); });
     if (gbnns::mlp_net_serves(n)) {
