@@ -172,6 +172,8 @@ std::atomic<int> g_knob_spec_any_form{knob_env("GBNNS_SPEC_ANY_FORM", 0)};
 std::atomic<int> g_knob_mlp_small{std::max(0, knob_env("GBNNS_MLP_SMALL", 4096))};
 // "mlp_net" 0 = never the one-launch projection (mlp_net.hip), 1 = for the shapes and batch sizes it serves (GBNNS_MLP_NET)
 std::atomic<int> g_knob_mlp_net{knob_env("GBNNS_MLP_NET", 1)};
+// "mlp_slab" 0 = never the slab kernel for single layers (mlp_net.hip, mlp_slab_kernel), 1 = where a layer is one round of it (GBNNS_MLP_SLAB)
+std::atomic<int> g_knob_mlp_slab{knob_env("GBNNS_MLP_SLAB", 1)};
 // "spec_tail" = largest partial last round of a lone launch, in percent of the device's wavefront slots, whose wavefronts
 // request their rows before the visited test (0 = off)
 std::atomic<int> g_knob_spec_tail{std::max(0, std::min(100, knob_env("GBNNS_SPEC_TAIL", 50)))};
@@ -401,7 +403,7 @@ int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint
     bool slab_used = false;
     auto layer = [&](const LayerParams& lp) {
         if (mfma) return launch_mlp_layer_mfma(lp, s);
-        if (!lp.small_footprint && mlp_slab_wins(lp, ix->cus)) {
+        if (!lp.small_footprint && g_knob_mlp_slab.load(std::memory_order_relaxed) && mlp_slab_wins(lp, ix->cus)) {
             slab_used = true;
             return launch_mlp_slab(lp, ix->cus, s);
         }
@@ -491,6 +493,7 @@ int gbnns_debug_knob(const char* name, int value) {
     else if (!std::strcmp(name, "spec_min_nq")) g_knob_spec_min_nq.store(std::max(0, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "mlp_small")) g_knob_mlp_small.store(std::max(0, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "mlp_net")) g_knob_mlp_net.store(value != 0, std::memory_order_relaxed);
+    else if (!std::strcmp(name, "mlp_slab")) g_knob_mlp_slab.store(value != 0, std::memory_order_relaxed);
     else if (!std::strcmp(name, "spec_tail")) g_knob_spec_tail.store(std::max(0, std::min(100, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_chunk")) g_knob_knn_chunk.store(std::max(64, value & ~63), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_pool_min_k")) g_knob_knn_pool_min_k.store(std::max(1, value), std::memory_order_relaxed);

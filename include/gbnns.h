@@ -273,6 +273,8 @@ int gbnns_profile_enable(gbnns_index* index, int on);
  * "mlp_net": 1 (default) = batches of 2 048 queries and more whose net has d % 8 == 0 and d_hidden % 8 == 0 are projected
  * by the one-launch kernel (mlp_net_kernel: the three layers of a strip of queries in one workgroup, activations in LDS),
  * 0 = always the per-layer kernels; identical outputs either way (GBNNS_MLP_NET).
+ * "mlp_slab": 1 (default) = a projection layer that is one round of the machine for mlp_slab_kernel (small batches; the GIST
+ * shape's 1 000 queries through 960 -> 1 024 -> 1 024 -> 64) takes it, 0 = never; identical outputs either way (GBNNS_MLP_SLAB).
  * "knn_chunk": most base rows per filtered chunk of gbnns_exact_knn (default 32 768; the pool path takes four times that;
  * GBNNS_KNN_CHUNK).
  * "knn_pool_min_k": shortest list gbnns_exact_knn's filter path keeps as an unordered pool with a radix select (one

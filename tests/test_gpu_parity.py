@@ -469,13 +469,60 @@ def test_projection_one_launch_kernel(g, orc):
             for o in outs:
                 assert np.array_equal(gu.bits(o["q_low"].cpu().numpy()), gu.bits(want_q)), (d, dh, dl, nq)
             assert lib.gbnns_debug_knob(b"mlp_net", 0) == 0
+            assert lib.gbnns_debug_knob(b"mlp_slab", 0) == 0
+            r0 = ix.search(q, 40, entry_ids=e, want=("q_low",), out={})
+            torch.cuda.synchronize()
+            assert ix.profile_read(reset=False)["project_kernel"] == "mlp_layer_kernels"
+            assert np.array_equal(gu.bits(r0["q_low"].cpu().numpy()), gu.bits(want_q)), (d, dh, dl, nq)
+            assert lib.gbnns_debug_knob(b"mlp_slab", 1) == 0
+            ix.close()
+    finally:
+        lib.gbnns_debug_knob(b"mlp_net", 1)
+        lib.gbnns_debug_knob(b"mlp_slab", 1)
+
+
+def test_projection_slab_kernel(g, orc):
+    """A projection layer that is one round of the machine for mlp_slab_kernel (csrc/mlp_net.hip: 8 A queries x 128 neurons per
+    workgroup with the one-launch kernel's inner loop, the inputs a slab of 256 at a time through two LDS images; layers of up
+    to 64 neurons one wavefront per 16 neurons and the normalise step inside) takes it: small batches of any net with
+    d % 8 == 0, the GIST shape's 960 -> 1 024 -> 1 024 -> 64.  q_low bit patterns and answers equal the oracle's
+    (GetLowQueryFromNet, support_func.h:645-658) and the per-layer kernels' (knob "mlp_slab" 0) -- for widths that are not
+    multiples of the 16- / 32-input blocks or of a slab, one slab and several, d_low of 16 .. 64, batches that end inside a strip."""
+    import torch
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lib = g.load_library()
+    try:
+        for si, (d, dh, dl, nq) in enumerate(((960, 1024, 64, 1000), (200, 264, 32, 777), (96, 72, 48, 130), (128, 256, 32, 33),
+                                              (520, 136, 16, 301), (64, 64, 64, 1))):
+            assert lib.gbnns_debug_knob(b"mlp_slab", 1) == 0
+            c, off, nbr, db_low, ent = _oracle_case(orc, 9300 + si, 3000, nq, d, dl, dh)
+            want_q = orc.project(c.net, c.queries)
+            sref = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, 40, db_low=db_low, net=c.net, entries=ent, threads=8)
+            ix = g.Index(t(c.base), off, nbr, db_low=t(db_low), net=tuple(t(x) for x in c.net))
+            q, e = t(c.queries), t(ent.astype(np.int32))
+            r = ix.search(q, 40, entry_ids=e, want=("q_low",), out={})
+            torch.cuda.synchronize()
+            assert ix.profile_read(reset=False)["project_kernel"] == "mlp_slab_kernel", (d, dh, dl)
+            assert np.array_equal(gu.bits(r["q_low"].cpu().numpy()), gu.bits(want_q)), (d, dh, dl, nq)
+            assert np.array_equal(r["ids"].cpu().numpy().view(np.uint32), sref["ids"]), (d, dh, dl, nq)
+            outs = [ix.search(q, 40, entry_ids=e, want=("q_low",), out={}, flags=g.FLAG_DEFER_JOIN, defer_depth=3) for _ in range(3)]
+            ix.join()
+            torch.cuda.synchronize()
+            for o in outs:
+                assert np.array_equal(gu.bits(o["q_low"].cpu().numpy()), gu.bits(want_q)), (d, dh, dl, nq)
+            # the base-set projection (gbnns_project) in its batches
+            pl = ix.project(t(c.base[:700]))
+            torch.cuda.synchronize()
+            assert np.array_equal(gu.bits(pl.cpu().numpy()), gu.bits(orc.project(c.net, c.base[:700]))), (d, dh, dl)
+            assert lib.gbnns_debug_knob(b"mlp_slab", 0) == 0
             r0 = ix.search(q, 40, entry_ids=e, want=("q_low",), out={})
             torch.cuda.synchronize()
             assert ix.profile_read(reset=False)["project_kernel"] == "mlp_layer_kernels"
             assert np.array_equal(gu.bits(r0["q_low"].cpu().numpy()), gu.bits(want_q)), (d, dh, dl, nq)
             ix.close()
     finally:
-        lib.gbnns_debug_knob(b"mlp_net", 1)
+        lib.gbnns_debug_knob(b"mlp_slab", 1)
 
 
 def test_matrix_core_projection_option(g, orc):
