@@ -403,7 +403,10 @@ int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint
     bool slab_used = false;
     auto layer = [&](const LayerParams& lp) {
         if (mfma) return launch_mlp_layer_mfma(lp, s);
-        if (!lp.small_footprint && g_knob_mlp_slab.load(std::memory_order_relaxed) && mlp_slab_wins(lp, ix->cus)) {
+        // (batches in flight: only the narrow shape -- 35 KB, 256 threads -- finds room beside the other lanes' walk wavefronts; the
+        // wide one's 103 KB workgroups wait for a CU to drain: GIST 2.27 against 2.58 M queries/s.  Knob value 2 = wide in flight too.)
+        const int slab = g_knob_mlp_slab.load(std::memory_order_relaxed);
+        if (!lp.small_footprint && slab && (!in_flight || lp.dout <= 64u || slab >= 2) && mlp_slab_wins(lp, ix->cus)) {
             slab_used = true;
             return launch_mlp_slab(lp, ix->cus, s);
         }
@@ -493,7 +496,7 @@ int gbnns_debug_knob(const char* name, int value) {
     else if (!std::strcmp(name, "spec_min_nq")) g_knob_spec_min_nq.store(std::max(0, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "mlp_small")) g_knob_mlp_small.store(std::max(0, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "mlp_net")) g_knob_mlp_net.store(value != 0, std::memory_order_relaxed);
-    else if (!std::strcmp(name, "mlp_slab")) g_knob_mlp_slab.store(value != 0, std::memory_order_relaxed);
+    else if (!std::strcmp(name, "mlp_slab")) g_knob_mlp_slab.store(std::max(0, std::min(2, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "spec_tail")) g_knob_spec_tail.store(std::max(0, std::min(100, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_chunk")) g_knob_knn_chunk.store(std::max(64, value & ~63), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_pool_min_k")) g_knob_knn_pool_min_k.store(std::max(1, value), std::memory_order_relaxed);

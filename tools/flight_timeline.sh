@@ -15,7 +15,7 @@ for f in glob.glob("$OUT/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the timed steps: the last dispatches before the final idle period; take the last N of the densest stretch
-rows = [r for r in rows if re.search(r"walk_hot_kernel|mlp_|walk_general", r["Kernel_Name"])]
+rows = [r for r in rows if re.search(r"walk_|mlp_", r["Kernel_Name"])]
 # a stretch in which the dispatches come from three queues and more (batches in flight): the last such, its middle
 qs = [r.get("Queue_Id", "?") for r in rows]
 good = [i for i in range(len(rows) - 12) if len(set(qs[i:i + 12])) >= 3]
