@@ -864,15 +864,19 @@ def other_configs(args, t_start):
     while the wall-clock budget lasts, DEEP10M-shaped at full size (n = 10^7, ONE 1 M-query batch).  Per configuration:
     the same figures as the headline line's (in-flight value, serial rate, first-pass kernel, its time, algorithmic
     bytes, roofline fraction, recall) and the answers of a 1 000-query sample compared with the compiled reference."""
-    plan = [("gist", 20, 150), ("glove", 20, 120), ("glove-dot", 20, 90), ("deep", 3, 300)]
+    # ("sift-M30": the headline workload on the graph of prepare_graph.cpp's M = 30 -- adjacency rows of up to 60 slots, the
+    # walk_hotw* instances: the library's tuning constants on a second degree distribution, every round)
+    plan = [("gist", 20, 150), ("glove", 20, 120), ("glove-dot", 20, 90), ("sift-M30", 20, 120), ("deep", 3, 200)]
     out = {}
     for name, steps, need_s in plan:
         left = args.budget_s - (time.time() - t_start)
         if left < need_s:
             out[name] = {"skipped": "%.0f s of the %.0f s budget left, this configuration is given %d s" % (left, args.budget_s, need_s)}
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "3" if steps > 3 else "1",
-               "--no-extras", "--cpu-sample", "1000", "--cache-dir", args.cache_dir]
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name.split("-M")[0] if "-M" in name else name, "--steps", str(steps),
+               "--warmup", "3" if steps > 3 else "1", "--no-extras", "--cpu-sample", "1000", "--cache-dir", args.cache_dir]
+        if "-M" in name:
+            cmd += ["--graph-M", name.split("-M")[1]]
         t1 = time.time()
         try:
             pr = subprocess.run(cmd, capture_output=True, text=True, timeout=need_s)
