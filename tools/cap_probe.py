@@ -28,6 +28,10 @@ def main():
               cache_dir="/tmp/gbnns_cache")
     if cfg.get("unit_norm"):
         kw["unit_norm"] = True
+    if cfg.get("native_knn") and cfg["n"] > 2_000_000:
+        kw["native_knn"] = True
+    if cfg.get("strong"):
+        kw["gt_queries"] = 20_000
     os.makedirs("/tmp/gbnns_cache", exist_ok=True)
     ds = synth.make_dataset(device="cuda:0", **kw)
     ix = ds.index()

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for CAP in "$@"; do
   OUT=$R/gpurun_out/cap_${EF}_$CAP
   rm -rf $OUT; mkdir -p $OUT
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/cap_probe.py --ef $EF --caps $CAP --reps 10 > $OUT/probe.txt 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/tools/cap_probe.py --config ${CONFIG:-sift} --ef $EF --caps $CAP --reps ${REPS:-10} > $OUT/probe.txt 2>&1
   grep "^cap" $OUT/probe.txt
   python3 - <<PY
 import csv, glob
