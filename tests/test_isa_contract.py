@@ -173,12 +173,12 @@ def test_hot_kernel_register_budgets(tmp_path):
     for k, v in hits.items():
         assert v["vgpr_count"] <= 256 and v["private_segment_fixed_size"] == 0 and v.get("vgpr_spill_count", 0) == 0, (k, v)
     # the slab kernel for single layers: the same two wavefronts per SIMD in its wide shape (8 wavefronts x 8 A queries, A <= 5),
-    # three per SIMD and more in the narrow one (<= 168 registers), nothing spilled
+    # and at least as many in the narrow ones (<= 192 registers; 140 in the 1 000 x 64-neuron shape), nothing spilled
     hits = {k: v for k, v in meta.items() if "mlp_slab_kernel" in k}
     assert len(hits) >= 12, sorted(hits)
     for k, v in hits.items():
         assert v["private_segment_fixed_size"] == 0 and v.get("vgpr_spill_count", 0) == 0, (k, v)
-        assert v["vgpr_count"] <= (256 if "mlp_slab_kernelILi8E" in k else 168), (k, v)
+        assert v["vgpr_count"] <= (256 if "mlp_slab_kernelILi8E" in k else 192), (k, v)
     # no bit-exact distance kernel may spill to scratch at all (a spill in a latency chain is a hidden HBM round trip),
     # and the generic two-list / bitmap walks stay within 3 wavefronts per SIMD (<= 168 registers)
     for k, v in meta.items():
