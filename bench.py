@@ -59,7 +59,7 @@ CONFIGS = {
     # the reference's own GloVe row (parameters_of_databases.txt:35-45): 10^6 vectors, 300 -> 144 (576-byte walked rows)
     # (d_hidden 512 instead of the file's 256: the synthetic net realises its projection exactly through ReLU and needs
     # d_hidden >= 2 d_low; the walk and the re-rank are what this row is about)
-    "glove1m": dict(n=1_000_000, nq=10_000, d=300, d_low=144, d_hidden=512, ef=300, efs=[400, 600], unit_norm=True,
+    "glove1m": dict(n=1_000_000, nq=10_000, d=300, d_low=144, d_hidden=512, ef=300, efs=[400, 600, 800, 1000], unit_norm=True,
                     label="GloVe1M 300->144 (the reference's parameter file)", shape="GloVe1M-shaped"),
     "deep": dict(n=10_000_000, nq=1_000_000, d=96, d_low=32, d_hidden=128, ef=40, efs=[60, 120], strong=True,
                  native_knn=True, label="DEEP10M 96->32, 1M-query batch", shape="DEEP10M-shaped"),

@@ -212,7 +212,11 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // with the quotient form of the table (round 3) the crossover moved up: GloVe-like ef = 400 3.85 ms (table) against
         // 4.85 (bitmap pass), ef = 500 5.61 / 5.51, ef = 600 8.86 / 6.83; SIFT-like ef = 450 4.41 / 4.68, ef = 500 5.30 / 5.29
         static const int min_ef_env = getenv("GBNNS_BITMAP_MIN_EF") ? atoi(getenv("GBNNS_BITMAP_MIN_EF")) : 0;  // (tuning runs)
-        const int min_ef = min_ef_env ? min_ef_env : (form == 2 ? 480 : 385);
+        // 576-byte rows (the reference's glove 300 -> 144; pair form of the two-list kernels, 8 wavefronts per CU by registers whatever
+        // the table): the table wins up to ef = 1 000 -- 10.7 / 17.4 / 22.3 ms at ef 600 / 800 / 1 000 against 13.5 / 18.0 / 22.4 with
+        // the bitmap pass in the same form
+        const bool rows576 = w.dim == 144u && w.dstride == 144u && ix->metric == GBNNS_METRIC_L2;
+        const int min_ef = min_ef_env ? min_ef_env : (rows576 ? kRegListMaxEf + 1 : (form == 2 ? 480 : 385));
         const bool forced = (a->flags & GBNNS_FLAG_BITMAP_PASS) != 0;  // diagnostic: whatever ef and batch size
         if (!w.all_general && (ef >= min_ef || forced) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && (a->hash_capacity == 0 || forced)) {
             const size_t gran = kLdsGran;

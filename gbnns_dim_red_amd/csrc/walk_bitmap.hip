@@ -9,7 +9,8 @@ namespace gbnns {
 // 128-byte rows of a compact index, the two-list walk for 256-byte rows with L2, else the LDS-list walk.
 bool walk_bitmap_uses_reg(const WalkParams& p, int metric) {
     const bool rows128 = p.dim == 32u && p.dstride == 32u, rows256 = p.dim == 64u && p.dstride == 64u && metric == 0 && p.ef > kHot2MaxEf;
-    return (metric == 0 || p.ef > kHot2MaxEf) && p.ef <= kRegListMaxEf && (rows128 || rows256) && walk_off32(p) && !p.aux_ell;
+    const bool rows576 = p.dim == 144u && p.dstride == 144u && metric == 0 && p.ef > kHot2MaxEf;  // (the reference's glove 300 -> 144)
+    return (metric == 0 || p.ef > kHot2MaxEf) && p.ef <= kRegListMaxEf && (rows128 || rows256 || rows576) && walk_off32(p) && !p.aux_ell;
 }
 
 // LDS of the bitmap first pass: result list (or merge buffer) + tie list + query (no visited table)
@@ -51,6 +52,7 @@ hipError_t launch_walk_bitmap(const WalkParams& p, int metric, unsigned slots, h
         };
         const bool one = p.ell_stride <= 32u;
         if (p.dim == 64u) return one ? go(walk_bitmap_big_kernel<0, 16, true>) : go(walk_bitmap_big_kernel<0, 16, false>);  // 256-byte rows, L2 (pair form)
+        if (p.dim == 144u) return one ? go(walk_bitmap_big_kernel<0, 36, true>) : go(walk_bitmap_big_kernel<0, 36, false>);  // 576-byte rows, L2 (pair form)
         if (metric == 1) return one ? go(walk_bitmap_big_kernel<1, 8, true>) : go(walk_bitmap_big_kernel<1, 8, false>);
         return one ? go(walk_bitmap_big_kernel<0, 8, true>) : go(walk_bitmap_big_kernel<0, 8, false>);
     }

@@ -553,7 +553,7 @@ template <int METRIC, int STEPS, bool OFF32, bool AUX = false, bool BITMAP = fal
 __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                                  uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
     constexpr bool kEarlyLoad = (STEPS > 0);
-    constexpr bool kPair = (STEPS == 8) || ((STEPS == 12 || STEPS == 16) && METRIC == 0);  // 128-byte rows, and 192- / 256-byte rows with L2: two lanes per neighbour
+    constexpr bool kPair = (STEPS == 8) || ((STEPS == 12 || STEPS == 16 || STEPS == 36) && METRIC == 0);  // 128-byte rows, and 192- / 256- / 576-byte rows with L2: two lanes per neighbour
     constexpr bool kAlt = (STEPS == 8 && METRIC == 1);
     constexpr int kQSteps = kPair ? STEPS / 2 : STEPS;        // row steps (16 bytes) per lane
     constexpr uint32_t kRowBytes = (uint32_t)STEPS * 16u;

@@ -64,6 +64,7 @@ static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, h
             case 32: return launch_fast_t<0, 8>(p, retry, s);
             case 48: return launch_walk_wide(p, 12, retry, s);
             case 64: return launch_walk_wide(p, 16, retry, s);
+            case 144: return launch_walk_wide(p, 36, retry, s);
             default: break;
         }
     }
