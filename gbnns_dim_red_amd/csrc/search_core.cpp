@@ -216,7 +216,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // the table): the table wins up to ef = 1 000 -- 10.7 / 17.4 / 22.3 ms at ef 600 / 800 / 1 000 against 13.5 / 18.0 / 22.4 with
         // the bitmap pass in the same form
         const bool rows576 = w.dim == 144u && w.dstride == 144u && ix->metric == GBNNS_METRIC_L2;
-        const int min_ef = min_ef_env ? min_ef_env : (rows576 ? kRegListMaxEf + 1 : (form == 2 ? 480 : 385));
+        const int min_ef = min_ef_env ? min_ef_env : (rows576 ? 1025 /* beyond the two-list kernels' range (walk_lists.h kRegListMaxEf) */ : (form == 2 ? 480 : 385));
         const bool forced = (a->flags & GBNNS_FLAG_BITMAP_PASS) != 0;  // diagnostic: whatever ef and batch size
         if (!w.all_general && (ef >= min_ef || forced) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && (a->hash_capacity == 0 || forced)) {
             const size_t gran = kLdsGran;
