@@ -775,6 +775,7 @@ def test_full_size_properties(g, orc):
     dict(name="glove", n=30000, nq=300, d=200, dlow=32, dh=64, efs=(64, 300), metric=1),
     dict(name="deep", n=40000, nq=400, d=96, dlow=32, dh=64, efs=(40, 120), metric=0),
     dict(name="deep48", n=20000, nq=200, d=96, dlow=48, dh=64, efs=(40, 200), metric=0),  # reference's own deep row
+    dict(name="glove144", n=20000, nq=200, d=300, dlow=144, dh=256, efs=(300, 600), metric=0),  # reference's own glove row (576-byte rows)
     # GIST with the hidden width the reference's parameter file names (second_part ... w_1024), and GloVe walked /
     # re-ranked with L2 on its 200-float rows (what final_test.cpp:20 does)
     dict(name="gist1024", n=6000, nq=100, d=960, dlow=64, dh=1024, efs=(200,), metric=0),
@@ -1475,6 +1476,11 @@ def test_two_list_kernels_by_name(g, orc):
         (96, 48, 64, 0, 30, [(8, 0, "walk_reg_wide_kernel<12>"), (40, 0, "walk_reg_wide_kernel<12>"), (100, 0, "walk_reg_kernel<0, 12,"),
                              (200, 0, "walk_reg_big_kernel<0, 12,")]),
         (64, 32, 64, 0, 70, [(300, 0, "walk_reg_big_kernel<0, 8,")]),  # adjacency rows of more than 64 slots: generic kernel
+        # (the reference's glove shape, 300 -> 144: 576-byte rows -- pair form, 18 sixteen-byte steps per lane, in the two-list kernels;
+        # beams of up to 128 stay on the generic one-lane-per-neighbour instances; the table form is kept up to ef = 1 000)
+        (304, 144, 304, 0, 30, [(40, 0, "walk_reg_kernel<0, 0,"), (100, 0, "walk_reg_kernel<0, 0,"), (300, 0, "walk_reg_big_kernel<0, 36,"),
+                                (1000, 0, "walk_reg_big_kernel<0, 36,"), (600, "bitmap", "walk_bitmap_big_kernel<0, 36,")]),
+        (304, 144, 304, 0, 50, [(300, 0, "walk_reg_big_kernel<0, 36,"), (400, "bitmap", "walk_bitmap_big_kernel<0, 36,")]),  # two 32-slot passes
         # adjacency rows of 33 .. 64 slots (hnswlib M = 18 / 20 level-0 lists, prepare_graph.cpp's M = 30): the hot
         # instances with a second expansion pass
         (64, 32, 64, 0, 60, [(8, 0, "walk_hotw_kernel"), (64, 0, "walk_hotw_kernel"), (100, 0, "walk_hotw2_kernel"),
