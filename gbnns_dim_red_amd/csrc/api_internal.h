@@ -203,7 +203,7 @@ constexpr size_t kLdsGran = GBNNS_LDS_GRAN;
 
 // the diagnostic knobs (gbnns_debug_knob; defined and documented in handle.cpp)
 extern std::atomic<int> g_knob_quotient, g_knob_vs_disp, g_knob_max_waves, g_knob_spec_min_nq, g_knob_spec_any_form, g_knob_mlp_small,
-    g_knob_mlp_net, g_knob_mlp_slab, g_knob_spec_tail, g_knob_knn_chunk, g_knob_knn_pool_min_k, g_knob_knn_filter;
+    g_knob_mlp_net, g_knob_mlp_slab, g_knob_late_rows, g_knob_spec_tail, g_knob_knn_chunk, g_knob_knn_pool_min_k, g_knob_knn_filter;
 
 // lanes.cpp
 int enter_stream(gbnns_index* ix, hipStream_t s);

@@ -176,6 +176,9 @@ std::atomic<int> g_knob_mlp_net{knob_env("GBNNS_MLP_NET", 1)};
 std::atomic<int> g_knob_mlp_slab{knob_env("GBNNS_MLP_SLAB", 1)};
 // "spec_tail" = largest partial last round of a lone launch, in percent of the device's wavefront slots, whose wavefronts
 // request their rows before the visited test (0 = off)
+// "late_rows": generic two-list kernels over 192- / 256- / 576-byte rows -- -1 = by shape and residency (search_core.cpp), 0 = rows
+// requested before the visited test, 1 = after it (GBNNS_LATE_ROWS)
+std::atomic<int> g_knob_late_rows{std::max(-1, std::min(1, knob_env("GBNNS_LATE_ROWS", -1)))};
 std::atomic<int> g_knob_spec_tail{std::max(0, std::min(100, knob_env("GBNNS_SPEC_TAIL", 50)))};
 // "knn_chunk" = most rows per filtered chunk (a multiple of 64)
 std::atomic<int> g_knob_knn_chunk{std::max(64, knob_env("GBNNS_KNN_CHUNK", 1 << 15) & ~63)};  // (a multiple of 64, never 0: the chunk loops step by it)
@@ -497,6 +500,7 @@ int gbnns_debug_knob(const char* name, int value) {
     else if (!std::strcmp(name, "mlp_small")) g_knob_mlp_small.store(std::max(0, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "mlp_net")) g_knob_mlp_net.store(value != 0, std::memory_order_relaxed);
     else if (!std::strcmp(name, "mlp_slab")) g_knob_mlp_slab.store(std::max(0, std::min(2, value)), std::memory_order_relaxed);
+    else if (!std::strcmp(name, "late_rows")) g_knob_late_rows.store(std::max(-1, std::min(1, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "spec_tail")) g_knob_spec_tail.store(std::max(0, std::min(100, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_chunk")) g_knob_knn_chunk.store(std::max(64, value & ~63), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_pool_min_k")) g_knob_knn_pool_min_k.store(std::max(1, value), std::memory_order_relaxed);

@@ -80,6 +80,7 @@ struct WalkParams {
     // its probe number reaches 15, or 7 << 1 with 13 remainder bits; less in test runs)
     uint32_t vs_shr;
     int32_t spec_rows;       // ef <= 64 hot first pass: 1 = request the rows before the visited test (big launches, see sizing.cpp)
+    int32_t late_rows;       // generic two-list kernels over 192- / 256- / 576-byte rows: 1 = request a hop's rows after its visited test (new ids only)
     uint32_t spec_from;      // ... and in the tested-first instances, for the wavefronts from this work item on (the last, partial round
                              // of a launch walks a draining machine: the shorter hop wins there); 0xFFFFFFFF = none
     const uint32_t* order;   // optional [nq]: work item b of a first pass runs query order[b] (a permutation: locality order of a deep batch)

@@ -232,6 +232,16 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
                 bitmap_per_cu = per_cu;
         }
     }
+    {
+        // Two-list kernels over wide rows: rows after the visited test where the launch is bound by bandwidth -- 576-byte rows with at
+        // least five wavefronts per CU by LDS (ef 300 / 400 / 600: 4.15 / 5.36 / 10.4 against 5.08 / 6.74 / 10.7 ms; ef 800 / 1 000, four and
+        // fewer per CU: 18.2 / 23.8 against 17.4 / 22.3) on a batch that fills the machine
+        const int knob = g_knob_late_rows.load(std::memory_order_relaxed);
+        const size_t per_wave = (walk_fast_lds_bytes(w, hot) + kLdsGran - 1) / kLdsGran * kLdsGran;
+        const size_t lds_waves = per_wave ? kMaxLds / per_wave : 0;
+        const bool auto_late = w.dim == 144u && w.dstride == 144u && ix->metric == GBNNS_METRIC_L2 && lds_waves >= 5 && nq >= 2048u;
+        w.late_rows = knob < 0 ? (auto_late ? 1 : 0) : knob;
+    }
     // (the ef > 128 hot instance keeps its result list in LDS and stages the re-rank query in the visited-set area)
     const size_t rr_room = walk_rr_room(w, ix->metric, hot, bitmap_per_cu != 0);
     const bool fuse = !walk_uses_lds_list(w) && (!bitmap_per_cu || walk_bitmap_uses_reg(w, ix->metric)) && want_fuse && !w.all_general &&

@@ -554,6 +554,12 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                                                  uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
     constexpr bool kEarlyLoad = (STEPS > 0);
     constexpr bool kPair = (STEPS == 8) || ((STEPS == 12 || STEPS == 16 || STEPS == 36) && METRIC == 0);  // 128-byte rows, and 192- / 256- / 576-byte rows with L2: two lanes per neighbour
+    // Wide rows (12 steps and more): the rows may be requested AFTER the visited test, for the new ids only (WalkParams::late_rows,
+    // wave-uniform; the host decides, search_core.cpp).  Requested before it -- one memory round trip less per hop, what a launch
+    // that is short of wavefronts wants -- a 10 000-query launch over 576-byte rows at ef = 300 moved 35.8 GB for 23.5 GB of algorithmic
+    // bytes, 7 TB/s of HBM traffic: there bandwidth, not latency, is what runs out (5.08 -> 4.15 ms with the rows requested late).
+    constexpr bool kLateLoad = kPair && STEPS >= 12;
+    const bool late = kLateLoad && p.late_rows != 0;
     constexpr bool kAlt = (STEPS == 8 && METRIC == 1);
     constexpr int kQSteps = kPair ? STEPS / 2 : STEPS;        // row steps (16 bytes) per lane
     constexpr uint32_t kRowBytes = (uint32_t)STEPS * 16u;
@@ -692,14 +698,15 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
             edges += __popcll(mv & kSlotLanes);
             RowRegs<kQSteps> rr;
             uint32_t roff = 0;
-            if constexpr (kEarlyLoad) {
+            // the row loads of this pass; `want` = lanes whose row is needed (the others read row 0, all of them the same lines)
+            auto request_rows = [&](bool want) {
                 // Rows of 12 / 16 steps (48 / 64 registers per lane): EVERY lane loads -- empty slots read row 0, all of them
                 // the same lines -- so that the row registers are defined by this pass alone.  Loaded under `if (valid)`
                 // the other lanes keep "the previous value", the compiler carries 64 registers around the hop loop and
                 // copies them twice per hop (measured in the code object: 2 x 32 v_mov_b64 per hop on 256-byte rows).
                 constexpr bool kAllLanes = kPair || kQSteps >= 12;
-                const uint32_t nbl = kAllLanes ? (valid ? nb : 0u) : nb;
-                const bool ld = kAllLanes || valid;
+                const uint32_t nbl = kAllLanes ? (want ? nb : 0u) : nb;
+                const bool ld = kAllLanes || want;
                 if constexpr (OFF32) {
                     roff = kPair ? nbl * kRowBytes + half * (kAlt ? 16u : kRowBytes / 2u) : nbl * (p.dstride * 4u);
                     const float* rp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff);
@@ -710,6 +717,9 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                     if constexpr (kAlt) { if (ld) load_row_alt(rr, rp); }
                     else { if (ld) load_row<kQSteps>(rr, rp); }
                 }
+            };
+            if constexpr (kEarlyLoad) {
+                if (!late) request_rows(valid);
             }
             uint64_t mclaimed;
             if constexpr (BITMAP) {
@@ -731,6 +741,9 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
             STAMP(t4)
             STAMP_ADD(3, t3, t4)
             const bool fresh = __builtin_amdgcn_inverse_ballot_w64(mfresh);
+            if constexpr (kEarlyLoad && kLateLoad) {
+                if (late) request_rows(__builtin_amdgcn_inverse_ballot_w64(mclaimed | mfresh));  // (both lanes of a new id's pair)
+            }
             uint32_t dk = 0xFFFFFFFFu;
             if constexpr (kEarlyLoad) {
                 if constexpr (kAlt) {
