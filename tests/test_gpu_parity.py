@@ -1512,6 +1512,36 @@ def test_two_list_kernels_by_name(g, orc):
         ix.close()
 
 
+@pytest.mark.gpu
+def test_two_list_wide_rows_requested_after_the_visited_test(g, orc):
+    """The generic two-list kernels over 192- / 256- / 576-byte rows (pair form) request a hop's rows before its visited test or --
+    knob "late_rows" 1; by default where the launch is bandwidth-bound: 576-byte rows at five wavefronts per CU and more -- after it, for
+    the new ids only.  Same walk either way: ids, pop order, distance bits, hops, dist_calc equal the oracle's; table and bitmap forms,
+    one- and two-pass adjacency rows."""
+    lib = g.load_library()
+    try:
+        for si, (d, dlow, dh, deg, cases) in enumerate((
+                (304, 144, 304, 30, ((300, 0), (600, g.FLAG_BITMAP_PASS))), (304, 144, 304, 50, ((200, 0),)),
+                (96, 48, 64, 30, ((200, 0),)), (128, 64, 128, 30, ((200, 0), (600, g.FLAG_BITMAP_PASS))))):
+            c, off, nbr, db_low, ent = _oracle_case(orc, 2700 + si, 6000, 150, d, dlow, dh, deg=(2, deg))
+            q_low = orc.project(c.net, c.queries)
+            ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+            for ef, flags in cases:
+                w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, threads=8)
+                s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net, entries=ent, threads=8)
+                for late in (1, 0, -1):
+                    assert lib.gbnns_debug_knob(b"late_rows", late) == 0
+                    r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), flags=flags)
+                    key = (dlow, deg, ef, flags, late)
+                    assert np.array_equal(r["cand"], w["ids"]), key
+                    assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
+                    assert np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]), key
+                    assert np.array_equal(r["ids"], s["ids"]), key
+            ix.close()
+    finally:
+        lib.gbnns_debug_knob(b"late_rows", -1)
+
+
 def _knobs(g, quotient=1, vs_disp=15, spec_min_nq=32768):
     """The process-wide diagnostic knobs of the library (include/gbnns.h, gbnns_debug_knob), back to their defaults unless named.
     (A lowered spec_min_nq means "the speculative instance, whatever the table's form": by default only big batches on
