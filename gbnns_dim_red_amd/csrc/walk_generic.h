@@ -395,16 +395,19 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                 if ((uint32_t)dist_calc + 64u > p.hash_limit) { status = 2; break; }
             const bool valid = nb != kInvalidId;
             edges += __popcll(mv & kSlotLanes);
-            // row loads go out before the visited test: its LDS round trips overlap the memory latency
-            // (rows of already-visited neighbours are fetched in vain -- we are not bandwidth bound)
+            // row loads go out before the visited test: its LDS round trips overlap the memory latency (rows of already-visited
+            // neighbours are fetched in vain) -- or, wide rows in the pair form with WalkParams::late_rows, after it for the new ids only:
+            // the 192-byte-row launch at ef = 40 moved 2.24 GB for 1.62 GB of algorithmic bytes, 6.5 TB/s -- bandwidth-bound on those
             RowRegs<kQSteps> rr;
             uint32_t roff = 0;  // row byte offset, kept live past the loads (see below)
-            if constexpr (kEarlyLoad) {
+            constexpr bool kLateLoad = kPair && ONE_CHUNK && STEPS >= 12;
+            const bool late = kLateLoad && p.late_rows != 0;
+            auto request_rows = [&](bool want) {
                 // (see walk_reg_big_one: every lane loads, empty slots read row 0; measured: the pair form gains in the one-pass
                 // hop only, 12- / 16-step rows one lane each wherever their 48 / 64 row registers would be carried around the loop)
                 constexpr bool kAllLanes = (kPair && ONE_CHUNK) || (!kPair && kQSteps >= 12);
-                const uint32_t nbl = kAllLanes ? (valid ? nb : 0u) : nb;
-                const bool ld = kAllLanes || valid;
+                const uint32_t nbl = kAllLanes ? (want ? nb : 0u) : nb;
+                const bool ld = kAllLanes || want;
                 if constexpr (OFF32) {
                     roff = kPair ? nbl * kRowBytes + half * (kAlt ? 16u : kRowBytes / 2u) : nbl * (p.dstride * 4u);
                     const float* rp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff);
@@ -415,6 +418,9 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                     if constexpr (kAlt) { if (ld) load_row_alt(rr, rp); }
                     else { if (ld) load_row<kQSteps>(rr, rp); }
                 }
+            };
+            if constexpr (kEarlyLoad) {
+                if (!late) request_rows(valid);
             }
             // pair form: the even lane of a pair tests / claims the id, the odd lane ends up with the distance
             uint64_t mclaimed;
@@ -437,6 +443,9 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             const bool fresh = __builtin_amdgcn_inverse_ballot_w64(mfresh);
             STAMP(t4)
             STAMP_ADD(3, t3, t4)
+            if constexpr (kEarlyLoad && kLateLoad) {
+                if (late) request_rows(__builtin_amdgcn_inverse_ballot_w64(mclaimed | mfresh));  // (both lanes of a new id's pair)
+            }
             uint32_t dk = 0xFFFFFFFFu;
             if constexpr (kEarlyLoad) {
                 if constexpr (kAlt) {
