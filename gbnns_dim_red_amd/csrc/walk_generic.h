@@ -165,7 +165,8 @@ __global__ __launch_bounds__(64) void walk_bitmap_kernel(WalkParams p) {
 // AUX: the auxiliary-graph walk (search_function.h:73-89): a hop expands the node's auxiliary row first (while
 // hops < hops_bound), then -- unless llf and that step inserted something -- its main row.
 // BITMAP: visited set = one bit per node in HBM (`bitmap`, this wavefront's slot), see walk_bitmap_kernel.
-template <int METRIC, int STEPS, bool OFF32, int R, bool ONE_CHUNK = false, bool AUX = false, bool BITMAP = false, bool QLDS_W = false>
+// LATE: rows requested after the visited test -- 1 always, 0 never, -1 by WalkParams::late_rows (both orders in the kernel)
+template <int METRIC, int STEPS, bool OFF32, int R, bool ONE_CHUNK = false, bool AUX = false, bool BITMAP = false, bool QLDS_W = false, int LATE = -1>
 __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                              uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
     static_assert(!(AUX && ONE_CHUNK), "auxiliary rows have their own length");
@@ -400,8 +401,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             // the 192-byte-row launch at ef = 40 moved 2.24 GB for 1.62 GB of algorithmic bytes, 6.5 TB/s -- bandwidth-bound on those
             RowRegs<kQSteps> rr;
             uint32_t roff = 0;  // row byte offset, kept live past the loads (see below)
-            constexpr bool kLateLoad = kPair && ONE_CHUNK && STEPS >= 12;
-            const bool late = kLateLoad && p.late_rows != 0;
+            constexpr bool kLateLoad = kPair && ONE_CHUNK && STEPS >= 12 && LATE != 0;
+            const bool late = kLateLoad && (LATE > 0 || p.late_rows != 0);
             auto request_rows = [&](bool want) {
                 // (see walk_reg_big_one: every lane loads, empty slots read row 0; measured: the pair form gains in the one-pass
                 // hop only, 12- / 16-step rows one lane each wherever their 48 / 64 row registers would be carried around the loop)
@@ -558,17 +559,19 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
 // ef <= 64 whatever ef is (the R-register lists spent 28 % of a hop selecting and 30 % inserting at ef = 300).
 // LDS: [BigList: big_list_fixed_bytes(ef)][query: dstride floats][visited set | (BITMAP) re-rank scratch].
 // ONE_PASS: adjacency rows of one pass (the host checks ell_stride), no auxiliary graph -- the hop is straight-line code.
-template <int METRIC, int STEPS, bool OFF32, bool AUX = false, bool BITMAP = false, bool ONE_PASS = false>
+template <int METRIC, int STEPS, bool OFF32, bool AUX = false, bool BITMAP = false, bool ONE_PASS = false, bool LATE = false>
 __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                                  uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
     constexpr bool kEarlyLoad = (STEPS > 0);
     constexpr bool kPair = (STEPS == 8) || ((STEPS == 12 || STEPS == 16 || STEPS == 36) && METRIC == 0);  // 128-byte rows, and 192- / 256- / 576-byte rows with L2: two lanes per neighbour
-    // Wide rows (12 steps and more): the rows may be requested AFTER the visited test, for the new ids only (WalkParams::late_rows,
-    // wave-uniform; the host decides, search_core.cpp).  Requested before it -- one memory round trip less per hop, what a launch
-    // that is short of wavefronts wants -- a 10 000-query launch over 576-byte rows at ef = 300 moved 35.8 GB for 23.5 GB of algorithmic
-    // bytes, 7 TB/s of HBM traffic: there bandwidth, not latency, is what runs out (5.08 -> 4.15 ms with the rows requested late).
-    constexpr bool kLateLoad = kPair && STEPS >= 12;
-    const bool late = kLateLoad && p.late_rows != 0;
+    // LATE (an instance of its own -- both orders in one kernel cost 30 registers): the rows are requested AFTER the visited test, for
+    // the new ids only.  Requested before it -- one memory round trip less per hop, what a launch that is short of wavefronts wants
+    // -- a 10 000-query launch over 576-byte rows at ef = 300 moved 35.8 GB for 23.5 GB of algorithmic bytes, 7 TB/s of HBM traffic:
+    // there bandwidth, not latency, is what runs out (5.08 -> 4.15 ms with the rows requested late).  The host decides
+    // (WalkParams::late_rows, search_core.cpp).
+    constexpr bool kLateLoad = LATE;
+    static_assert(!LATE || (kPair && STEPS >= 12), "LATE: pair-form instances over wide rows");
+    constexpr bool late = LATE;
     constexpr bool kAlt = (STEPS == 8 && METRIC == 1);
     constexpr int kQSteps = kPair ? STEPS / 2 : STEPS;        // row steps (16 bytes) per lane
     constexpr uint32_t kRowBytes = (uint32_t)STEPS * 16u;
@@ -842,13 +845,13 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
     B.template finish<(STEPS >= 12 ? 24 : 8)>(p, qi, hops, dist_calc, edges, after_q, lane);
 }
 
-template <int METRIC, int STEPS, bool OFF32, bool RETRY, bool AUX = false, bool ONE_PASS = false>
+template <int METRIC, int STEPS, bool OFF32, bool RETRY, bool AUX = false, bool ONE_PASS = false, bool LATE = false>
 __global__ __launch_bounds__(64) void walk_reg_big_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if constexpr (RETRY) {
         retry_loop(p, [&](uint32_t qi) { walk_reg_big_one<METRIC, STEPS, OFF32, AUX>(p, qi, smem, p.ovf2_count, p.ovf2_list); });
     } else {
-        walk_reg_big_one<METRIC, STEPS, OFF32, AUX, false, ONE_PASS>(p, walk_query_of(p, blockIdx.x), smem, p.ovf_count, p.ovf_list);
+        walk_reg_big_one<METRIC, STEPS, OFF32, AUX, false, ONE_PASS, LATE>(p, walk_query_of(p, blockIdx.x), smem, p.ovf_count, p.ovf_list);
     }
 }
 
@@ -864,10 +867,11 @@ __global__ __launch_bounds__(64) void walk_reg_kernel(WalkParams p) {
 
 // The reference's deep shape (96 -> 48: 192-byte rows) and 256-byte rows at ef <= 64, compact index, adjacency rows of one pass:
 // the generic hop with the query in LDS, held to GBNNS_WIDE_VGPRS vector registers (6 wavefronts per SIMD instead of 5).
-template <int STEPS>
+// LATE: its rows requested after the visited test (an instance of its own: with both orders in one kernel the register budget is gone).
+template <int STEPS, bool LATE = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(GBNNS_WIDE_VGPRS))) void walk_reg_wide_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    walk_reg_one<0, STEPS, true, 1, true, false, false, true>(p, walk_query_of(p, blockIdx.x), smem, p.ovf_count, p.ovf_list);
+    walk_reg_one<0, STEPS, true, 1, true, false, false, true, LATE ? 1 : 0>(p, walk_query_of(p, blockIdx.x), smem, p.ovf_count, p.ovf_list);
 }
 
 // First pass with HBM visited bitmaps on register lists (128-byte rows, L2 or dot): persistent wavefronts.

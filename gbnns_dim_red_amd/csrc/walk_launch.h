@@ -22,8 +22,12 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, true>, p, false, lds, s);
         if (off32) {
             // the common shape (compact index, adjacency rows of one pass) gets the hop without the pass loop
-            if (!retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16 || STEPS == 36) && METRIC == 0)) ? 32u : 64u))  // pair form: 32 slots per pass
+            if (!retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16 || STEPS == 36) && METRIC == 0)) ? 32u : 64u)) {  // pair form: 32 slots per pass
+                if constexpr (STEPS == 36 && METRIC == 0) {  // (the one shape whose rows are requested after the visited test: WalkParams::late_rows)
+                    if (p.late_rows) return launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, false, true, true>, p, false, lds, s);
+                }
                 return launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, false, true>, p, false, lds, s);
+            }
             return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, true>, p, true, lds, s)
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false>, p, false, lds, s);
         }
@@ -41,7 +45,9 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
         }
         if (off32 && !retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16) && METRIC == 0)) ? 32u : 64u)) {  // pair form: 32 slots per pass
             if constexpr (METRIC == 0 && (STEPS == 12 || STEPS == 16)) {
-                if (!p.stamps_on) return launch_walk_k(walk_reg_wide_kernel<STEPS>, p, false, lds, s);
+                if (!p.stamps_on)
+                    return p.late_rows ? launch_walk_k(walk_reg_wide_kernel<STEPS, true>, p, false, lds, s)
+                                       : launch_walk_k(walk_reg_wide_kernel<STEPS, false>, p, false, lds, s);
             }
             return launch_walk_k(walk_reg_kernel<METRIC, STEPS, true, false, 1, true>, p, false, lds, s);
         }

@@ -275,9 +275,9 @@ int gbnns_profile_enable(gbnns_index* index, int on);
  * 0 = always the per-layer kernels; identical outputs either way (GBNNS_MLP_NET).
  * "mlp_slab": 1 (default) = a projection layer that is one round of the machine for mlp_slab_kernel (small batches; the GIST
  * shape's 1 000 queries through 960 -> 1 024 -> 1 024 -> 64) takes it, 0 = never; identical outputs either way (GBNNS_MLP_SLAB).
- * "late_rows": the generic two-list kernels over 192- / 256- / 576-byte rows request a hop's rows before its visited test (0) or after
- * it, for the new ids only (1); -1 (default) = by shape and residency (576-byte rows with at least five wavefronts per CU: after;
- * GBNNS_LATE_ROWS).
+ * "late_rows": the wide-row instances that have both forms (walk_reg_wide_kernel: 192- / 256-byte rows at ef <= 64; the two-list kernel
+ * over 576-byte rows) request a hop's rows before its visited test (0) or after it, for the new ids only (1); -1 (default) = by
+ * shape and residency (576-byte rows with at least five wavefronts per CU, 192-byte rows at ef <= 64: after; GBNNS_LATE_ROWS).
  * "knn_chunk": most base rows per filtered chunk of gbnns_exact_knn (default 32 768; the pool path takes four times that;
  * GBNNS_KNN_CHUNK).
  * "knn_pool_min_k": shortest list gbnns_exact_knn's filter path keeps as an unordered pool with a radix select (one

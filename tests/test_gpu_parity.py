@@ -1470,10 +1470,10 @@ def test_two_list_kernels_by_name(g, orc):
         (64, 32, 64, 1, 60, [(64, 0, "walk_hot_dot_kernel<1, true>"), (100, 0, "walk_hot_dot_kernel<2, true>"),
                              (300, 0, "walk_hot_dot_big_kernel<true>")]),
         (64, 32, 64, 1, 90, [(64, 0, "walk_reg_kernel<1, 8,"), (200, 0, "walk_reg_big_kernel<1, 8,")]),  # > 64 slots: generic
-        (128, 64, 128, 0, 30, [(64, 0, "walk_reg_wide_kernel<16>"), (200, 0, "walk_reg_big_kernel<0, 16,"),
+        (128, 64, 128, 0, 30, [(64, 0, "walk_reg_wide_kernel<16,"), (200, 0, "walk_reg_big_kernel<0, 16,"),
                                (1000, 0, "walk_reg_big_kernel<0, 16,"), (600, "bitmap", "walk_bitmap_big_kernel<0, 16,")]),
         # (the reference's deep shape, 96 -> 48: ef <= 64 on the instance with the query in LDS, 6 wavefronts per SIMD)
-        (96, 48, 64, 0, 30, [(8, 0, "walk_reg_wide_kernel<12>"), (40, 0, "walk_reg_wide_kernel<12>"), (100, 0, "walk_reg_kernel<0, 12,"),
+        (96, 48, 64, 0, 30, [(8, 0, "walk_reg_wide_kernel<12,"), (40, 0, "walk_reg_wide_kernel<12,"), (100, 0, "walk_reg_kernel<0, 12,"),
                              (200, 0, "walk_reg_big_kernel<0, 12,")]),
         (64, 32, 64, 0, 70, [(300, 0, "walk_reg_big_kernel<0, 8,")]),  # adjacency rows of more than 64 slots: generic kernel
         # (the reference's glove shape, 300 -> 144: 576-byte rows -- pair form, 18 sixteen-byte steps per lane, in the two-list kernels;
