@@ -38,5 +38,6 @@ hipError_t launch_walk_hot(const WalkParams& p, int metric, hipStream_t s);
 // the walk launchers of the dot-metric and the wide-row (192 / 256-byte, L2) translation units
 hipError_t launch_walk_dot(const WalkParams& p, bool retry, hipStream_t s);
 hipError_t launch_walk_wide(const WalkParams& p, int steps, bool retry, hipStream_t s);
+hipError_t launch_walk_wide2(const WalkParams& p, int steps, bool retry, hipStream_t s);
 
 }  // namespace gbnns

@@ -242,7 +242,10 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // ... and 192-byte rows at ef <= 64 (walk_reg_wide_kernel<12>, the reference's deep 96 -> 48: 2.24 GB moved for 1.62 GB of
         // algorithmic bytes at ef = 40, 6.5 TB/s; 0.351 -> 0.342 ms alone, 29.4 -> 30.9 M queries/s in flight; its longer beams: no gain)
         const bool l2 = ix->metric == GBNNS_METRIC_L2 && w.dim == w.dstride && nq >= 2048u;
-        const bool auto_late = l2 && ((w.dim == 144u && lds_waves >= 5) || (w.dim == 48u && ef <= 64));
+        // ... and the 384- / 512-byte rows of PLAIN walks over deep / sift vectors at beams of more than 128 (2.15 -> 2.08 ms at d = 128,
+        // ef = 140; 1.63 -> 1.52 ms at d = 96, ef = 160)
+        const bool big_rows = w.dim == 144u || ((w.dim == 96u || w.dim == 128u) && ef > 128);
+        const bool auto_late = l2 && ((big_rows && lds_waves >= 5) || (w.dim == 48u && ef <= 64));
         w.late_rows = knob < 0 ? (auto_late ? 1 : 0) : knob;
     }
     // (the ef > 128 hot instance keeps its result list in LDS and stages the re-rank query in the visited-set area)

@@ -563,7 +563,8 @@ template <int METRIC, int STEPS, bool OFF32, bool AUX = false, bool BITMAP = fal
 __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t qi, unsigned char* smem,
                                                  uint32_t* ovf_count, uint32_t* ovf_list, uint32_t* bitmap = nullptr) {
     constexpr bool kEarlyLoad = (STEPS > 0);
-    constexpr bool kPair = (STEPS == 8) || ((STEPS == 12 || STEPS == 16 || STEPS == 36) && METRIC == 0);  // 128-byte rows, and 192- / 256- / 576-byte rows with L2: two lanes per neighbour
+    // 128-byte rows, and 192- / 256- / 384- / 512- / 576-byte rows with L2: two lanes per neighbour
+    constexpr bool kPair = (STEPS == 8) || ((STEPS == 12 || STEPS == 16 || STEPS == 24 || STEPS == 32 || STEPS == 36) && METRIC == 0);
     // LATE (an instance of its own -- both orders in one kernel cost 30 registers): the rows are requested AFTER the visited test, for
     // the new ids only.  Requested before it -- one memory round trip less per hop, what a launch that is short of wavefronts wants
     // -- a 10 000-query launch over 576-byte rows at ef = 300 moved 35.8 GB for 23.5 GB of algorithmic bytes, 7 TB/s of HBM traffic:

@@ -65,6 +65,9 @@ static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, h
             case 48: return launch_walk_wide(p, 12, retry, s);
             case 64: return launch_walk_wide(p, 16, retry, s);
             case 144: return launch_walk_wide(p, 36, retry, s);
+            // (beams of more than 128 only: the instances for shorter beams would be the generic ones anyway)
+            case 96: if (p.ef > kHot2MaxEf && p.ef <= kRegListMaxEf) return launch_walk_wide2(p, 24, retry, s); break;
+            case 128: if (p.ef > kHot2MaxEf && p.ef <= kRegListMaxEf) return launch_walk_wide2(p, 32, retry, s); break;
             default: break;
         }
     }

@@ -22,8 +22,8 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, true>, p, false, lds, s);
         if (off32) {
             // the common shape (compact index, adjacency rows of one pass) gets the hop without the pass loop
-            if (!retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16 || STEPS == 36) && METRIC == 0)) ? 32u : 64u)) {  // pair form: 32 slots per pass
-                if constexpr (STEPS == 36 && METRIC == 0) {  // (the one shape whose rows are requested after the visited test: WalkParams::late_rows)
+            if (!retry && p.ell_stride <= ((STEPS == 8 || ((STEPS == 12 || STEPS == 16 || STEPS >= 24) && METRIC == 0)) ? 32u : 64u)) {  // pair form: 32 slots per pass
+                if constexpr (STEPS >= 24 && METRIC == 0) {  // (the shapes with an instance whose rows are requested after the visited test: WalkParams::late_rows)
                     if (p.late_rows) return launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, false, true, true>, p, false, lds, s);
                 }
                 return launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, false, true>, p, false, lds, s);
@@ -80,12 +80,13 @@ static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) 
         return retry ? launch_walk_k(walk_fast_kernel<METRIC, STEPS, true, false>, p, true, lds, s)
                      : launch_walk_k(walk_fast_kernel<METRIC, STEPS, false, false>, p, false, lds, s);
     }
-    // (576-byte rows -- the reference's glove 300 -> 144 -- have the pair form in the two-list kernels only: 2 x 72 registers of
-    // row and query; its beams start at 300)
-    constexpr int kListSteps = STEPS == 36 ? 0 : STEPS;
-    constexpr int kBigSteps = STEPS == 36 ? 36 : kWideSteps48;
+    // (576-byte rows -- the reference's glove 300 -> 144 -- and the 384- / 512-byte rows of its PLAIN walks over deep / sift vectors
+    // have the pair form in the two-list kernels only: 2 x 48 .. 72 registers of row and query; shorter beams take the generic instances)
+    constexpr bool kBigOnly = STEPS >= 24;
+    constexpr int kListSteps = kBigOnly ? 0 : STEPS;
+    constexpr int kBigSteps = kBigOnly ? STEPS : kWideSteps48;
     if (p.ef <= 64) return launch_reg_t<METRIC, kListSteps, 1>(p, retry, lds, s);
-    if (p.ef <= kHot2MaxEf) return launch_reg_t<METRIC, STEPS == 36 ? 0 : kWideSteps48, 2>(p, retry, lds, s);  // (12- / 16-step rows keep the unrolled distance)
+    if (p.ef <= kHot2MaxEf) return launch_reg_t<METRIC, kBigOnly ? 0 : kWideSteps48, 2>(p, retry, lds, s);  // (12- / 16-step rows keep the unrolled distance)
     return launch_reg_t<METRIC, kBigSteps, 4>(p, retry, lds, s);  // (R >= 4: the two-list kernels, one instance for every ef up to 512)
 }
 
