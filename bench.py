@@ -931,7 +931,8 @@ def roofline_of(ds, res, prof, ef, nq, max_degree, cfg, rank, launches=1):
     general_ms = prof["walk_general_ms"] / calls
     # the register-list / two-list first passes (ef <= 1024) re-rank at the end of the walk: then no re-rank kernel is
     # launched and the library's re-rank interval is an empty pair of events (~0.006 ms)
-    fused = ds.d % 8 == 0 and rerank_ms < 0.02
+    # (L2: d % 8 == 4 too -- glove's 300 -- since round 5)
+    fused = (ds.d % 8 == 0 or (ds.d % 4 == 0 and not cfg.get("negdot"))) and rerank_ms < 0.02
     kernel_bytes = walk_bytes + (rerank_bytes if fused else 0.0)
     achieved = kernel_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
     pmc = counters_for(cfg["name"], ef)

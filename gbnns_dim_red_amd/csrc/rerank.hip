@@ -64,7 +64,8 @@ __global__ __launch_bounds__(64) void rerank_pair_kernel(RerankParams p) {
 hipError_t launch_rerank(const RerankParams& p, int metric, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
     const size_t lds = (size_t)p.dstride * 4;
-    const bool pairs = p.dim % 8 == 0 && p.dim > 0;  // pair form (both metrics)
+    // pair form: both metrics at dim % 8 == 0; L2 at dim % 8 == 4 too (the last 16-byte step is the even lane's alone)
+    const bool pairs = p.dim > 0 && (p.dim % 8 == 0 || (metric == 0 && p.dim % 4 == 0));
     hipError_t e;
     if (metric == 1) {
         if (pairs) {

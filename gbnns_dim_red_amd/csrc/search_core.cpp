@@ -202,7 +202,9 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     // keeps its visited sets as bitmaps in HBM and runs as many persistent wavefronts as the LDS holds result
     // lists (LDS-list kernel); taken when that at least doubles the resident wavefronts.
     size_t bitmap_per_cu = 0;
-    const bool want_fuse = !plain && ix->d % 8 == 0 && !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
+    // (L2: d % 8 == 4 too -- glove's 300 -- the pair form's last 16-byte step is the even lane's alone)
+    const bool pair_form = ix->d % 8 == 0 || (ix->d % 4 == 0 && ix->metric == GBNNS_METRIC_L2);
+    const bool want_fuse = !plain && pair_form && !(a->flags & GBNNS_FLAG_NO_FUSED_RERANK);
     w.rr_reserve = want_fuse ? (uint32_t)ix->d_pad * 4u : 0u;
     {
         // measured crossover on the GloVe-like shape: ef = 300 is faster with the register list + LDS table

@@ -938,6 +938,20 @@ def test_fused_and_separate_rerank_agree(g, orc):
         assert np.array_equal(fused["ids"], s["ids"]), (ef, cap)
         assert np.array_equal(apart["ids"], s["ids"]), (ef, cap)
     ix.close()
+    # d % 8 == 4 with L2 (glove's 300; 12; 44): the pair form's last 16-byte step belongs to the even lane alone -- fused and apart,
+    # and gbnns_rerank on candidate lists of its own; d % 4 != 0 stays on the one-lane form
+    for si, (d, dlow) in enumerate(((300, 32), (12, 8), (44, 32), (30, 16))):
+        c, off, nbr, db_low, ent = _oracle_case(orc, 885 + si, 6000, 200, d, dlow, 24)
+        ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+        for ef in (8, 64, 200):
+            s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net, entries=ent, threads=8)
+            fused = ix.search(c.queries, ef, entry_ids=ent, want=("cand",))
+            apart = ix.search(c.queries, ef, entry_ids=ent, want=(), flags=g.FLAG_NO_FUSED_RERANK)
+            assert np.array_equal(fused["ids"], s["ids"]), (d, ef)
+            assert np.array_equal(apart["ids"], s["ids"]), (d, ef)
+            again = ix.rerank(c.queries, fused["cand"])
+            assert np.array_equal(again, s["ids"]), (d, ef)
+        ix.close()
 
 
 def test_calm_batches_then_surprise(g, orc):
