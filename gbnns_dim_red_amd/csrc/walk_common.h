@@ -595,9 +595,13 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
                 v0 = dpp_swap_pair(u0) + p0; v1 = dpp_swap_pair(u1) + p1; v2 = dpp_swap_pair(u2) + p2; v3 = dpp_swap_pair(u3) + p3;
             }
         }
-        for (; k < pairs; ++k) {
-            const float4 rv = row[2 * k];
-            const float4 qv = qh[2 * k];
+        // (dim % 8 == 4 -- glove's 300: one more 16-byte step, the even lane's alone; the odd lane adds +0 to the sums it takes over, which
+        // leaves a sum of squares as it is)
+        const uint32_t pairs_t = pairs + ((a.dim >> 2) & 1u);
+        for (; k < pairs_t; ++k) {
+            const bool mine = k < pairs || !half;
+            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), qv = rv;
+            if (mine) { rv = row[2 * k]; qv = qh[2 * k]; }
             float e;
             e = rv.x - qv.x; const float p0 = e * e;
             e = rv.y - qv.y; const float p1 = e * e;
@@ -605,18 +609,6 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
             e = rv.w - qv.w; const float p3 = e * e;
             u0 = dpp_swap_pair(v0) + p0; u1 = dpp_swap_pair(v1) + p1; u2 = dpp_swap_pair(v2) + p2; u3 = dpp_swap_pair(v3) + p3;
             v0 = dpp_swap_pair(u0) + p0; v1 = dpp_swap_pair(u1) + p1; v2 = dpp_swap_pair(u2) + p2; v3 = dpp_swap_pair(u3) + p3;
-        }
-        if (a.dim & 4u) {
-            // dim % 8 == 4 (glove's 300): one more 16-byte step, the even lane's; the odd lane takes the even lane's sums over as they are
-            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), qv = rv;
-            if (!half) { rv = row[2 * pairs]; qv = qh[2 * pairs]; }
-            float e;
-            e = rv.x - qv.x; const float p0 = e * e;
-            e = rv.y - qv.y; const float p1 = e * e;
-            e = rv.z - qv.z; const float p2 = e * e;
-            e = rv.w - qv.w; const float p3 = e * e;
-            u0 = dpp_swap_pair(v0) + p0; u1 = dpp_swap_pair(v1) + p1; u2 = dpp_swap_pair(v2) + p2; u3 = dpp_swap_pair(v3) + p3;
-            v0 = dpp_swap_pair(u0); v1 = dpp_swap_pair(u1); v2 = dpp_swap_pair(u2); v3 = dpp_swap_pair(u3);
         }
         // the odd lane's v holds all steps: in the even lane `u` is the valid one, in the odd lane `v`
         const float dv = ((v0 + v1) + v2) + v3;
