@@ -215,15 +215,15 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // 4.85 (bitmap pass), ef = 500 5.61 / 5.51, ef = 600 8.86 / 6.83; SIFT-like ef = 450 4.41 / 4.68, ef = 500 5.30 / 5.29
         static const int min_ef_env = getenv("GBNNS_BITMAP_MIN_EF") ? atoi(getenv("GBNNS_BITMAP_MIN_EF")) : 0;  // (tuning runs)
         // 576-byte rows (the reference's glove 300 -> 144; pair form of the two-list kernels, 8 wavefronts per CU by registers whatever
-        // the table): the table wins up to ef = 1 000 -- 10.7 / 17.4 / 22.3 ms at ef 600 / 800 / 1 000 against 13.5 / 18.0 / 22.4 with
-        // the bitmap pass in the same form
+        // the table): walk + re-rank at ef 600 / 800 / 1 000 11.2 / 18.5 / 23.7 ms with the table against 12.5 / 16.3 / 20.1 with the
+        // bitmap pass in the same form and its rows requested after the bit test -- the bitmap pass from ef = 700
         const bool rows576 = w.dim == 144u && w.dstride == 144u && ix->metric == GBNNS_METRIC_L2;
-        const int min_ef = min_ef_env ? min_ef_env : (rows576 ? 1025 /* beyond the two-list kernels' range (walk_lists.h kRegListMaxEf) */ : (form == 2 ? 480 : 385));
+        const int min_ef = min_ef_env ? min_ef_env : (rows576 ? 700 : (form == 2 ? 480 : 385));
         const bool forced = (a->flags & GBNNS_FLAG_BITMAP_PASS) != 0;  // diagnostic: whatever ef and batch size
         if (!w.all_general && (ef >= min_ef || forced) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && (a->hash_capacity == 0 || forced)) {
             const size_t gran = kLdsGran;
             const size_t per_wave = (walk_bitmap_lds_bytes(w, ix->metric) + gran - 1) / gran * gran;
-            const size_t per_cu = std::min<size_t>(32, kMaxLds / per_wave);
+            const size_t per_cu = std::min<size_t>(rows576 ? 8 : 32, kMaxLds / per_wave);  // (576-byte rows: 223 registers, two wavefronts per SIMD)
             const size_t table_waves = std::min<size_t>(32, kMaxLds / ((walk_fast_lds_bytes(w, hot) + gran - 1) / gran * gran));
             // ... and only when the batch is deeper than 1.5 rounds of the wavefronts the table would allow (a
             // 1 000-query batch is resident at once either way, and the register list is faster per hop)
@@ -248,7 +248,9 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // ef = 140; 1.63 -> 1.52 ms at d = 96, ef = 160)
         const bool big_rows = w.dim == 144u || ((w.dim == 96u || w.dim == 128u) && ef > 128);
         const bool auto_late = l2 && ((big_rows && lds_waves >= 5) || (w.dim == 48u && ef <= 64));
-        w.late_rows = knob < 0 ? (auto_late ? 1 : 0) : knob;
+        // (the bitmap pass over 576-byte rows: always -- 8 wavefronts per CU whatever the beam)
+        const bool bitmap_late = bitmap_per_cu != 0 && w.dim == 144u && l2;
+        w.late_rows = knob < 0 ? ((auto_late || bitmap_late) ? 1 : 0) : knob;
     }
     // (the ef > 128 hot instance keeps its result list in LDS and stages the re-rank query in the visited-set area)
     const size_t rr_room = walk_rr_room(w, ix->metric, hot, bitmap_per_cu != 0);

@@ -892,7 +892,7 @@ __global__ __launch_bounds__(64) void walk_bitmap_reg_kernel(WalkParams p) {
     }
 }
 
-template <int METRIC, int STEPS = 8, bool ONE_PASS = false>
+template <int METRIC, int STEPS = 8, bool ONE_PASS = false, bool LATE = false>
 __global__ __launch_bounds__(64) void walk_bitmap_big_kernel(WalkParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* bitmap = p.fp_bitmap + (size_t)blockIdx.x * p.bitmap_words;
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(64) void walk_bitmap_big_kernel(WalkParams p) {
         if (lane_id() == 0) w = atomicAdd(p.fp_cursor, 1u);
         w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
         if (w >= p.nq) break;
-        walk_reg_big_one<METRIC, STEPS, true, false, true, ONE_PASS>(p, walk_query_of(p, w), smem, p.ovf_count, p.ovf_list, bitmap);
+        walk_reg_big_one<METRIC, STEPS, true, false, true, ONE_PASS, LATE>(p, walk_query_of(p, w), smem, p.ovf_count, p.ovf_list, bitmap);
         wave_sync();
     }
 }
