@@ -9,6 +9,10 @@ namespace gbnns {
 
 namespace {
 
+// rows of at least this many floats take the four-lanes-per-row distance in the run-time-length instances (l2_quad_rows, walk_lists.h)
+constexpr uint32_t kQuadRowsMinDim = 128;  // (measured: d = 96 is faster a lane per row -- 1.56 against 1.86 ms at ef 120 --, d = 128 four lanes per row: 1.39 against 1.75)
+
+
 // ---- fast kernel: result list, tie list, visited hash set and the query all live in LDS -------
 //
 // LDS layout (dynamic): [keys: ef_pad x u64][tie: kTieCap x u64][q: dstride x f32][hash: cap x u32]
@@ -82,8 +86,15 @@ __device__ __forceinline__ void walk_fast_one(const WalkParams& p, uint32_t qi, 
             } else if constexpr (PACKED) fresh = __builtin_amdgcn_inverse_ballot_w64(visited_claim_mask_packed(hash_lds, nbuckets, nb, mv));
             else fresh = visited_claim(hash, nbuckets, nb, valid);
             uint32_t dk = 0xFFFFFFFFu;
-            if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, p.db + (size_t)nb * p.dstride, p.dim));
             const uint64_t mf = __ballot(fresh);
+            if constexpr (METRIC == 0 && STEPS == 0) {
+                if (p.dim >= kQuadRowsMinDim) {
+                    const float dq = l2_quad_rows<false>(mf, nb, p.db, p.dstride, p.dim, qf, lane);
+                    dk = fresh ? fkey(dq) : 0xFFFFFFFFu;
+                } else if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, p.db + (size_t)nb * p.dstride, p.dim));
+            } else {
+                if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, p.db + (size_t)nb * p.dstride, p.dim));
+            }
             st.dist_calc += __popcll(mf);
             // reference order: neighbours are offered one by one in list order
             const uint32_t worst0 = key_hi(keys[st.size - 1]);
@@ -473,7 +484,15 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
                 // serialises the adjacency prefetch with the gather (tools/check_isa.sh).
                 asm volatile("" ::"v"(roff));
             } else {
-                if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, nb, p.dstride), p.dim));
+                if constexpr (METRIC == 0 && STEPS == 0) {
+                    // long rows (PLAIN walks over the original vectors): four lanes per row (l2_quad_rows); short ones: a lane per row
+                    if (p.dim >= kQuadRowsMinDim) {
+                        const float dq = l2_quad_rows<OFF32>(mfresh, nb, p.db, p.dstride, p.dim, qf, lane);
+                        dk = fresh ? fkey(dq) : 0xFFFFFFFFu;
+                    } else if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, nb, p.dstride), p.dim));
+                } else {
+                    if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, nb, p.dstride), p.dim));
+                }
             }
             dist_calc += __popcll(mfresh);
             const bool offer_it = fresh && (size < ef || dk < worst);
@@ -773,7 +792,15 @@ __device__ __forceinline__ void walk_reg_big_one(const WalkParams& p, uint32_t q
                 }
                 asm volatile("" ::"v"(roff));  // the address register must not double as a load destination
             } else {
-                if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, nb, p.dstride), p.dim));
+                if constexpr (METRIC == 0 && STEPS == 0) {
+                    // long rows (PLAIN walks over the original vectors): four lanes per row (l2_quad_rows); short ones: a lane per row
+                    if (p.dim >= kQuadRowsMinDim) {
+                        const float dq = l2_quad_rows<OFF32>(mfresh, nb, p.db, p.dstride, p.dim, qf, lane);
+                        dk = fresh ? fkey(dq) : 0xFFFFFFFFu;
+                    } else if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, nb, p.dstride), p.dim));
+                } else {
+                    if (fresh) dk = fkey(walk_dist<METRIC, STEPS>(qs, row_ptr<OFF32>(p.db, nb, p.dstride), p.dim));
+                }
             }
             dist_calc += __popcll(mfresh);
             const uint64_t m = (B.l + B.f < ef) ? mfresh : __ballot(fresh && dk < B.worst);

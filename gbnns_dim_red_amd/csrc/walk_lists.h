@@ -256,6 +256,77 @@ __device__ __forceinline__ const float* row_ptr(const float* base, uint32_t id, 
     }
 }
 
+// L2Metric::Dist (support_func.h:107-128) for LONG rows whose length is a run-time value -- the PLAIN walks over gist / glove / sift /
+// deep vectors at the beams the pair-form instances do not take -- four lanes per row: lane j of a quad owns the reference's running
+// sum j (the four sums are independent chains: no hand-over between lanes), reads element j of every 16-byte step -- the quad reads 16
+// contiguous bytes per load instruction, 16 rows per instruction instead of the 64 cache lines of one lane per row -- and the quad
+// folds ((s0 + s1) + s2) + s3 at the end.  `mfresh` = the lanes that need the distance of their row `nb`; 16 of them per round.
+// Returns the distance in those lanes.  Same operations in the same order as l2_ordered ((q - r)^2, sum = sum + that, dim % 4 ignored).
+template <bool OFF32>
+__device__ __forceinline__ float l2_quad_rows(uint64_t mfresh, uint32_t nb, const float* db, uint32_t dstride, uint32_t dim, const float* qf, int lane) {
+    float out = 0.f;
+    const uint32_t steps = dim >> 2;
+    const int g = lane >> 2, j = lane & 3;
+    const float* q = qf + j;
+    uint64_t m = mfresh;
+    while (m) {
+        // this round's rows: the lowest (up to) sixteen set bits; quad i takes the i-th of them
+        uint64_t round = 0ull, mm = m;
+        int src = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int pos = mm ? __ffsll((unsigned long long)mm) - 1 : 0;
+            round |= mm ? (1ull << pos) : 0ull;
+            mm &= mm - 1ull;
+            src = (g == i) ? pos : src;
+        }
+        const int nrows = __popcll(round);
+        uint32_t id = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)nb);
+        id = g < nrows ? id : 0u;  // (idle quads read row 0)
+        const float* row = row_ptr<OFF32>(db, id, dstride) + j;
+        float sum = 0.f;
+        // sixteen loads in flight per round trip; what is left -- fewer than sixteen steps -- as ONE masked batch (steps beyond the row read
+        // nothing and add +0 to a sum of squares: no change): step by step it costs a round trip per step (d = 300: 75 steps = 4 x 16 + 11)
+        uint32_t t = 0;
+        for (; t + 16 <= steps; t += 16) {
+            float r[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) r[k] = row[4u * (t + k)];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float e = q[4u * (t + k)] - r[k];
+                sum = sum + e * e;
+            }
+        }
+        if (t < steps) {
+            float r[16], qv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const bool in = t + k < steps;
+                r[k] = in ? row[4u * (t + k)] : 0.f;
+                qv[k] = in ? q[4u * (t + k)] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float e = qv[k] - r[k];
+                sum = sum + e * e;
+            }
+        }
+        const int si = __float_as_int(sum);
+        const float s0 = __int_as_float(__builtin_amdgcn_update_dpp(0, si, 0x00, 0xf, 0xf, false));  // quad_perm [0,0,0,0]
+        const float s1 = __int_as_float(__builtin_amdgcn_update_dpp(0, si, 0x55, 0xf, 0xf, false));  // [1,1,1,1]
+        const float s2 = __int_as_float(__builtin_amdgcn_update_dpp(0, si, 0xAA, 0xf, 0xf, false));  // [2,2,2,2]
+        const float s3 = __int_as_float(__builtin_amdgcn_update_dpp(0, si, 0xFF, 0xf, 0xf, false));  // [3,3,3,3]
+        const float d = ((s0 + s1) + s2) + s3;
+        // an owner lane is the rank-th row of the round: its distance sits in quad `rank`
+        const int rank = __popcll(round & ((1ull << lane) - 1ull));
+        const float dv = __int_as_float(__builtin_amdgcn_ds_bpermute(rank << 4, __float_as_int(d)));
+        out = ((round >> lane) & 1ull) ? dv : out;
+        m &= ~round;
+    }
+    return out;
+}
+
 // Register-resident result list: entry of rank i lives in register i / 64 of lane i % 64
 // (R registers per lane, ef <= 64 * R).  Empty slots hold all-ones, which reads as "expanded".
 template <int R>

@@ -1590,6 +1590,30 @@ def test_plain_walks_over_wide_rows_two_list_pair_form(g, orc):
         lib.gbnns_debug_knob(b"late_rows", -1)
 
 
+@pytest.mark.gpu
+def test_plain_walks_over_long_rows_four_lanes_per_row(g, orc):
+    """PLAIN walks over rows of 128 floats and more in the run-time-length instances (gist d = 960, glove d = 300, sift d = 128 at beams
+    of up to 128, any d at beams beyond the two-list kernels) compute their distances four lanes per row (l2_quad_rows, csrc/walk_lists.h:
+    lane j of a quad owns L2Metric::Dist's running sum j).  Candidate lists in pop order, distance bits, hops, dist_calc equal the oracle's:
+    step counts that are multiples of sixteen and not (a masked last batch), every kernel family (one- / two-register lists, two-list,
+    LDS list at ef > 1 024, the bitmap forms), more than sixteen new ids in a pass (two rounds)."""
+    for si, (d, deg, efs) in enumerate(((960, 30, (8, 100, 200)), (300, 30, (40, 300, 1100)), (128, 60, (64, 100)), (132, 30, (64, 200)),
+                                        (516, 30, (8, 64)))):
+        c, off, nbr, _, ent = _oracle_case(orc, 3100 + si, 3000, 70, d, 8, 8, deg=(2, deg))
+        ix = g.Index(c.base, off, nbr)
+        ix.profile_enable(True)
+        for ef in efs:
+            w = orc.walk(c.queries, c.base, off, nbr, ef, entries=ent, threads=8)
+            for flags in (0, g.FLAG_BITMAP_PASS):
+                ix.profile_read(reset=True)
+                r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), flags=flags)
+                key = (d, deg, ef, flags, ix.profile_read(reset=True)["walk_kernel"])
+                assert np.array_equal(r["cand"], w["ids"]), key
+                assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
+                assert np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]), key
+        ix.close()
+
+
 def _knobs(g, quotient=1, vs_disp=15, spec_min_nq=32768):
     """The process-wide diagnostic knobs of the library (include/gbnns.h, gbnns_debug_knob), back to their defaults unless named.
     (A lowered spec_min_nq means "the speculative instance, whatever the table's form": by default only big batches on
