@@ -38,14 +38,19 @@ int gbnns_host_pin(void* ptr, size_t bytes) {
     }
     if (at < hi) gaps.push_back({at, hi});
     if (held.empty() && pinned_alias(static_cast<char*>(ptr), bytes)) return GBNNS_OK;  // page-locked by the caller: nothing to do, nothing to undo
+    const size_t shared = held.size();  // ranges of earlier calls; what follows them in `held` is registered by this call
     for (const auto& gp : gaps) {
         const hipError_t e = hipHostRegister(reinterpret_cast<void*>(gp.first), gp.second - gp.first, hipHostRegisterDefault);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             // (part of the range is page-locked by someone else, or the pages are not ours to lock: the buffer stays
-            // pageable for the calls that probe it -- pinned_alias -- and what was registered so far is kept for its users)
-            for (uintptr_t h : held) g_pin_ranges[h].users += 1;
-            g_pin_users[ptr] = held;
+            // pageable for the calls that probe it -- pinned_alias.  Nothing of this call is kept: the gaps registered so
+            // far are given back and no user entry is left, so a retry tries again instead of reporting "pinned already"
+            // for a buffer that is not)
+            for (size_t i = shared; i < held.size(); ++i) {
+                if (hipHostUnregister(reinterpret_cast<void*>(held[i])) != hipSuccess) (void)hipGetLastError();
+                g_pin_ranges.erase(held[i]);
+            }
             return fail(GBNNS_ERR_HIP, "hipHostRegister: %s", hipGetErrorString(e));
         }
         g_pin_ranges[gp.first] = PinRange{gp.second, 0};
