@@ -569,7 +569,7 @@ def main():
     if extras and small and cfg["name"] != "plain":
         result["throughput_option"] = throughput_option(g, ix, q, ef, res, batches, depth if pipelined else 1, nq_rank)
     if extras:
-        result["graph_prep"] = graph_prep_figures()
+        result["graph_prep"] = graph_prep_figures(g, ds) if small and cfg["name"] == "sift" else graph_prep_figures()
 
     # ---- the multi-device path's exchange leg on the one GPU there is (gbnns_multi_*, csrc/multi.cpp): one replica, librccl
     # loaded, a one-rank communicator, ncclAllGather of the single block per batch -- answers compared, the RCCL version
@@ -704,6 +704,23 @@ def throughput_option(g, ix, q, ef, res_exact, batches, depth, nq):
     return out
 
 
+def cpu_threads_available(detail=False):
+    """Host threads this process may really use: affinity mask, cgroup v2 CPU quota, and the GPU pool's share of 16 per GPU."""
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
+    quota = None  # cgroup v2 CPU quota of this container, in cores
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            quota = float(a) / float(b)
+    except (OSError, ValueError):
+        pass
+    avail = max(1, min(affinity, int(quota) if quota and quota >= 1 else affinity, 16))
+    return (affinity, quota, avail) if detail else avail
+
+
 def profile_figure(path, pattern):
     import re
     try:
@@ -713,17 +730,82 @@ def profile_figure(path, pattern):
         return None
 
 
-def graph_prep_figures():
-    """Graph preparation (exact kNN with the matrix-core filter + GD pruning) is not part of a timed step; its
-    figures come from the committed builder-run profiles (tools/knn_bench.py, tools/gd_bench.py on the GPU box)."""
-    return {
-        "knn_s": profile_figure("profiles/r04_knn_summary.txt", r"matrix-core filter \+ exact distances of the kept rows: n=1000000 d=32 k=48\s+([0-9.]+) s"),
-        "knn_exact_scan_s": profile_figure("profiles/r04_knn_summary.txt", r"exact scan of every row \(rounds 1-3\): n=1000000 d=32 k=48\s+([0-9.]+) s"),
+def graph_prep_figures(g=None, ds=None):
+    """Graph preparation (exact kNN with the matrix-core filter + GD pruning, prepare_graph.cpp:64-74) is not part of
+    a timed step.  With the bench workload at hand it is measured live, once, on the workload's own low-dim base set: 48-NN lists by
+    gbnns_exact_knn (checked byte for byte against the exact scan on a 4 096-row sample), GD pruning M = 16 on the device
+    (gbnns_build_graph_gd_device) and the same on the host's threads -- the two graphs compared.  The matrix-pipe utilisation needs
+    counters: it stays the committed builder-run figure (tools/knn_profile.sh)."""
+    out = {
         "knn_mfma_util": profile_figure("profiles/r04_knn_summary.txt", r"matrix-pipe utilisation = [^=]*= ([0-9.]+)"),
-        "gd_s": profile_figure("profiles/r05_graph_prep.txt", r"with the pruning on the device: ([0-9.]+) s"),
-        "workload": "48-NN lists of 10^6 x 32 rows (gbnns_exact_knn), then GD pruning M = 16 (gbnns_build_graph_gd_device)",
-        "source": "profiles/r04_knn_summary.txt, profiles/r05_graph_prep.txt (builder-run on the GPU box; not re-measured in this run)",
+        "knn_mfma_util_source": "profiles/r04_knn_summary.txt (rocprofv3 --pmc, builder-run)",
+        "workload": "48-NN lists of the bench workload's low-dim base set (gbnns_exact_knn), then GD pruning M = 16 "
+                    "(gbnns_build_graph_gd_device / gbnns_build_graph_gd)",
     }
+    if g is None or ds is None or ds.n > 2_000_000:
+        out.update({
+            "knn_s": profile_figure("profiles/r04_knn_summary.txt", r"matrix-core filter \+ exact distances of the kept rows: n=1000000 d=32 k=48\s+([0-9.]+) s"),
+            "knn_exact_scan_s": profile_figure("profiles/r04_knn_summary.txt", r"exact scan of every row \(rounds 1-3\): n=1000000 d=32 k=48\s+([0-9.]+) s"),
+            "gd_s": profile_figure("profiles/r05_graph_prep.txt", r"with the pruning on the device: ([0-9.]+) s"),
+            "source": "profiles/r04_knn_summary.txt, profiles/r05_graph_prep.txt (builder-run on the GPU box; not re-measured in this run)",
+        })
+        return out
+    try:
+        K, M = 48, 16
+        x = ds.db_low.contiguous()
+        n = int(x.shape[0])
+        lib = g.load_library()
+        step = 1 << 18
+        g.exact_knn(x, x[:4096], K, self_offset=0)  # (first call: the library's buffers)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        knn = torch.cat([g.exact_knn(x, x[s0:s0 + step], K, self_offset=s0) for s0 in range(0, n, step)])
+        torch.cuda.synchronize()
+        knn_s = time.perf_counter() - t0
+        # the filter's lists against the exact scan of every row (knob knn_filter 0) on a sample
+        s0 = (n // 2) & ~63
+        assert lib.gbnns_debug_knob(b"knn_filter", 0) == 0
+        try:
+            t0 = time.perf_counter()
+            scan = g.exact_knn(x, x[s0:s0 + 4096], K, self_offset=s0)
+            torch.cuda.synchronize()
+            scan_s = time.perf_counter() - t0
+        finally:
+            lib.gbnns_debug_knob(b"knn_filter", 1)
+        same = bool(torch.equal(scan, knn[s0:s0 + 4096]))
+        t0 = time.perf_counter()
+        g.exact_knn(x, x[s0:s0 + 4096], K, self_offset=s0)
+        torch.cuda.synchronize()
+        filt_s = time.perf_counter() - t0
+        knn_h = knn.cpu().numpy().astype(np.uint32).reshape(-1)
+        xh = x.cpu().numpy()
+        koff = np.arange(n + 1, dtype=np.uint64) * np.uint64(K)
+        t0 = time.perf_counter()
+        off, nbr, on_host = g.build_graph_gd_device(koff, knn_h, xh, M)
+        gd_s = time.perf_counter() - t0
+        threads = cpu_threads_available()
+        t0 = time.perf_counter()
+        off2, nbr2 = g.build_graph_gd(koff, knn_h, xh, M, threads=threads)
+        gd_host_s = time.perf_counter() - t0
+        out.update({
+            "measured": "live, this run",
+            "n": n, "d_low": int(x.shape[1]), "knn_k": K, "M": M,
+            "knn_s": round(knn_s, 3),
+            "knn_rows_per_s": round(n / knn_s, 1),
+            "knn_sample_4096_rows_s": {"matrix_core_filter": round(filt_s, 4), "exact_scan": round(scan_s, 4)},
+            "knn_exact_scan_s": profile_figure("profiles/r04_knn_summary.txt", r"exact scan of every row \(rounds 1-3\): n=1000000 d=32 k=48\s+([0-9.]+) s"),
+            "knn_exact_scan_s_source": "profiles/r04_knn_summary.txt (the whole 10^6-row job on the exact scan, builder-run)",
+            "knn_sample_identical_to_exact_scan": same,
+            "gd_s": round(gd_s, 3),
+            "gd_nodes_finished_on_host": int(on_host),
+            "gd_host_s": round(gd_host_s, 2),
+            "gd_host_threads": threads,
+            "gd_device_graph_identical_to_host": bool(np.array_equal(off, off2) and np.array_equal(nbr, nbr2)),
+            "avg_degree": round(len(nbr) / n, 2),
+        })
+    except Exception as e:  # reported, never fatal
+        out["error"] = repr(e)
+    return out
 
 
 def rccl_single_rank(g, ds, q, ef, metric_id, ref_ids, nq):
@@ -1056,19 +1138,7 @@ def cpu_baseline(ds, q, ef, gpu_ids, metric_id, sample=0):
         impl, kind = oracle.Oracle(), "port"
         flags = "g++ -O2 -std=c++17 -fopenmp -ffp-contract=off -fno-fast-math (oracle/Makefile ORACLE_FLAGS)"
     omp_max = impl.max_threads()   # honours OMP_NUM_THREADS (the GPU boxes export 1); explicit counts below override it
-    try:
-        affinity = len(os.sched_getaffinity(0))
-    except AttributeError:
-        affinity = os.cpu_count() or 1
-    quota = None  # cgroup v2 CPU quota of this container, in cores
-    try:
-        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if a != "max":
-            quota = float(a) / float(b)
-    except (OSError, ValueError):
-        pass
-    # cores this process may really use: affinity mask, cgroup quota, and the pool's share of 16 per GPU
-    avail = max(1, min(affinity, int(quota) if quota and quota >= 1 else affinity, 16))
+    affinity, quota, avail = cpu_threads_available(detail=True)
 
     def run(nqs, threads):
         t0 = time.perf_counter()
