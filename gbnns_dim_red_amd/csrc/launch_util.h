@@ -39,5 +39,6 @@ hipError_t launch_walk_hot(const WalkParams& p, int metric, hipStream_t s);
 hipError_t launch_walk_dot(const WalkParams& p, bool retry, hipStream_t s);
 hipError_t launch_walk_wide(const WalkParams& p, int steps, bool retry, hipStream_t s);
 hipError_t launch_walk_wide2(const WalkParams& p, int steps, bool retry, hipStream_t s);
+hipError_t launch_walk_wide2_list(const WalkParams& p, hipStream_t s);  // 384-byte rows, ef <= 128: pair-form register-list instances (walk_wide3.hip)
 
 }  // namespace gbnns

@@ -189,7 +189,9 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
 #endif
     constexpr bool kEarlyLoad = (STEPS > 0);  // speculative row loads (METRIC 1 is instantiated with STEPS 0 or 8 only)
     // 128-byte rows: two lanes per neighbour (lane = 2 * slot + half), 32 adjacency slots per pass
-    constexpr bool kPair = (STEPS == 8) || ((STEPS == 12 || STEPS == 16) && METRIC == 0);  // 128-byte rows; 192- / 256-byte rows with L2
+    // (STEPS == 24: the 384-byte rows of the reference's PLAIN walks over deep vectors, beams of up to 128 -- a lane per row ran them at
+    // 0.61 - 0.65 of the HBM peak, the pair form of the two-list instance at ef = 160 at 0.84)
+    constexpr bool kPair = (STEPS == 8) || ((STEPS == 12 || STEPS == 16 || STEPS == 24) && METRIC == 0);  // 128-byte rows; 192- / 256- / 384-byte rows with L2
     constexpr bool kAlt = (STEPS == 8 && METRIC == 1);        // dot metric: even / odd 16-B pieces instead of halves
     constexpr int kQSteps = kPair ? STEPS / 2 : STEPS;        // 16-B steps of the row one lane holds
     constexpr uint32_t kRowBytes = (uint32_t)STEPS * 16u;
@@ -412,7 +414,7 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             // the 192-byte-row launch at ef = 40 moved 2.24 GB for 1.62 GB of algorithmic bytes, 6.5 TB/s -- bandwidth-bound on those
             RowRegs<kQSteps> rr;
             uint32_t roff = 0;  // row byte offset, kept live past the loads (see below)
-            constexpr bool kLateLoad = kPair && ONE_CHUNK && STEPS >= 12 && LATE != 0;
+            constexpr bool kLateLoad = kPair && ONE_CHUNK && STEPS >= 12 && STEPS <= 16 && LATE != 0;
             const bool late = kLateLoad && (LATE > 0 || p.late_rows != 0);
             auto request_rows = [&](bool want) {
                 // (see walk_reg_big_one: every lane loads, empty slots read row 0; measured: the pair form gains in the one-pass

@@ -56,9 +56,13 @@ const char* walk_first_pass_name(hipStream_t s) {
     return g_walk_first_fn ? hipKernelNameRefByPtr(g_walk_first_fn, s) : nullptr;
 }
 
+constexpr int kPlain512PairMinEf = 200;  // 512-byte rows (PLAIN walks over sift vectors): beams beyond this take the pair-form two-list instance
+
 static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
     if (metric == 1) return launch_walk_dot(p, retry, s);
+    // (A/B switch: GBNNS_WIDE2=0 sends the 384- / 512-byte rows to the run-time-length instances at every beam)
+    static const bool wide2 = !getenv("GBNNS_WIDE2") || atoi(getenv("GBNNS_WIDE2")) != 0;
     if (p.dstride == p.dim) {
         switch (p.dim) {
             case 32: return launch_fast_t<0, 8>(p, retry, s);
@@ -66,8 +70,17 @@ static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, h
             case 64: return launch_walk_wide(p, 16, retry, s);
             case 144: return launch_walk_wide(p, 36, retry, s);
             // (beams of more than 128 only: the instances for shorter beams would be the generic ones anyway)
-            case 96: if (p.ef > kHot2MaxEf && p.ef <= kRegListMaxEf) return launch_walk_wide2(p, 24, retry, s); break;
-            case 128: if (p.ef > kHot2MaxEf && p.ef <= kRegListMaxEf) return launch_walk_wide2(p, 32, retry, s); break;
+            case 96:
+                if (wide2 && p.ef > kHot2MaxEf && p.ef <= kRegListMaxEf) return launch_walk_wide2(p, 24, retry, s);
+                // (shorter beams: the pair form in the one- / two-register list kernels for the first pass of a compact index over one-pass
+                // adjacency rows -- a lane per row ran the reference's deep efs_hnsw 40 / 80 / 120 at 0.61 - 0.65 of the HBM peak)
+                if (wide2 && p.ef <= kHot2MaxEf && !retry && walk_off32(p) && !p.aux_ell && p.ell_stride <= 32u && !p.stamps_on)
+                    return launch_walk_wide2_list(p, s);
+                break;
+            // (512-byte rows: up to ef = 200 the run-time-length two-list instance with four lanes per row is the faster one -- 10 000-query
+            // batches in flight at ef 130 / 200: 1.72 / 2.77 ms against 1.93 / 2.87 on the pair form; at ef 300 / 400 5.25 / 8.25 against
+            // 4.20 / 5.51: tools/ref_sweep.py --config sift --only plain --efs ..., GBNNS_WIDE2=0 / 1)
+            case 128: if (wide2 && p.ef > kPlain512PairMinEf && p.ef <= kRegListMaxEf) return launch_walk_wide2(p, 32, retry, s); break;
             default: break;
         }
     }

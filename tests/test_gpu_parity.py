@@ -1560,16 +1560,16 @@ def test_two_list_wide_rows_requested_after_the_visited_test(g, orc):
 def test_plain_walks_over_wide_rows_two_list_pair_form(g, orc):
     """PLAIN walks (final_test.cpp:84, performRealTests: the graph walked in the ORIGINAL space) over deep (d = 96: 384-byte rows) and
     sift (d = 128: 512-byte rows) vectors at beams of more than 128 run on pair-form instances of the two-list kernel
-    (walk_reg_big_kernel<0, 24 | 32, ...>: two lanes per neighbour, 12 / 16 sixteen-byte steps each), rows requested before or after the
-    visited test (knob "late_rows"); shorter beams stay on the generic instances.  Candidate lists in pop order, distance bits, hops,
+    (walk_reg_big_kernel<0, 24 | 32, ...>: two lanes per neighbour, 12 / 16 sixteen-byte steps each; 512-byte rows from ef = 201 on), rows
+    requested before or after the visited test (knob "late_rows"); shorter beams stay on the generic instances.  Candidate lists in pop order, distance bits, hops,
     dist_calc equal the oracle's; one- and two-pass adjacency rows, k = 1 and k = ef."""
     lib = g.load_library()
     try:
-        for si, (d, deg) in enumerate(((96, 30), (128, 30), (128, 50))):
+        for si, (d, deg) in enumerate(((96, 30), (128, 30), (128, 50), (96, 50))):
             c, off, nbr, _, ent = _oracle_case(orc, 2900 + si, 5000, 130, d, 16, 16, deg=(2, deg))
             ix = g.Index(c.base, off, nbr)
             ix.profile_enable(True)
-            for ef in (100, 200, 700):
+            for ef in ((1, 40, 64, 100, 128, 200, 700) if d == 96 else (100, 200, 700)):
                 w = orc.walk(c.queries, c.base, off, nbr, ef, entries=ent, threads=8)
                 w1 = orc.walk(c.queries, c.base, off, nbr, ef, k=1, entries=ent, threads=8)
                 for late in (0, 1):
@@ -1581,10 +1581,20 @@ def test_plain_walks_over_wide_rows_two_list_pair_form(g, orc):
                     assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
                     assert np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]), key
                     launched = ix.profile_read(reset=True)["walk_kernel"]
-                    want_k = "walk_reg_kernel<0, 0," if ef <= 128 else "walk_reg_big_kernel<0, %d," % (d // 4)
+                    # (512-byte rows up to ef = 200: the run-time-length two-list instance, four lanes per row, is the faster one)
+                    # (384-byte rows at ef <= 128: pair-form list instances over one-pass adjacency rows, walk_wide3.hip)
+                    want_k = (("walk_reg_kernel<0, 24," if d == 96 and deg <= 32 else "walk_reg_kernel<0, 0,") if ef <= 128 else
+                              "walk_reg_big_kernel<0, 0," if d == 128 and ef <= 200 else "walk_reg_big_kernel<0, %d," % (d // 4))
                     assert launched.startswith(want_k), (key, launched)
                     r1 = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=1, entry_ids=ent, want=())
                     assert np.array_equal(r1["ids"], w1["ids"][:, 0]), key
+                if d == 96 and ef in (40, 100):
+                    # a visited set too small for most walks: the pair-form list instances hand over to the retry / general passes
+                    # (run-time-length instances over the same LDS layout)
+                    r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"),
+                                  hash_capacity=256)
+                    assert np.array_equal(r["cand"], w["ids"]) and np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), (d, deg, ef, "small table")
+                    assert np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]), (d, deg, ef, "small table")
             ix.close()
     finally:
         lib.gbnns_debug_knob(b"late_rows", -1)
