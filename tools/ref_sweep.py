@@ -4,7 +4,7 @@
 dataset, on the bench's synthetic workload of that shape.  Per beam: the first-pass kernel that took it, ms per batch one
 call at a time and three in flight, and the answers / hops / dist_calc of the first `--sample` queries against the compiled
 reference (oracle/_ref, the checker) on the host's threads.
-usage: ref_sweep.py --config sift|gist|deep1m|glove1m [--sample 256] [--reps 5] [--only net|plain]"""
+usage: ref_sweep.py --config sift|gist|deep1m|glove1m|glove|glove-dot [--sample 256] [--reps 5] [--only net|plain]"""
 import argparse
 import os
 import sys
@@ -26,6 +26,9 @@ SWEEPS = {
     "gist": ([200, 400, 600, 800, 1000], [100, 150, 200, 300, 400]),
     "deep1m": ([40, 80, 120, 160, 200], [40, 80, 120, 160, 200]),
     "glove1m": ([300, 400, 600, 800, 1000], [300, 400, 600, 800, 1000]),
+    # BASELINE.json config 4 (GloVe-1.2M 200 -> 32; L2 on unit vectors and the negative-dot metric): the bench's beam + the reference's glove beams
+    "glove": ([64, 300, 400, 600, 800, 1000], [64, 300, 400, 600]),
+    "glove-dot": ([64, 300, 400, 600, 800, 1000], [64, 300, 400, 600]),
 }
 
 
@@ -45,7 +48,8 @@ def main():
         kw["unit_norm"] = True
     os.makedirs(kw["cache_dir"], exist_ok=True)
     ds = synth.make_dataset(device="cuda:0", **kw)
-    ix = ds.index()
+    metric_id = g.METRIC_NEG_DOT if cfg.get("negdot") else g.METRIC_L2
+    ix = ds.index(metric=metric_id)
     q = ds.queries
     nq = ds.nq
     S = min(args.sample, nq)
@@ -91,9 +95,9 @@ def main():
         torch.cuda.synchronize()
         flight = (time.perf_counter() - t0) / n_fl
         if plain:
-            e = ref.search_batch(oracle.MODE_PLAIN, qh, base_h, ds.graph_off, ds.graph_nbr, ef, k=1, threads=threads)
+            e = ref.search_batch(oracle.MODE_PLAIN, qh, base_h, ds.graph_off, ds.graph_nbr, ef, k=1, threads=threads, metric=metric_id)
         else:
-            e = ref.search_batch(oracle.MODE_NET, qh, base_h, ds.graph_off, ds.graph_nbr, ef, db_low=dbl_h, net=net_h, threads=threads)
+            e = ref.search_batch(oracle.MODE_NET, qh, base_h, ds.graph_off, ds.graph_nbr, ef, db_low=dbl_h, net=net_h, threads=threads, metric=metric_id)
         ids = r["ids"][:S].cpu().numpy().astype(np.int64)
         hops = r["hops"][:S].cpu().numpy().astype(np.int64)
         dc = r["dist_calc"][:S].cpu().numpy().astype(np.int64)
