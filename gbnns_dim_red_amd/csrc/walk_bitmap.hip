@@ -53,7 +53,7 @@ hipError_t launch_walk_bitmap(const WalkParams& p, int metric, unsigned slots, h
         const bool one = p.ell_stride <= 32u;
         if (p.dim == 64u) return one ? go(walk_bitmap_big_kernel<0, 16, true>) : go(walk_bitmap_big_kernel<0, 16, false>);  // 256-byte rows, L2 (pair form)
         if (p.dim == 144u) {  // 576-byte rows, L2 (pair form; WalkParams::late_rows: the rows after the bit test)
-            if (one && p.late_rows) return go(walk_bitmap_big_kernel<0, 36, true, true>);
+            if (p.late_rows) return one ? go(walk_bitmap_big_kernel<0, 36, true, true>) : go(walk_bitmap_big_kernel<0, 36, false, true>);
             return one ? go(walk_bitmap_big_kernel<0, 36, true>) : go(walk_bitmap_big_kernel<0, 36, false>);
         }
         if (metric == 1) return one ? go(walk_bitmap_big_kernel<1, 8, true>) : go(walk_bitmap_big_kernel<1, 8, false>);

@@ -28,6 +28,11 @@ static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipS
                 }
                 return launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, false, true>, p, false, lds, s);
             }
+            // (adjacency rows of two passes -- the reference's M18 / M20 hnsw graphs have rows of up to 36 / 40 slots: the rows-after-the-test
+            // order in the pass loop too; glove 300 -> 144 on a GD(M = 20) graph at ef 300 / 400 / 600: 6.96 / 9.64 / 16.1 ms with the rows first)
+            if constexpr (STEPS >= 24 && METRIC == 0) {
+                if (!retry && p.late_rows) return launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false, false, false, true>, p, false, lds, s);
+            }
             return retry ? launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, true>, p, true, lds, s)
                          : launch_walk_k(walk_reg_big_kernel<METRIC, STEPS, true, false>, p, false, lds, s);
         }

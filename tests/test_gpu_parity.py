@@ -1535,18 +1535,26 @@ def test_two_list_wide_rows_requested_after_the_visited_test(g, orc):
     lib = g.load_library()
     try:
         for si, (d, dlow, dh, deg, cases) in enumerate((
-                (304, 144, 304, 30, ((300, 0), (600, g.FLAG_BITMAP_PASS))), (304, 144, 304, 50, ((200, 0),)),
+                (304, 144, 304, 30, ((300, 0), (600, g.FLAG_BITMAP_PASS))), (304, 144, 304, 50, ((200, 0), (600, g.FLAG_BITMAP_PASS))),
                 (96, 48, 64, 30, ((200, 0),)), (128, 64, 128, 30, ((200, 0), (600, g.FLAG_BITMAP_PASS))))):
             c, off, nbr, db_low, ent = _oracle_case(orc, 2700 + si, 6000, 150, d, dlow, dh, deg=(2, deg))
             q_low = orc.project(c.net, c.queries)
             ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+            ix.profile_enable(True)
             for ef, flags in cases:
                 w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, threads=8)
                 s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net, entries=ent, threads=8)
                 for late in (1, 0, -1):
                     assert lib.gbnns_debug_knob(b"late_rows", late) == 0
+                    ix.profile_read(reset=True)
                     r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), flags=flags)
                     key = (dlow, deg, ef, flags, late)
+                    if dlow == 144 and late >= 0:
+                        # the 576-byte-row instances by name: <..., ONE_PASS, LATE> -- two-pass adjacency rows (the reference's M20 graphs)
+                        # have the rows-after-the-test order too
+                        launched = ix.profile_read(reset=True)["walk_kernel"].split(" (")[0]
+                        tail = "%s, %s>" % ("true" if deg <= 32 else "false", "true" if late else "false")
+                        assert launched.startswith("walk_bitmap_big_kernel<0, 36," if flags else "walk_reg_big_kernel<0, 36,") and launched.endswith(tail), (key, launched)
                     assert np.array_equal(r["cand"], w["ids"]), key
                     assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
                     assert np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]), key

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--sample", type=int, default=256)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default=None, choices=["net", "plain"])
+    ap.add_argument("--graph-M", type=int, default=None, help="GD pruning parameter of the workload's graph (default 16: rows of <= 32 slots; "
+                    "20 / 30: rows of two passes, like the reference's M18 / M20 hnsw graphs)")
     ap.add_argument("--efs", default=None, help="comma-separated beams instead of the reference's lists (A/B runs)")
     args = ap.parse_args()
     cfg = bench.CONFIGS[args.config]
@@ -46,6 +48,8 @@ def main():
               cache_dir=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"))
     if cfg.get("unit_norm"):
         kw["unit_norm"] = True
+    if args.graph_M:
+        kw["M"] = args.graph_M
     os.makedirs(kw["cache_dir"], exist_ok=True)
     ds = synth.make_dataset(device="cuda:0", **kw)
     metric_id = g.METRIC_NEG_DOT if cfg.get("negdot") else g.METRIC_L2
@@ -61,7 +65,8 @@ def main():
     qh = q[:S].cpu().numpy()
     ref.prepare(base_h)
     print("# %s-shaped synthetic, n = %d, %d-query batches, %d -> %d (d_hidden %d); reference = oracle/_ref on %d host threads, "
-          "first %d queries of the batch" % (args.config, ds.n, nq, ds.d, ds.d_low, ds.d_hidden, threads, S), flush=True)
+          "first %d queries of the batch; graph: GD(M = %d), longest adjacency row %d"
+          % (args.config, ds.n, nq, ds.d, ds.d_low, ds.d_hidden, threads, S, args.graph_M or 16, int(np.diff(ds.graph_off.astype(np.int64)).max())), flush=True)
     print("# mode   ef   kernel                                            ms/batch  in flight  M q/s   hops  dist_calc   "
           "ids hops dist_calc vs reference (of %d)" % S, flush=True)
 
