@@ -419,7 +419,8 @@ __device__ __forceinline__ void walk_reg_one(const WalkParams& p, uint32_t qi, u
             auto request_rows = [&](bool want) {
                 // (see walk_reg_big_one: every lane loads, empty slots read row 0; measured: the pair form gains in the one-pass
                 // hop only, 12- / 16-step rows one lane each wherever their 48 / 64 row registers would be carried around the loop)
-                constexpr bool kAllLanes = (kPair && ONE_CHUNK) || (!kPair && kQSteps >= 12);
+                // (384-byte rows: every lane loads in the pass loop too, as in walk_reg_big_one)
+                constexpr bool kAllLanes = (kPair && (ONE_CHUNK || STEPS == 24)) || (!kPair && kQSteps >= 12);
                 const uint32_t nbl = kAllLanes ? (want ? nb : 0u) : nb;
                 const bool ld = kAllLanes || want;
                 if constexpr (OFF32) {

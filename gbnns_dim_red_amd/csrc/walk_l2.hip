@@ -73,8 +73,8 @@ static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, h
             case 96:
                 if (wide2 && p.ef > kHot2MaxEf && p.ef <= kRegListMaxEf) return launch_walk_wide2(p, 24, retry, s);
                 // (shorter beams: the pair form in the one- / two-register list kernels for the first pass of a compact index over one-pass
-                // adjacency rows -- a lane per row ran the reference's deep efs_hnsw 40 / 80 / 120 at 0.61 - 0.65 of the HBM peak)
-                if (wide2 && p.ef <= kHot2MaxEf && !retry && walk_off32(p) && !p.aux_ell && p.ell_stride <= 32u && !p.stamps_on)
+                // adjacency rows (two-pass ones: <= 64 slots) -- a lane per row ran the reference's deep efs_hnsw 40 / 80 / 120 at 0.61 - 0.65 of the HBM peak)
+                if (wide2 && p.ef <= kHot2MaxEf && !retry && walk_off32(p) && !p.aux_ell && (p.ell_stride <= 32u || (p.ell_stride <= 64u && p.ef <= 64)) && !p.stamps_on)
                     return launch_walk_wide2_list(p, s);
                 break;
             // (512-byte rows: up to ef = 200 the run-time-length two-list instance with four lanes per row is the faster one -- 10 000-query

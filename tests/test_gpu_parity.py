@@ -1590,8 +1590,8 @@ def test_plain_walks_over_wide_rows_two_list_pair_form(g, orc):
                     assert np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]), key
                     launched = ix.profile_read(reset=True)["walk_kernel"]
                     # (512-byte rows up to ef = 200: the run-time-length two-list instance, four lanes per row, is the faster one)
-                    # (384-byte rows at ef <= 128: pair-form list instances over one-pass adjacency rows, walk_wide3.hip)
-                    want_k = (("walk_reg_kernel<0, 24," if d == 96 and deg <= 32 else "walk_reg_kernel<0, 0,") if ef <= 128 else
+                    # (384-byte rows at ef <= 128: pair-form list instances; adjacency rows of two passes at ef <= 64 only, walk_wide3.hip)
+                    want_k = (("walk_reg_kernel<0, 24," if d == 96 and (deg <= 32 or ef <= 64) else "walk_reg_kernel<0, 0,") if ef <= 128 else
                               "walk_reg_big_kernel<0, 0," if d == 128 and ef <= 200 else "walk_reg_big_kernel<0, %d," % (d // 4))
                     assert launched.startswith(want_k), (key, launched)
                     r1 = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=1, entry_ids=ent, want=())
