@@ -160,7 +160,7 @@ def test_hot_kernel_register_budgets(tmp_path):
                # the generic hop over 192-byte rows at ef <= 64 (the reference's deep 96 -> 48 shape): query in LDS, 6 wavefronts per SIMD
                ("20walk_reg_wide_kernelILi12E", 80, 96),
                # the pair-form list instances over 384-byte rows (PLAIN walks over deep vectors at ef <= 128): three wavefronts per SIMD
-               ("15walk_reg_kernelILi0ELi24E", 136, 104)]
+               ("15walk_reg_kernelILi0ELi24E", 136, 112)]
     for sub, cap, scap in budgets:
         hits = {k: v for k, v in meta.items() if sub in k}
         assert hits, sub
