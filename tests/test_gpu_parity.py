@@ -697,6 +697,59 @@ def test_multi_replicas_equal_single_handle(g, orc):
     one.close()
 
 
+_SIFT_FULL = []
+
+
+def _sift_full():
+    """The SIFT1M-shaped bench workload (n = 1e6, 10 000 queries, 128 -> 32), built once per test session."""
+    if not _SIFT_FULL:
+        from gbnns_dim_red_amd import synth
+        _SIFT_FULL.append(synth.make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=1234, device="cuda:0"))
+    return _SIFT_FULL[0]
+
+
+def test_reference_sweeps_full_size(g, orc):
+    """The reference's OWN sweeps of the sift row of search/parameters_of_databases.txt:7-8 at full size (n = 1e6, one 10 000-query
+    batch per beam): every `efs` beam through the two-stage search (final_test.cpp:87) and every `efs_hnsw` beam through the plain walk
+    over the original vectors (final_test.cpp:84) -- each a different kernel family / list form / row form -- with the answers, hop
+    counts and dist_calc of the batch's first and last 48 queries against the compiled reference (tools/ref_sweep.py is the same on
+    every shape, with timings)."""
+    import torch
+    if not orc_mod.have_ref():
+        pytest.skip("needs the compiled reference (oracle/_ref)")
+    ds = _sift_full()
+    ix = ds.index()
+    ix.profile_enable(True)
+    q = ds.queries
+    ref = orc_mod.Ref()
+    base, dbl = ds.base.cpu().numpy(), ds.db_low.cpu().numpy()
+    net = tuple(t.cpu().numpy() for t in ds.net)
+    ref.prepare(base)
+    sel = np.r_[0:48, len(q) - 48:len(q)]
+    qh = q.cpu().numpy()[sel]
+    kernels = set()
+    for mode, efs in (("net", (1, 3, 8, 15, 20, 25, 40, 60, 80, 100, 120, 140, 160, 180)),
+                      ("plain", (1, 4, 7, 11, 15, 20, 30, 40, 60, 80, 100, 120, 130, 140))):
+        for ef in efs:
+            ix.profile_read(reset=True)
+            if mode == "net":
+                r = ix.search(q, ef, want=("hops", "dist_calc"))
+                e = ref.search_batch(orc_mod.MODE_NET, qh, base, ds.graph_off, ds.graph_nbr, ef, db_low=dbl, net=net, threads=8)
+            else:
+                r = ix.search(q, ef, mode=g.MODE_PLAIN, k=1, want=("hops", "dist_calc"))
+                e = ref.search_batch(orc_mod.MODE_PLAIN, qh, base, ds.graph_off, ds.graph_nbr, ef, k=1, threads=8)
+            torch.cuda.synchronize()
+            kernels.add(ix.profile_read(reset=True)["walk_kernel"].split(" (")[0])
+            assert np.array_equal(r["ids"].cpu().numpy()[sel].astype(np.int64), e["ids"].astype(np.int64)), (mode, ef)
+            assert np.array_equal(r["hops"].cpu().numpy()[sel], e["hops"]), (mode, ef)
+            # (performNetTest counts the re-ranked candidates too: search_function.h:362)
+            assert np.array_equal(r["dist_calc"].cpu().numpy()[sel] + (ef if mode == "net" else 0), e["dist_calc"]), (mode, ef)
+    # the sweep crosses every list form: one / two registers, two-list; hand-laid-out 128-byte rows and run-time-length 512-byte rows
+    assert {"walk_hot_kernel", "walk_hot2_kernel", "walk_hot_big_kernel"} <= kernels, kernels
+    assert any(k.startswith("walk_reg_kernel<0, 0,") for k in kernels) and any(k.startswith("walk_reg_big_kernel<0, 0,") for k in kernels), kernels
+    ix.close()
+
+
 def test_full_size_properties(g, orc):
     """SIFT1M-shaped workload at full size (n = 1e6, 10k queries, 128->32, ef = 64 and the recall-gate beam 36): the
     first and the last 1 200 queries against the compiled reference (oracle.Ref; the restatement where it is absent) -- ids, hops,
@@ -704,9 +757,7 @@ def test_full_size_properties(g, orc):
     determinism, candidate lists sorted worst->best with exact recomputed distances, answer is
     the argmin of exact original-space distances over its candidate list, shard invariance."""
     import torch
-    from gbnns_dim_red_amd import synth
-    ds = synth.make_dataset(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, seed=1234,
-                            device="cuda:0")
+    ds = _sift_full()
     ix = ds.index()
     q = ds.queries
     r1 = ix.search(q, 64, want=("hops", "dist_calc", "cand", "cand_dist", "q_low"))
