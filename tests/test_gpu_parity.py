@@ -750,6 +750,45 @@ def test_reference_sweeps_full_size(g, orc):
     ix.close()
 
 
+@pytest.mark.parametrize("shape", ["gist", "deep1m", "glove1m"])
+def test_reference_sweeps_full_size_other_rows(g, orc, shape):
+    """The same for the other rows of search/parameters_of_databases.txt at full size (n = 1e6): gist 960 -> 64 (1 000-query batches, efs
+    200 .. 1 000, efs_hnsw 100 .. 400 over 3 840-byte rows), deep 96 -> 48 (efs / efs_hnsw 40 .. 200: 192-byte walked rows, 384-byte rows
+    in the plain walks), glove 300 -> 144 (300 .. 1 000: 576-byte walked rows, the bitmap pass from ef 700; 1 200-byte rows in the plain
+    walks) -- the first 64 queries of each beam against the compiled reference."""
+    import torch
+    from gbnns_dim_red_amd import synth
+    if not orc_mod.have_ref():
+        pytest.skip("needs the compiled reference (oracle/_ref)")
+    dims = {"gist": dict(nq=1_000, d=960, d_low=64, d_hidden=1024), "deep1m": dict(nq=10_000, d=96, d_low=48, d_hidden=128),
+            "glove1m": dict(nq=10_000, d=300, d_low=144, d_hidden=512, unit_norm=True)}[shape]
+    sweeps = {"gist": ((200, 400, 600, 800, 1000), (100, 150, 200, 300, 400)), "deep1m": ((40, 80, 120, 160, 200),) * 2,
+              "glove1m": ((300, 400, 600, 800, 1000),) * 2}[shape]
+    ds = synth.make_dataset(n=1_000_000, seed=1234, device="cuda:0", **dims)
+    ix = ds.index()
+    q = ds.queries
+    ref = orc_mod.Ref()
+    base, dbl = ds.base.cpu().numpy(), ds.db_low.cpu().numpy()
+    net = tuple(t.cpu().numpy() for t in ds.net)
+    ref.prepare(base)
+    qh = q[:64].cpu().numpy()
+    for mode, efs in zip(("net", "plain"), sweeps):
+        for ef in efs:
+            if mode == "net":
+                r = ix.search(q, ef, want=("hops", "dist_calc"))
+                e = ref.search_batch(orc_mod.MODE_NET, qh, base, ds.graph_off, ds.graph_nbr, ef, db_low=dbl, net=net, threads=8)
+            else:
+                r = ix.search(q, ef, mode=g.MODE_PLAIN, k=1, want=("hops", "dist_calc"))
+                e = ref.search_batch(orc_mod.MODE_PLAIN, qh, base, ds.graph_off, ds.graph_nbr, ef, k=1, threads=8)
+            torch.cuda.synchronize()
+            assert np.array_equal(r["ids"][:64].cpu().numpy().astype(np.int64), e["ids"].astype(np.int64)), (shape, mode, ef)
+            assert np.array_equal(r["hops"][:64].cpu().numpy(), e["hops"]), (shape, mode, ef)
+            assert np.array_equal(r["dist_calc"][:64].cpu().numpy() + (ef if mode == "net" else 0), e["dist_calc"]), (shape, mode, ef)
+    ix.close()
+    del ds
+    torch.cuda.empty_cache()
+
+
 def test_full_size_properties(g, orc):
     """SIFT1M-shaped workload at full size (n = 1e6, 10k queries, 128->32, ef = 64 and the recall-gate beam 36): the
     first and the last 1 200 queries against the compiled reference (oracle.Ref; the restatement where it is absent) -- ids, hops,
