@@ -1694,6 +1694,19 @@ def test_plain_walks_over_wide_rows_two_list_pair_form(g, orc):
                     assert np.array_equal(r["cand"], w["ids"]) and np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), (d, deg, ef, "small table")
                     assert np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]), (d, deg, ef, "small table")
             ix.close()
+        # the same instances under the two-stage search (walked rows of 96 floats: d_low = 96) -- the fused re-rank behind them
+        c, off, nbr, db_low, ent = _oracle_case(orc, 2950, 6000, 150, 200, 96, 192, deg=(2, 30))
+        ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+        ix.profile_enable(True)
+        for ef in (40, 100, 200):
+            s2 = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net, entries=ent, threads=8)
+            ix.profile_read(reset=True)
+            r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc"))
+            launched = ix.profile_read(reset=True)["walk_kernel"]
+            assert launched.startswith("walk_reg_kernel<0, 24," if ef <= 128 else "walk_reg_big_kernel<0, 24,"), (ef, launched)
+            assert np.array_equal(r["ids"], s2["ids"]) and np.array_equal(r["hops"], s2["hops"]), ef
+            assert np.array_equal(r["dist_calc"] + ef, s2["dist_calc"]), ef
+        ix.close()
     finally:
         lib.gbnns_debug_knob(b"late_rows", -1)
 
