@@ -69,7 +69,7 @@ static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, h
             case 48: return launch_walk_wide(p, 12, retry, s);
             case 64: return launch_walk_wide(p, 16, retry, s);
             case 144: return launch_walk_wide(p, 36, retry, s);
-            // (beams of more than 128 only: the instances for shorter beams would be the generic ones anyway)
+            // 384- / 512-byte rows (PLAIN walks over deep / sift vectors): pair-form instances by beam, the rest on the run-time-length ones
             case 96:
                 if (wide2 && p.ef > kHot2MaxEf && p.ef <= kRegListMaxEf) return launch_walk_wide2(p, 24, retry, s);
                 // (shorter beams: the pair form in the one- / two-register list kernels for the first pass of a compact index over one-pass

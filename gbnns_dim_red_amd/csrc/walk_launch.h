@@ -86,7 +86,8 @@ static hipError_t launch_fast_t(const WalkParams& p, bool retry, hipStream_t s) 
                      : launch_walk_k(walk_fast_kernel<METRIC, STEPS, false, false>, p, false, lds, s);
     }
     // (576-byte rows -- the reference's glove 300 -> 144 -- and the 384- / 512-byte rows of its PLAIN walks over deep / sift vectors
-    // have the pair form in the two-list kernels only: 2 x 48 .. 72 registers of row and query; shorter beams take the generic instances)
+    // have the pair form in the two-list kernels: 2 x 48 .. 72 registers of row and query; shorter beams take the generic instances
+    // here -- 384-byte rows have pair-form list instances of their own, dispatched before this function: walk_wide3.hip)
     constexpr bool kBigOnly = STEPS >= 24;
     constexpr int kListSteps = kBigOnly ? 0 : STEPS;
     constexpr int kBigSteps = kBigOnly ? STEPS : kWideSteps48;
