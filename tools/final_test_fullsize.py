@@ -3,7 +3,7 @@
 full size -- the bench's SIFT1M-shaped synthetic workload written to disk in the reference's file formats (fvecs / ivecs / edge lists /
 net-as-matrix / parameter table with the reference's own efs lists), then the binary run as a user would run it.  Prints its result
 lines (the reference's format) with work_time turned into queries/s, and where the wall time of the whole run goes.
-usage: final_test_fullsize.py [--config sift|deep1m] [--keep]"""
+usage: final_test_fullsize.py [--config sift|deep1m|gist|glove1m] [--keep]"""
 import argparse
 import os
 import shutil
@@ -23,7 +23,10 @@ BIN = os.path.join(ROOT, "gbnns_dim_red_amd", "search", "final_test")
 SWEEPS = {  # search/parameters_of_databases.txt:7-8, 29-30
     "sift": ("1,3,8,15,20,25,40,60,80,100,120,140,160,180", "1,4,7,11,15,20,30,40,60,80,100,120,130,140"),
     "deep1m": ("40,80,120,160,200", "40,80,120,160,200"),
+    "gist": ("200,400,600,800,1000", "100,150,200,300,400"),      # :18-19 (no d_hidden row there: the width comes from second_part, :20)
+    "glove1m": ("300,400,600,800,1000", "300,400,600,800,1000"),  # :40-41
 }
+NAMES = {"sift": "sift", "deep1m": "deep", "gist": "gist", "glove1m": "glove"}
 
 
 def write_xvecs(path, a):
@@ -55,11 +58,14 @@ def main():
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
     cfg = bench.CONFIGS[args.config]
-    name = "sift" if args.config == "sift" else "deep"
+    name = NAMES[args.config]
     g.load_library()
     t0 = time.time()
-    ds = synth.make_dataset(device="cuda:0", n=cfg["n"], nq=cfg["nq"], d=cfg["d"], d_low=cfg["d_low"], d_hidden=cfg["d_hidden"], seed=1234,
-                            cache_dir=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"))
+    kw = dict(n=cfg["n"], nq=cfg["nq"], d=cfg["d"], d_low=cfg["d_low"], d_hidden=cfg["d_hidden"], seed=1234,
+              cache_dir=os.environ.get("GBNNS_CACHE", "/tmp/gbnns_cache"))
+    if cfg.get("unit_norm"):
+        kw["unit_norm"] = True
+    ds = synth.make_dataset(device="cuda:0", **kw)
     data, models, out = (os.path.join(args.dir, x) for x in ("data", "models", "out"))
     for p in (data, models, out):
         os.makedirs(p, exist_ok=True)
@@ -75,7 +81,8 @@ def main():
     params = os.path.join(args.dir, "params.txt")
     with open(params, "w") as f:
         f.write("\n".join([f"{name} n {ds.n}", f"{name} n_q {ds.nq}", f"{name} n_tr 2", f"{name} d {ds.d}", f"{name} d_low {ds.d_low}",
-                           f"{name} d_hidden {ds.d_hidden}", f"{name} efs {efs}", f"{name} efs_hnsw {efs_hnsw}",
+                           (f"{name} second_part _{ds.d_low}_l_2_1m_5_40_w_{ds.d_hidden}_e_40" if name == "gist" else f"{name} d_hidden {ds.d_hidden}"),
+                           f"{name} efs {efs}", f"{name} efs_hnsw {efs_hnsw}",
                            f"{name} hnsw_name synthgraph"]) + "\n")
     print("# %s-shaped synthetic (n = %d, %d queries, %d -> %d) written in the reference's file formats: %.1f s"
           % (args.config, ds.n, ds.nq, ds.d, ds.d_low, time.time() - t0), flush=True)
