@@ -948,7 +948,10 @@ def other_configs(args, t_start):
     bytes, roofline fraction, recall) and the answers of a 1 000-query sample compared with the compiled reference."""
     # ("sift-M30": the headline workload on the graph of prepare_graph.cpp's M = 30 -- adjacency rows of up to 60 slots, the
     # walk_hotw* instances: the library's tuning constants on a second degree distribution, every round)
-    plan = [("gist", 20, 150), ("glove", 20, 120), ("glove-dot", 20, 90), ("sift-M30", 20, 120), ("deep", 3, 200)]
+    # ("deep1m" / "glove1m": the two rows of the reference's own parameter file that BASELINE.json does not name -- deep 96 -> 48 at
+    # ef 40, glove 300 -> 144 at ef 300: 192- and 576-byte walked rows)
+    plan = [("gist", 20, 150), ("glove", 20, 120), ("glove-dot", 20, 90), ("sift-M30", 20, 120), ("deep1m", 20, 100), ("glove1m", 10, 120),
+            ("deep", 3, 200)]
     out = {}
     for name, steps, need_s in plan:
         left = args.budget_s - (time.time() - t_start)
