@@ -218,7 +218,10 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // the table): walk + re-rank at ef 600 / 800 / 1 000 11.2 / 18.5 / 23.7 ms with the table against 12.5 / 16.3 / 20.1 with the
         // bitmap pass in the same form and its rows requested after the bit test -- the bitmap pass from ef = 700
         const bool rows576 = w.dim == 144u && w.dstride == 144u && ix->metric == GBNNS_METRIC_L2;
-        const int min_ef = min_ef_env ? min_ef_env : (rows576 ? 700 : (form == 2 ? 480 : 385));
+        // (second half of round 5: for 576-byte rows the beam alone does not decide -- on a GD(M = 30) graph ef = 600 computes 10 500
+        // distances per query, four wavefronts per CU by LDS, 21.4 ms on the table against 1.75 us per distance on the bitmap pass; the rule
+        // below -- the pass must at least double the resident wavefronts: 8 by registers against <= 4 by the table -- does from ef 450 on)
+        const int min_ef = min_ef_env ? min_ef_env : (rows576 ? 450 : (form == 2 ? 480 : 385));
         const bool forced = (a->flags & GBNNS_FLAG_BITMAP_PASS) != 0;  // diagnostic: whatever ef and batch size
         if (!w.all_general && (ef >= min_ef || forced) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && (a->hash_capacity == 0 || forced)) {
             const size_t gran = kLdsGran;
