@@ -127,6 +127,7 @@ struct Lane {
     bool stats_pending = false;
     int stats_ef = 0;
     uint32_t stats_cap = 0;
+    bool stats_hot2 = false;     // that call ran a hand-laid-out kernel over two-pass adjacency rows (sizing: knob vs_fill2)
     // which of the two control-word blocks the next call uses, and whether each is known to be zero
     int ctrl_phase = 0;
     bool ctrl_clean[2] = {true, true};
@@ -203,7 +204,7 @@ constexpr size_t kLdsGran = GBNNS_LDS_GRAN;
 
 // the diagnostic knobs (gbnns_debug_knob; defined and documented in handle.cpp)
 extern std::atomic<int> g_knob_quotient, g_knob_vs_disp, g_knob_max_waves, g_knob_spec_min_nq, g_knob_spec_any_form, g_knob_mlp_small,
-    g_knob_mlp_net, g_knob_mlp_slab, g_knob_late_rows, g_knob_spec_tail, g_knob_knn_chunk, g_knob_knn_pool_min_k, g_knob_knn_filter;
+    g_knob_mlp_net, g_knob_mlp_slab, g_knob_late_rows, g_knob_vs_fill2, g_knob_spec_tail, g_knob_knn_chunk, g_knob_knn_pool_min_k, g_knob_knn_filter;
 
 // lanes.cpp
 int enter_stream(gbnns_index* ix, hipStream_t s);

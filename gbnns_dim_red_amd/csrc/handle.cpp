@@ -179,6 +179,13 @@ std::atomic<int> g_knob_mlp_slab{knob_env("GBNNS_MLP_SLAB", 1)};
 // "late_rows": generic two-list kernels over 192- / 256- / 576-byte rows -- -1 = by shape and residency (search_core.cpp), 0 = rows
 // requested before the visited test, 1 = after it (GBNNS_LATE_ROWS)
 std::atomic<int> g_knob_late_rows{std::max(-1, std::min(1, knob_env("GBNNS_LATE_ROWS", -1)))};
+// "vs_fill2": the visited set's fill (longest walk seen / capacity, per cent) that the sizing rule aims at for the hand-laid-out kernels
+// (128-byte rows) on graphs whose adjacency rows take two passes (rows of 33 .. 64 slots: the reference's M18 / M20 hnsw graphs) -- their
+// hops test up to twice the ids, and the hop waits for the longest probe sequence among its lanes: SIFT-shaped on a GD(M = 30) graph, ef 120 /
+// 140 / 160 / 180 one batch at a time 1.25 / 1.49 / 1.76 / 2.38 ms at the one-pass rule's ~0.8 - 0.86 against 0.98 / 1.24 / 1.44 / 1.68 at
+// 0.72 (tools/fill_scan.sh, fill2_ab.sh).  The generic wide-row kernels lose by it (deep 96 -> 48 ef 200 +7 %, glove 300 -> 144 +9 %: they
+// are short of wavefronts, not of probes) and keep the one-pass rule.  0 = that rule for every kernel.
+std::atomic<int> g_knob_vs_fill2{std::max(0, std::min(95, knob_env("GBNNS_VS_FILL2", 72)))};
 std::atomic<int> g_knob_spec_tail{std::max(0, std::min(100, knob_env("GBNNS_SPEC_TAIL", 50)))};
 // "knn_chunk" = most rows per filtered chunk (a multiple of 64)
 std::atomic<int> g_knob_knn_chunk{std::max(64, knob_env("GBNNS_KNN_CHUNK", 1 << 15) & ~63)};  // (a multiple of 64, never 0: the chunk loops step by it)
@@ -501,6 +508,7 @@ int gbnns_debug_knob(const char* name, int value) {
     else if (!std::strcmp(name, "mlp_net")) g_knob_mlp_net.store(value != 0, std::memory_order_relaxed);
     else if (!std::strcmp(name, "mlp_slab")) g_knob_mlp_slab.store(std::max(0, std::min(2, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "late_rows")) g_knob_late_rows.store(std::max(-1, std::min(1, value)), std::memory_order_relaxed);
+    else if (!std::strcmp(name, "vs_fill2")) g_knob_vs_fill2.store(std::max(0, std::min(95, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "spec_tail")) g_knob_spec_tail.store(std::max(0, std::min(100, value)), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_chunk")) g_knob_knn_chunk.store(std::max(64, value & ~63), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_pool_min_k")) g_knob_knn_pool_min_k.store(std::max(1, value), std::memory_order_relaxed);

@@ -166,6 +166,9 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // entries so that the largest walk seen (+ 1/16 margin + one pass of new ids) stays under the
         // 15/16 fill limit
         uint32_t need = (maxdc + maxdc / 16 + 64) / 15 * 16 + 16;
+        // (the hand-laid-out kernels over adjacency rows of two passes: a lower fill -- knob vs_fill2, handle.cpp)
+        const int fill2 = g_knob_vs_fill2.load(std::memory_order_relaxed);
+        if (L.stats_hot2 && fill2 > 0) need = std::max<uint32_t>(need, (uint32_t)((uint64_t)maxdc * 100u / (uint32_t)fill2) + 64u);
         // max_dc covers the retry / general passes too, so a hand-over needs no extra sizing rule
         uint32_t& seen = ix->maxdc_for_ef[L.stats_ef];
         seen = std::max(seen, maxdc);
@@ -332,6 +335,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         L.stats_pending = true;
         L.stats_ef = skey;
         L.stats_cap = cap;
+        L.stats_hot2 = hot && ix->ell_stride > 32u;
     }
 
     g_slow.mark("stats");

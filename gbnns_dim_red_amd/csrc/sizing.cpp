@@ -42,7 +42,10 @@ FirstPassSizing size_first_pass(gbnns_index* ix, WalkParams& w, const gbnns_sear
         // raises the requirement for good -- it never shrinks).
         if (slots < wave_cap && ix->maxdc_for_ef.count(skey)) {
             const uint32_t m = ix->maxdc_for_ef[skey];
-            const uint32_t need_min = std::max((m + m / 32 + 64) / 15 * 16 + 16 + extra, floor_entries);
+            uint32_t need_min = std::max((m + m / 32 + 64) / 15 * 16 + 16 + extra, floor_entries);
+            // (the hand-laid-out kernels over two-pass adjacency rows: the extra wavefront must leave the table at the fill the rule aims at + 4 points)
+            const int fill2 = g_knob_vs_fill2.load(std::memory_order_relaxed);
+            if (hot && ix->ell_stride > 32u && fill2 > 0) need_min = std::max(need_min, (uint32_t)((uint64_t)m * 100u / (uint32_t)(fill2 + 4)) + extra);
             const size_t share1 = kMaxLds / (slots + 1) / gran * gran;
             if (share1 > lds_fixed && walk_hash_entries(share1 - lds_fixed, f) >= need_min + 4) slots += 1;
         }
