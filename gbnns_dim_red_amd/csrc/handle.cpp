@@ -179,13 +179,13 @@ std::atomic<int> g_knob_mlp_slab{knob_env("GBNNS_MLP_SLAB", 1)};
 // "late_rows": generic two-list kernels over 192- / 256- / 576-byte rows -- -1 = by shape and residency (search_core.cpp), 0 = rows
 // requested before the visited test, 1 = after it (GBNNS_LATE_ROWS)
 std::atomic<int> g_knob_late_rows{std::max(-1, std::min(1, knob_env("GBNNS_LATE_ROWS", -1)))};
-// "vs_fill2": the visited set's fill (longest walk seen / capacity, per cent) that the sizing rule aims at for the hand-laid-out kernels
-// (128-byte rows) on graphs whose adjacency rows take two passes (rows of 33 .. 64 slots: the reference's M18 / M20 hnsw graphs) -- their
-// hops test up to twice the ids, and the hop waits for the longest probe sequence among its lanes: SIFT-shaped on a GD(M = 30) graph, ef 120 /
-// 140 / 160 / 180 one batch at a time 1.25 / 1.49 / 1.76 / 2.38 ms at the one-pass rule's ~0.8 - 0.86 against 0.98 / 1.24 / 1.44 / 1.68 at
-// 0.72 (tools/fill_scan.sh, fill2_ab.sh).  The generic wide-row kernels lose by it (deep 96 -> 48 ef 200 +7 %, glove 300 -> 144 +9 %: they
-// are short of wavefronts, not of probes) and keep the one-pass rule.  0 = that rule for every kernel.
-std::atomic<int> g_knob_vs_fill2{std::max(0, std::min(95, knob_env("GBNNS_VS_FILL2", 72)))};
+// "vs_fill2": a visited-set fill (longest walk seen / capacity, per cent) for the sizing rule to aim at in the hand-laid-out kernels over
+// two-pass adjacency rows; 0 = the one-pass rule (default).  History (second half of round 5): those kernels fell off a cliff as their
+// tables filled (GD(M = 30) graph, ef 180: first-pass kernel 2.33 ms at a fill of 0.86, 1.63 at 0.72, 11.6 at 0.95 -- tools/fill_scan.sh)
+// and a target of 0.72 bought 17 - 30 %; the cause was that they handed a query over whenever a probe sequence ran out instead of using
+// the stash (walk_hot.hip) -- with the stash there too the one-pass rule is the better one again (ef 140 / 160 / 180 in flight 1.03 / 1.26 /
+// 1.43 ms against 1.10 / 1.31 / 1.56 at 0.72; before either change 1.21 / 1.42 / 2.16).  Kept as an A/B knob.
+std::atomic<int> g_knob_vs_fill2{std::max(0, std::min(95, knob_env("GBNNS_VS_FILL2", 0)))};
 std::atomic<int> g_knob_spec_tail{std::max(0, std::min(100, knob_env("GBNNS_SPEC_TAIL", 50)))};
 // "knn_chunk" = most rows per filtered chunk (a multiple of 64)
 std::atomic<int> g_knob_knn_chunk{std::max(64, knob_env("GBNNS_KNN_CHUNK", 1 << 15) & ~63)};  // (a multiple of 64, never 0: the chunk loops step by it)

@@ -667,9 +667,8 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
             // (R = 1, tested-first: the order is a run-time choice per wavefront, WalkParams::spec_from)
             const uint32_t kd = hot_expand<METRIC, QLDS, SPEC, (QLDS && !SPEC)>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, qaddr, mclaimed, vs_shr, movf, spec_tail);
             if (__builtin_expect(movf != 0, 0)) {  // a probe sequence ran out (quotient form): the stash takes the id
-                // (the two-pass instances are at their scalar-register budget -- tests/test_isa_contract.py -- and hand over)
-                if constexpr (WIDE) return false;
-                else if (!stash_claim(hash_lds, nbuckets, movf >> 1, nb, mclaimed, lane)) return false;  // (reported in the odd bits)
+                // (the two-pass instances too since the second half of round 5: see walk_hot_big)
+                if (!stash_claim(hash_lds, nbuckets, movf >> 1, nb, mclaimed, lane)) return false;  // (reported in the odd bits)
             }
             const uint64_t mfresh = mclaimed << 1;  // odd lanes hold the distances
             const uint32_t dk = __builtin_amdgcn_inverse_ballot_w64(mfresh) ? kd : 0xFFFFFFFFu;
@@ -849,9 +848,10 @@ __device__ __forceinline__ void walk_hot_big(const WalkParams& p, uint32_t qi, u
             uint64_t mclaimed, movf;
             const uint32_t kd = hot_expand<METRIC, false, true>(db_base, (nb << 7) + half * (METRIC == 0 ? 64u : 16u), nb, mv, hash_lds, nbuckets, qreg.v, 0u, mclaimed, vs_shr, movf);
             if (__builtin_expect(movf != 0, 0)) {  // a probe sequence ran out (quotient form): the stash takes the id
-                // (the two-pass instances are at their scalar-register budget -- tests/test_isa_contract.py -- and hand over)
-                if constexpr (WIDE) return false;
-                else if (!stash_claim(hash_lds, nbuckets, movf >> 1, nb, mclaimed, lane)) return false;  // (reported in the odd bits)
+                // (second half of round 5: the two-pass instance too -- it used to hand the whole query over here, which made it
+                // fall off a cliff as the table filled: GD(M = 30) graph, ef 180, first-pass kernel 2.33 ms at a fill of 0.86, 11.6 at
+                // 0.95; this kernel's wavefronts per CU are bounded by LDS, not by its scalar registers)
+                if (!stash_claim(hash_lds, nbuckets, movf >> 1, nb, mclaimed, lane)) return false;  // (reported in the odd bits)
             }
             const uint64_t mfresh = mclaimed << 1;  // odd lanes hold the distances
             const uint32_t dk = __builtin_amdgcn_inverse_ballot_w64(mfresh) ? kd : 0xFFFFFFFFu;

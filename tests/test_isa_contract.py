@@ -156,7 +156,9 @@ def test_hot_kernel_register_budgets(tmp_path):
                # the instances for adjacency rows of 33 .. 64 slots (second expansion pass)
                ("16walk_hotw_kernelE", 64, 80), ("17walk_hotw2_kernelE", 72, 112), ("20walk_hotw_big_kernelE", 96, 112),
                # the negative-dot metric on the same shapes
-               ("19walk_hot_dot_kernelILi1E", 64, 80), ("19walk_hot_dot_kernelILi2E", 72, 112), ("23walk_hot_dot_big_kernelI", 96, 112),
+               ("19walk_hot_dot_kernelILi1E", 64, 80), ("19walk_hot_dot_kernelILi2ELb0E", 72, 112), ("23walk_hot_dot_big_kernelI", 96, 112),
+               # (its two-pass instance with the stash: 73 registers = six wavefronts per SIMD, 24 per CU -- the two-register lists' LDS allows 21)
+               ("19walk_hot_dot_kernelILi2ELb1E", 80, 112),
                # the generic hop over 192-byte rows at ef <= 64 (the reference's deep 96 -> 48 shape): query in LDS, 6 wavefronts per SIMD
                ("20walk_reg_wide_kernelILi12E", 80, 96),
                # the pair-form list instances over 384-byte rows (PLAIN walks over deep vectors at ef <= 128): three wavefronts per SIMD
