@@ -163,6 +163,12 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     if (L.stats_pending && hipEventQuery(L.stats_ev) == hipSuccess) {
         L.stats_pending = false;
         const uint32_t ovf = L.h_stats[0], maxdc = L.h_stats[2];
+        {   // diagnostic (GBNNS_DEBUG_SIZING): what the first pass of that call handed over -- hand-overs stay exact but cost a retry pass
+            static const bool dbg = getenv("GBNNS_DEBUG_SIZING") != nullptr;
+            if (dbg && (ovf || L.h_stats[3]))
+                std::fprintf(stderr, "[gbnns stats] key %d: first pass handed over %u queries, %u went on to the general kernel (longest walk %u, capacity %u)\n",
+                             L.stats_ef, ovf, L.h_stats[3], maxdc, L.stats_cap);
+        }
         // entries so that the largest walk seen (+ 1/16 margin + one pass of new ids) stays under the
         // 15/16 fill limit
         uint32_t need = (maxdc + maxdc / 16 + 64) / 15 * 16 + 16;
