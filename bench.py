@@ -61,6 +61,12 @@ CONFIGS = {
     # d_hidden >= 2 d_low; the walk and the re-rank are what this row is about)
     "glove1m": dict(n=1_000_000, nq=10_000, d=300, d_low=144, d_hidden=512, ef=300, efs=[400, 600, 800, 1000], unit_norm=True,
                     label="GloVe1M 300->144 (the reference's parameter file)", shape="GloVe1M-shaped"),
+    # a harder data recipe for the tuning constants (tools/dist_probe.py; DESIGN_APPENDIX_R5 6): less clustered, more intrinsic
+    # dimensions, more noise -- the longest walk of a batch is 1.5 x the median instead of 1.28 x; timed at ITS OWN recall gate (the
+    # sweep below walks the beam up; `recall_gate_failed` when no beam up to 1 000 reaches 0.95 on it)
+    "sift-hard": dict(n=1_000_000, nq=10_000, d=128, d_low=32, d_hidden=256, ef=160, efs=[64],
+                      recipe=dict(intrinsic=24, n_clusters=100, cluster_scale=1.0, sigma=0.1),
+                      label="SIFT1M 128->32 (harder synthetic recipe)", shape="SIFT1M-shaped, harder recipe"),
     "deep": dict(n=10_000_000, nq=1_000_000, d=96, d_low=32, d_hidden=128, ef=40, efs=[60, 120], strong=True,
                  native_knn=True, label="DEEP10M 96->32, 1M-query batch", shape="DEEP10M-shaped"),
 }
@@ -138,6 +144,13 @@ def main():
     ap.add_argument("--capi-multi-child", default=None,
                     help="internal: run the C-ABI multi-replica section (gbnns_multi_*) over --gpus devices in this fresh process; "
                          "the value is the .npy file with the ranks' answer ids of batch 0 to compare with")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the complete record on stdout instead of the compact line (tools, the other_configs child runs)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling for the per-rank-batch configurations (sift, gist, glove*): ONE batch of --strong-nq queries "
+                         "(default 80 000: eight times the configuration's batch) block-sharded over the ranks, total work fixed as N grows; "
+                         "the default stays weak scaling (a 10 000-query batch per rank)")
+    ap.add_argument("--strong-nq", type=int, default=None, help="--strong: queries of the one sharded batch (default 8 x the configuration's)")
     ap.add_argument("--no-capi-multi", action="store_true", help="N > 1: skip the C-ABI multi-replica section")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default sift run at N = 1: do not append the gist / glove / glove-dot (/ deep) lines under other_configs")
@@ -167,6 +180,10 @@ def main():
         cfg["n"] = args.n
     if args.nq:
         cfg["nq"] = args.nq
+    if args.strong and not cfg.get("strong"):
+        cfg["strong"] = True
+        cfg["strong_by_flag"] = True
+        cfg["nq"] = args.strong_nq or 8 * cfg["nq"]
 
     if args.capi_multi_child:
         capi_multi_child(args, cfg)
@@ -202,7 +219,9 @@ def main():
         kw["unit_norm"] = True  # GloVe vectors are normalised before anything else (train_naive_triplet.py:233-237)
     if args.graph_M:
         kw["M"] = args.graph_M
-    if cfg.get("strong"):
+    if cfg.get("recipe"):
+        kw.update(cfg["recipe"])
+    if cfg.get("strong") and cfg["nq"] > 200_000:
         kw["gt_queries"] = 20_000  # exact ground truth for the first 20 000 queries of the 1M batch (recall sample)
     if rank == 0:
         ds = synth.make_dataset(device=str(dev), verbose=args.config == "deep", **kw)
@@ -399,14 +418,31 @@ def main():
         step()
     drain()  # every step's join and gather is inside the timed region
     torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0   # this rank's K steps, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        # per rank (diagnostic, after the timed region): its own ms per step, how long it then waited at the closing barrier, and the
+        # exchange step alone -- one all-gather of the id vectors, timed by itself
+        tg0 = time.perf_counter()
+        for b in range(4):
+            gather(b % nbuf)
+            pending[b % nbuf].wait()
+            pending[b % nbuf] = None
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg0) * 1e3 / 4
+        mine = torch.tensor([own_elapsed * 1e3 / args.steps, (elapsed - own_elapsed) * 1e3, gather_ms, float(nq_rank)], dtype=torch.float64, device=dev)
+        allr = torch.empty(world * 4, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(world, 4).cpu().tolist()
+        per_rank = {"ms_per_step": [round(v[0], 4) for v in allr], "barrier_wait_ms": [round(v[1], 3) for v in allr],
+                    "gather_alone_ms": [round(v[2], 4) for v in allr], "queries": [int(v[3]) for v in allr]}
 
     ms_per_step = elapsed * 1e3 / args.steps
     qps = nq_total * args.steps / elapsed
@@ -484,8 +520,11 @@ def main():
             "parallelism": "query-sharded replicas x%d" % world,
             "recipe": ds.recipe,
         },
+        "config_nq": nq_rank,
         "ranks_seen": dist.get_world_size() if world > 1 else 1,
         "gather_self_check": gather_ok,
+        "per_rank": per_rank,
+        "strong_batch": nq_total if strong else None,
         "roofline": rl["roofline"],
         "kernels_ms": rl["kernels_ms"],
         "batches_rotated": nb,
@@ -632,6 +671,13 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ds, q, ef, res["ids"], metric_id, sample=args.cpu_sample)
 
+    if isinstance(result.get("throughput_option"), dict) and "_ids" in result["throughput_option"]:
+        cbl = result.get("cpu_baseline") or {}
+        if "_ref_ids" in cbl:   # measured against the reference's own answers of this run (never inferred)
+            nref = len(cbl["_ref_ids"])
+            result["throughput_option"]["id_mismatches_vs_reference"] = int((result["throughput_option"]["_ids"][:nref] != cbl["_ref_ids"]).sum())
+            result["throughput_option"]["reference_sample"] = nref
+
     # ---- the other BASELINE.json configurations, each as a short run of its own in a child process --------------
     if world == 1 and args.config == "sift" and not args.no_extras and not args.no_other_configs and not args.n and not args.nq:
         ix.close()
@@ -652,7 +698,7 @@ def main():
             log(f"sweep ef={e}: recall={recall_of(r['ids']):.4f} qps={nq_rank / dt:.0f}")
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result, args)
     if ix is not None:
         ix.close()
     if world > 1:
@@ -667,9 +713,10 @@ def throughput_option(g, ix, q, ef, res_exact, batches, depth, nq):
         ex = ix.search(q, ef, want=("q_low",), flags=g.FLAG_SERIAL)
         op = ix.search(q, ef, want=("q_low",), flags=fl | g.FLAG_SERIAL)
         torch.cuda.synchronize()
+        out["_ids"] = op["ids"].cpu().numpy().astype(np.int64)   # (for the comparison with the reference's own ids; dropped before printing)
         out["max_abs_q_low_err"] = float((op["q_low"] - ex["q_low"]).abs().max().item())
         out["id_mismatches_vs_exact_path"] = int((op["ids"] != res_exact["ids"]).sum().item())
-        out["id_mismatches_vs_reference"] = out["id_mismatches_vs_exact_path"]  # (the exact path's ids ARE the reference's: cpu_baseline.gpu_ids_identical)
+        # (against the reference itself: filled in by main() from THIS run's cpu_baseline ids, where that section ran -- never an alias)
         out["batch"] = nq
         for _ in range(3):
             ix.search(q, ef, want=(), flags=fl | g.FLAG_SERIAL)
@@ -883,8 +930,10 @@ def capi_multi_child(args, cfg):
             kw["unit_norm"] = True
         if args.graph_M:
             kw["M"] = args.graph_M
-        if cfg.get("strong"):
+        if cfg.get("strong") and cfg["nq"] > 200_000:
             kw["gt_queries"] = 20_000
+        if cfg.get("recipe"):
+            kw.update(cfg["recipe"])
         ds = synth.make_dataset(device="cuda:0", **kw)
         ef = args.ef or cfg["ef"]
         metric_id = g.METRIC_NEG_DOT if cfg.get("negdot") else g.METRIC_L2
@@ -951,7 +1000,10 @@ def other_configs(args, t_start):
     # ("deep1m" / "glove1m": the two rows of the reference's own parameter file that BASELINE.json does not name -- deep 96 -> 48 at
     # ef 40, glove 300 -> 144 at ef 300: 192- and 576-byte walked rows)
     plan = [("gist", 20, 150), ("glove", 20, 120), ("glove-dot", 20, 90), ("sift-M30", 20, 120), ("deep1m", 20, 100), ("glove1m", 10, 120),
-            ("deep", 3, 200)]
+            ("deep", 3, 200),
+            # (round 6, after DEEP10M so that they never cost it its slot) the headline shape on a harder data recipe, at its own recall
+            # gate, and on a GD(M = 24) graph -- adjacency rows of up to 48 slots, what hnswlib's M = 18 level-0 lists look like
+            ("sift-hard", 20, 80), ("sift-M24", 20, 80)]
     out = {}
     for name, steps, need_s in plan:
         left = args.budget_s - (time.time() - t_start)
@@ -959,7 +1011,7 @@ def other_configs(args, t_start):
             out[name] = {"skipped": "%.0f s of the %.0f s budget left, this configuration is given %d s" % (left, args.budget_s, need_s)}
             continue
         cmd = [sys.executable, os.path.abspath(__file__), "--config", name.split("-M")[0] if "-M" in name else name, "--steps", str(steps),
-               "--warmup", "3" if steps > 3 else "1", "--no-extras", "--cpu-sample", "1000", "--cache-dir", args.cache_dir]
+               "--warmup", "3" if steps > 3 else "1", "--no-extras", "--cpu-sample", "1000", "--cache-dir", args.cache_dir, "--full-line"]
         if "-M" in name:
             cmd += ["--graph-M", name.split("-M")[1]]
         t1 = time.time()
@@ -1223,7 +1275,124 @@ def cpu_baseline(ds, q, ef, gpu_ids, metric_id, sample=0):
         "build_flags": flags,
         "gpu_ids_identical": same == nfull,
         "gpu_id_mismatches": nfull - same,
+        "_ref_ids": r["ids"].astype(np.int64),   # (the reference's answers to the first nfull queries; dropped before printing)
     }
+
+
+def emit(result, args):
+    """Rank 0's output.  stdout gets ONE line: the compact record (every contract field, `roofline`, `cpu_baseline`, and one-row summaries
+    of the diagnostic sections; under 8 KB so that a driver that keeps a bounded tail of stdout keeps all of it) -- or the complete record
+    with --full-line.  The complete record always goes to stderr as one line prefixed `BENCH_FULL ` and, when GBNNS_BENCH_FULL names a file
+    (or gpurun_out/ exists), into that file."""
+    result = {k: v for k, v in result.items() if not k.startswith("_")}
+    for sec in ("throughput_option", "cpu_baseline"):
+        if isinstance(result.get(sec), dict):
+            result[sec] = {k: v for k, v in result[sec].items() if not k.startswith("_")}
+    full = json.dumps(result)
+    log("BENCH_FULL " + full)
+    path = os.environ.get("GBNNS_BENCH_FULL")
+    if not path and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        path = os.path.join(ROOT, "gpurun_out", "bench_full_%s.json" % result["config"]["name"])
+    if path:
+        try:
+            with open(path, "w") as f:
+                f.write(full + "\n")
+        except OSError:
+            pass
+    if args.full_line or (args.no_extras and len(full) <= 8000):   # (a --no-extras record is small: tools read it whole)
+        print(full, flush=True)
+        return
+    line = json.dumps(compact(result))
+    if len(line) > 8000:   # never silently: drop the least essential summaries until it fits, and say so
+        c = compact(result)
+        for k in ("graph_prep", "rccl_single_rank", "cold", "separate_stages", "host", "throughput_option"):
+            if len(json.dumps(c)) <= 8000:
+                break
+            c.pop(k, None)
+            c.setdefault("dropped_for_size", []).append(k)
+        line = json.dumps(c)
+    print(line, flush=True)
+
+
+def compact(r):
+    """The record in under 8 KB: contract fields verbatim; sections as rows (the column names ride along once)."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+    mq = lambda v: None if v is None else round(v / 1e6, 3)
+    c = pick(r, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "settle_steps_before_warmup", "ms_per_step", "higher_is_better",
+                 "scaling", "vs_baseline", "dtype", "data"))
+    cfg = r["config"]
+    c["config"] = pick(cfg, ("workload", "name", "ef", "recall_at_1", "recall_scored_queries", "mean_hops", "mean_dist_calc", "graph", "parallelism"))
+    c["config"]["recall_sweep"] = cfg.get("recall_sweep")
+    c["config"]["recipe"] = cfg.get("recipe")
+    rl = dict(r["roofline"])
+    rl.pop("kernel_ms_mode", None)
+    if isinstance(rl.get("traffic_source"), str):
+        rl["traffic_source"] = rl["traffic_source"].split(" (")[0]
+    c["roofline"] = rl
+    c["kernels_ms"] = r.get("kernels_ms")
+    c.update(pick(r, ("ranks_seen", "gather_self_check", "batches_rotated", "pipelined", "batches_in_flight", "recall_gate_failed",
+                      "per_rank", "strong_batch")))
+    if "serial" in r:
+        c["serial"] = pick(r["serial"], ("ms_per_step", "queries_per_s"))
+    c["value_definition"] = "all ranks' queries / wall time of K steps; inputs, outputs and index resident in HBM; %s" % (
+        "%d batches in flight inside the library (GBNNS_FLAG_DEFER_JOIN), joins and drains timed" % r["batches_in_flight"]
+        if r.get("pipelined") else "one batch at a time")
+    cb = r.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "sample", "value_1thread", "queries_per_s_by_threads", "cpu_model",
+                                      "value_readme_flags", "value_readme_flags_1thread", "readme_flags_ids_identical_to_strict",
+                                      "gpu_ids_identical", "gpu_id_mismatches"))
+    if "cold" in r:
+        c["cold"] = pick(r["cold"], ("first_call_ms", "second_call_ms", "calls_until_steady", "steady_call_ms"))
+    if "best_ef_at_recall_gate" in r:
+        b = r["best_ef_at_recall_gate"]
+        c["best_ef_at_recall_gate"] = pick(b, ("ef", "recall_at_1", "queries_per_s", "queries_per_s_in_flight", "kernel_ms", "achieved_GBps", "frac"))
+    if "ef_sweep" in r:
+        c["ef_sweep"] = {"columns": ["ef", "recall_at_1", "Mq_per_s_serial", "Mq_per_s_in_flight", "kernel", "kernel_ms", "frac", "frac_whole_step_in_flight"],
+                         "rows": [[e["ef"], e["recall_at_1"], mq(e["queries_per_s"]), mq(e["queries_per_s_in_flight"]),
+                                   e["kernel"].split("<")[0].split(" (")[0], e["kernel_ms"], e["frac"],
+                                   None if not e.get("queries_per_s_in_flight") else
+                                   round(e["algorithmic_bytes_per_launch"] * e["queries_per_s_in_flight"] / r["config_nq"] / 1e9 / HBM_PEAK_GBS, 4)]
+                                  for e in r["ef_sweep"]]}
+    if "separate_stages" in r:
+        c["separate_stages"] = r["separate_stages"]
+    host = pick(r, ("survey_8d_value", "survey_8d_in_flight", "host_buffers_pinned_qps", "host_batches_in_flight_ids_identical",
+                    "survey_8d_blocks"))
+    if host:
+        c["host"] = host
+        c["survey_8d_value"] = r.get("survey_8d_value")
+        c["survey_8d_in_flight"] = r.get("survey_8d_in_flight")
+    if "throughput_option" in r:
+        c["throughput_option"] = pick(r["throughput_option"], ("kernel", "project_ms", "mfma_util", "mfma_util_source", "value_in_flight",
+                                                               "max_abs_q_low_err", "id_mismatches_vs_exact_path", "id_mismatches_vs_reference",
+                                                               "reference_sample", "batch", "failed", "project_ms_exact"))
+        if "kernel" in c["throughput_option"]:
+            c["throughput_option"]["kernel"] = c["throughput_option"]["kernel"].split(" (")[0]
+    if "graph_prep" in r:
+        c["graph_prep"] = pick(r["graph_prep"], ("measured", "knn_s", "gd_s", "gd_host_s", "gd_host_threads", "knn_mfma_util",
+                                                 "knn_sample_identical_to_exact_scan", "gd_device_graph_identical_to_host", "error"))
+    if "rccl_single_rank" in r:
+        c["rccl_single_rank"] = pick(r["rccl_single_rank"], ("rccl_version", "ms_per_step", "ids_identical_to_single_handle", "failed"))
+    if "capi_multi" in r:
+        c["capi_multi"] = pick(r["capi_multi"], ("ranks", "queries_per_s", "ms_per_step", "rccl_loaded", "ids_identical_to_rank_results",
+                                                 "every_replica_holds_all_ids", "failed"))
+    oc = r.get("other_configs")
+    if oc:
+        cols = ["ef", "recall_at_1", "Mq_per_s_in_flight", "Mq_per_s_serial", "kernel", "kernel_ms", "frac", "project_ms", "gpu_ids_identical",
+                "cpu_q_per_s", "cpu_cores"]
+        rows = {}
+        for name, o in oc.items():
+            if "value" not in o:
+                rows[name] = o.get("skipped") or o.get("failed")
+                continue
+            rows[name] = [o["ef"], o["recall_at_1"], mq(o["value"]), mq(o["serial"]), o["kernel"].split(" (")[0].replace("false", "0").replace("true", "1"),
+                          o["kernel_ms"], o["frac"], o["project_ms"], o["gpu_ids_identical"], o["cpu_value"], o["cpu_cores"]]
+            if o.get("recall_gate_failed"):
+                rows[name].append("recall_gate_failed")
+        c["other_configs"] = {"columns": cols, "rows": rows}
+    c["full_record"] = "stderr line `BENCH_FULL {...}` of this run (and gpurun_out/bench_full_<config>.json where that directory exists)"
+    return c
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@ FLAG_MFMA_PROJECTION = 256
 # every symbol include/gbnns.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "gbnns_index_create", "gbnns_index_destroy", "gbnns_index_set_aux_graph", "gbnns_search_ex", "gbnns_search_batch", "gbnns_index_join", "gbnns_index_wait", "gbnns_host_pin", "gbnns_host_unpin",
-    "gbnns_project", "gbnns_rerank", "gbnns_debug_knob", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd", "gbnns_build_graph_gd_device",
+    "gbnns_project", "gbnns_rerank", "gbnns_debug_knob", "gbnns_index_knob", "gbnns_index_knob_get", "gbnns_profile_enable", "gbnns_profile_read", "gbnns_build_graph_gd", "gbnns_build_graph_gd_device",
     "gbnns_free", "gbnns_exact_knn", "gbnns_device_count", "gbnns_version", "gbnns_last_error",
     "gbnns_index_n", "gbnns_index_d", "gbnns_index_d_low", "gbnns_index_device",
     "gbnns_multi_create", "gbnns_multi_destroy", "gbnns_multi_size", "gbnns_multi_replica", "gbnns_multi_device_of",
@@ -114,6 +114,9 @@ def load_library():
                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     if hasattr(lib, "gbnns_debug_knob"):  # (absent from the rounds 1-3 libraries that tools/ab4.sh may put in place of this one)
         lib.gbnns_debug_knob.argtypes = [C.c_char_p, C.c_int]
+    if hasattr(lib, "gbnns_index_knob"):
+        lib.gbnns_index_knob.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        lib.gbnns_index_knob_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
     lib.gbnns_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.gbnns_profile_read.argtypes = [C.c_void_p, C.POINTER(Profile), C.c_int]
     lib.gbnns_build_graph_gd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -581,7 +584,17 @@ class Index:
     def profile_enable(self, on=True):
         _check(self._lib.gbnns_profile_enable(self._h, int(on)))
 
+    def knob(self, name, value):
+        """A diagnostic knob of THIS handle (gbnns_index_knob; include/gbnns.h lists them).  Results never depend on it."""
+        _check(self._lib.gbnns_index_knob(self._h, name.encode() if isinstance(name, str) else name, int(value)))
+
+    def knob_get(self, name):
+        v = C.c_int(0)
+        _check(self._lib.gbnns_index_knob_get(self._h, name.encode() if isinstance(name, str) else name, C.byref(v)))
+        return v.value
+
     def profile_read(self, reset=True):
         p = Profile()
+        p.struct_size = C.sizeof(Profile)   # the callee writes no more than this
         _check(self._lib.gbnns_profile_read(self._h, C.byref(p), int(reset)))
         return p.as_dict()

@@ -140,6 +140,17 @@ struct Lane {
     }
 };
 
+// The diagnostic knobs (defined and documented in handle.cpp).  Round 6: the eleven that steer a handle's searches live IN the handle
+// (gbnns_index::knob, set with gbnns_index_knob); the process-wide values (environment, gbnns_debug_knob) are only the defaults a handle
+// starts from, so a test or an A/B run that flips one no longer changes every other handle of the process.  The three knobs of
+// gbnns_exact_knn -- a function without a handle -- stay process-wide.
+struct Knobs {
+    int quotient, vs_disp, max_waves, spec_min_nq, spec_any_form, mlp_small, mlp_net, mlp_slab, late_rows, vs_fill2, spec_tail, coop;
+};
+Knobs knob_defaults();                                    // the process-wide defaults as they stand now
+bool knob_set(Knobs& k, const char* name, int value);     // clamps like the environment does; false = no such handle knob
+extern std::atomic<int> g_knob_knn_chunk, g_knob_knn_pool_min_k, g_knob_knn_filter;
+
 }  // namespace gbnns_api
 
 struct gbnns_index {
@@ -160,6 +171,7 @@ struct gbnns_index {
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     uint32_t ws1 = 0, ws2 = 0, ws3 = 0;
     int cus = 0;                    // compute units of the device (sizes the one-launch projection's query strips)
+    gbnns_api::Knobs knob{};        // this handle's diagnostic knobs (gbnns_index_knob; start: the process defaults at creation)
     // workspaces: lane 0 serves plain calls on the caller's stream; the batches of deferred calls rotate over
     // lanes 0 .. n_lanes-1, each on its own internal stream (see gbnns_search_ex)
     Lane lanes[gbnns_api::kMaxLanes];
@@ -201,10 +213,6 @@ constexpr size_t kMaxLds = 160 * 1024;
 #define GBNNS_LDS_GRAN 1280
 #endif
 constexpr size_t kLdsGran = GBNNS_LDS_GRAN;
-
-// the diagnostic knobs (gbnns_debug_knob; defined and documented in handle.cpp)
-extern std::atomic<int> g_knob_quotient, g_knob_vs_disp, g_knob_max_waves, g_knob_spec_min_nq, g_knob_spec_any_form, g_knob_mlp_small,
-    g_knob_mlp_net, g_knob_mlp_slab, g_knob_late_rows, g_knob_vs_fill2, g_knob_spec_tail, g_knob_knn_chunk, g_knob_knn_pool_min_k, g_knob_knn_filter;
 
 // lanes.cpp
 int enter_stream(gbnns_index* ix, hipStream_t s);

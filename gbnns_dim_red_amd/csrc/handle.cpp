@@ -150,48 +150,89 @@ int build_ell(const uint64_t* off, const uint32_t* nbr, uint64_t n, std::vector<
     return GBNNS_OK;
 }
 
-// Diagnostic knobs (gbnns_debug_knob; the environment gives their initial values, read once when the library loads):
-// "quotient" 0 = never the quotient form of the visited set (GBNNS_QUOTIENT); "vs_disp" = probe number at which a probe
-// sequence of that form gives up, 1 .. 15 (GBNNS_DEBUG_VS_DISP; 15 = the product's).
+// Diagnostic knobs.  The environment gives the process-wide defaults (read once when the library loads), gbnns_debug_knob changes
+// them; a handle copies the defaults when it is created and from then on has its own (gbnns_index_knob) -- round 6: until then they were
+// fourteen process-global atomics and a test that flipped one changed every handle of the process.  Results never depend on them.
+//   "quotient"      0 = never the quotient form of the visited set (GBNNS_QUOTIENT)
+//   "vs_disp"       probe number at which a probe sequence of that form gives up, 1 .. 15 (GBNNS_DEBUG_VS_DISP; 15 = the product's)
+//   "max_waves"     most first-pass wavefronts per CU the LDS shares are cut for (GBNNS_MAX_WAVES; 0 = the per-kernel defaults)
+//   "spec_min_nq"   smallest batch whose ef <= 64 first pass requests the rows before the visited test (walk_hot_spec_kernel;
+//                   GBNNS_SPEC_MIN_NQ; 0 = never)
+//   "spec_any_form" 1: ... whatever the form of the visited set (tests; default: only tables NOT in the quotient form)
+//   "mlp_small"     smallest batch IN FLIGHT whose hidden projection layers run on the small-footprint kernel (0 = never)
+//   "mlp_net"       0 = never the one-launch projection (mlp_net.hip), 1 = for the shapes and batch sizes it serves (GBNNS_MLP_NET)
+//   "mlp_slab"      0 = never the slab kernel for single layers (mlp_net.hip, mlp_slab_kernel), 1 = where a layer is one round of it
+//   "late_rows"     generic two-list kernels over 192- / 256- / 576-byte rows -- -1 = by shape and residency (search_core.cpp), 0 = rows
+//                   requested before the visited test, 1 = after it (GBNNS_LATE_ROWS)
+//   "vs_fill2"      a visited-set fill (longest walk seen / capacity, per cent) for the sizing rule to aim at in the hand-laid-out kernels
+//                   over two-pass adjacency rows; 0 = the one-pass rule (default).  History (second half of round 5): those kernels fell
+//                   off a cliff as their tables filled (GD(M = 30) graph, ef 180: first-pass kernel 2.33 ms at a fill of 0.86, 1.63 at
+//                   0.72, 11.6 at 0.95 -- tools/fill_scan.sh) and a target of 0.72 bought 17 - 30 %; the cause was that they handed a
+//                   query over whenever a probe sequence ran out instead of using the stash (walk_hot.hip) -- with the stash there too the
+//                   one-pass rule is the better one again (ef 140 / 160 / 180 in flight 1.03 / 1.26 / 1.43 ms against 1.10 / 1.31 / 1.56
+//                   at 0.72; before either change 1.21 / 1.42 / 2.16).  Kept as an A/B knob.
+//   "spec_tail"     largest partial last round of a lone launch, in percent of the device's wavefront slots, whose wavefronts request
+//                   their rows before the visited test (0 = off)
+//   "coop"          the two-wavefront walk for small batches (walk_coop.hip): -1 = where it serves and the batch leaves the room
+//                   (default), 0 = never, 1 = wherever the shape allows (tests; GBNNS_COOP)
+// Process-wide only (gbnns_exact_knn has no handle):
+//   "knn_chunk"      most rows per filtered chunk (a multiple of 64)
+//   "knn_pool_min_k" shortest list gbnns_exact_knn keeps as an unordered pool (one wavefront per query and chunk) instead of a heap
+//                    (measured on 10^6 x 32: k = 48 0.327 against 0.333 s, k = 100 0.425 against 0.536 s, k = 1 000 2.4 against 7.6 s)
+//   "knn_filter"     0 = gbnns_exact_knn without the matrix-core filter (GBNNS_KNN_FILTER; tests compare the two paths)
 int knob_env(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-std::atomic<int> g_knob_quotient{knob_env("GBNNS_QUOTIENT", 1)};
-std::atomic<int> g_knob_vs_disp{[] { const int v = knob_env("GBNNS_DEBUG_VS_DISP", 15); return v <= 0 ? 15 : v; }()};
-// "max_waves" = most first-pass wavefronts per CU the LDS shares are cut for (GBNNS_MAX_WAVES; 0 = the per-kernel defaults)
-std::atomic<int> g_knob_max_waves{std::max(0, std::min(32, knob_env("GBNNS_MAX_WAVES", 0)))};
-// "spec_min_nq" = smallest batch whose ef <= 64 first pass requests the rows before the visited test (walk_hot_spec_kernel;
-// GBNNS_SPEC_MIN_NQ; 0 = never)
-std::atomic<int> g_knob_spec_min_nq{std::max(0, knob_env("GBNNS_SPEC_MIN_NQ", 32768))};
-// "spec_any_form" = 1: ... whatever the form of the visited set (tests; default: only tables NOT in the quotient form)
-std::atomic<int> g_knob_spec_any_form{knob_env("GBNNS_SPEC_ANY_FORM", 0)};
-// "knn_pool_min_k" = shortest list gbnns_exact_knn keeps as an unordered pool (one wavefront per query and chunk) instead of a heap
-// (measured on 10^6 x 32: k = 48 0.327 against 0.333 s, k = 100 0.425 against 0.536 s, k = 1 000 2.4 against 7.6 s)
-// "mlp_small" = smallest batch IN FLIGHT whose hidden projection layers run on the small-footprint kernel (0 = never)
-std::atomic<int> g_knob_mlp_small{std::max(0, knob_env("GBNNS_MLP_SMALL", 4096))};
-// "mlp_net" 0 = never the one-launch projection (mlp_net.hip), 1 = for the shapes and batch sizes it serves (GBNNS_MLP_NET)
-std::atomic<int> g_knob_mlp_net{knob_env("GBNNS_MLP_NET", 1)};
-// "mlp_slab" 0 = never the slab kernel for single layers (mlp_net.hip, mlp_slab_kernel), 1 = where a layer is one round of it (GBNNS_MLP_SLAB)
-std::atomic<int> g_knob_mlp_slab{knob_env("GBNNS_MLP_SLAB", 1)};
-// "spec_tail" = largest partial last round of a lone launch, in percent of the device's wavefront slots, whose wavefronts
-// request their rows before the visited test (0 = off)
-// "late_rows": generic two-list kernels over 192- / 256- / 576-byte rows -- -1 = by shape and residency (search_core.cpp), 0 = rows
-// requested before the visited test, 1 = after it (GBNNS_LATE_ROWS)
-std::atomic<int> g_knob_late_rows{std::max(-1, std::min(1, knob_env("GBNNS_LATE_ROWS", -1)))};
-// "vs_fill2": a visited-set fill (longest walk seen / capacity, per cent) for the sizing rule to aim at in the hand-laid-out kernels over
-// two-pass adjacency rows; 0 = the one-pass rule (default).  History (second half of round 5): those kernels fell off a cliff as their
-// tables filled (GD(M = 30) graph, ef 180: first-pass kernel 2.33 ms at a fill of 0.86, 1.63 at 0.72, 11.6 at 0.95 -- tools/fill_scan.sh)
-// and a target of 0.72 bought 17 - 30 %; the cause was that they handed a query over whenever a probe sequence ran out instead of using
-// the stash (walk_hot.hip) -- with the stash there too the one-pass rule is the better one again (ef 140 / 160 / 180 in flight 1.03 / 1.26 /
-// 1.43 ms against 1.10 / 1.31 / 1.56 at 0.72; before either change 1.21 / 1.42 / 2.16).  Kept as an A/B knob.
-std::atomic<int> g_knob_vs_fill2{std::max(0, std::min(95, knob_env("GBNNS_VS_FILL2", 0)))};
-std::atomic<int> g_knob_spec_tail{std::max(0, std::min(100, knob_env("GBNNS_SPEC_TAIL", 50)))};
-// "knn_chunk" = most rows per filtered chunk (a multiple of 64)
+bool knob_set(Knobs& k, const char* name, int value) {
+    if (!std::strcmp(name, "quotient")) k.quotient = value != 0;
+    else if (!std::strcmp(name, "vs_disp")) k.vs_disp = value <= 0 ? 15 : std::min(15, value);
+    else if (!std::strcmp(name, "max_waves")) k.max_waves = std::max(0, std::min(32, value));
+    else if (!std::strcmp(name, "spec_any_form")) k.spec_any_form = value != 0;
+    else if (!std::strcmp(name, "spec_min_nq")) k.spec_min_nq = std::max(0, value);
+    else if (!std::strcmp(name, "mlp_small")) k.mlp_small = std::max(0, value);
+    else if (!std::strcmp(name, "mlp_net")) k.mlp_net = value != 0;
+    else if (!std::strcmp(name, "mlp_slab")) k.mlp_slab = std::max(0, std::min(2, value));
+    else if (!std::strcmp(name, "late_rows")) k.late_rows = std::max(-1, std::min(1, value));
+    else if (!std::strcmp(name, "vs_fill2")) k.vs_fill2 = std::max(0, std::min(95, value));
+    else if (!std::strcmp(name, "spec_tail")) k.spec_tail = std::max(0, std::min(100, value));
+    else if (!std::strcmp(name, "coop")) k.coop = std::max(-1, std::min(1, value));
+    else return false;
+    return true;
+}
+static std::mutex g_knob_mu;
+static Knobs& knob_default_ref() {  // (function-local: initialised on first use, whatever the order of the static initialisers)
+    static Knobs d = [] {
+        Knobs k{};
+        knob_set(k, "quotient", knob_env("GBNNS_QUOTIENT", 1));
+        knob_set(k, "vs_disp", knob_env("GBNNS_DEBUG_VS_DISP", 15));
+        knob_set(k, "max_waves", knob_env("GBNNS_MAX_WAVES", 0));
+        knob_set(k, "spec_min_nq", knob_env("GBNNS_SPEC_MIN_NQ", 32768));
+        knob_set(k, "spec_any_form", knob_env("GBNNS_SPEC_ANY_FORM", 0));
+        knob_set(k, "mlp_small", knob_env("GBNNS_MLP_SMALL", 4096));
+        knob_set(k, "mlp_net", knob_env("GBNNS_MLP_NET", 1));
+        knob_set(k, "mlp_slab", knob_env("GBNNS_MLP_SLAB", 1));
+        knob_set(k, "late_rows", knob_env("GBNNS_LATE_ROWS", -1));
+        knob_set(k, "vs_fill2", knob_env("GBNNS_VS_FILL2", 0));
+        knob_set(k, "spec_tail", knob_env("GBNNS_SPEC_TAIL", 50));
+        knob_set(k, "coop", knob_env("GBNNS_COOP", -1));
+        return k;
+    }();
+    return d;
+}
+Knobs knob_defaults() {
+    std::lock_guard<std::mutex> g(g_knob_mu);
+    return knob_default_ref();
+}
 std::atomic<int> g_knob_knn_chunk{std::max(64, knob_env("GBNNS_KNN_CHUNK", 1 << 15) & ~63)};  // (a multiple of 64, never 0: the chunk loops step by it)
 std::atomic<int> g_knob_knn_pool_min_k{std::max(1, knob_env("GBNNS_KNN_POOL_MIN_K", 64))};
-// "knn_filter" 0 = gbnns_exact_knn without the matrix-core filter (GBNNS_KNN_FILTER; tests compare the two paths)
 std::atomic<int> g_knob_knn_filter{knob_env("GBNNS_KNN_FILTER", 1)};
+
+// (defined here, beside the defaults, so that gbnns_debug_knob below can reach them under the lock)
+static bool knob_default_set(const char* name, int value) {
+    std::lock_guard<std::mutex> g(g_knob_mu);
+    return knob_set(knob_default_ref(), name, value);
+}
 
 }  // namespace gbnns_api
 
@@ -244,6 +285,7 @@ int gbnns_index_create(const gbnns_index_desc* desc, gbnns_index** out) {
     ix->d_low = desc->d_low;
     ix->d_hidden = desc->d_hidden;
     (void)hipDeviceGetAttribute(&ix->cus, hipDeviceAttributeMultiprocessorCount, ix->device);
+    ix->knob = knob_defaults();
     ix->d_pad = round_up(desc->d, 4);
     ix->dl_pad = round_up(desc->d_low, 4);
     int rc = GBNNS_OK;
@@ -382,7 +424,7 @@ int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint
                 hipStream_t s, bool in_flight, bool mfma) {
     // the whole net in one launch where it serves (round 5, mlp_net.hip: 0.048 against 0.075 ms on the SIFT shape; the
     // round-2 one-launch form -- csrc/project.hip, deleted in round 4 -- was slower than the three launches)
-    if (!mfma && g_knob_mlp_net.load(std::memory_order_relaxed)) {
+    if (!mfma && ix->knob.mlp_net) {
         NetLaunch n{};
         n.x = x; n.xstride = xstride; n.nq = nx; n.out = out; n.ostride = ix->dl_pad; n.cus = ix->cus;
         n.w[0] = ix->w1; n.w[1] = ix->w2; n.w[2] = ix->w3;
@@ -404,7 +446,7 @@ int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint
     // batches in flight whose walks fill the machine: the small-footprint kernel for the hidden layers (mlp.hip; sift-like
     // +2.5 % at ef 64, +3.6 % at ef 36; a 1 000-query GIST batch -- one walk wavefront per SIMD, nothing to squeeze in
     // beside -- and every batch that runs alone are faster on the big-tile kernel)
-    const int small_min = g_knob_mlp_small.load(std::memory_order_relaxed);
+    const int small_min = ix->knob.mlp_small;
     // (... up to 32 times that: a 1 M-query DEEP batch is twenty rounds of the machine on its own, its projection is not
     // waiting for room, and the big-tile kernel's 12 % matter again: 43.1 against 41.5 M queries/s)
     p.small_footprint = (in_flight && small_min > 0 && nx >= (uint32_t)small_min && (uint64_t)nx <= 32ull * (uint64_t)small_min) ? 1 : 0;
@@ -415,7 +457,7 @@ int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint
         if (mfma) return launch_mlp_layer_mfma(lp, s);
         // (batches in flight: only the narrow shape -- 35 KB, 256 threads -- finds room beside the other lanes' walk wavefronts; the
         // wide one's 103 KB workgroups wait for a CU to drain: GIST 2.27 against 2.58 M queries/s.  Knob value 2 = wide in flight too.)
-        const int slab = g_knob_mlp_slab.load(std::memory_order_relaxed);
+        const int slab = ix->knob.mlp_slab;
         if (!lp.small_footprint && slab && (!in_flight || lp.dout <= 64u || slab >= 2) && mlp_slab_wins(lp, ix->cus)) {
             slab_used = true;
             return launch_mlp_slab(lp, ix->cus, s);
@@ -499,21 +541,29 @@ int gbnns_debug_merge(int regs, const unsigned long long* entries, int size, con
 
 int gbnns_debug_knob(const char* name, int value) {
     if (!name) return fail(GBNNS_ERR_INVALID, "gbnns_debug_knob: null name");
-    if (!std::strcmp(name, "quotient")) g_knob_quotient.store(value, std::memory_order_relaxed);
-    else if (!std::strcmp(name, "vs_disp")) g_knob_vs_disp.store(value <= 0 ? 15 : value, std::memory_order_relaxed);
-    else if (!std::strcmp(name, "max_waves")) g_knob_max_waves.store(std::max(0, std::min(32, value)), std::memory_order_relaxed);
-    else if (!std::strcmp(name, "spec_any_form")) g_knob_spec_any_form.store(value != 0, std::memory_order_relaxed);
-    else if (!std::strcmp(name, "spec_min_nq")) g_knob_spec_min_nq.store(std::max(0, value), std::memory_order_relaxed);
-    else if (!std::strcmp(name, "mlp_small")) g_knob_mlp_small.store(std::max(0, value), std::memory_order_relaxed);
-    else if (!std::strcmp(name, "mlp_net")) g_knob_mlp_net.store(value != 0, std::memory_order_relaxed);
-    else if (!std::strcmp(name, "mlp_slab")) g_knob_mlp_slab.store(std::max(0, std::min(2, value)), std::memory_order_relaxed);
-    else if (!std::strcmp(name, "late_rows")) g_knob_late_rows.store(std::max(-1, std::min(1, value)), std::memory_order_relaxed);
-    else if (!std::strcmp(name, "vs_fill2")) g_knob_vs_fill2.store(std::max(0, std::min(95, value)), std::memory_order_relaxed);
-    else if (!std::strcmp(name, "spec_tail")) g_knob_spec_tail.store(std::max(0, std::min(100, value)), std::memory_order_relaxed);
-    else if (!std::strcmp(name, "knn_chunk")) g_knob_knn_chunk.store(std::max(64, value & ~63), std::memory_order_relaxed);
+    if (knob_default_set(name, value)) return GBNNS_OK;  // a handle knob: the default of the handles created from now on
+    if (!std::strcmp(name, "knn_chunk")) g_knob_knn_chunk.store(std::max(64, value & ~63), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_pool_min_k")) g_knob_knn_pool_min_k.store(std::max(1, value), std::memory_order_relaxed);
     else if (!std::strcmp(name, "knn_filter")) g_knob_knn_filter.store(value, std::memory_order_relaxed);
     else return fail(GBNNS_ERR_INVALID, "gbnns_debug_knob: unknown knob '%s'", name);
+    return GBNNS_OK;
+}
+
+int gbnns_index_knob_get(gbnns_index* ix, const char* name, int* out) {
+    if (!ix || !name || !out) return fail(GBNNS_ERR_INVALID, "gbnns_index_knob_get: null argument");
+    const Knobs& k = ix->knob;
+    const struct { const char* n; int v; } all[] = {
+        {"quotient", k.quotient}, {"vs_disp", k.vs_disp}, {"max_waves", k.max_waves}, {"spec_min_nq", k.spec_min_nq},
+        {"spec_any_form", k.spec_any_form}, {"mlp_small", k.mlp_small}, {"mlp_net", k.mlp_net}, {"mlp_slab", k.mlp_slab},
+        {"late_rows", k.late_rows}, {"vs_fill2", k.vs_fill2}, {"spec_tail", k.spec_tail}, {"coop", k.coop}};
+    for (const auto& e : all)
+        if (!std::strcmp(name, e.n)) { *out = e.v; return GBNNS_OK; }
+    return fail(GBNNS_ERR_INVALID, "gbnns_index_knob_get: unknown handle knob '%s'", name);
+}
+
+int gbnns_index_knob(gbnns_index* ix, const char* name, int value) {
+    if (!ix || !name) return fail(GBNNS_ERR_INVALID, "gbnns_index_knob: null argument");
+    if (!knob_set(ix->knob, name, value)) return fail(GBNNS_ERR_INVALID, "gbnns_index_knob: unknown handle knob '%s'", name);
     return GBNNS_OK;
 }
 
@@ -533,7 +583,15 @@ int gbnns_profile_read(gbnns_index* ix, gbnns_profile* out, int reset) {
     HIP_TRY(hipMemcpy(&total, ix->lanes[0].ctrl.as<uint32_t>() + 5, 4, hipMemcpyDeviceToHost));
     ix->acc.general_queries = total;
     ix->acc.struct_size = sizeof(gbnns_profile);
-    *out = ix->acc;
+    // out->struct_size on entry = the caller's sizeof(gbnns_profile): a caller built against an older header (the struct grew from 160 to
+    // 192 bytes in round 5) gets the prefix it knows and nothing written past it; 0 (callers that never set it) = the 160-byte round-4 layout
+    {
+        const size_t theirs = out->struct_size ? out->struct_size : 160u;
+        const size_t take = std::min(theirs, sizeof(gbnns_profile));
+        if (take < 8) return fail(GBNNS_ERR_INVALID, "gbnns_profile.struct_size %zu too small", theirs);
+        std::memcpy(out, &ix->acc, take);
+        out->struct_size = (uint32_t)take;
+    }
     if (reset) {
         ix->acc = gbnns_profile{};
         HIP_TRY(hipMemset(ix->lanes[0].ctrl.as<uint32_t>() + 5, 0, 4));

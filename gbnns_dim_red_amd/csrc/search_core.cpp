@@ -173,7 +173,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // 15/16 fill limit
         uint32_t need = (maxdc + maxdc / 16 + 64) / 15 * 16 + 16;
         // (the hand-laid-out kernels over adjacency rows of two passes: a lower fill -- knob vs_fill2, handle.cpp)
-        const int fill2 = g_knob_vs_fill2.load(std::memory_order_relaxed);
+        const int fill2 = ix->knob.vs_fill2;
         if (L.stats_hot2 && fill2 > 0) need = std::max<uint32_t>(need, (uint32_t)((uint64_t)maxdc * 100u / (uint32_t)fill2) + 64u);
         // max_dc covers the retry / general passes too, so a hand-over needs no extra sizing rule
         uint32_t& seen = ix->maxdc_for_ef[L.stats_ef];
@@ -234,15 +234,16 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         const bool forced = (a->flags & GBNNS_FLAG_BITMAP_PASS) != 0;  // diagnostic: whatever ef and batch size
         if (!w.all_general && (ef >= min_ef || forced) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && (a->hash_capacity == 0 || forced)) {
             const size_t gran = kLdsGran;
+            const size_t cus = ix->cus > 0 ? (size_t)ix->cus : 256;  // (the device's, as in sizing.cpp: the slot counts below follow it)
             const size_t per_wave = (walk_bitmap_lds_bytes(w, ix->metric) + gran - 1) / gran * gran;
             const size_t per_cu = std::min<size_t>(rows576 ? 8 : 32, kMaxLds / per_wave);  // (576-byte rows: 223 registers, two wavefronts per SIMD)
             const size_t table_waves = std::min<size_t>(32, kMaxLds / ((walk_fast_lds_bytes(w, hot) + gran - 1) / gran * gran));
             // ... and only when the batch is deeper than 1.5 rounds of the wavefronts the table would allow (a
             // 1 000-query batch is resident at once either way, and the register list is faster per hop)
             // ... or, short of that, when the table needs a second round and the bitmap pass holds the whole batch at once
-            const bool one_round = (size_t)nq > table_waves * 256 && (size_t)nq <= per_cu * 256;
-            if (((per_cu >= 2 * std::max<size_t>(table_waves, 1) && (2 * (size_t)nq > 3 * table_waves * 256 || one_round)) || forced) &&
-                per_cu >= 1 && per_cu * 256 * (size_t)bitmap_words * 4 <= (8ull << 30))
+            const bool one_round = (size_t)nq > table_waves * cus && (size_t)nq <= per_cu * cus;
+            if (((per_cu >= 2 * std::max<size_t>(table_waves, 1) && (2 * (size_t)nq > 3 * table_waves * cus || one_round)) || forced) &&
+                per_cu >= 1 && per_cu * cus * (size_t)bitmap_words * 4 <= (8ull << 30))
                 bitmap_per_cu = per_cu;
         }
     }
@@ -250,7 +251,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // Two-list kernels over wide rows: rows after the visited test where the launch is bound by bandwidth -- 576-byte rows with at
         // least five wavefronts per CU by LDS (ef 300 / 400 / 600: 4.15 / 5.36 / 10.4 against 5.08 / 6.74 / 10.7 ms; ef 800 / 1 000, four and
         // fewer per CU: 18.2 / 23.8 against 17.4 / 22.3) on a batch that fills the machine
-        const int knob = g_knob_late_rows.load(std::memory_order_relaxed);
+        const int knob = ix->knob.late_rows;
         const size_t per_wave = (walk_fast_lds_bytes(w, hot) + kLdsGran - 1) / kLdsGran * kLdsGran;
         const size_t lds_waves = per_wave ? kMaxLds / per_wave : 0;
         // ... and 192-byte rows at ef <= 64 (walk_reg_wide_kernel<12>, the reference's deep 96 -> 48: 2.24 GB moved for 1.62 GB of
@@ -283,10 +284,11 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
     }
     bool bitmap_pass = false;
     if (bitmap_per_cu) {
-        if ((rc = L.fp_bitmap.ensure(bitmap_per_cu * 256 * (size_t)bitmap_words * 4))) return rc;
+        const size_t cus = ix->cus > 0 ? (size_t)ix->cus : 256;
+        if ((rc = L.fp_bitmap.ensure(bitmap_per_cu * cus * (size_t)bitmap_words * 4))) return rc;
         w.fp_bitmap = L.fp_bitmap.as<uint32_t>();
         w.fp_cursor = ctrl + 6;
-        HIP_TRY(launch_walk_bitmap(w, ix->metric, (unsigned)(bitmap_per_cu * 256), s));
+        HIP_TRY(launch_walk_bitmap(w, ix->metric, (unsigned)(bitmap_per_cu * cus), s));
         bitmap_pass = true;
     }
     if (!w.all_general) {

@@ -18,7 +18,7 @@ FirstPassSizing size_first_pass(gbnns_index* ix, WalkParams& w, const gbnns_sear
     // bits (n <= 2^W), so the table needs at least 2^(W-13) buckets.
     uint32_t idbits = 1;
     while (idbits < 32 && (1ull << idbits) < ix->n) ++idbits;
-    const bool quotient_on = g_knob_quotient.load(std::memory_order_relaxed) != 0;  // tuning / A-B runs, tests: gbnns_debug_knob
+    const bool quotient_on = ix->knob.quotient != 0;  // tuning / A-B runs, tests: gbnns_debug_knob
     const bool vs_ok = walk_knows_quotient(w, ix->metric);
     constexpr uint32_t kStashBuckets = 4;  // (walk_common.h: the table's last four "buckets" are the stash)
     const uint32_t quotient_min = 7u * ((idbits > 13 ? 1u << (idbits - 13) : 1u) + kStashBuckets + 8u);  // entries (>= 8 real buckets: probe steps of up to 8)
@@ -27,7 +27,7 @@ FirstPassSizing size_first_pass(gbnns_index* ix, WalkParams& w, const gbnns_sear
     const bool auto_cap = a->hash_capacity == 0;
     // (most wavefronts per CU worth cutting the LDS for: the register files' limit of the first-pass kernel -- 32 for the
     // one-register hot instances, 28 / 24 / 20 for the others -- or the diagnostic knob)
-    const int knob_waves = g_knob_max_waves.load(std::memory_order_relaxed);
+    const int knob_waves = ix->knob.max_waves;
     const size_t wave_cap = knob_waves > 0 ? (size_t)knob_waves : 32;
     // visited-set capacity for `need` entries in the given form, and the wavefronts per CU it leaves (0: no fit)
     auto size_table = [&](int f, uint32_t need, size_t& slots) -> uint32_t {
@@ -44,7 +44,7 @@ FirstPassSizing size_first_pass(gbnns_index* ix, WalkParams& w, const gbnns_sear
             const uint32_t m = ix->maxdc_for_ef[skey];
             uint32_t need_min = std::max((m + m / 32 + 64) / 15 * 16 + 16 + extra, floor_entries);
             // (the hand-laid-out kernels over two-pass adjacency rows: the extra wavefront must leave the table at the fill the rule aims at + 4 points)
-            const int fill2 = g_knob_vs_fill2.load(std::memory_order_relaxed);
+            const int fill2 = ix->knob.vs_fill2;
             if (hot && ix->ell_stride > 32u && fill2 > 0) need_min = std::max(need_min, (uint32_t)((uint64_t)m * 100u / (uint32_t)(fill2 + 4)) + extra);
             const size_t share1 = kMaxLds / (slots + 1) / gran * gran;
             if (share1 > lds_fixed && walk_hash_entries(share1 - lds_fixed, f) >= need_min + 4) slots += 1;
@@ -92,7 +92,7 @@ FirstPassSizing size_first_pass(gbnns_index* ix, WalkParams& w, const gbnns_sear
             cap = walk_hash_entries(walk_hash_bytes(cap, form), form);
         } else {
             // (tests: gbnns_debug_knob("vs_disp", 1..15) makes probe sequences give up that early, to exercise the hand-over)
-            const uint32_t disp = (uint32_t)std::min(15, std::max(1, g_knob_vs_disp.load(std::memory_order_relaxed)));
+            const uint32_t disp = (uint32_t)std::min(15, std::max(1, ix->knob.vs_disp));
             // twelve remainder bits and a 4-bit probe number when the table has 2^(W-12) buckets, else thirteen and 3 bits
             const bool r13 = idbits > lg + 12;
             w.vs_shr = (32u - idbits + lg) | (32u - idbits) << 8 | (r13 ? 1u << 16 | std::min(disp, 7u) << 29 : disp << 28);
@@ -102,8 +102,8 @@ FirstPassSizing size_first_pass(gbnns_index* ix, WalkParams& w, const gbnns_sear
         // Big batches over an index too large for the quotient form (DEEP10M: 24-bit ids) request a hop's rows before its
         // visited test (walk_hot_spec_kernel: 21.6 against 23.1 ms per 1 M-query launch); with the quotient form testing
         // first wins at every batch size (SIFT-shaped 65 536-query launch 0.90 against 0.79 of the peak).  DESIGN.md 5.1.
-        const int spec_min = g_knob_spec_min_nq.load(std::memory_order_relaxed);
-        w.spec_rows = (spec_min > 0 && nq >= (uint32_t)spec_min && (w.vs_shr == 0 || g_knob_spec_any_form.load(std::memory_order_relaxed))) ? 1 : 0;
+        const int spec_min = ix->knob.spec_min_nq;
+        w.spec_rows = (spec_min > 0 && nq >= (uint32_t)spec_min && (w.vs_shr == 0 || ix->knob.spec_any_form)) ? 1 : 0;
     }
     {
         // A launch's last round, when it is a partial one (10 000 queries on 8 192 wavefront slots: 1 808 of them), walks a
@@ -112,7 +112,7 @@ FirstPassSizing size_first_pass(gbnns_index* ix, WalkParams& w, const gbnns_sear
         // batch that runs alone: with batches in flight the neighbours fill that tail and the extra rows cost 2 - 4 %.
         // wavefront slots of the device (ef <= 64 hot instances: 8 per SIMD, 32 per CU; the CU count is the device's, not a literal)
         const uint32_t slots = (uint32_t)(ix->cus > 0 ? ix->cus : 256) * 32u;
-        const int knob = g_knob_spec_tail.load(std::memory_order_relaxed);
+        const int knob = ix->knob.spec_tail;
         w.spec_from = 0xFFFFFFFFu;
         if (sync_host && knob > 0 && nq > slots && nq % slots != 0 && nq % slots <= slots * (uint32_t)knob / 100u) w.spec_from = nq - nq % slots;
         // ... and a lone batch that never fills the machine runs that way from its first wavefront (2 000 / 4 096 / 6 000 queries:

@@ -71,7 +71,9 @@ static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, h
             case 144: return launch_walk_wide(p, 36, retry, s);
             // 384- / 512-byte rows (PLAIN walks over deep / sift vectors): pair-form instances by beam, the rest on the run-time-length ones
             case 96:
-                if (wide2 && p.ef > kHot2MaxEf && p.ef <= kRegListMaxEf) return launch_walk_wide2(p, 24, retry, s);
+                // (never a shape launch_fast_t gives to the LDS-list kernel -- an auxiliary-graph walk over a non-compact index: the two-list
+                // instance's auxiliary branch is the 32-bit-offset one, and the host has sized the LDS for the LDS-list layout)
+                if (wide2 && p.ef > kHot2MaxEf && p.ef <= kRegListMaxEf && !walk_uses_lds_list(p)) return launch_walk_wide2(p, 24, retry, s);
                 // (shorter beams: the pair form in the one- / two-register list kernels for the first pass of a compact index over one-pass
                 // adjacency rows (two-pass ones: <= 64 slots) -- a lane per row ran the reference's deep efs_hnsw 40 / 80 / 120 at 0.61 - 0.65 of the HBM peak)
                 if (wide2 && p.ef <= kHot2MaxEf && !retry && walk_off32(p) && !p.aux_ell && (p.ell_stride <= 32u || (p.ell_stride <= 64u && p.ef <= 64)) && !p.stamps_on)
@@ -80,7 +82,7 @@ static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, h
             // (512-byte rows: up to ef = 200 the run-time-length two-list instance with four lanes per row is the faster one -- 10 000-query
             // batches in flight at ef 130 / 200: 1.72 / 2.77 ms against 1.93 / 2.87 on the pair form; at ef 300 / 400 5.25 / 8.25 against
             // 4.20 / 5.51: tools/ref_sweep.py --config sift --only plain --efs ..., GBNNS_WIDE2=0 / 1)
-            case 128: if (wide2 && p.ef > kPlain512PairMinEf && p.ef <= kRegListMaxEf) return launch_walk_wide2(p, 32, retry, s); break;
+            case 128: if (wide2 && p.ef > kPlain512PairMinEf && p.ef <= kRegListMaxEf && !walk_uses_lds_list(p)) return launch_walk_wide2(p, 32, retry, s); break;
             default: break;
         }
     }

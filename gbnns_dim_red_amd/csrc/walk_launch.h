@@ -12,6 +12,9 @@ template <int METRIC, int STEPS, int R>
 static hipError_t launch_reg_t(const WalkParams& p, bool retry, size_t lds, hipStream_t s) {
     // 32-bit byte offsets when both tables are < 4 GiB
     const bool off32 = walk_off32(p);
+    // the register-list / two-list kernels have their auxiliary-graph hop in the 32-bit-offset instances only: an auxiliary-graph walk over a
+    // non-compact index belongs to the LDS-list kernel (walk_uses_lds_list; launch_fast_t sends it there, and so must every other caller)
+    if (p.aux_ell && !off32) return hipErrorInvalidValue;
     if constexpr (R >= 4) {
         // ef > 128: base list in LDS + front list in one register (walk_reg_big_one), whatever the shape
         if constexpr ((METRIC == 0 || METRIC == 1) && STEPS == 8) {

@@ -243,7 +243,8 @@ int gbnns_rerank(gbnns_index* index, const float* queries, uint64_t n_q, const u
 /* Per-kernel device timing (hipEvent pairs on the launch stream), accumulated since the last
  * reset.  Reading synchronises the recorded events. */
 typedef struct {
-    uint32_t struct_size;
+    uint32_t struct_size;         /* in: the caller's sizeof(gbnns_profile) (0 = the 160-byte layout of rounds 1-4, which ends before
+                                     project_kernel); out: the bytes gbnns_profile_read filled in -- never more than the caller said */
     uint32_t calls;               /* search calls accumulated */
     double project_ms;            /* MLP layers + normalise */
     double walk_ms;               /* LDS-resident beam-walk kernel */
@@ -257,7 +258,15 @@ typedef struct {
 } gbnns_profile;
 
 int gbnns_profile_enable(gbnns_index* index, int on);
-/* Diagnostic knobs of the process (tests, A/B runs); results never depend on them.  "quotient": 0 keeps the walk_hot*
+/* Diagnostic knobs (tests, A/B runs); results never depend on them.  Since round 6 every knob that steers a handle's searches
+ * belongs to the handle: gbnns_index_knob(index, name, value) sets it for that handle alone, and gbnns_debug_knob(name, value)
+ * only changes the process-wide DEFAULT a handle created afterwards starts from (initial defaults: the environment variables
+ * named below).  Two handles of one process can therefore run with different settings side by side.  The three "knn_*" knobs
+ * steer gbnns_exact_knn, which has no handle, and stay process-wide (gbnns_debug_knob only).
+ * "coop": the two-wavefront walk for small batches (one query per workgroup of two wavefronts: one keeps the result lists, one
+ * expands the predicted next node) -- -1 (default) where the shape has it and the batch leaves the room, 0 never,
+ * 1 wherever the shape has it (GBNNS_COOP).
+ * "quotient": 0 keeps the walk_hot*
  * kernels' visited set in its packed form (default 1: the denser quotient form where it fits; initial value from the
  * environment variable GBNNS_QUOTIENT).  "vs_disp": probe number at which a probe sequence of the quotient form gives
  * up and the id goes to the stash / the query is handed over, 1 .. 15 (default 15; <= 0 restores it; GBNNS_DEBUG_VS_DISP).
@@ -285,6 +294,8 @@ int gbnns_profile_enable(gbnns_index* index, int on);
  * "knn_filter": gbnns_exact_knn's matrix-core filter -- 0 never, 1 by size (default), 2 whenever the shape allows
  * (GBNNS_KNN_FILTER). */
 int gbnns_debug_knob(const char* name, int value);
+int gbnns_index_knob(gbnns_index* index, const char* name, int value);   /* GBNNS_ERR_INVALID: not a handle knob */
+int gbnns_index_knob_get(gbnns_index* index, const char* name, int* out_value);   /* the handle's current value */
 int gbnns_profile_read(gbnns_index* index, gbnns_profile* out, int reset);
 
 /* hnswlikeGD (support_func.h:521-575, need_const_degree = false) + addReverseEdgesForGD

@@ -21,8 +21,12 @@ def orc():
 
 
 @pytest.fixture(scope="session")
-def ref():
+def ref(request):
     import oracle
     if not oracle.have_ref():
+        # a GPU run is expected to carry the prebuilt reference (it travels with the tree): losing it must not pass silently
+        if "gpu" in (request.config.getoption("-m") or "") and "not gpu" not in (request.config.getoption("-m") or "") \
+                and os.environ.get("GBNNS_ALLOW_NO_REF") != "1":
+            pytest.fail("oracle/_ref/libgbnns_ref.so is missing on a GPU run (GBNNS_ALLOW_NO_REF=1 to skip knowingly)")
         pytest.skip("compiled reference (oracle/_ref) not present")
     return oracle.Ref()

@@ -24,6 +24,19 @@ def g():
     return g
 
 
+def _need_ref():
+    """The compiled reference (oracle/_ref/libgbnns_ref.so) is built by __graft_entry__.build() where /root/reference exists and
+    travels to the GPU box with the tree: a GPU run without it has lost its strongest parity evidence and FAILS (it used to skip);
+    GBNNS_ALLOW_NO_REF=1 turns that back into a skip for a tree that never had the reference."""
+    import os
+    if orc_mod.have_ref():
+        return
+    if os.environ.get("GBNNS_ALLOW_NO_REF") == "1":
+        pytest.skip("compiled reference (oracle/_ref) absent and GBNNS_ALLOW_NO_REF=1")
+    pytest.fail("oracle/_ref/libgbnns_ref.so is missing: the full-size comparisons against the compiled reference cannot run "
+                "(run __graft_entry__.build() where /root/reference exists; GBNNS_ALLOW_NO_REF=1 to skip knowingly)")
+
+
 def _index(g, gd, orc, metric=None):
     c = gd.case
     db_low = orc.project(c.net, c.base, threads=8)
@@ -420,11 +433,11 @@ def test_projection_of_batches_in_flight_small_footprint_kernel(g, orc):
     lib = g.load_library()
     try:
         for si, (d, dh, nq, small) in enumerate(((40, 64, 1000, 1), (44, 72, 777, 1), (132, 136, 300, 1), (64, 64, 4500, 4096))):
-            assert lib.gbnns_debug_knob(b"mlp_small", small) == 0
             c, off, nbr, db_low, ent = _oracle_case(orc, 8700 + si, 8000, nq, d, 32, dh)
             want_q = orc.project(c.net, c.queries)
             sref = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, 48, db_low=db_low, net=c.net, entries=ent, threads=8)
             ix = g.Index(t(c.base), off, nbr, db_low=t(db_low), net=tuple(t(x) for x in c.net))
+            ix.knob("mlp_small", small)
             q, e = t(c.queries), t(ent.astype(np.int32))
             outs = [ix.search(q, 48, entry_ids=e, want=("q_low",), out={}, flags=g.FLAG_DEFER_JOIN, defer_depth=3) for _ in range(4)]
             ix.join()
@@ -434,7 +447,7 @@ def test_projection_of_batches_in_flight_small_footprint_kernel(g, orc):
                 assert np.array_equal(r["ids"].cpu().numpy().view(np.uint32), sref["ids"]), (d, dh, nq)
             ix.close()
     finally:
-        lib.gbnns_debug_knob(b"mlp_small", 4096)
+        pass   # (the knobs belong to the handle since round 6: nothing process-wide to restore)
 
 
 def test_projection_one_launch_kernel(g, orc):
@@ -452,7 +465,6 @@ def test_projection_one_launch_kernel(g, orc):
     try:
         for si, (d, dh, dl, nq) in enumerate(((128, 256, 32, 2500), (96, 128, 48, 2049), (200, 72, 32, 3001), (40, 264, 64, 2048),
                                               (16, 8, 16, 2100))):
-            assert lib.gbnns_debug_knob(b"mlp_net", 1) == 0
             c, off, nbr, db_low, ent = _oracle_case(orc, 9100 + si, 6000, nq, d, dl, dh)
             want_q = orc.project(c.net, c.queries)
             sref = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, 40, db_low=db_low, net=c.net, entries=ent, threads=8)
@@ -468,17 +480,15 @@ def test_projection_one_launch_kernel(g, orc):
             torch.cuda.synchronize()
             for o in outs:
                 assert np.array_equal(gu.bits(o["q_low"].cpu().numpy()), gu.bits(want_q)), (d, dh, dl, nq)
-            assert lib.gbnns_debug_knob(b"mlp_net", 0) == 0
-            assert lib.gbnns_debug_knob(b"mlp_slab", 0) == 0
+            ix.knob("mlp_net", 0)
+            ix.knob("mlp_slab", 0)
             r0 = ix.search(q, 40, entry_ids=e, want=("q_low",), out={})
             torch.cuda.synchronize()
             assert ix.profile_read(reset=False)["project_kernel"] == "mlp_layer_kernels"
             assert np.array_equal(gu.bits(r0["q_low"].cpu().numpy()), gu.bits(want_q)), (d, dh, dl, nq)
-            assert lib.gbnns_debug_knob(b"mlp_slab", 1) == 0
             ix.close()
     finally:
-        lib.gbnns_debug_knob(b"mlp_net", 1)
-        lib.gbnns_debug_knob(b"mlp_slab", 1)
+        pass   # (the knobs belong to the handle since round 6: nothing process-wide to restore)
 
 
 def test_projection_slab_kernel(g, orc):
@@ -495,7 +505,6 @@ def test_projection_slab_kernel(g, orc):
     try:
         for si, (d, dh, dl, nq) in enumerate(((960, 1024, 64, 1000), (200, 264, 32, 777), (96, 72, 48, 130), (128, 256, 32, 33),
                                               (520, 136, 16, 301), (64, 64, 64, 1))):
-            assert lib.gbnns_debug_knob(b"mlp_slab", 1) == 0
             c, off, nbr, db_low, ent = _oracle_case(orc, 9300 + si, 3000, nq, d, dl, dh)
             want_q = orc.project(c.net, c.queries)
             sref = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, 40, db_low=db_low, net=c.net, entries=ent, threads=8)
@@ -515,14 +524,14 @@ def test_projection_slab_kernel(g, orc):
             pl = ix.project(t(c.base[:700]))
             torch.cuda.synchronize()
             assert np.array_equal(gu.bits(pl.cpu().numpy()), gu.bits(orc.project(c.net, c.base[:700]))), (d, dh, dl)
-            assert lib.gbnns_debug_knob(b"mlp_slab", 0) == 0
+            ix.knob("mlp_slab", 0)
             r0 = ix.search(q, 40, entry_ids=e, want=("q_low",), out={})
             torch.cuda.synchronize()
             assert ix.profile_read(reset=False)["project_kernel"] == "mlp_layer_kernels"
             assert np.array_equal(gu.bits(r0["q_low"].cpu().numpy()), gu.bits(want_q)), (d, dh, dl, nq)
             ix.close()
     finally:
-        lib.gbnns_debug_knob(b"mlp_slab", 1)
+        pass   # (the knobs belong to the handle since round 6: nothing process-wide to restore)
 
 
 def test_matrix_core_projection_option(g, orc):
@@ -620,7 +629,9 @@ def test_bench_two_ranks_rehearsal():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GBNNS_BENCH_REHEARSAL="1", GBNNS_CACHE="/tmp/gbnns_cache_rehearsal")
     env.pop("WORLD_SIZE", None)
-    for extra in ([], ["--config", "deep", "--ef", "40"]):
+    # (third run, round 6: `--strong` on the headline configuration -- ONE batch block-sharded over the ranks, uneven blocks through
+    # the padded gather)
+    for extra in ([], ["--config", "deep", "--ef", "40"], ["--strong", "--strong-nq", "5001"]):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                             "--n", "60000", "--nq", "3000", "--no-extras", "--no-cpu-baseline"] + extra,
                            env=env, capture_output=True, text=True, timeout=900)
@@ -631,6 +642,12 @@ def test_bench_two_ranks_rehearsal():
         assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["steps"] == 3 and r["gather_self_check"] is True
         assert r["value"] > 0 and r["roofline"]["frac"] > 0
         assert r["scaling"] == ("strong" if extra else "weak")
+        # per-rank diagnostics of the N > 1 line: each rank's own ms per step, its wait at the closing barrier, the exchange step alone
+        pr = r["per_rank"]
+        assert len(pr["ms_per_step"]) == 2 and all(v > 0 for v in pr["ms_per_step"]) and len(pr["gather_alone_ms"]) == 2, pr
+        if "--strong" in extra:
+            assert r["strong_batch"] == 5001 and sorted(pr["queries"]) == [2500, 2501], (r["strong_batch"], pr)
+            assert "one 5001-query batch block-sharded over 2 GPU(s)" in r["config"]["workload"]
         # the C ABI's own multi-replica path, driven by a child of rank 0 while the ranks are parked (rehearsal: the host
         # form, both replicas on the one GPU): same answers as the ranks'
         cm = r["capi_multi"]
@@ -715,8 +732,7 @@ def test_reference_sweeps_full_size(g, orc):
     counts and dist_calc of the batch's first and last 48 queries against the compiled reference (tools/ref_sweep.py is the same on
     every shape, with timings)."""
     import torch
-    if not orc_mod.have_ref():
-        pytest.skip("needs the compiled reference (oracle/_ref)")
+    _need_ref()
     ds = _sift_full()
     ix = ds.index()
     ix.profile_enable(True)
@@ -758,8 +774,7 @@ def test_reference_sweeps_full_size_other_rows(g, orc, shape):
     walks) -- the first 64 queries of each beam against the compiled reference."""
     import torch
     from gbnns_dim_red_amd import synth
-    if not orc_mod.have_ref():
-        pytest.skip("needs the compiled reference (oracle/_ref)")
+    _need_ref()
     dims = {"gist": dict(nq=1_000, d=960, d_low=64, d_hidden=1024), "deep1m": dict(nq=10_000, d=96, d_low=48, d_hidden=128),
             "glove1m": dict(nq=10_000, d=300, d_low=144, d_hidden=512, unit_norm=True)}[shape]
     sweeps = {"gist": ((200, 400, 600, 800, 1000), (100, 150, 200, 300, 400)), "deep1m": ((40, 80, 120, 160, 200),) * 2,
@@ -850,12 +865,12 @@ def test_full_size_properties(g, orc):
     try:
         ref64 = ix.search(q, 64, want=("hops", "dist_calc"))
         for pct in (0, 100):
-            assert lib.gbnns_debug_knob(b"spec_tail", pct) == 0
+            ix.knob("spec_tail", pct)
             r = ix.search(q, 64, want=("hops", "dist_calc"))
             for key in ("ids", "hops", "dist_calc"):
                 assert torch.equal(r[key], ref64[key]), (pct, key)
     finally:
-        lib.gbnns_debug_knob(b"spec_tail", 50)
+        pass   # (the knobs belong to the handle since round 6: nothing process-wide to restore)
     ix.close()
 
 
@@ -1383,6 +1398,37 @@ def test_wide_index_kernels(g, orc):
             ix.close()
 
 
+def test_plain_aux_walk_on_wide_index_long_rows(g, orc):
+    """PLAIN walks over 384- / 512-byte rows (d = 96 / 128: the reference's deep / sift vectors, final_test.cpp:84) with an
+    auxiliary graph on a non-compact index (forced with the diagnostic flag) at beams beyond the register lists' pair-form
+    crossovers (ef 160 / 300): such a shape belongs to the LDS-list kernel -- 64-bit offsets, 4-byte visited-set slots -- and
+    must not reach the 32-bit-offset auxiliary branch of the two-list kernels (round-5 advisor finding); compact runs of the
+    same shapes ride along."""
+    for d in (96, 128):
+        c = datagen.Case("x", 2600 + d, 5000, 96, d, 16, 32)
+        rng = np.random.Generator(np.random.PCG64(2601 + d))
+        off, nbr = datagen.random_graph(rng, c.n, 4, 28)
+        aux = datagen.random_graph(rng, c.n, 0, 6)
+        ent = rng.integers(0, c.n, size=c.queries.shape[0]).astype(np.uint32)
+        ix = g.Index(c.base, off, nbr)
+        ix.set_aux_graph(*aux)
+        for ef in (160, 300):
+            for use_aux in (True, False):
+                okw = dict(aux=aux, llf=True, hops_bound=50) if use_aux else {}
+                gkw = dict(aux=True, llf=True, hops_bound=50) if use_aux else {}
+                w = orc.walk(c.queries, c.base, off, nbr, ef, entries=ent, threads=8, **okw)
+                for flags in (g.FLAG_WIDE_INDEX, 0):
+                    for hcap in (0, 256):   # 256: a hand-over chain through the retry pass as well
+                        r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, flags=flags, hash_capacity=hcap,
+                                      want=("hops", "dist_calc", "cand", "cand_dist"), **gkw)
+                        key = (d, ef, use_aux, flags, hcap)
+                        assert np.array_equal(r["cand"], w["ids"]), key
+                        assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
+                        assert np.array_equal(r["hops"], w["hops"]), key
+                        assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
+        ix.close()
+
+
 def test_index_beyond_2pow24_nodes(g, orc):
     """A REAL large index (n = 2^24 + 2 048 nodes: ids need more than 24 bits, so every walk runs the 64-bit-offset /
     4-byte-slot instantiations without the diagnostic flag): cheap synthetic vectors, a random fixed-degree graph
@@ -1598,7 +1644,7 @@ def test_two_list_kernels_by_name(g, orc):
         ix.profile_enable(True)
         for ef, fl, kname in cases:
             flags = g.FLAG_BITMAP_PASS if fl == "bitmap" else 0
-            _knobs(g, spec_min_nq=1 if fl == "spec" else 32768)
+            _knobs(ix, spec_min_nq=1 if fl == "spec" else 32768)
             w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, metric=metric, threads=8)
             s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net,
                                  entries=ent, metric=metric, threads=8)
@@ -1612,7 +1658,6 @@ def test_two_list_kernels_by_name(g, orc):
             assert np.array_equal(r["ids"], s["ids"]), key
             launched = ix.profile_read(reset=True)["walk_kernel"]
             assert launched.startswith(kname), (key, launched)
-        _knobs(g)
         ix.close()
 
 
@@ -1635,7 +1680,7 @@ def test_two_list_wide_rows_requested_after_the_visited_test(g, orc):
                 w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, threads=8)
                 s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net, entries=ent, threads=8)
                 for late in (1, 0, -1):
-                    assert lib.gbnns_debug_knob(b"late_rows", late) == 0
+                    ix.knob("late_rows", late)
                     ix.profile_read(reset=True)
                     r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), flags=flags)
                     key = (dlow, deg, ef, flags, late)
@@ -1651,7 +1696,7 @@ def test_two_list_wide_rows_requested_after_the_visited_test(g, orc):
                     assert np.array_equal(r["ids"], s["ids"]), key
             ix.close()
     finally:
-        lib.gbnns_debug_knob(b"late_rows", -1)
+        pass   # (the knobs belong to the handle since round 6: nothing process-wide to restore)
 
 
 @pytest.mark.gpu
@@ -1671,7 +1716,7 @@ def test_plain_walks_over_wide_rows_two_list_pair_form(g, orc):
                 w = orc.walk(c.queries, c.base, off, nbr, ef, entries=ent, threads=8)
                 w1 = orc.walk(c.queries, c.base, off, nbr, ef, k=1, entries=ent, threads=8)
                 for late in (0, 1):
-                    assert lib.gbnns_debug_knob(b"late_rows", late) == 0
+                    ix.knob("late_rows", late)
                     ix.profile_read(reset=True)
                     r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"))
                     key = (d, deg, ef, late)
@@ -1708,7 +1753,7 @@ def test_plain_walks_over_wide_rows_two_list_pair_form(g, orc):
             assert np.array_equal(r["dist_calc"] + ef, s2["dist_calc"]), ef
         ix.close()
     finally:
-        lib.gbnns_debug_knob(b"late_rows", -1)
+        pass   # (the knobs belong to the handle since round 6: nothing process-wide to restore)
 
 
 @pytest.mark.gpu
@@ -1735,15 +1780,56 @@ def test_plain_walks_over_long_rows_four_lanes_per_row(g, orc):
         ix.close()
 
 
-def _knobs(g, quotient=1, vs_disp=15, spec_min_nq=32768):
-    """The process-wide diagnostic knobs of the library (include/gbnns.h, gbnns_debug_knob), back to their defaults unless named.
-    (A lowered spec_min_nq means "the speculative instance, whatever the table's form": by default only big batches on
-    indexes beyond the quotient form take it.)"""
+def test_knobs_belong_to_the_handle(g, orc):
+    """Round 6: the diagnostic knobs that steer a search live in the handle (gbnns_index_knob), the process-wide value
+    (gbnns_debug_knob, the environment) is only what a NEW handle starts from.  Two handles side by side: flipping one's knobs
+    changes its kernel choice (observable through the profile's kernel names) and leaves the other's alone; a changed process
+    default reaches neither; a handle created afterwards starts from it; answers never depend on any of it."""
     lib = g.load_library()
-    assert lib.gbnns_debug_knob(b"quotient", quotient) == 0
-    assert lib.gbnns_debug_knob(b"vs_disp", vs_disp) == 0
-    assert lib.gbnns_debug_knob(b"spec_min_nq", spec_min_nq) == 0
-    assert lib.gbnns_debug_knob(b"spec_any_form", 1 if spec_min_nq != 32768 else 0) == 0
+    c, off, nbr, db_low, ent = _oracle_case(orc, 6600, 6000, 2100, 128, 48, 64)
+    sref = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, 40, db_low=db_low, net=c.net, entries=ent, threads=8)
+    a = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+    b = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+    try:
+        for ix in (a, b):
+            ix.profile_enable(True)
+        a.knob("quotient", 0); a.knob("mlp_net", 0); a.knob("mlp_slab", 0); a.knob("late_rows", 0)
+        b.knob("late_rows", 1)
+        assert (a.knob_get("quotient"), b.knob_get("quotient")) == (0, 1)
+        seen = {}
+        for name, ix in (("a", a), ("b", b), ("a", a)):
+            ix.profile_read(reset=True)
+            r = ix.search(c.queries, 40, entry_ids=ent)
+            assert np.array_equal(r["ids"], sref["ids"]), name
+            pr = ix.profile_read(reset=True)
+            seen[name] = (pr["project_kernel"], pr["walk_kernel"].split(" (")[0])
+        assert seen["a"][0] == "mlp_layer_kernels" and seen["b"][0] == "mlp_net_kernel", seen
+        # 192-byte walked rows at ef <= 64: walk_reg_wide_kernel<12, LATE> -- the two handles took different instances
+        assert seen["a"][1] == "walk_reg_wide_kernel<12, false>" and seen["b"][1] == "walk_reg_wide_kernel<12, true>", seen
+        # the process default: no live handle sees it, the next one starts from it
+        assert lib.gbnns_debug_knob(b"quotient", 0) == 0 and lib.gbnns_debug_knob(b"mlp_net", 0) == 0
+        assert (a.knob_get("quotient"), b.knob_get("quotient"), b.knob_get("mlp_net")) == (0, 1, 1)
+        c2 = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+        assert (c2.knob_get("quotient"), c2.knob_get("mlp_net")) == (0, 0)
+        c2.close()
+        with pytest.raises(g.GbnnsError):
+            a.knob("knn_filter", 0)     # gbnns_exact_knn has no handle: process-wide only
+        with pytest.raises(g.GbnnsError):
+            a.knob("no_such_knob", 1)
+    finally:
+        lib.gbnns_debug_knob(b"quotient", 1)
+        lib.gbnns_debug_knob(b"mlp_net", 1)
+        a.close()
+        b.close()
+
+
+def _knobs(ix, quotient=1, vs_disp=15, spec_min_nq=32768):
+    """Diagnostic knobs of ONE handle (include/gbnns.h, gbnns_index_knob; process-wide until round 6), back to their defaults unless
+    named.  Nothing to restore afterwards: the knobs go with the handle."""
+    ix.knob("quotient", quotient)
+    ix.knob("vs_disp", vs_disp)
+    ix.knob("spec_min_nq", spec_min_nq)
+    ix.knob("spec_any_form", 1 if spec_min_nq != 32768 else 0)
 
 
 def test_visited_set_forms_of_the_hot_kernels(g, orc):
@@ -1765,7 +1851,7 @@ def test_visited_set_forms_of_the_hot_kernels(g, orc):
                              ({"vs_disp": 1}, 0), ({"vs_disp": 2}, maxdc + maxdc // 8 + 64),
                              # the big-batch instance of the ef <= 64 kernel (rows requested before the visited test)
                              ({"spec_min_nq": 1}, 0), ({"spec_min_nq": 1, "quotient": 0}, 0), ({"spec_min_nq": 1, "vs_disp": 1}, 0)):
-                _knobs(g, **env)
+                _knobs(ix, **env)
                 for rep in range(2):  # (the second call runs with the capacity the first one's statistics ask for)
                     r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"), hash_capacity=cap)
                     key = (metric, deg, ef, tuple(env.items()), cap, rep)
@@ -1774,7 +1860,6 @@ def test_visited_set_forms_of_the_hot_kernels(g, orc):
                     assert np.array_equal(r["hops"], w["hops"]), key
                     assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
                     assert np.array_equal(r["ids"], s["ids"]), key
-        _knobs(g)
         ix.close()
 
 
@@ -1799,14 +1884,13 @@ def test_quotient_form_thirteen_remainder_bits(g, orc):
             maxdc = int(w["dist_calc"].max())
             for cap, disp in ((max(1900, maxdc + maxdc // 14 + 8), 15), (max(1900, maxdc + maxdc // 8), 15), (0, 15), (max(1900, maxdc + maxdc // 14 + 8), 3)):
                 assert cap < 3584  # (fewer than 2^(21-12) buckets of seven entries: the 13-bit form)
-                _knobs(g, vs_disp=disp)
+                _knobs(ix, vs_disp=disp)
                 r = ix.search(queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand"), hash_capacity=cap)
                 key = (ef, cap, disp)
                 assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
                 assert np.array_equal(r["hops"], w["hops"]), key
                 assert np.array_equal(r["cand"], w["ids"]), key
     finally:
-        _knobs(g)
         ix.close()
 
 
