@@ -554,11 +554,19 @@ def main():
     if world > 1 and not args.no_capi_multi:
         ref = ix.search(q, ef, want=(), flags=tune_flags | g.FLAG_SERIAL)["ids"].clone()
         torch.cuda.synchronize()
-        pieces = None
         if not strong or nq_total % world == 0:   # (equal blocks: one all-gather of the ranks' answers to batch 0)
             allv = torch.empty(world * nq_rank, dtype=ref.dtype, device=dev)
             dist.all_gather_into_tensor(allv, ref)
             pieces = [allv]
+        else:   # uneven blocks: padded pieces, the padding cut out again by the shard bounds
+            mine = torch.full((pad,), -1, dtype=ref.dtype, device=dev)
+            mine[:nq_rank] = ref
+            allv = torch.empty(world * pad, dtype=ref.dtype, device=dev)
+            dist.all_gather_into_tensor(allv, mine)
+            pieces = []
+            for r_ in range(world):
+                lo_, hi_ = sharding.shard_bounds(nq_total, world, r_)
+                pieces.append(allv[r_ * pad: r_ * pad + (hi_ - lo_)])
         dist.barrier()
         if rank == 0:
             result["capi_multi"] = capi_multi_parent(args, argv, world, pieces, rehearsal)

@@ -198,8 +198,32 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
 #ifdef GBNNS_STAMPS
     w.stamps_on = 1;
 #endif
+    // A small batch that runs ALONE (the reference's gist row: 1 000 queries per synchronous call, final_test.cpp:87) on the shapes that
+    // have it: the two-wavefront walk (walk_coop.hip) -- a keeper wavefront with the result lists, a scout wavefront that expands the
+    // predicted next node ahead.  One wavefront per query leaves such a launch a chain of dependent latencies on a mostly idle machine
+    // (at most four queries per CU); measured on the gist shape at ef 200: first-pass kernel 0.487 against 0.526 ms.  NOT with batches in
+    // flight: those fill the machine by themselves and are bound by bytes, and the second wavefront's issue slots and speculative rows
+    // cost them (1.8 against 2.5 M queries/s).  Knob "coop": 0 never, 1 whenever the shape allows (tests), -1 this rule.
+    {
+        const int knob = ix->knob.coop;
+        const uint32_t cus = (uint32_t)(ix->cus > 0 ? ix->cus : 256);
+        const bool in_flight = s == L.stream && L.stream != nullptr;
+        w.coop = 0;
+        if (knob != 0 && n_ent == 1 && !(a->flags & (GBNNS_FLAG_BITMAP_PASS | GBNNS_FLAG_WIDE_INDEX)) && walk_coop_serves(w, ix->metric) &&
+            (knob > 0 || (nq <= 4u * cus && !in_flight)))
+            w.coop = 1;
+    }
     // the first pass's visited set: capacity, form (packed / quotient), the wavefronts per CU it leaves (sizing.cpp)
-    const FirstPassSizing fps = size_first_pass(ix, w, a, ef, skey, nq, sync_host);
+    FirstPassSizing fps = size_first_pass(ix, w, a, ef, skey, nq, sync_host);
+    if (w.coop && ix->knob.coop < 0) {
+        // (auto: only when every workgroup of the batch is resident at once -- LDS share per query, eight workgroups of two wavefronts per CU)
+        const size_t per_wg = (walk_fast_lds_bytes(w, false) + kLdsGran - 1) / kLdsGran * kLdsGran;
+        const size_t per_cu = std::min<size_t>(8, per_wg ? kMaxLds / per_wg : 0);
+        if ((size_t)nq > per_cu * (size_t)(ix->cus > 0 ? ix->cus : 256)) {
+            w.coop = 0;
+            fps = size_first_pass(ix, w, a, ef, skey, nq, sync_host);
+        }
+    }
     const bool hot = fps.hot, packed = fps.packed, auto_cap = fps.auto_cap;
     const int form = fps.form;
     const uint32_t cap = fps.cap;
@@ -232,7 +256,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // below -- the pass must at least double the resident wavefronts: 8 by registers against <= 4 by the table -- does from ef 450 on)
         const int min_ef = min_ef_env ? min_ef_env : (rows576 ? 450 : (form == 2 ? 480 : 385));
         const bool forced = (a->flags & GBNNS_FLAG_BITMAP_PASS) != 0;  // diagnostic: whatever ef and batch size
-        if (!w.all_general && (ef >= min_ef || forced) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && (a->hash_capacity == 0 || forced)) {
+        if (!w.all_general && !w.coop && (ef >= min_ef || forced) && !(a->flags & GBNNS_FLAG_WIDE_INDEX) && (a->hash_capacity == 0 || forced)) {
             const size_t gran = kLdsGran;
             const size_t cus = ix->cus > 0 ? (size_t)ix->cus : 256;  // (the device's, as in sizing.cpp: the slot counts below follow it)
             const size_t per_wave = (walk_bitmap_lds_bytes(w, ix->metric) + gran - 1) / gran * gran;
@@ -296,6 +320,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         // retry pass: hand-overs of the first pass, one wavefront per CU with all the LDS
         WalkParams w2 = w;
         w2.vs_shr = 0;  // (the retry kernels keep the packed form)
+        w2.coop = 0;    // (... and one wavefront per query)
         const size_t gran = kLdsGran;
         w2.hash_cap = walk_hash_entries(kMaxLds / gran * gran - walk_fast_lds_fixed_bytes(ef, w.dstride, false, walk_uses_lds_list(w)), packed);
         w2.hash_limit = w2.hash_cap - w2.hash_cap / 16;

@@ -32,7 +32,18 @@ __device__ __forceinline__ uint32_t walk_query_of(const P& p, uint32_t b) {
 
 // One wavefront per workgroup: the barrier degenerates to a wave-local fence that orders LDS /
 // global traffic between lanes of the wave.
+// GBNNS_WAVE_LOCAL_SYNC (walk_coop.hip: workgroups of TWO wavefronts, each running its own code path around explicit
+// s_barriers): a real barrier here would pair up with the other wavefront's unrelated ones, so the fence is spelled out --
+// LDS operations of one wavefront are performed in issue order, what is needed is that the compiler keeps that order and
+// that outstanding LDS / scalar traffic has landed before the next access.
+#ifdef GBNNS_WAVE_LOCAL_SYNC
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+#else
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
+#endif
 
 // Monotone float -> u32 map (a < b  <=>  fkey(a) < fkey(b)); -0 and +0 map to the same key, as
 // they compare equal in the reference's std::pair<float,int> ordering.
@@ -500,8 +511,12 @@ __device__ __forceinline__ float dpp_from_odd(float x) {  // even lane <- its od
 // streams its candidates' rows at (bytes in flight) / latency: 200 rows of 960 floats (GIST, ef = 200) take it 0.095 ms
 // with 8 loads in flight and 0.070 ms with 24 (rocprofv3, one-query launches).  The generic wide-row walk kernels and
 // the stand-alone kernel have the registers for 24 (same operations, same order).
+// `pass0` / `pass_step` (walk_coop.hip: two wavefronts share a query's candidates): this wavefront takes the 32-candidate passes
+// pass0, pass0 + pass_step, ...; `best_key` (optional) receives min (fkey(dist) << 32 | pop index) over them, all-ones when it
+// saw none -- the minimum over the wavefronts' keys is the minimum over all candidates.
 template <int METRIC, int DEEP = 8, typename IdAt>
-__device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi, int cnt, float* qf, int lane, IdAt id_at) {
+__device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi, int cnt, float* qf, int lane, IdAt id_at,
+                                                 int pass0 = 0, int pass_step = 1, uint64_t* best_key = nullptr) {
     const uint32_t half = (uint32_t)lane & 1u, slot = (uint32_t)lane >> 1;
     const float4* qs = reinterpret_cast<const float4*>(qf);
     for (uint32_t i = lane; i < a.dstride; i += 64)
@@ -509,7 +524,7 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
     wave_sync();
     const uint32_t pairs = a.dim >> 3;  // steps / 2
     uint64_t bestk = ~0ull;
-    for (int base = 0; base < cnt; base += 32) {
+    for (int base = 32 * pass0; base < cnt; base += 32 * pass_step) {
         const int r = base + (int)slot;
         const bool valid = r < cnt;
         uint32_t id = id_at(valid ? r : base);  // lanes beyond the list redo the first row (discarded)
@@ -624,7 +639,8 @@ __device__ __forceinline__ int rerank_pairs_core(const RerankSrc& a, uint32_t qi
     }
     bestk = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bestk >> 32)) << 32) |
             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bestk);
-    return cnt > 0 ? (int)(uint32_t)(bestk & 0xFFFFFFFFu) : -1;
+    if (best_key) *best_key = bestk;
+    return (cnt > 0 && bestk != ~0ull) ? (int)(uint32_t)(bestk & 0xFFFFFFFFu) : -1;
 }
 
 // Fused re-rank at the end of a walk: the wavefront re-ranks its own query's candidates (pop index r =

@@ -9,13 +9,15 @@ bool walk_uses_lds_list(const WalkParams& p) { return p.ef > kRegListMaxEf || (p
 
 bool walk_uses_hot(const WalkParams& p, int metric) {
     const bool off32 = walk_off32(p);
+    if (p.coop) return false;  // (the two-wavefront walk has its own launcher and LDS layout)
     return (metric == 0 || metric == 1) && p.dim == 32u && p.dstride == 32u && p.ef <= kBigMaxEf && p.ell_stride <= 64u && off32 && (!p.stamps_on || (p.ef > kHot2MaxEf && !getenv("GBNNS_STAMPS_GENERIC"))) &&
            !p.aux_ell;  // (off32 includes n < 2^24: its visited set stores 24-bit ids)
 }
 
 // LDS of one wavefront without the visited set.  Register kernels: tie list + merge buffer + query; the
 // hot kernel stages the query inside the merge buffer (it lives in registers once the walk starts).
-size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list) {
+size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list, bool coop) {
+    if (coop) return big_list_fixed_bytes(ef) + (size_t)dstride * 4 + kCoopExtraLds;  // (walk_coop.hip: the two-list layout + result buffers)
     if (hot)  // tie list + merge buffer of 1 / 2 list registers; ef > 128: + the base list and the flush's flag bytes (walk_hot_big)
         return ef <= 64 ? (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (GBNNS_HOT1_QLDS ? 128 : 0)   // (+ the query, re-read every hop)
                         : (ef <= kHot2MaxEf ? (size_t)kRegTieCap * 8 + (size_t)(64 * 2 + 2) * 8 : big_list_fixed_bytes(ef));
@@ -48,7 +50,7 @@ bool walk_knows_quotient(const WalkParams& p, int metric) {
 bool walk_uses_packed(const WalkParams& p) { return walk_uses_lds_list(p) ? (p.n <= 0xFFFFFFu && !p.force_wide) : walk_off32(p); }
 
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot) {
-    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p)) + walk_hash_bytes(p.hash_cap, walk_hash_form(p, hot));
+    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p), p.coop != 0) + walk_hash_bytes(p.hash_cap, walk_hash_form(p, hot));
 }
 
 thread_local const void* g_walk_first_fn = nullptr;
@@ -60,6 +62,7 @@ constexpr int kPlain512PairMinEf = 200;  // 512-byte rows (PLAIN walks over sift
 
 static hipError_t launch_walk_any(const WalkParams& p, int metric, bool retry, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
+    if (p.coop && !retry) return launch_walk_coop(p, s);  // (the retry pass re-runs hand-overs on the one-wavefront kernels)
     if (metric == 1) return launch_walk_dot(p, retry, s);
     // (A/B switch: GBNNS_WIDE2=0 sends the 384- / 512-byte rows to the run-time-length instances at every beam)
     static const bool wide2 = !getenv("GBNNS_WIDE2") || atoi(getenv("GBNNS_WIDE2")) != 0;

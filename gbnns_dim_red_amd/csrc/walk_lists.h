@@ -689,6 +689,9 @@ struct BigList {
     bool c_valid;
     int p1, p2;             // ranks, -1 = none
     uint32_t h1, n1, h2, n2;
+#ifdef GBNNS_COOP_HINT
+    uint32_t hint3;         // select(): the id after the runner-up, probably (unvalidated: may be garbage when the lists run dry -- a prefetch hint only)
+#endif
 #ifdef GBNNS_STAMPS
     unsigned long long st_flush = 0, st_refresh = 0, st_evict = 0;  // cycles inside flush / refresh_cache / the eviction step
     unsigned st_nflush = 0, st_nrefresh = 0, st_nbase = 0, st_nseq = 0, st_ninsert = 0, st_slow = 0;
@@ -976,6 +979,14 @@ struct BigList {
         //   pred = runner-up id, -1 when there is none or the two runner-up candidates have equal distances
         uint32_t ok, fb, q1, q2, hf1, hf2, nf1, nf2, hw, ha, na, hb, nb2, hr, t0;
         uint64_t fm;
+#ifdef GBNNS_COOP_HINT   // one more scalar select inside the block below: the candidate the runner-up's comparison did NOT pick
+        uint32_t hint_;
+#define GBNNS_SEL_HINT_LINE "s_cselect_b32 %[hint], %[nb2], %[na]\n\t"
+#define GBNNS_SEL_HINT_OUT , [hint] "=&s"(hint_)
+#else
+#define GBNNS_SEL_HINT_LINE
+#define GBNNS_SEL_HINT_OUT
+#endif
         // (rfl: a no-op where the compiler already keeps the cache in scalar registers; where it chose vector registers for
         // it -- it may, the values come out of LDS -- the asm below still gets scalars)
         auto rfl = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
@@ -1007,6 +1018,7 @@ struct BigList {
             "s_min_u32 %[hr], %[ha], %[hb]\n\t"
             "s_cmp_lt_u32 %[ha], %[hb]\n\t"
             "s_cselect_b32 %[pred], %[na], %[nb2]\n\t"
+            GBNNS_SEL_HINT_LINE
             "s_cmp_lg_u32 %[h1], %[hf1]\n\t"                // equal: a tie across the lists, or both lists empty
             "s_cselect_b32 %[ok], 1, 0\n\t"
             "s_cmp_lg_u32 %[hr], %[hw]\n\t"                 // the runner-up ties the winner
@@ -1020,10 +1032,13 @@ struct BigList {
             "s_cselect_b32 %[pred], %[pred], -1"
             : [ok] "=&s"(ok), [fb] "=&s"(fb), [q1] "=&s"(q1), [q2] "=&s"(q2), [hf1] "=&s"(hf1), [hf2] "=&s"(hf2),
               [nf1] "=&s"(nf1), [nf2] "=&s"(nf2), [hw] "=&s"(hw), [ha] "=&s"(ha), [na] "=&s"(na), [hb] "=&s"(hb),
-              [nb2] "=&s"(nb2), [hr] "=&s"(hr), [t0] "=&v"(t0), [fm] "=&s"(fm), [node] "=&s"(node), [pred] "=&s"(pred)
+              [nb2] "=&s"(nb2), [hr] "=&s"(hr), [t0] "=&v"(t0), [fm] "=&s"(fm), [node] "=&s"(node), [pred] "=&s"(pred) GBNNS_SEL_HINT_OUT
             : [flo] "v"(F.lo[0]), [fhi] "v"(F.hi[0]), [h1] "s"(rfl(h1)), [n1] "s"(rfl(n1)), [h2] "s"(rfl(h2)), [n2] "s"(rfl(n2)), [ts] "s"(rfl((uint32_t)tsize))
             : "vcc", "scc");
         h2k = hr;
+#ifdef GBNNS_COOP_HINT
+        hint3 = hint_;   // (walk_coop.hip) of {the winning list's second entry, the other list's first} the one that is NOT the runner-up
+#endif
         if (__builtin_expect(ok != 0, 1)) {
             if (fb) expand_base(p1, lane);
             else F.lo[0] |= (lane == (int)q1) ? 1u : 0u;

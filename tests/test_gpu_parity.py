@@ -1780,6 +1780,104 @@ def test_plain_walks_over_long_rows_four_lanes_per_row(g, orc):
         ix.close()
 
 
+def test_two_wavefront_walk_vs_oracle(g, orc):
+    """The two-wavefront walk for small batches (csrc/walk_coop.hip: a keeper wavefront with the result lists and the exact visited
+    set, a scout wavefront that expands the predicted next node ahead; getOneSearchResults + makeStep, search_function.h:15-102) --
+    every shape it serves (walked rows of 128 / 192 / 256 bytes), beams across the two-list range, both forms of the visited set,
+    rows requested before / after the scout's test, visited sets too small (hand-over chain through the retry pass and the general
+    kernel), probe sequences cut short (stash), no re-rank room, PLAIN walks with k = 1 and k = ef: candidate lists in pop order,
+    distance bits, hops, dist_calc and answers equal the oracle's, and equal the one-wavefront kernels' (knob "coop" 0)."""
+    for si, (d, dlow, dh) in enumerate(((96, 64, 96), (40, 32, 64), (72, 48, 64))):
+        c, off, nbr, db_low, ent = _oracle_case(orc, 6100 + si, 9000, 150, d, dlow, dh, deg=(3, 30))
+        q_low = orc.project(c.net, c.queries)
+        ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net)
+        ix.profile_enable(True)
+        for ef in (129, 200, 400, 1000):
+            w = orc.walk(q_low, db_low, off, nbr, ef, entries=ent, threads=8)
+            s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, ef, db_low=db_low, net=c.net, entries=ent, threads=8)
+            maxdc = int(w["dist_calc"].max())
+            for knobs, cap, flags in (({}, 0, 0), ({"quotient": 0}, 0, 0), ({"late_rows": 1}, 0, 0), ({"late_rows": 0}, 0, 0),
+                                      ({}, max(256, maxdc // 2), 0), ({"quotient": 0}, max(256, maxdc // 2), 0), ({"vs_disp": 1}, 0, 0),
+                                      ({"vs_disp": 2}, maxdc + maxdc // 8 + 64, 0), ({}, 0, g.FLAG_NO_FUSED_RERANK), ({"coop": 0}, 0, 0)):
+                for name, val in {**dict(coop=1, quotient=1, late_rows=-1, vs_disp=15), **knobs}.items():
+                    ix.knob(name, val)
+                for rep in range(2):  # (the second call runs with the capacity the first one's statistics ask for)
+                    ix.profile_read(reset=True)
+                    r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist", "edges"), hash_capacity=cap, flags=flags)
+                    key = (dlow, ef, tuple(knobs.items()), cap, flags, rep)
+                    launched = ix.profile_read(reset=True)["walk_kernel"]
+                    assert launched.startswith("walk_coop_kernel<%d," % (dlow // 4)) == (knobs.get("coop", 1) == 1), (key, launched)
+                    assert np.array_equal(r["cand"], w["ids"]), key
+                    assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
+                    assert np.array_equal(r["hops"], w["hops"]), key
+                    assert np.array_equal(r["dist_calc"], w["dist_calc"]), key
+                    assert np.array_equal(r["ids"], s["ids"]), key
+        # PLAIN walks over the low-dimensional vectors themselves (an index whose original space IS the walked one), k = 1 and k = ef
+        ixp = g.Index(db_low, off, nbr)
+        ixp.knob("coop", 1)
+        ixp.profile_enable(True)
+        for ef, k in ((150, 150), (300, 1), (300, 7)):
+            w = orc.walk(q_low, db_low, off, nbr, ef, k=k, entries=ent, threads=8)
+            r = ixp.search(q_low, ef, mode=g.MODE_PLAIN, k=k, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"))
+            assert ixp.profile_read(reset=True)["walk_kernel"].startswith("walk_coop_kernel<"), (dlow, ef, k)
+            assert np.array_equal(r["cand"], w["ids"]) and np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), (dlow, ef, k)
+            assert np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]), (dlow, ef, k)
+            assert np.array_equal(r["ids"], w["ids"][:, 0]), (dlow, ef, k)
+        ixp.close()
+        ix.close()
+    # who takes it by default: a small batch that runs alone (a synchronous call) -- not batches in flight, which keep one wavefront per
+    # query; forced (knob 1) it serves batches in flight too, same answers
+    import torch
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    c, off, nbr, db_low, ent = _oracle_case(orc, 6150, 9000, 300, 96, 64, 96, deg=(3, 30))
+    s = orc.search_batch(orc_mod.MODE_NET, c.queries, c.base, off, nbr, 200, db_low=db_low, net=c.net, entries=ent, threads=8)
+    ix = g.Index(t(c.base), off, nbr, db_low=t(db_low), net=tuple(t(x) for x in c.net))
+    ix.profile_enable(True)
+    q, e = t(c.queries), t(ent.astype(np.int32))
+    r = ix.search(q, 200, entry_ids=e, out={})
+    torch.cuda.synchronize()
+    assert ix.profile_read(reset=True)["walk_kernel"].startswith("walk_coop_kernel<16,")
+    assert np.array_equal(r["ids"].cpu().numpy().view(np.uint32), s["ids"])
+    ix.profile_enable(False)
+    for knob in (-1, 1):
+        ix.knob("coop", knob)
+        outs = [ix.search(q, 200, entry_ids=e, want=("hops",), out={}, flags=g.FLAG_DEFER_JOIN, defer_depth=3) for _ in range(5)]
+        ix.join()
+        torch.cuda.synchronize()
+        for o in outs:
+            assert np.array_equal(o["ids"].cpu().numpy().view(np.uint32), s["ids"]), knob
+            assert np.array_equal(o["hops"].cpu().numpy(), s["hops"]), knob
+    ix.close()
+    # equal distances everywhere (integer lattice, every vector three times): tie lists, boundary ties in the batch insert, the slow
+    # selection path -- and an entry id outside the index (empty result, no row touched)
+    c = datagen.Case("x", 6190, 6000, 128, 32, 8, 16, kind="lattice")
+    rng = np.random.Generator(np.random.PCG64(6191))
+    off, nbr = datagen.random_graph(rng, c.n, 3, 30)
+    ent = rng.integers(0, c.n, size=c.nq).astype(np.uint32)
+    ix = g.Index(c.base, off, nbr)
+    ix.knob("coop", 1)
+    ix.profile_enable(True)
+    for ef in (130, 250, 600):
+        w = orc.walk(c.queries, c.base, off, nbr, ef, entries=ent, threads=8)
+        ix.profile_read(reset=True)
+        r = ix.search(c.queries, ef, mode=g.MODE_PLAIN, k=ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist"))
+        assert ix.profile_read(reset=True)["walk_kernel"].startswith("walk_coop_kernel<8,"), ef
+        assert np.array_equal(r["cand"], w["ids"]) and np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), ef
+        assert np.array_equal(r["hops"], w["hops"]) and np.array_equal(r["dist_calc"], w["dist_calc"]), ef
+    bad = ent.astype(np.int64).copy()
+    bad[5], bad[77] = c.n, 2**31 - 1
+    rb = ix.search(torch.from_numpy(c.queries).to(dev), 200, mode=g.MODE_PLAIN, k=200, entry_ids=torch.from_numpy(bad.astype(np.int32)).to(dev),
+                   want=("hops", "dist_calc", "cand"), out={})
+    torch.cuda.synchronize()
+    ids = rb["ids"].cpu().numpy().view(np.uint32)
+    assert ids[5] == 0xFFFFFFFF and ids[77] == 0xFFFFFFFF and int(rb["hops"][5]) == 0
+    w = orc.walk(c.queries, c.base, off, nbr, 200, entries=ent, threads=8)
+    ok = np.ones(c.nq, bool); ok[[5, 77]] = False
+    assert np.array_equal(rb["cand"].cpu().numpy().view(np.uint32)[ok], w["ids"][ok])
+    ix.close()
+
+
 def test_knobs_belong_to_the_handle(g, orc):
     """Round 6: the diagnostic knobs that steer a search live in the handle (gbnns_index_knob), the process-wide value
     (gbnns_debug_knob, the environment) is only what a NEW handle starts from.  Two handles side by side: flipping one's knobs

@@ -192,4 +192,7 @@ def test_hot_kernel_register_budgets(tmp_path):
                 # (the pair form over 384- / 512- / 576-byte rows -- Li24E / Li32E / Li36E -- holds 2 x 12 .. 18 sixteen-byte steps of row and
                 # query per lane: two wavefronts per SIMD by design, one for the auxiliary-graph instances)
                 wide = re.search(r"walk_(reg|bitmap)_big_kernelILi0ELi(24|32|36)E", k) is not None
+                # (the two-wavefront walk for small batches -- walk_coop.hip -- runs at most two wavefronts per SIMD by design: workgroups of
+                # two wavefronts, at most four of them per CU; its re-rank keeps 24 sixteen-byte loads in flight per lane)
+                wide = wide or "walk_coop_kernel" in k
                 assert v["vgpr_count"] <= (264 if wide else 176), (k, v)
