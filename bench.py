@@ -714,8 +714,7 @@ def main():
 
 
 def throughput_option(g, ix, q, ef, res_exact, batches, depth, nq):
-    out = {"flag": "GBNNS_FLAG_MFMA_PROJECTION", "kernel": "mlp_layer_mfma_kernel (v_mfma_f32_32x32x2_f32, 64 x 64 tiles through LDS) x 3 + "
-                   "normalize_kernel", "never_the_default": True}
+    out = {"flag": "GBNNS_FLAG_MFMA_PROJECTION", "kernel": None, "never_the_default": True}
     try:
         fl = g.FLAG_MFMA_PROJECTION
         ex = ix.search(q, ef, want=("q_low",), flags=g.FLAG_SERIAL)
@@ -737,6 +736,9 @@ def throughput_option(g, ix, q, ef, res_exact, batches, depth, nq):
         p = ix.profile_read(reset=True)
         ix.profile_enable(False)
         out["project_ms"] = round(p["project_ms"] / max(p["calls"], 1), 4)
+        # (round 6: mlp_mfma_net_kernel -- the three layers of a 32-query tile in one launch, v_mfma_f32_32x32x2_f32, weights repacked into
+        # the B-operand order, activations in LDS; nets that do not fit keep mlp_layer_mfma_kernel x 3 + normalize_kernel)
+        out["kernel"] = p["project_kernel"]
         if depth > 1 and batches:
             bufs = [{} for _ in range(depth)]
             for i in range(60):
@@ -751,9 +753,10 @@ def throughput_option(g, ix, q, ef, res_exact, batches, depth, nq):
             out["value_in_flight"] = round(120 * nq / (time.perf_counter() - t1), 1)
         # matrix-pipe utilisation of the layer kernel: SQ_VALU_MFMA_BUSY_CYCLES / (1 024 SIMDs x kernel cycles), from the
         # committed counter pass of this command line (rocprofv3 cannot run inside this process)
-        mu = profile_figure("profiles/r05_mfma_option_summary.txt", r"mlp_layer_mfma_kernel matrix-pipe utilisation = [^\n]*= ([0-9.]+)")
+        src = "profiles/r06_mfma_option_summary.txt" if out["kernel"] == "mlp_mfma_net_kernel" else "profiles/r05_mfma_option_summary.txt"
+        mu = profile_figure(src, r"%s matrix-pipe utilisation = [^\n]*= ([0-9.]+)" % out["kernel"])
         out["mfma_util"] = mu
-        out["mfma_util_source"] = "profiles/r05_mfma_option_summary.txt" if mu is not None else None
+        out["mfma_util_source"] = src if mu is not None else None
     except Exception as e:
         out["failed"] = str(e)[-300:]
     return out

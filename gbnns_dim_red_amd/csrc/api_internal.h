@@ -165,6 +165,8 @@ struct gbnns_index {
     const float* db = nullptr;      // [n x d_pad]
     const float* db_low = nullptr;  // [n x dl_pad]
     DevBuf db_own, db_low_own, ell, net, aux_ell;
+    DevBuf net_mfma;                // the net repacked for the one-launch matrix-core projection (filled on the option's first use)
+    bool net_mfma_ready = false;
     uint32_t ell_stride = 0, aux_stride = 0;
     bool has_aux = false;
     bool has_net = false;

@@ -408,7 +408,7 @@ int gbnns_index_destroy(gbnns_index* ix) {
         if (L.stream) (void)hipStreamDestroy(L.stream);
         for (int i = 0; DevBuf* b = L.bufs(i); ++i) b->release();
     }
-    DevBuf* bufs[] = {&ix->db_own, &ix->db_low_own, &ix->ell, &ix->aux_ell, &ix->net};
+    DevBuf* bufs[] = {&ix->db_own, &ix->db_low_own, &ix->ell, &ix->aux_ell, &ix->net, &ix->net_mfma};
     for (DevBuf* b : bufs) b->release();
     delete ix;
     return GBNNS_OK;
@@ -437,6 +437,26 @@ int run_project(gbnns_index* ix, Lane& L, const float* x, uint32_t xstride, uint
             std::snprintf(ix->acc.project_kernel, sizeof(ix->acc.project_kernel), "mlp_net_kernel");
             return GBNNS_OK;
         }
+    }
+    if (mfma && !getenv("GBNNS_MFMA_LAYERS") && mlp_mfma_net_serves(ix->d, ix->d_hidden, ix->d_low)) {
+        // the throughput option in one launch (round 6, mlp_mfma_net.hip); GBNNS_MFMA_LAYERS=1 keeps round 5's three launches (A/B)
+        NetLaunch n{};
+        n.x = x; n.xstride = xstride; n.nq = nx; n.out = out; n.ostride = ix->dl_pad; n.cus = ix->cus;
+        n.w[0] = ix->w1; n.w[1] = ix->w2; n.w[2] = ix->w3;
+        n.wstride[0] = ix->ws1; n.wstride[1] = ix->ws2; n.wstride[2] = ix->ws3;
+        n.bias[0] = ix->b1; n.bias[1] = ix->b2; n.bias[2] = ix->b3;
+        n.din[0] = ix->d; n.din[1] = n.din[2] = ix->d_hidden;
+        n.dout[0] = n.dout[1] = ix->d_hidden; n.dout[2] = ix->d_low;
+        if (!ix->net_mfma_ready) {
+            int rc0 = ix->net_mfma.ensure(mlp_mfma_net_packed_floats(ix->d, ix->d_hidden, ix->d_low) * 4);
+            if (rc0) return rc0;
+            HIP_TRY(launch_mlp_mfma_pack(n, ix->net_mfma.as<float>(), s));   // (stream order: before this call's projection; later calls on
+            HIP_TRY(hipStreamSynchronize(s));                                  //  other streams find it finished)
+            ix->net_mfma_ready = true;
+        }
+        HIP_TRY(launch_mlp_mfma_net(n, ix->net_mfma.as<float>(), s));
+        std::snprintf(ix->acc.project_kernel, sizeof(ix->acc.project_kernel), "mlp_mfma_net_kernel");
+        return GBNNS_OK;
     }
     std::snprintf(ix->acc.project_kernel, sizeof(ix->acc.project_kernel), mfma ? "mlp_layer_mfma_kernel" : "mlp_layer_kernels");
     int rc = L.h1.ensure((size_t)nx * ix->d_hidden * 4);

@@ -167,6 +167,12 @@ struct NetLaunch {
 };
 bool mlp_net_serves(const NetLaunch& n);   // shape, alignment and batch size fit the one-launch kernel
 hipError_t launch_mlp_net(const NetLaunch& n, hipStream_t s);
+// The throughput option as ONE launch (mlp_mfma_net.hip): v_mfma_f32_16x16x4_f32, one workgroup per CU over its share of the batch, weights
+// repacked once per handle into the instruction's B-operand order, activations in LDS.  NOT bit-exact.
+bool mlp_mfma_net_serves(uint32_t d, uint32_t d_hidden, uint32_t d_low);
+size_t mlp_mfma_net_packed_floats(uint32_t d, uint32_t d_hidden, uint32_t d_low);
+hipError_t launch_mlp_mfma_pack(const NetLaunch& n, float* packed, hipStream_t s);
+hipError_t launch_mlp_mfma_net(const NetLaunch& n, const float* packed, hipStream_t s);
 // y [nq x stride]: y /= sqrt(L2(y, 0)) over dim (4-lane order, d%4 tail ignored in the norm),
 // pad columns [dim, stride) are written as zero.
 hipError_t launch_normalize(float* y, uint32_t stride, uint32_t dim, uint32_t nq, hipStream_t s);

@@ -535,15 +535,20 @@ def test_projection_slab_kernel(g, orc):
 
 
 def test_matrix_core_projection_option(g, orc):
-    """GBNNS_FLAG_MFMA_PROJECTION (gbnns.h): the projection as v_mfma_f32_32x32x2_f32 GEMMs -- the throughput option, NOT
-    bit-exact (one k-ordered fma chain per output instead of eight separately rounded running sums).  What is promised and
-    checked: it is opt-in (the same handle without the flag gives the exact bits), q_low stays within 2e-6 of the exact
-    projection on unit-norm outputs, and the answers of a batch differ from the exact path's for at most 0.5 % of the
-    queries (bench.py states the count on its own workload: throughput_option.id_mismatches_vs_reference)."""
+    """GBNNS_FLAG_MFMA_PROJECTION (gbnns.h): the projection on the matrix cores, v_mfma_f32_32x32x2_f32 -- the throughput option, NOT
+    bit-exact (one k-ordered fma chain per output instead of eight separately rounded running sums).  Round 6: the whole net of a
+    32-query tile in ONE launch (csrc/mlp_mfma_net.hip: weights repacked into the instruction's B-operand order, activations in LDS);
+    nets whose activation images do not fit (d_hidden 1 024) keep round 5's three per-layer launches.  What is promised and checked: it
+    is opt-in (the same handle without the flag gives the exact bits), q_low stays within 2e-6 of the exact projection on unit-norm
+    outputs, and the answers of a batch differ from the exact path's for at most 0.5 % of the queries (bench.py states the count on its
+    own workload: throughput_option.id_mismatches_vs_reference) -- widths that are and are not multiples of the 32-neuron blocks and
+    of the 16-input steps, d_low of 32 / 48 / 64, batches that end inside a tile, batches in flight."""
     import torch
     dev = torch.device("cuda:0")
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    for si, (d, dh, dl, nq) in enumerate(((128, 256, 32, 3000), (100, 72, 48, 500))):
+    for si, (d, dh, dl, nq, kernel) in enumerate(((128, 256, 32, 3000, "mlp_mfma_net_kernel"), (100, 72, 48, 500, "mlp_mfma_net_kernel"),
+                                                  (200, 232, 64, 1001, "mlp_mfma_net_kernel"), (96, 128, 32, 33, "mlp_mfma_net_kernel"),
+                                                  (64, 1024, 32, 300, "mlp_layer_mfma_kernel"))):
         c, off, nbr, db_low, ent = _oracle_case(orc, 9300 + si, 8000, nq, d, dl, dh)
         want_q = orc.project(c.net, c.queries)
         ix = g.Index(t(c.base), off, nbr, db_low=t(db_low), net=tuple(t(x) for x in c.net))
@@ -551,12 +556,17 @@ def test_matrix_core_projection_option(g, orc):
         exact = ix.search(q, 48, entry_ids=e, want=("q_low",), out={})
         opt = ix.search(q, 48, entry_ids=e, want=("q_low",), out={}, flags=g.FLAG_MFMA_PROJECTION)
         torch.cuda.synchronize()
-        assert ix.profile_read(reset=False)["project_kernel"] == "mlp_layer_mfma_kernel"
+        assert ix.profile_read(reset=False)["project_kernel"] == kernel, (d, dh, dl)
         assert np.array_equal(gu.bits(exact["q_low"].cpu().numpy()), gu.bits(want_q))
         err = np.abs(opt["q_low"].cpu().numpy() - want_q).max()
-        assert 0 < err < 2e-6, err          # (> 0: the option really ran a different arithmetic)
+        assert 0 < err < 2e-6, (err, d, dh, dl)          # (> 0: the option really ran a different arithmetic)
         diff = int((opt["ids"] != exact["ids"]).sum().item())
         assert diff <= max(1, nq // 200), (diff, nq)
+        outs = [ix.search(q, 48, entry_ids=e, want=("q_low",), out={}, flags=g.FLAG_MFMA_PROJECTION | g.FLAG_DEFER_JOIN, defer_depth=3) for _ in range(3)]
+        ix.join()
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o["q_low"], opt["q_low"]) and torch.equal(o["ids"], opt["ids"]), (d, dh, dl)
         again = ix.search(q, 48, entry_ids=e, want=("q_low",), out={})
         torch.cuda.synchronize()
         assert np.array_equal(gu.bits(again["q_low"].cpu().numpy()), gu.bits(want_q))

@@ -89,10 +89,10 @@ def test_projection_kernels_fma_only_in_div_sqrt_expansion(kernels):
             assert re.search(r"Lb[01]ELb1E", name) or "mlp_net_kernel" in name, \
                 "fma in a projection kernel without the normalise step: " + name
             assert n_fma < 64, (name, n_fma)  # a div + a sqrt expansion, not a dot-product loop
-    # the matrix cores serve the throughput option only (mlp_layer_mfma_kernel, GBNNS_FLAG_MFMA_PROJECTION)
+    # the matrix cores serve the throughput option only (mlp_mfma_net_kernel / mlp_layer_mfma_kernel, GBNNS_FLAG_MFMA_PROJECTION)
     for name, insts in kernels.items():
         if "mlp_" in name:
-            assert any(i.startswith("v_mfma") for i in insts) == ("mlp_layer_mfma_kernel" in name), name
+            assert any(i.startswith("v_mfma") for i in insts) == ("mlp_layer_mfma_kernel" in name or "mlp_mfma_net_kernel" in name), name
     net = [v for k, v in kernels.items() if "mlp_net_kernel" in k]
     assert net, "mlp_net_kernel not found"
     for insts in net:  # its products and sums are the separately rounded packed forms, its folds the row swaps

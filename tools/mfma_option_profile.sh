@@ -1,17 +1,18 @@
 #!/bin/bash
-# Counters of the throughput option's layer kernel (mlp_layer_mfma_kernel) and of the exact one-launch projection beside it
-# (run on the GPU box from the repo root).  Writes gpurun_out/r05_mfma_option_summary.txt (copy it to profiles/).
+# Counters of the throughput option's projection kernel (round 6: mlp_mfma_net_kernel, one launch; GBNNS_MFMA_LAYERS=1: round 5's
+# mlp_layer_mfma_kernel x 3) and of the exact one-launch projection beside it (run on the GPU box from the repo root; tools/mfma_probe.py
+# is the workload).  Writes gpurun_out/r06_mfma_option_summary.txt (copy it to profiles/).
 OUT=$GRAFT_REPO_ROOT/gpurun_out/mfma_opt
 mkdir -p $OUT
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --steps 5 --warmup 2 --no-other-configs --no-cpu-baseline"
+ARGS="$R/tools/mfma_probe.py"
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc -- python3 $ARGS > /dev/null 2> $OUT/pmc.err
 cd $R
-python3 - <<PY > gpurun_out/r05_mfma_option_summary.txt
+python3 - <<PY > gpurun_out/r06_mfma_option_summary.txt
 import csv, glob, re, collections, json
-print("# projection kernels of \`python bench.py --steps 5 --warmup 2 --no-other-configs --no-cpu-baseline\` (SIFT1M-shaped, 10 000-query batches)")
+print("# projection kernels of \`python tools/mfma_probe.py\` (SIFT1M-shaped, 10 000-query batches: 25 calls with the exact projection, 25 with the option)")
 print("# rocprofv3 --kernel-trace (durations) and a separate --pmc pass (counters, mean per dispatch)")
 dur = collections.defaultdict(list)
 for f in glob.glob("$OUT/trace/**/*kernel_trace.csv", recursive=True):
@@ -37,8 +38,8 @@ for k, v in sorted(acc.items()):
         cyc = v["GRBM_GUI_ACTIVE"] / n / 8
         print("%s VALU issue = SQ_INSTS_VALU x 4 / (1024 SIMDs x kernel cycles %.0f) = %.3f" % (k, cyc, v["SQ_INSTS_VALU"] / n * 4 / (1024 * cyc)))
 try:
-    j = json.load(open("$OUT/bench.json"))
-    print("bench line of the traced run: value %.1f, throughput_option %s" % (j["value"], json.dumps(j.get("throughput_option"))))
+    j = json.loads([l for l in open("$OUT/bench.json") if l.startswith("{")][-1])
+    print("probe line of the traced run: %s" % json.dumps(j))
 except Exception as e:
     print("bench line unreadable:", e)
 PY
