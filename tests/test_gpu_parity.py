@@ -1652,6 +1652,17 @@ def test_two_list_kernels_by_name(g, orc):
         q_low = orc.project(c.net, c.queries)
         ix = g.Index(c.base, off, nbr, db_low=db_low, net=c.net, metric=metric)
         ix.profile_enable(True)
+        # (round 6) these 120-query batches run alone: by default the shapes that have it take the two-wavefront walk -- L2, walked rows of
+        # 128 / 192 / 256 bytes, 128 < ef <= 1 024, one-pass adjacency rows, no forced bitmap pass; checked by name here, against the oracle
+        # in test_two_wavefront_walk_vs_oracle.  The table below is about the one-wavefront kernels: knob "coop" 0.
+        for ef, fl, kname in cases:
+            served = metric == 0 and dlow in (32, 48, 64) and 128 < ef <= 1024 and deg <= 32 and fl != "bitmap"
+            ix.knob("coop", -1)
+            ix.profile_read(reset=True)
+            r = ix.search(c.queries, ef, entry_ids=ent, flags=g.FLAG_BITMAP_PASS if fl == "bitmap" else 0)
+            launched = ix.profile_read(reset=True)["walk_kernel"]
+            assert launched.startswith("walk_coop_kernel<%d," % (dlow // 4)) == served, ((d, dlow, metric, deg, ef, fl), launched)
+        ix.knob("coop", 0)
         for ef, fl, kname in cases:
             flags = g.FLAG_BITMAP_PASS if fl == "bitmap" else 0
             _knobs(ix, spec_min_nq=1 if fl == "spec" else 32768)
