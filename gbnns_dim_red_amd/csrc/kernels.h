@@ -101,7 +101,7 @@ bool walk_knows_quotient(const WalkParams& p, int metric);      // the first-pas
 int walk_hash_form(const WalkParams& p, bool hot);              // the form the first pass uses (p.vs_shr chooses 2 for the hot kernels)
 size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list = false, bool coop = false);  // everything but the visited set
                                                                                              // (lds_list: walk_uses_lds_list; coop: WalkParams::coop)
-constexpr size_t kCoopExtraLds = 1536;  // the two-wavefront walk's two 64-word result buffers + three 64-word slots of adjacency words requested ahead + 64 scratch words (its mailbox lives in the query area)
+constexpr size_t kCoopExtraLds = 1280;  // the two-wavefront walk's two 64-word result buffers + three 64-word slots of adjacency words requested ahead (its mailbox lives in the query area)
 bool walk_coop_serves(const WalkParams& p, int metric);   // shape the two-wavefront walk has an instance for (walk_coop.hip)
 hipError_t launch_walk_coop(const WalkParams& p, hipStream_t s);
 hipError_t launch_walk_fast(const WalkParams& p, int metric, hipStream_t s);

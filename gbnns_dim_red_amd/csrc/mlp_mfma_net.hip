@@ -35,7 +35,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kGroup = 8;      // instructions (steps of four inputs) whose B operands come in together: two float4 per lane
-constexpr int kWaves = 8;      // wavefronts per workgroup: two per SIMD
+constexpr int kWaves = 8;      // wavefronts per workgroup: two per SIMD (sixteen: the same 31 us -- shorter layers, longer barriers)
 constexpr int kMaxRB = 3;      // row blocks of 16 queries per workgroup (LDS: two activation images of up to 304 inputs x 49 floats)
 
 struct MfmaNet {

@@ -241,7 +241,7 @@ __device__ __forceinline__ void coop_flag(uint32_t* w, uint32_t value, int lane)
     if (lane == 0) __hip_atomic_store(w, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// LDS: [BigList: big_list_fixed_bytes(ef)][mailbox: dstride floats][result buffers: 2 x 64 words][adjacency words requested ahead: 3 x 64][64 words of scratch]
+// LDS: [BigList: big_list_fixed_bytes(ef)][mailbox: dstride floats][result buffers: 2 x 64 words][adjacency words requested ahead: 3 x 64]
 //      [visited set | re-rank scratch]
 // Result buffer word 2 s     = slot s's id | 0x80000000 when the id is NEW (the scout's claim won); all-ones: empty slot
 //               word 2 s + 1 = its distance key (meaningful with the flag)
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int ef = p.ef;
     uint32_t* const mbox = reinterpret_cast<uint32_t*>(smem + big_list_fixed_bytes(ef));
     uint32_t* const bufs = mbox + p.dstride;                          // 2 x 64 words
-    uint32_t* const pfs = bufs + 128;                                 // 3 x 64 words: adjacency words requested ahead (scout) + 64 words nobody reads
-    uint32_t* const hash = pfs + 256;
+    uint32_t* const pfs = bufs + 128;                                 // 3 x 64 words: adjacency words requested ahead (scout)
+    uint32_t* const hash = pfs + 192;
     unsigned char* const after_q = reinterpret_cast<unsigned char*>(hash);
     const uint32_t cap = p.hash_cap;
     const uint32_t vs_shr = p.vs_shr;
@@ -424,8 +424,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         return (slot < p.ell_stride) ? row[slot] : kInvalidId;
     };
     const uint32_t pfs_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(pfs));
-    static const bool touch_env = true;
-    const bool touch = touch_env && p.spec_rows == 0;   // (WalkParams::spec_rows doubles as the A/B switch of the row touches here: 1 = off)
     auto request_adjacency = [&](uint32_t k, uint32_t node) {   // node's adjacency words -> LDS slot k (wave-uniform arguments)
         const uint32_t* src = reinterpret_cast<const uint32_t*>(row_ptr<true>(reinterpret_cast<const float*>(ell), node, p.ell_stride)) + aslot;
         const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pfs_lds + 256u * k));
@@ -434,18 +432,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                      : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     };
     auto requested_slot = [&](uint32_t node) -> int { return node == pfn0 ? 0 : (node == pfn1 ? 1 : (node == pfn2 ? 2 : -1)); };
-    // Rows a LATER hop will probably want, touched now so that they are in this XCD's L2 by then: the rows of slot k's adjacency words
-    // (one 4-byte load per 128-byte line of every row, thrown away into the scratch words).  The row gather is the longest wait of an
-    // expansion (~1 700 cycles from request to data on this launch); an L2 hit is a third of that.
-    auto touch_rows = [&](uint32_t k) {
-        const uint32_t wv = pfs[64u * k + lane];
-        const bool ok = slot < p.ell_stride && wv < p.n;
-        const char* src = reinterpret_cast<const char*>(p.db) + (ok ? wv : 0u) * kRowBytes + half * (kRowBytes > 128u ? 128u : 64u);
-        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pfs_lds + 768u));
-        uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    };
     // (ahead1 / ahead2: nodes whose adjacency words are worth requesting now -- the runner-up when it is not being expanded, the hint)
     auto expand = [&](uint32_t node, uint32_t bufno, bool prepared, uint32_t ahead1, uint32_t ahead2) -> bool {
         uint32_t* const buf = bufs + 64 * bufno;
@@ -511,15 +497,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         STAMP(e3)
         STAMP_ADD(5, e2, e3)
         r_won = won;
-        // rows of the runner-up's / the hint's neighbours (their adjacency words were requested at the start of this expansion)
-        if (touch) {
-            const bool t1 = pfn1 != kCoopNoNode && pfn1 != node, t2 = pfn2 != kCoopNoNode && pfn2 != node;
-            if (t1 || t2) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (t1) touch_rows(1u);
-                if (t2) touch_rows(2u);
-            }
-        }
         // the closest new id (for the prediction), and its adjacency word requested now
         uint32_t x = (fresh && half) ? kd : 0xFFFFFFFFu;
         const uint32_t dkf = x;

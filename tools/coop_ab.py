@@ -1,0 +1,29 @@
+import os, sys, json
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+import gbnns_dim_red_amd as g
+from gbnns_dim_red_amd import synth
+import bench
+cfg = bench.CONFIGS["gist"]
+kw = dict(n=cfg["n"], nq=cfg["nq"], d=cfg["d"], d_low=cfg["d_low"], d_hidden=cfg["d_hidden"], seed=1234)
+ds = synth.make_dataset(device="cuda:0", cache_dir="/tmp/gbnns_cache", **kw)
+ix = ds.index()
+q = ds.queries
+ref = None
+for name, knobs in (("one wavefront", dict(coop=0)), ("coop, rows touched ahead", dict(coop=1)), ("coop, no touches", dict(coop=1, spec_min_nq=1, spec_any_form=1)),
+                    ("one wavefront", dict(coop=0)), ("coop, rows touched ahead", dict(coop=1))):
+    for k, v in {**dict(coop=-1, spec_min_nq=32768, spec_any_form=0), **knobs}.items():
+        ix.knob(k, v)
+    for ef in (200, 400):
+        for _ in range(5):
+            r = ix.search(q, ef, want=())
+        torch.cuda.synchronize()
+        ix.profile_read(reset=True); ix.profile_enable(True)
+        for _ in range(20):
+            r = ix.search(q, ef, want=())
+        torch.cuda.synchronize()
+        p = ix.profile_read(reset=True); ix.profile_enable(False)
+        if ref is None or ef not in ref:
+            ref = ref or {}
+            ref[ef] = r["ids"].clone()
+        print("%-26s ef %4d: %s  %.4f ms  ids identical %s" % (name, ef, p["walk_kernel"].split(" (")[0][:34], p["walk_ms"] / p["calls"], bool((r["ids"] == ref[ef]).all())), flush=True)
