@@ -117,6 +117,8 @@ inline uint64_t gbnnsFingerprint(const float* p, size_t count) {
     return h;
 }
 
+inline void gbnnsForget(gbnns_index* ix);   // (the warm-up record of a handle that is being destroyed: below, with gbnnsFirstUse)
+
 inline gbnns_index* gbnnsIndexFor(vector<vector<uint32_t>>& graph, const float* db, size_t n, size_t d,
                                   const float* db_low, size_t d_low, const Net* net, size_t d_hidden,
                                   Metric* metric) {
@@ -134,6 +136,7 @@ inline gbnns_index* gbnnsIndexFor(vector<vector<uint32_t>>& graph, const float* 
         if (std::get<0>(k) == std::get<0>(key) && std::get<1>(k) == std::get<1>(key) && std::get<2>(k) == std::get<2>(key) &&
             std::get<3>(k) == std::get<3>(key) && std::get<7>(k) == std::get<7>(key)) {
             gbnnsAttached().erase(old->second);
+            gbnnsForget(old->second);
             auto mi = gbnnsMultiOf().find(old->second);
             if (mi != gbnnsMultiOf().end()) {
                 gbnns_multi_destroy(mi->second);
@@ -279,20 +282,37 @@ inline void gbnnsBatch(gbnns_index* ix, int mode, const float* queries, const fl
     }
 }
 
-// First use of a handle in a mode: two UNTIMED batches with the arguments of the timed ones.  It is where the handle's workspaces (sized
-// by n_q), its stream and the kernels' code objects come into being -- 2.5 ms once per handle, which would otherwise sit inside the
-// first repeat of a sweep's first beam and halve that line's rate (final_test at full size: 14.6 M queries/s on the ef = 1 line, 26.8 M on
-// the next).  The reference does its own set-up at this very spot, outside its StopW region: `new VisitedListPool(1, n)`
-// (search_function.h:142-144, :331-333).  GBNNS_NO_WARMUP=1 leaves the first use inside the timed region.
-inline void gbnnsFirstUse(gbnns_index* ix, int mode, const float* queries, const float* queries_low, size_t n_q, int ef, int k,
-                          const vector<uint32_t>& entries, vector<uint32_t>& ans, vector<int32_t>& hops, vector<int32_t>& dist_calc,
-                          const GbnnsAux& aux, uint32_t n_entries, vector<int32_t>* edges) {
-    static std::set<std::pair<gbnns_index*, int>> used;
+// Untimed batches in front of a timed region, the same for every line of a sweep (round 6; until then only the FIRST beam of a sweep got
+// them, and the low-dimensional-only branch none):
+//   * first use of a handle in a mode: one batch with the arguments of the timed ones.  It is where the handle's workspaces (sized by
+//     n_q), its stream and the kernels' code objects come into being -- 2.5 ms once per handle, which would otherwise sit inside the first
+//     repeat of a sweep's first beam and halve that line's rate (final_test at full size: 14.6 M queries/s on the ef = 1 line, 26.8 M on the
+//     next).  The reference does its own set-up at this very spot, outside its StopW region: `new VisitedListPool(1, n)`
+//     (search_function.h:142-144, :331-333);
+//   * first use of a (handle, mode, beam): one more batch -- the library sizes a beam's visited sets from the walks it has seen, so every
+//     beam's timed repeats now run on measured sizes, not only the first beam's.
+// The record is keyed by handle and forgotten when gbnnsIndexFor destroys the handle (a new handle at the same address starts over); the
+// results sidecar says how many untimed batches a line had (`warmup_batches`).  GBNNS_NO_WARMUP=1 leaves everything inside the timed
+// region.  Host code of the drop-in is single-threaded, like the reference's drivers.
+inline std::set<std::tuple<gbnns_index*, int, int>>& gbnnsUsed() {
+    static std::set<std::tuple<gbnns_index*, int, int>> used;   // (handle, mode, ef); ef = -1: the handle + mode entry
+    return used;
+}
+inline void gbnnsForget(gbnns_index* ix) {
+    auto& used = gbnnsUsed();
+    for (auto it = used.begin(); it != used.end();) it = std::get<0>(*it) == ix ? used.erase(it) : std::next(it);
+}
+inline int gbnnsFirstUse(gbnns_index* ix, int mode, const float* queries, const float* queries_low, size_t n_q, int ef, int k,
+                         const vector<uint32_t>& entries, vector<uint32_t>& ans, vector<int32_t>& hops, vector<int32_t>& dist_calc,
+                         const GbnnsAux& aux, uint32_t n_entries, vector<int32_t>* edges) {
     static const bool off = getenv("GBNNS_NO_WARMUP") && atoi(getenv("GBNNS_NO_WARMUP")) != 0;
-    if (off || !used.insert({ix, mode}).second) return;
-    // (two calls: the second runs on the visited-set sizing the first one measured -- bench.py `cold`: 2.9 / 0.46 / 0.40 ms for calls 1 / 2 / 3)
-    for (int i = 0; i < 2; ++i)
+    if (off) return 0;
+    int batches = 0;
+    if (gbnnsUsed().insert(std::make_tuple(ix, mode, -1)).second) batches += 1;
+    if (gbnnsUsed().insert(std::make_tuple(ix, mode, ef)).second) batches += 1;
+    for (int i = 0; i < batches; ++i)
         gbnnsBatch(ix, mode, queries, queries_low, n_q, ef, k, entries, ans, hops, dist_calc, aux, n_entries, edges);
+    return batches;
 }
 
 // ---- per-query entry points (single-query device calls; the batch functions below are the fast
@@ -381,6 +401,7 @@ struct GbnnsTraffic {
     double edges;           // mean neighbour ids read
     int walked_dim;         // dimension of the walked space
     bool rerank;            // original-space re-rank of `ef` candidates
+    int warmup_batches;     // untimed batches in front of this line's timed region (gbnnsFirstUse)
 };
 
 // one JSON object per sweep point, appended to <output_txt>.json
@@ -400,6 +421,7 @@ inline void gbnnsSidecar(const char* output_txt, const string& graph_name, int e
        << ", \"mean_dist_calc\": " << dist_calc << ", \"sec_per_query\": " << sec_per_query
        << ", \"queries_per_s\": " << (sec_per_query > 0 ? 1.0 / sec_per_query : 0.0)
        << ", \"timed_region\": \"host buffers in, answers out (H2D + kernels + D2H), as search_function.h:346-387\""
+       << ", \"warmup_batches\": " << t.warmup_batches
        << ", \"algorithmic_bytes_per_query\": " << (walk_bytes + rerank_bytes)
        << ", \"algorithmic_bytes_walk_part\": " << walk_bytes << ", \"mean_edges_read\": " << t.edges
        << ", \"GBps\": " << gbps << ", \"roofline_peak_GBps\": " << peak_gbps
@@ -465,7 +487,7 @@ void performTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>>& 
         pin_ql(q_low, (size_t)n_q * d_low * sizeof(float)), pin_e(entries.data(), entries.size() * sizeof(uint32_t)),
         pin_a(ans.data(), ans.size() * 4), pin_h(q_hops.data(), q_hops.size() * 4), pin_d(q_dc.data(), q_dc.size() * 4),
         pin_g(q_edges.data(), q_edges.size() * 4);
-    gbnnsFirstUse(ix, mode, q_main, q_low, n_q, run_ef, run_k, entries, ans, q_hops, q_dc, aux, n_entries, &q_edges);
+    const int warmup_batches = gbnnsFirstUse(ix, mode, q_main, q_low, n_q, run_ef, run_k, entries, ans, q_hops, q_dc, aux, n_entries, &q_edges);
     for (int v = 0; v < number_exper; ++v) {
         num_exp += 1;
         StopW stopw = StopW();
@@ -481,7 +503,7 @@ void performTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>>& 
     }
     gbnnsReport(outfile, graph_name, acc, hops, dist_calc, work_time, num_exp, n_q);
     const double per = (double)num_exp * n_q;
-    const GbnnsTraffic traffic = {walk_dc / per, edges / per, d != d_low ? d_low : d, mode == GBNNS_MODE_LOWQ};
+    const GbnnsTraffic traffic = {walk_dc / per, edges / per, d != d_low ? d_low : d, mode == GBNNS_MODE_LOWQ, warmup_batches};
     gbnnsSidecar(output_txt, graph_name, run_ef, run_k, recheck_size, acc / per, (double)hops / per, (double)dist_calc / per,
                  work_time / (num_exp * 1e6 * n_q), num_exp, n_q, n, d, d_low, traffic);
 }
@@ -583,11 +605,18 @@ void performNetTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>
     const GbnnsPin pin_q(queries.data(), queries.size() * sizeof(float)), pin_ql(q_low.data(), q_low.size() * sizeof(float)),
         pin_e(entries.data(), entries.size() * sizeof(uint32_t)), pin_a(ans.data(), ans.size() * 4),
         pin_h(q_hops.data(), q_hops.size() * 4), pin_d(q_dc.data(), q_dc.size() * 4), pin_g(q_edges.data(), q_edges.size() * 4);
-    if (two_stage)
-        gbnnsFirstUse(ix, GBNNS_MODE_NET, queries.data(), nullptr, n_q, recheck_size, recheck_size, entries, ans, q_hops, q_dc, aux,
-                      n_entries, &q_edges);
-    else if (!low_only)
-        gbnnsFirstUse(ix, GBNNS_MODE_PLAIN, queries.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux, n_entries, &q_edges);
+    int warmup_batches = 0;
+    if (two_stage) {
+        warmup_batches = gbnnsFirstUse(ix, GBNNS_MODE_NET, queries.data(), nullptr, n_q, recheck_size, recheck_size, entries, ans, q_hops, q_dc,
+                                       aux, n_entries, &q_edges);
+    } else if (low_only) {   // (the projection + a plain walk over the low-dimensional index: both handles get their first use here)
+        if (gbnns_project(ix, queries.data(), n_q, q_low.data(), GBNNS_MEM_HOST, nullptr)) gbnnsDie("gbnns_project");
+        warmup_batches = gbnnsFirstUse(ix_low, GBNNS_MODE_PLAIN, q_low.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux, n_entries,
+                                       &q_edges);
+    } else {
+        warmup_batches = gbnnsFirstUse(ix, GBNNS_MODE_PLAIN, queries.data(), nullptr, n_q, ef, k, entries, ans, q_hops, q_dc, aux, n_entries,
+                                       &q_edges);
+    }
     for (int v = 0; v < number_exper; ++v) {
         num_exp += 1;
         StopW stopw = StopW();
@@ -613,7 +642,7 @@ void performNetTest(vector<vector<uint32_t>>& knn_graph, vector<vector<uint32_t>
     }
     gbnnsReport(outfile, graph_name, acc, hops, dist_calc, work_time, num_exp, n_q);
     const double per = (double)num_exp * n_q;
-    const GbnnsTraffic traffic = {walk_dc / per, edges / per, d != d_low ? d_low : d, two_stage};
+    const GbnnsTraffic traffic = {walk_dc / per, edges / per, d != d_low ? d_low : d, two_stage, warmup_batches};
     gbnnsSidecar(output_txt, graph_name, two_stage ? recheck_size : ef, two_stage ? recheck_size : k, recheck_size,
                  acc / per, (double)hops / per, (double)dist_calc / per, work_time / (num_exp * 1e6 * n_q), num_exp, n_q, n, d,
                  d_low, traffic);
