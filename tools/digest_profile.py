@@ -22,6 +22,8 @@ def short(name):
             retry = len(args) > idx and args[idx] in ("true", "1")
             regs = "/R%s" % args[4] if key == "walk_reg_kernel" and len(args) > 4 and args[4] != "1" else ""
             return key + regs + ("/retry" if retry else "")
+    if "walk_coop_kernel" in name:   # walk_coop_kernel<STEPS, LATE>: the two-wavefront walk (round 6)
+        return "walk_coop_kernel"
     if "walk_reg_big_kernel" in name:  # walk_reg_big_kernel<METRIC, STEPS, OFF32, RETRY, AUX>
         args = name[name.find("<") + 1:name.rfind(">")].replace(" ", "").split(",")
         return "walk_reg_big_kernel" + ("/retry" if len(args) > 3 and args[3] in ("true", "1") else "")
@@ -37,7 +39,7 @@ def short(name):
             return key
     if "walk_hotN_kernel" in name:
         return "walk_hotN_kernel<" + name[name.find("<") + 1:name.find(">")] + ">"
-    for key in ("walk_hot_kernel", "walk_general_kernel", "rerank_pair_kernel", "rerank_kernel", "mlp_layer_mfma_kernel", "mlp_layer_vec_kernel", "mlp_layer_kernel",
+    for key in ("walk_hot_kernel", "walk_general_kernel", "rerank_pair_kernel", "rerank_kernel", "mlp_mfma_net_kernel", "mlp_mfma_pack_kernel", "mlp_slab_kernel", "mlp_layer_mfma_kernel", "mlp_layer_vec_kernel", "mlp_layer_kernel",
                 "normalize_kernel", "fill_u32_kernel", "order_hist_kernel", "order_scan_kernel", "order_scatter_kernel"):
         if key in name:
             return key
