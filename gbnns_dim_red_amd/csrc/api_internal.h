@@ -145,7 +145,7 @@ struct Lane {
 // starts from, so a test or an A/B run that flips one no longer changes every other handle of the process.  The three knobs of
 // gbnns_exact_knn -- a function without a handle -- stay process-wide.
 struct Knobs {
-    int quotient, vs_disp, max_waves, spec_min_nq, spec_any_form, mlp_small, mlp_net, mlp_slab, late_rows, vs_fill2, spec_tail, coop;
+    int quotient, vs_disp, max_waves, spec_min_nq, spec_any_form, mlp_small, mlp_net, mlp_slab, late_rows, vs_fill2, spec_tail, coop, coop_pack;
 };
 Knobs knob_defaults();                                    // the process-wide defaults as they stand now
 bool knob_set(Knobs& k, const char* name, int value);     // clamps like the environment does; false = no such handle knob

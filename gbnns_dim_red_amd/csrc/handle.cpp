@@ -174,7 +174,10 @@ int build_ell(const uint64_t* off, const uint32_t* nbr, uint64_t n, std::vector<
 //   "spec_tail"     largest partial last round of a lone launch, in percent of the device's wavefront slots, whose wavefronts request
 //                   their rows before the visited test (0 = off)
 //   "coop"          the two-wavefront walk for small batches (walk_coop.hip): -1 = where it serves and the batch leaves the room
-//                   (default), 0 = never, 1 = wherever the shape allows (tests; GBNNS_COOP)
+//                   (default), 0 = never, 1 / 2 = wherever the shape allows, with two / three wavefronts per query (tests, A/B runs;
+//                   the three-wavefront form measured slower; GBNNS_COOP)
+//   "coop_pack"     1 = launch the three-wavefront form with its own LDS only (default 0: a launch of at most c workgroups per CU asks for
+//                   1 / c of the CU's LDS each, so that the dispatcher spreads them evenly; GBNNS_COOP_PACK, A/B runs)
 // Process-wide only (gbnns_exact_knn has no handle):
 //   "knn_chunk"      most rows per filtered chunk (a multiple of 64)
 //   "knn_pool_min_k" shortest list gbnns_exact_knn keeps as an unordered pool (one wavefront per query and chunk) instead of a heap
@@ -196,7 +199,8 @@ bool knob_set(Knobs& k, const char* name, int value) {
     else if (!std::strcmp(name, "late_rows")) k.late_rows = std::max(-1, std::min(1, value));
     else if (!std::strcmp(name, "vs_fill2")) k.vs_fill2 = std::max(0, std::min(95, value));
     else if (!std::strcmp(name, "spec_tail")) k.spec_tail = std::max(0, std::min(100, value));
-    else if (!std::strcmp(name, "coop")) k.coop = std::max(-1, std::min(1, value));
+    else if (!std::strcmp(name, "coop")) k.coop = std::max(-1, std::min(2, value));
+    else if (!std::strcmp(name, "coop_pack")) k.coop_pack = value != 0;
     else return false;
     return true;
 }
@@ -216,6 +220,7 @@ static Knobs& knob_default_ref() {  // (function-local: initialised on first use
         knob_set(k, "vs_fill2", knob_env("GBNNS_VS_FILL2", 0));
         knob_set(k, "spec_tail", knob_env("GBNNS_SPEC_TAIL", 50));
         knob_set(k, "coop", knob_env("GBNNS_COOP", -1));
+        knob_set(k, "coop_pack", knob_env("GBNNS_COOP_PACK", 0));
         return k;
     }();
     return d;
@@ -575,7 +580,7 @@ int gbnns_index_knob_get(gbnns_index* ix, const char* name, int* out) {
     const struct { const char* n; int v; } all[] = {
         {"quotient", k.quotient}, {"vs_disp", k.vs_disp}, {"max_waves", k.max_waves}, {"spec_min_nq", k.spec_min_nq},
         {"spec_any_form", k.spec_any_form}, {"mlp_small", k.mlp_small}, {"mlp_net", k.mlp_net}, {"mlp_slab", k.mlp_slab},
-        {"late_rows", k.late_rows}, {"vs_fill2", k.vs_fill2}, {"spec_tail", k.spec_tail}, {"coop", k.coop}};
+        {"late_rows", k.late_rows}, {"vs_fill2", k.vs_fill2}, {"spec_tail", k.spec_tail}, {"coop", k.coop}, {"coop_pack", k.coop_pack}};
     for (const auto& e : all)
         if (!std::strcmp(name, e.n)) { *out = e.v; return GBNNS_OK; }
     return fail(GBNNS_ERR_INVALID, "gbnns_index_knob_get: unknown handle knob '%s'", name);

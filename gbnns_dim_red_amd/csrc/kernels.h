@@ -84,7 +84,9 @@ struct WalkParams {
     uint32_t spec_from;      // ... and in the tested-first instances, for the wavefronts from this work item on (the last, partial round
                              // of a launch walks a draining machine: the shorter hop wins there); 0xFFFFFFFF = none
     const uint32_t* order;   // optional [nq]: work item b of a first pass runs query order[b] (a permutation: locality order of a deep batch)
-    int32_t coop;            // 1: the first pass is the two-wavefront walk (walk_coop.hip: kCoopExtraLds more bytes of LDS per query)
+    int32_t coop;            // 1: the first pass is the two-wavefront walk (walk_coop.hip: kCoopExtraLds more bytes of LDS per query), 2: its three-wavefront form (+ kCoop3MoreLds)
+    uint32_t coop_lds_floor; // ... launched with at least this much LDS per workgroup: a batch of at most c workgroups per CU asks for 1 / c of the CU's LDS,
+                             // so that the dispatcher cannot stack more than c on one CU and leave others short (0: none)
     int32_t force_wide;      // diagnostic: treat the index as a large one (64-bit offsets, 4-byte visited-set slots)
     unsigned long long* stamps;  // diagnostic builds only (GBNNS_STAMPS): [32] segment cycle sums / histograms
     int32_t stamps_on;           // 1 in diagnostic builds: use the instrumented generic kernel
@@ -99,8 +101,9 @@ size_t walk_hash_bytes(uint32_t entries, int form);             // LDS bytes of 
 uint32_t walk_hash_entries(size_t bytes, int form);             // ids that fit into `bytes` (whole buckets)
 bool walk_knows_quotient(const WalkParams& p, int metric);      // the first-pass kernel of this shape reads p.vs_shr
 int walk_hash_form(const WalkParams& p, bool hot);              // the form the first pass uses (p.vs_shr chooses 2 for the hot kernels)
-size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list = false, bool coop = false);  // everything but the visited set
+size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list = false, int coop = 0);  // everything but the visited set
                                                                                              // (lds_list: walk_uses_lds_list; coop: WalkParams::coop)
+constexpr size_t kCoop3MoreLds = 768;   // three wavefronts: the ranger's own three slots of adjacency words
 constexpr size_t kCoopExtraLds = 1280;  // the two-wavefront walk's two 64-word result buffers + three 64-word slots of adjacency words requested ahead (its mailbox lives in the query area)
 bool walk_coop_serves(const WalkParams& p, int metric);   // shape the two-wavefront walk has an instance for (walk_coop.hip)
 hipError_t launch_walk_coop(const WalkParams& p, hipStream_t s);

@@ -211,7 +211,7 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
         w.coop = 0;
         if (knob != 0 && n_ent == 1 && !(a->flags & (GBNNS_FLAG_BITMAP_PASS | GBNNS_FLAG_WIDE_INDEX)) && walk_coop_serves(w, ix->metric) &&
             (knob > 0 || (nq <= 4u * cus && !in_flight)))
-            w.coop = 1;
+            w.coop = knob == 2 ? 2 : 1;   // (2: the three-wavefront form -- measured slower, 0.54 against 0.49 ms on the gist shape: tests and A/B runs only)
     }
     // the first pass's visited set: capacity, form (packed / quotient), the wavefronts per CU it leaves (sizing.cpp)
     FirstPassSizing fps = size_first_pass(ix, w, a, ef, skey, nq, sync_host);
@@ -223,6 +223,15 @@ int search_core(gbnns_index* ix, Lane& L, const gbnns_search_args* a, hipStream_
             w.coop = 0;
             fps = size_first_pass(ix, w, a, ef, skey, nq, sync_host);
         }
+    }
+    w.coop_lds_floor = 0;
+    if (w.coop) {
+        // (three-wavefront form) every workgroup of such a batch is resident at once; with c = ceil(n_q / CUs) of them per CU the launch
+        // asks for 1 / c of a CU's LDS per workgroup -- its registers and its own LDS would let the dispatcher stack more on one CU (three
+        // wavefronts each: a SIMD with four or five of them is the launch's tail) while other CUs sit half empty
+        const size_t cus = (size_t)(ix->cus > 0 ? ix->cus : 256);
+        const size_t c = std::max<size_t>(1, ((size_t)nq + cus - 1) / cus);
+        if (w.coop >= 2 && c <= 4 && ix->knob.coop_pack == 0) w.coop_lds_floor = (uint32_t)std::min<size_t>(64 * 1024, kMaxLds / c / kLdsGran * kLdsGran);
     }
     const bool hot = fps.hot, packed = fps.packed, auto_cap = fps.auto_cap;
     const int form = fps.form;

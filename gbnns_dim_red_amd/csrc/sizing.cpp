@@ -12,7 +12,7 @@ namespace gbnns_api {
 FirstPassSizing size_first_pass(gbnns_index* ix, WalkParams& w, const gbnns_search_args* a, int ef, int skey, uint32_t nq, bool sync_host) {
     const bool hot = walk_uses_hot(w, ix->metric);
     const bool packed = walk_uses_packed(w);
-    const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride, hot, walk_uses_lds_list(w), w.coop != 0);
+    const size_t lds_fixed = walk_fast_lds_fixed_bytes(ef, w.dstride, hot, walk_uses_lds_list(w), w.coop);
     // The hot first pass may keep its visited set in the quotient form (walk_hot.hip, GBNNS_VS_ASM: seven 16-bit entries
     // per bucket instead of five 24-bit ids): ids are told apart inside a home bucket by W - floor(log2 buckets) <= 13
     // bits (n <= 2^W), so the table needs at least 2^(W-13) buckets.

@@ -34,6 +34,8 @@
 // (search_core.cpp; knob "coop").
 #define GBNNS_WAVE_LOCAL_SYNC 1
 #define GBNNS_COOP_HINT 1
+#include <algorithm>
+
 #include "launch_util.h"
 #include "walk_lists.h"
 
@@ -227,7 +229,13 @@ __device__ __forceinline__ void coop_unclaim(uint32_t won, bool quotient) {
 //   * The keeper can post at most ONE selection the scout has not read: the post after that needs an expansion the scout prepares only
 //     after reading -- so two post slots are enough, and a post the scout finds skipped (kMbSeq two ahead) was a hit: its prepared
 //     expansion has been taken, the post in front of it is the one the keeper is waiting on.
-enum { kMbPost0 = 0, kMbPost1 = 4, kMbReady = 8, kMbSeq = 9, kMbK0 = 10, kMbKept = 11, kMbBestB = 12 };
+// Three wavefronts (the scout split into a CLAIMER and a RANGER, see coop_agent3): the buffer of an expansion is a function of the post
+// it answers -- post s is answered from buffer s & 1, whether expanded on demand or prepared after post s - 1 -- so that both agents
+// write the halves of the same buffer, and each agent publishes PER BUFFER: kMbRdC + b / kMbRdR + b = the node whose claimer / ranger
+// half sits in buffer b (the claimer's with stash-full << 31).  A word keeps naming its node until its owner rewrites that buffer, two
+// posts later: an agent that lags a phase behind the other still finds the other's half of the expansion it is working on.
+// kMbBestC: the ranger's re-rank result.
+enum { kMbPost0 = 0, kMbPost1 = 4, kMbReady = 8, kMbSeq = 9, kMbK0 = 10, kMbKept = 11, kMbBestB = 12, kMbBestC = 14, kMbRdC = 16, kMbRdR = 18 };
 typedef __attribute__((address_space(3))) uint32_t coop_lds_u32;
 __device__ __forceinline__ uint32_t coop_peek(const uint32_t* w) {   // one LDS word, read now (never hoisted out of a polling loop)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -241,24 +249,255 @@ __device__ __forceinline__ void coop_flag(uint32_t* w, uint32_t value, int lane)
     if (lane == 0) __hip_atomic_store(w, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// ---- three wavefronts per query: the scout's two halves as two wavefronts -----------------------------------------------------------
+// Where the two-wavefront hop goes (profiles/r06_coop_stamps.txt, v8): the scout's expansion is 3 700 cycles -- adjacency words 480,
+// claims 1 200, rows + distances 1 060, closest new id 540 -- against 2 900 of list work in the keeper: the scout is the hop.  Its claims
+// and its distances do not need each other (rows are requested before the claims; a distance does not depend on the visited set), so
+// they are two wavefronts here: the CLAIMER (ROLE 1, wavefront 1) owns the visited set and publishes, per neighbour slot, the id and
+// whether it is new (even buffer words, kMbRdC); the RANGER (ROLE 2, wavefront 2) owns the query registers and publishes the distance
+// of every stored neighbour, new or not (odd buffer words, kMbRdR).  The keeper takes an expansion when both words of the post's buffer
+// name its node.  Both agents run the scout's loop -- read a post, expand its node now if it is not what they prepared, predict
+// the next node, expand that ahead -- and predict from the same data (the closest new id of the expansion just consumed needs the
+// claimer's flags and the ranger's distances: each waits for the other's half and reads the buffer), so they prepare the same node as a
+// rule; when they do not (a half read while it was being rewritten), one of them expands on demand: predictions only ever cost time.
+// Exactness is the two-wavefront argument: one writer of the visited set, claims kept in visit order, a wrong prepared expansion's
+// claims taken back before anything else is claimed; distances are stateless.  Every wait gives up after kCoopSpinLimit polls (a
+// protocol error, never seen): the keeper then hands the query to the retry pass, which is exact by itself.
+constexpr uint32_t kCoopSpinLimit = 1u << 21;
+
+template <int STEPS, int ROLE>
+__device__ __forceinline__ void coop_agent3(const WalkParams& p, uint32_t* mbox, uint32_t* bufs, uint32_t* pfs, uint32_t* hash, uint32_t nbuckets,
+                                            const RowRegs<STEPS / 2>& qreg, int lane) {
+    static_assert(ROLE == 1 || ROLE == 2, "claimer, ranger");
+    constexpr int kQSteps = STEPS / 2;
+    constexpr uint32_t kRowBytes = (uint32_t)STEPS * 16u;
+    constexpr bool kClaims = ROLE == 1;
+    const uint32_t slot = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;
+    const uint32_t vs_shr = p.vs_shr;
+    const uint32_t hash_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(hash));
+    uint32_t* const mine = mbox + (kClaims ? kMbRdC : kMbRdR);          // [buffer]
+    const uint32_t* const other = mbox + (kClaims ? kMbRdR : kMbRdC);
+    uint32_t prepared = kCoopNoNode, pbuf = 0u, r_won = 0u;      // the expansion held ready (its buffer; the slots its claims wrote)
+    uint32_t e_for = kCoopNoNode, e_cmin = 0xFFFFFFFFu, e_cnode = kCoopNoNode;   // closest new id of the expansion of node e_for
+    uint32_t pfn0 = kCoopNoNode, pfn1 = kCoopNoNode, pfn2 = kCoopNoNode;
+    const uint32_t* const ell = p.ell;
+    const uint32_t aslot = slot < p.ell_stride ? slot : p.ell_stride - 1u;
+    auto adjacency = [&](uint32_t node) -> uint32_t {
+        const uint32_t* row = reinterpret_cast<const uint32_t*>(row_ptr<true>(reinterpret_cast<const float*>(ell), node, p.ell_stride));
+        return (slot < p.ell_stride) ? row[slot] : kInvalidId;
+    };
+    const uint32_t pfs_lds = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(pfs));
+    auto request_adjacency = [&](uint32_t k, uint32_t node) {   // node's adjacency words -> this agent's LDS slot k (wave-uniform arguments)
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(row_ptr<true>(reinterpret_cast<const float*>(ell), node, p.ell_stride)) + aslot;
+        const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pfs_lds + 256u * k));
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
+    auto requested_slot = [&](uint32_t node) -> int { return node == pfn0 ? 0 : (node == pfn1 ? 1 : (node == pfn2 ? 2 : -1)); };
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto expand = [&](uint32_t node, uint32_t bufno, bool ahead, uint32_t ahead1, uint32_t ahead2) -> bool {
+        uint32_t* const buf = bufs + 64 * bufno;
+        uint32_t nb;
+        const int have = requested_slot(node);
+        if (have >= 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t wv = pfs[64 * have + lane];
+            nb = (slot < p.ell_stride) ? wv : kInvalidId;
+        } else {
+            nb = adjacency(node);
+        }
+        const bool valid = nb != kInvalidId;
+        const uint64_t mv = __ballot(valid);
+        RowRegs<kQSteps> rr;
+        uint32_t roff = 0;
+        if constexpr (!kClaims) {   // every lane loads (empty slots: row 0), as in walk_reg_big_one
+            const uint32_t nbl = valid ? nb : 0u;
+            roff = nbl * kRowBytes + half * (kRowBytes / 2u);
+            load_row<kQSteps>(rr, reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.db) + roff));
+        }
+        if (ahead1 != kInvalidId && ahead1 != node && requested_slot(ahead1) < 0) {
+            pfn1 = ahead1;
+            request_adjacency(1u, ahead1);
+        }
+        if (ahead2 < p.n && ahead2 != node && requested_slot(ahead2) < 0) {
+            pfn2 = ahead2;
+            request_adjacency(2u, ahead2);
+        }
+        if constexpr (kClaims) {
+            bool stash_full = false;
+            uint64_t mclaimed, movf = 0;
+            uint32_t won;
+            const uint32_t hl = uni(hash_lds), nbk = uni(nbuckets), ctl = uni(vs_shr);
+            if (ctl) mclaimed = coop_claim_quotient(hl, nbk, nb, mv & 0x5555555555555555ull, ctl, movf, won);
+            else mclaimed = coop_claim_packed(hl, nbk, nb, mv & 0x5555555555555555ull, won);
+            if (__builtin_expect(movf != 0, 0)) {
+                if (ahead) {   // a probe sequence ran out: not ahead of time (the stash cannot be undone)
+                    coop_unclaim(won, true);
+                    return false;
+                }
+                if (!stash_claim(hl, nbk, movf, nb, mclaimed, lane)) stash_full = true;   // the keeper hands the query over
+            }
+            const bool fresh = __builtin_amdgcn_inverse_ballot_w64(mclaimed);   // (even lanes)
+            if (!half) buf[lane] = valid ? (nb | (fresh ? 0x80000000u : 0u)) : 0xFFFFFFFFu;
+            coop_flag(mine + bufno, node | (stash_full ? 1u << 31 : 0u), lane);
+            r_won = won;
+        } else {
+            (void)mv;
+            uint32_t kd;
+            if constexpr (STEPS == 8) kd = fkey_sumsq(l2_pair_from_regs(rr, qreg.v));
+            else kd = fkey_sumsq(l2_pair_from_regs_wide<kQSteps>(rr, qreg.v));
+            asm volatile("" ::"v"(roff));  // the address register must not double as a load destination
+            if (half) buf[lane] = kd;
+            coop_flag(mine + bufno, node, lane);
+        }
+        return true;
+    };
+    // the closest NEW id of the expansion in buffer `bufno` (both halves there), and its adjacency words requested now
+    auto closest_new = [&](uint32_t bufno) {
+        const uint64_t rv = reinterpret_cast<const uint64_t*>(bufs + 64 * bufno)[lane & 31];
+        const uint32_t w0 = lane < 32 ? (uint32_t)rv : 0xFFFFFFFFu;
+        const bool fresh = w0 != 0xFFFFFFFFu && (w0 >> 31) != 0u;
+        uint32_t x = fresh ? (uint32_t)(rv >> 32) : 0xFFFFFFFFu;
+        const uint32_t dkf = x;
+        x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));   // quad_perm 1,0,3,2
+        x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));   // quad_perm 2,3,0,1
+        x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));  // row_half_mirror
+        x = min(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));  // row_mirror
+        const uint32_t dmin = min(readlane_u32(x, 0), readlane_u32(x, 16));
+        e_cmin = 0xFFFFFFFFu;
+        e_cnode = kCoopNoNode;
+        if (dmin != 0xFFFFFFFFu) {
+            const uint64_t me = __ballot(fresh && dkf == dmin);
+            if (me && (me & (me - 1)) == 0) {   // unique
+                const uint32_t c = readlane_u32(w0 & 0x7FFFFFFFu, __ffsll((unsigned long long)me) - 1);
+                if (c < p.n) {   // (a half read while its owner rewrites it can be anything: a prediction, checked)
+                    e_cmin = dmin;
+                    e_cnode = c;
+                    if (requested_slot(c) < 0) {
+                        pfn0 = c;
+                        request_adjacency(0u, c);
+                    }
+                }
+            }
+        }
+    };
+    // waits until the other agent's half of (node, bufno) is there, then takes the closest new id; gives up when the keeper has moved on
+    // (post number beyond `seen`: it consumed that expansion, the other agent may be rewriting the buffer)
+    auto pair_up = [&](uint32_t node, uint32_t bufno, uint32_t seen) {
+        uint32_t spins = 0;
+        while (true) {
+            if ((coop_peek(other + bufno) & 0x7FFFFFFFu) == node) {
+                asm volatile("" ::: "memory");
+                closest_new(bufno);
+                e_for = node;
+                return;
+            }
+            if (coop_peek(mbox + kMbSeq) > seen || ++spins > kCoopSpinLimit) return;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    uint32_t expect = 0;
+#ifdef GBNNS_STAMPS
+    unsigned long long seg[5] = {0, 0, 0, 0, 0};
+    unsigned n_hit = 0, n_miss = 0, n_noec = 0, n_gsurv = 0;
+#endif
+    while (true) {
+        STAMP(a0)
+        if (prepared != kCoopNoNode && e_for != prepared) pair_up(prepared, pbuf, expect);   // under the keeper's list work
+        STAMP(a1)
+        STAMP_ADD(3, a0, a1)
+        uint32_t seq, spins = 0;
+        while ((seq = coop_peek(mbox + kMbSeq)) <= expect) {
+            if (++spins > kCoopSpinLimit) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        if (seq <= expect) break;   // (gave up: the keeper's own wait hands the query over)
+        if (seq != expect + 1u) prepared = kCoopNoNode;   // a post was skipped: it took the prepared expansion (see the mailbox notes)
+        expect = seq;
+        const uint4 post = *reinterpret_cast<const uint4*>(mbox + (((seq - 1u) & 1u) ? kMbPost1 : kMbPost0));
+        const uint32_t node = uni(post.x), pred = uni(post.y), h2 = uni(post.z), hint = uni(post.w);
+        if (node == kCoopDone) break;
+        STAMP(a2)
+        STAMP_ADD(0, a1, a2)
+#ifdef GBNNS_STAMPS
+        if (node != prepared) n_miss += 1; else n_hit += 1;
+#endif
+        const uint32_t bufno = seq & 1u;
+        if (node != prepared) {   // not what was prepared (or nothing was): the keeper is waiting
+            if constexpr (kClaims) {
+                if (prepared != kCoopNoNode) coop_unclaim(r_won, vs_shr != 0u);
+            }
+            expand(node, bufno, false, pred, hint);
+        }
+        STAMP(a3)
+        STAMP_ADD(1, a2, a3)
+        if (e_for != node) pair_up(node, bufno, seq);
+        STAMP(a4)
+        STAMP_ADD(4, a3, a4)
+        // the next node, probably: the closest new id just handed over if it beats the runner-up, else the runner-up
+        uint32_t guess = pred == kInvalidId ? kCoopNoNode : pred;
+        if (e_for == node && e_cmin < h2 && e_cnode != kCoopNoNode) guess = e_cnode;
+#ifdef GBNNS_STAMPS
+        if (e_for != node) n_noec += 1;
+        if (e_for == node && e_cmin < h2 && e_cnode != kCoopNoNode) n_gsurv += 1;
+#endif
+        prepared = kCoopNoNode;
+        if (guess != kCoopNoNode && guess < p.n) {
+            pbuf = (seq + 1u) & 1u;
+            if (expand(guess, pbuf, true, pred, hint)) prepared = guess;
+        }
+        STAMP(a5)
+        STAMP_ADD(2, a4, a5)
+    }
+#ifdef GBNNS_STAMPS
+    if (lane == 0 && p.stamps) {   // claimer: words 8 .. 15 (+ 25), ranger: 16 .. 23 (+ 24)
+        unsigned long long* st = p.stamps + (kClaims ? 8 : 16);
+        for (int i = 0; i < 5; ++i) atomicAdd(st + i, seg[i]);
+        atomicAdd(st + 5, (unsigned long long)n_hit); atomicAdd(st + 6, (unsigned long long)n_miss); atomicAdd(st + 7, (unsigned long long)n_noec);
+        atomicAdd(p.stamps + (kClaims ? 25 : 24), (unsigned long long)n_gsurv);
+    }
+#endif
+}
+
 // LDS: [BigList: big_list_fixed_bytes(ef)][mailbox: dstride floats][result buffers: 2 x 64 words][adjacency words requested ahead: 3 x 64]
 //      [visited set | re-rank scratch]
 // Result buffer word 2 s     = slot s's id | 0x80000000 when the id is NEW (the scout's claim won); all-ones: empty slot
 //               word 2 s + 1 = its distance key (meaningful with the flag)
-template <int STEPS, bool LATE>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) void walk_coop_kernel(WalkParams p) {
+template <int STEPS, bool LATE, int NW>
+// (registers: the attribute's upper bound is what the compiler pads the allocation to.  Three wavefronts per SIMD is what a batch of four
+// workgroups per CU needs, but an allocation of exactly 512 / 3 leaves the dispatcher no slack -- a CU whose SIMDs are not filled in
+// rotation cannot take its fourth workgroup, and 15 - 30 of 1 000 workgroups started only when others had ended, half a millisecond
+// late: the three-wavefront form allows four per SIMD and leaves the per-CU count to the launch's LDS size, coop_lds_floor)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, NW == 3 ? 4 : 2))) void walk_coop_kernel(WalkParams p) {
     static_assert(STEPS == 8 || STEPS == 12 || STEPS == 16, "pair-form rows of 128 / 192 / 256 bytes");
+    static_assert(NW == 2 || (NW == 3 && !LATE), "keeper + scout, or keeper + claimer + ranger (whose rows never wait for the claims)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kQSteps = STEPS / 2;
     constexpr uint32_t kRowBytes = (uint32_t)STEPS * 16u;
+    constexpr int kRerankLoads = (STEPS >= 12 && NW == 2) ? 24 : 8;   // row pieces in flight per lane (three wavefronts share 512 registers a lane)
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t qi = walk_query_of(p, blockIdx.x);
     const int ef = p.ef;
+    STAMP(k_begin)
+#ifdef GBNNS_STAMPS
+#ifdef GBNNS_STAMPS_SPREAD
+    constexpr bool kSpread = true;    // (EXTRA_DEFS=-DGBNNS_STAMPS_SPREAD: the launch's residency stamps for the two-wavefront form too, in place of its scout's words 24 .. 31)
+#else
+    constexpr bool kSpread = NW == 3;
+#endif
+    if (kSpread && threadIdx.x == 0 && p.stamps) {   // how many workgroups are alive at once (30: now, 31: the most)
+        const unsigned long long alive = atomicAdd(p.stamps + 30, 1ull) + 1ull;
+        atomicMax(p.stamps + 31, alive);
+    }
+    const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();   // (100 MHz, one clock for the whole device)
+#endif
     uint32_t* const mbox = reinterpret_cast<uint32_t*>(smem + big_list_fixed_bytes(ef));
     uint32_t* const bufs = mbox + p.dstride;                          // 2 x 64 words
-    uint32_t* const pfs = bufs + 128;                                 // 3 x 64 words: adjacency words requested ahead (scout)
-    uint32_t* const hash = pfs + 192;
+    uint32_t* const pfs = bufs + 128;                                 // 3 x 64 words: adjacency words requested ahead (scout; NW == 3: claimer, then the ranger's)
+    uint32_t* const hash = pfs + 192 * (NW - 1);
     unsigned char* const after_q = reinterpret_cast<unsigned char*>(hash);
     const uint32_t cap = p.hash_cap;
     const uint32_t vs_shr = p.vs_shr;
@@ -269,8 +508,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     {
         const uint32_t words = vs_shr ? (nbuckets + kStashBuckets) * 4u : nbuckets * 4u;
         const uint32_t empty3 = vs_shr ? 0xF000FFFFu : 0x00FFFFFFu;
-        for (uint32_t i = threadIdx.x; i < words; i += 128) hash[i] = (i & 3u) == 3u ? empty3 : 0xFFFFFFFFu;
+        for (uint32_t i = threadIdx.x; i < words; i += 64 * NW) hash[i] = (i & 3u) == 3u ? empty3 : 0xFFFFFFFFu;
         if (threadIdx.x == 0) { mbox[kMbReady] = kCoopNoNode; mbox[kMbSeq] = 0u; }
+        if (NW == 3 && threadIdx.x < 4) mbox[kMbRdC + threadIdx.x] = kCoopNoNode;   // (kMbRdC + 0 / 1, kMbRdR + 0 / 1)
     }
     const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p.entries ? p.entries[qi] : 0u));
     if (entry >= p.n) {  // (both wavefronts take this exit)
@@ -278,8 +518,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         return;
     }
     const uint32_t slot = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;
-    RowRegs<kQSteps> qreg;   // scout: this lane's half of the query
-    if (wave == 1) {
+    RowRegs<kQSteps> qreg;   // scout (NW == 3: ranger): this lane's half of the query
+    if (wave == NW - 1) {
         const float4* q4 = reinterpret_cast<const float4*>(p.q + (size_t)qi * p.qstride);
 #pragma unroll
         for (int t = 0; t < kQSteps; ++t) qreg.v[t] = q4[kQSteps * half + t];
@@ -331,7 +571,18 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             coop_flag(mbox + kMbSeq, kseq, lane);   // posted (post number kseq sits in slot (kseq - 1) & 1)
             if (status) break;
             uint32_t rdy;     // the scout's expansion of `node` (prepared ahead: there already)
-            while (((rdy = coop_peek(mbox + kMbReady)) & 0x3FFFFFFFu) != node) __builtin_amdgcn_s_sleep(1);
+            if constexpr (NW == 2) {
+                while (((rdy = coop_peek(mbox + kMbReady)) & 0x3FFFFFFFu) != node) __builtin_amdgcn_s_sleep(1);
+            } else {          // the claimer's half and the ranger's in the buffer of this post
+                const uint32_t b = kseq & 1u;
+                uint32_t spins = 0;
+                while (true) {
+                    const uint32_t rc = coop_peek(mbox + kMbRdC + b), rr = coop_peek(mbox + kMbRdR + b);
+                    if ((rc & 0x7FFFFFFFu) == node && rr == node) { rdy = b << 30 | (rc & 0x80000000u); break; }
+                    if (++spins > kCoopSpinLimit) { rdy = 0x80000000u; break; }   // (never, unless the protocol is broken: hand the query over)
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
             asm volatile("" ::: "memory");
             const uint32_t rb = rdy >> 30;   // bit 0: buffer, bit 1: the scout's stash is full
             STAMP(t2)
@@ -368,6 +619,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             if (lane == 0 && p.stamps) {
                 for (int i = 0; i < 4; ++i) atomicAdd(p.stamps + i, seg[i]);
                 atomicAdd(p.stamps + 6, t_end - t_begin);
+                atomicAdd(p.stamps + 4, t_begin - k_begin);   // set-up
+                atomicMax(p.stamps + 7, t_end - t_begin);     // the longest walk
             }
         }
 #endif
@@ -392,18 +645,42 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const uint64_t* b = B.base;
         uint64_t bestk = ~0ull;
         auto id_at = [&](int r) { return key_id(b[kept - 1 - r]); };
-        if (p.rr_metric == 1) rerank_pairs_core<1>(a, qi, kept, reinterpret_cast<float*>(after_q), lane, id_at, 0, 2, &bestk);
-        else rerank_pairs_core<0, (STEPS >= 12 ? 24 : 8)>(a, qi, kept, reinterpret_cast<float*>(after_q), lane, id_at, 0, 2, &bestk);
-        coop_barrier();   // G: the scout's best key is posted
-        const uint64_t other = *reinterpret_cast<const uint64_t*>(mbox + kMbBestB);
+        if (p.rr_metric == 1) rerank_pairs_core<1>(a, qi, kept, reinterpret_cast<float*>(after_q), lane, id_at, 0, NW, &bestk);
+        else rerank_pairs_core<0, kRerankLoads>(a, qi, kept, reinterpret_cast<float*>(after_q), lane, id_at, 0, NW, &bestk);
+        coop_barrier();   // G: the other wavefronts' best keys are posted
+        uint64_t other = *reinterpret_cast<const uint64_t*>(mbox + kMbBestB);
+        if constexpr (NW == 3) {
+            const uint64_t o2 = *reinterpret_cast<const uint64_t*>(mbox + kMbBestC);
+            other = o2 < other ? o2 : other;
+        }
         const uint64_t best = other < bestk ? other : bestk;
         const int win = (kept > 0 && best != ~0ull) ? (int)(uint32_t)best : -1;
         const uint32_t ans = key_id(b[win >= 0 ? kept - 1 - win : 0]);
         if (lane == 0) p.rr_out[qi] = win >= 0 ? ans : kInvalidId;
+#ifdef GBNNS_STAMPS
+        {
+            STAMP(k_end)
+            if (lane == 0 && p.stamps) {
+                atomicAdd(p.stamps + 5, k_end - k_begin);      // the keeper's whole life
+                if (kSpread) {
+                    const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
+                    atomicMax(p.stamps + 26, (1ull << 62) - r_begin);   // (the earliest start, from 2^62 down)
+                    atomicMax(p.stamps + 27, r_begin);         // the latest start
+                    atomicMax(p.stamps + 28, r_end);           // the latest end
+                    atomicMax(p.stamps + 29, k_end - k_begin); // the longest life
+                    atomicAdd(p.stamps + 30, ~0ull);           // (one fewer alive)
+                }
+            }
+        }
+#endif
         return;
     }
 
     // ====================================================== SCOUT ======================================================
+    if constexpr (NW == 3) {
+        if (wave == 1) coop_agent3<STEPS, 1>(p, mbox, bufs, pfs, hash, nbuckets, qreg, lane);
+        else coop_agent3<STEPS, 2>(p, mbox, bufs, pfs + 192, hash, nbuckets, qreg, lane);
+    } else {
     // The expansion it holds ready: of node `spec_node`; r_won = the slots its claims wrote (even lanes).
     // e_cmin / e_cnode: the closest new id of the last expansion handed over or prepared (all-ones / none), for the prediction.
     // Adjacency words requested ahead go straight into LDS (global_load_lds_dword: no register is written while the load is in flight,
@@ -586,10 +863,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         atomicAdd(p.stamps + 19, (unsigned long long)n_hit); atomicAdd(p.stamps + 20, (unsigned long long)n_miss);
         atomicAdd(p.stamps + 21, (unsigned long long)n_noguess); atomicAdd(p.stamps + 22, (unsigned long long)n_guess_surv);
         atomicAdd(p.stamps + 23, (unsigned long long)n_abort);
+#ifndef GBNNS_STAMPS_SPREAD
         for (int i = 0; i < 4; ++i) atomicAdd(p.stamps + 28 + i, it_t[i]);   // 28 .. 31: when the scout's iterations 0 .. 3 began, since its loop started
         for (int i = 3; i < 7; ++i) atomicAdd(p.stamps + 21 + i, seg[i]);   // 24 .. 27: inside the expansions (adjacency word, claims, rows + distances, tail)
+#endif
     }
 #endif
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (adjacency words still in flight)
     coop_barrier();   // F
     const uint32_t keptw = (uint32_t)__builtin_amdgcn_readfirstlane((int)mbox[kMbKept]);
@@ -603,23 +883,24 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         // (the same staging area as the keeper's: both wavefronts write the whole original-space query there -- the same values -- and
         // each reads what it has written itself, in its own issue order)
         float* qf = reinterpret_cast<float*>(after_q);
-        if (p.rr_metric == 1) rerank_pairs_core<1>(a, qi, kept, qf, lane, id_at, 1, 2, &bestk);
-        else rerank_pairs_core<0, (STEPS >= 12 ? 24 : 8)>(a, qi, kept, qf, lane, id_at, 1, 2, &bestk);
-        if (lane == 0) *reinterpret_cast<uint64_t*>(mbox + kMbBestB) = bestk;
+        if (p.rr_metric == 1) rerank_pairs_core<1>(a, qi, kept, qf, lane, id_at, wave, NW, &bestk);
+        else rerank_pairs_core<0, kRerankLoads>(a, qi, kept, qf, lane, id_at, wave, NW, &bestk);
+        if (lane == 0) *reinterpret_cast<uint64_t*>(mbox + (wave == 1 ? kMbBestB : kMbBestC)) = bestk;
     }
     coop_barrier();   // G
 }
 
 template <int STEPS>
 hipError_t launch_coop_t(const WalkParams& p, size_t lds, hipStream_t s) {
-    auto go = [&](auto kernel) -> hipError_t {
+    auto go = [&](auto kernel, unsigned threads) -> hipError_t {
         hipError_t e = set_lds(kernel, lds);
         if (e != hipSuccess) return e;
         g_walk_first_fn = reinterpret_cast<const void*>(kernel);
-        hipLaunchKernelGGL(kernel, dim3(p.nq), dim3(128), lds, s, p);
+        hipLaunchKernelGGL(kernel, dim3(p.nq), dim3(threads), lds, s, p);
         return hipGetLastError();
     };
-    return p.late_rows ? go(walk_coop_kernel<STEPS, true>) : go(walk_coop_kernel<STEPS, false>);
+    if (p.coop >= 2) return go(walk_coop_kernel<STEPS, false, 3>, 192u);
+    return p.late_rows ? go(walk_coop_kernel<STEPS, true, 2>, 128u) : go(walk_coop_kernel<STEPS, false, 2>, 128u);
 }
 
 }  // namespace
@@ -634,7 +915,7 @@ bool walk_coop_serves(const WalkParams& p, int metric) {
 hipError_t launch_walk_coop(const WalkParams& p, hipStream_t s) {
     if (p.nq == 0) return hipSuccess;
     if (!walk_coop_serves(p, 0)) return hipErrorInvalidValue;
-    const size_t lds = walk_fast_lds_bytes(p, false);
+    const size_t lds = std::max<size_t>(walk_fast_lds_bytes(p, false), p.coop_lds_floor);
     switch (p.dim) {
         case 32: return launch_coop_t<8>(p, lds, s);
         case 48: return launch_coop_t<12>(p, lds, s);

@@ -16,8 +16,8 @@ bool walk_uses_hot(const WalkParams& p, int metric) {
 
 // LDS of one wavefront without the visited set.  Register kernels: tie list + merge buffer + query; the
 // hot kernel stages the query inside the merge buffer (it lives in registers once the walk starts).
-size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list, bool coop) {
-    if (coop) return big_list_fixed_bytes(ef) + (size_t)dstride * 4 + kCoopExtraLds;  // (walk_coop.hip: the two-list layout + result buffers)
+size_t walk_fast_lds_fixed_bytes(int ef, uint32_t dstride, bool hot, bool lds_list, int coop) {
+    if (coop) return big_list_fixed_bytes(ef) + (size_t)dstride * 4 + kCoopExtraLds + (coop >= 2 ? kCoop3MoreLds : 0);  // (walk_coop.hip: the two-list layout + result buffers)
     if (hot)  // tie list + merge buffer of 1 / 2 list registers; ef > 128: + the base list and the flush's flag bytes (walk_hot_big)
         return ef <= 64 ? (size_t)kRegTieCap * 8 + (size_t)kRegStageSlots * 8 + (GBNNS_HOT1_QLDS ? 128 : 0)   // (+ the query, re-read every hop)
                         : (ef <= kHot2MaxEf ? (size_t)kRegTieCap * 8 + (size_t)(64 * 2 + 2) * 8 : big_list_fixed_bytes(ef));
@@ -50,7 +50,7 @@ bool walk_knows_quotient(const WalkParams& p, int metric) {
 bool walk_uses_packed(const WalkParams& p) { return walk_uses_lds_list(p) ? (p.n <= 0xFFFFFFu && !p.force_wide) : walk_off32(p); }
 
 size_t walk_fast_lds_bytes(const WalkParams& p, bool hot) {
-    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p), p.coop != 0) + walk_hash_bytes(p.hash_cap, walk_hash_form(p, hot));
+    return walk_fast_lds_fixed_bytes(p.ef, p.dstride, hot, walk_uses_lds_list(p), p.coop) + walk_hash_bytes(p.hash_cap, walk_hash_form(p, hot));
 }
 
 thread_local const void* g_walk_first_fn = nullptr;

@@ -1801,9 +1801,11 @@ def test_plain_walks_over_long_rows_four_lanes_per_row(g, orc):
         ix.close()
 
 
-def test_two_wavefront_walk_vs_oracle(g, orc):
-    """The two-wavefront walk for small batches (csrc/walk_coop.hip: a keeper wavefront with the result lists and the exact visited
-    set, a scout wavefront that expands the predicted next node ahead; getOneSearchResults + makeStep, search_function.h:15-102) --
+@pytest.mark.parametrize("waves", [2, 3])
+def test_two_wavefront_walk_vs_oracle(g, orc, waves):
+    """The two- and three-wavefront walks for small batches (csrc/walk_coop.hip: a keeper wavefront with the result lists, a scout
+    wavefront with the exact visited set that expands the predicted next node ahead -- or, three wavefronts, a claimer with the visited
+    set and a ranger with the query; getOneSearchResults + makeStep, search_function.h:15-102) --
     every shape it serves (walked rows of 128 / 192 / 256 bytes), beams across the two-list range, both forms of the visited set,
     rows requested before / after the scout's test, visited sets too small (hand-over chain through the retry pass and the general
     kernel), probe sequences cut short (stash), no re-rank room, PLAIN walks with k = 1 and k = ef: candidate lists in pop order,
@@ -1820,14 +1822,15 @@ def test_two_wavefront_walk_vs_oracle(g, orc):
             for knobs, cap, flags in (({}, 0, 0), ({"quotient": 0}, 0, 0), ({"late_rows": 1}, 0, 0), ({"late_rows": 0}, 0, 0),
                                       ({}, max(256, maxdc // 2), 0), ({"quotient": 0}, max(256, maxdc // 2), 0), ({"vs_disp": 1}, 0, 0),
                                       ({"vs_disp": 2}, maxdc + maxdc // 8 + 64, 0), ({}, 0, g.FLAG_NO_FUSED_RERANK), ({"coop": 0}, 0, 0)):
-                for name, val in {**dict(coop=1, quotient=1, late_rows=-1, vs_disp=15), **knobs}.items():
+                for name, val in {**dict(coop=waves - 1, quotient=1, late_rows=-1, vs_disp=15), **knobs}.items():
                     ix.knob(name, val)
                 for rep in range(2):  # (the second call runs with the capacity the first one's statistics ask for)
                     ix.profile_read(reset=True)
                     r = ix.search(c.queries, ef, entry_ids=ent, want=("hops", "dist_calc", "cand", "cand_dist", "edges"), hash_capacity=cap, flags=flags)
                     key = (dlow, ef, tuple(knobs.items()), cap, flags, rep)
                     launched = ix.profile_read(reset=True)["walk_kernel"]
-                    assert launched.startswith("walk_coop_kernel<%d," % (dlow // 4)) == (knobs.get("coop", 1) == 1), (key, launched)
+                    assert launched.startswith("walk_coop_kernel<%d," % (dlow // 4)) == (knobs.get("coop", 1) != 0), (key, launched)
+                    assert knobs.get("coop", 1) == 0 or launched.split(" (")[0].endswith(", %d>" % waves), (key, launched)
                     assert np.array_equal(r["cand"], w["ids"]), key
                     assert np.array_equal(gu.bits(r["cand_dist"]), gu.bits(w["dists"])), key
                     assert np.array_equal(r["hops"], w["hops"]), key
@@ -1835,7 +1838,7 @@ def test_two_wavefront_walk_vs_oracle(g, orc):
                     assert np.array_equal(r["ids"], s["ids"]), key
         # PLAIN walks over the low-dimensional vectors themselves (an index whose original space IS the walked one), k = 1 and k = ef
         ixp = g.Index(db_low, off, nbr)
-        ixp.knob("coop", 1)
+        ixp.knob("coop", waves - 1)
         ixp.profile_enable(True)
         for ef, k in ((150, 150), (300, 1), (300, 7)):
             w = orc.walk(q_low, db_low, off, nbr, ef, k=k, entries=ent, threads=8)
@@ -1861,7 +1864,7 @@ def test_two_wavefront_walk_vs_oracle(g, orc):
     assert ix.profile_read(reset=True)["walk_kernel"].startswith("walk_coop_kernel<16,")
     assert np.array_equal(r["ids"].cpu().numpy().view(np.uint32), s["ids"])
     ix.profile_enable(False)
-    for knob in (-1, 1):
+    for knob in (-1, waves - 1):
         ix.knob("coop", knob)
         outs = [ix.search(q, 200, entry_ids=e, want=("hops",), out={}, flags=g.FLAG_DEFER_JOIN, defer_depth=3) for _ in range(5)]
         ix.join()
@@ -1877,7 +1880,7 @@ def test_two_wavefront_walk_vs_oracle(g, orc):
     off, nbr = datagen.random_graph(rng, c.n, 3, 30)
     ent = rng.integers(0, c.n, size=c.nq).astype(np.uint32)
     ix = g.Index(c.base, off, nbr)
-    ix.knob("coop", 1)
+    ix.knob("coop", waves - 1)
     ix.profile_enable(True)
     for ef in (130, 250, 600):
         w = orc.walk(c.queries, c.base, off, nbr, ef, entries=ent, threads=8)

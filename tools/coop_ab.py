@@ -10,11 +10,13 @@ ds = synth.make_dataset(device="cuda:0", cache_dir="/tmp/gbnns_cache", **kw)
 ix = ds.index()
 q = ds.queries
 ref = None
-for name, knobs in (("one wavefront", dict(coop=0)), ("coop, rows touched ahead", dict(coop=1)), ("coop, no touches", dict(coop=1, spec_min_nq=1, spec_any_form=1)),
-                    ("one wavefront", dict(coop=0)), ("coop, rows touched ahead", dict(coop=1))):
-    for k, v in {**dict(coop=-1, spec_min_nq=32768, spec_any_form=0), **knobs}.items():
+# A/B of the small-batch walks on the gist shape (1 000 queries): one / two / three wavefronts per query, twice (box drift)
+for name, knobs in (("one wavefront", dict(coop=0)), ("two wavefronts", dict(coop=1)), ("three wavefronts", dict(coop=2)),
+                    ("two wavefronts, packed", dict(coop=1, coop_pack=1)), ("three wavefronts, packed", dict(coop=2, coop_pack=1)),
+                    ("one wavefront", dict(coop=0)), ("two wavefronts", dict(coop=1)), ("three wavefronts", dict(coop=2))):
+    for k, v in {**dict(coop=-1, coop_pack=0), **knobs}.items():
         ix.knob(k, v)
-    for ef in (200, 400):
+    for ef in (200, 400, 1000):
         for _ in range(5):
             r = ix.search(q, ef, want=())
         torch.cuda.synchronize()
@@ -26,4 +28,4 @@ for name, knobs in (("one wavefront", dict(coop=0)), ("coop, rows touched ahead"
         if ref is None or ef not in ref:
             ref = ref or {}
             ref[ef] = r["ids"].clone()
-        print("%-26s ef %4d: %s  %.4f ms  ids identical %s" % (name, ef, p["walk_kernel"].split(" (")[0][:34], p["walk_ms"] / p["calls"], bool((r["ids"] == ref[ef]).all())), flush=True)
+        print("%-26s ef %4d: %s  %.4f ms  ids identical %s" % (name, ef, p["walk_kernel"].split(" (")[0][:40], p["walk_ms"] / p["calls"], bool((r["ids"] == ref[ef]).all())), flush=True)
