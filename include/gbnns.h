@@ -265,7 +265,9 @@ int gbnns_profile_enable(gbnns_index* index, int on);
  * steer gbnns_exact_knn, which has no handle, and stay process-wide (gbnns_debug_knob only).
  * "coop": the two-wavefront walk for small batches (one query per workgroup of two wavefronts: one keeps the result lists, one
  * expands the predicted next node) -- -1 (default) where the shape has it and the batch leaves the room, 0 never,
- * 1 wherever the shape has it (GBNNS_COOP).
+ * 1 wherever the shape has it, 2 the same with three wavefronts per query (the expanding wavefront split in two: measured slower,
+ * kept for tests and A/B runs) (GBNNS_COOP).  "coop_pack": 1 launches that three-wavefront form with its own LDS only (default 0:
+ * a batch of at most c workgroups per CU asks for 1 / c of a CU's LDS each, which spreads them evenly; GBNNS_COOP_PACK).
  * "quotient": 0 keeps the walk_hot*
  * kernels' visited set in its packed form (default 1: the denser quotient form where it fits; initial value from the
  * environment variable GBNNS_QUOTIENT).  "vs_disp": probe number at which a probe sequence of the quotient form gives
