@@ -11,10 +11,17 @@ ix = ds.index()
 q = ds.queries
 ref = None
 # A/B of the small-batch walks on the gist shape (1 000 queries): one / two / three wavefronts per query, twice (box drift)
-for name, knobs in (("one wavefront", dict(coop=0)), ("two wavefronts", dict(coop=1)), ("three wavefronts", dict(coop=2)),
-                    ("two wavefronts, packed", dict(coop=1, coop_pack=1)), ("three wavefronts, packed", dict(coop=2, coop_pack=1)),
-                    ("one wavefront", dict(coop=0)), ("two wavefronts", dict(coop=1)), ("three wavefronts", dict(coop=2))):
-    for k, v in {**dict(coop=-1, coop_pack=0), **knobs}.items():
+VARIANTS = {
+    "waves": (("one wavefront", dict(coop=0)), ("two wavefronts", dict(coop=1)), ("three wavefronts", dict(coop=2)),
+              ("two wavefronts, packed", dict(coop=1, coop_pack=1)), ("three wavefronts, packed", dict(coop=2, coop_pack=1)),
+              ("one wavefront", dict(coop=0)), ("two wavefronts", dict(coop=1)), ("three wavefronts", dict(coop=2))),
+    # the visited set's share of LDS: at most `max_waves` wavefronts (workgroups) per CU are planned for, the table takes the rest
+    "table": (("two wavefronts", dict(coop=1)), ("two wavefronts, 8 per CU", dict(coop=1, max_waves=8)), ("two wavefronts, 4 per CU", dict(coop=1, max_waves=4)),
+              ("one wavefront", dict(coop=0)), ("one wavefront, 8 per CU", dict(coop=0, max_waves=8)), ("one wavefront, 4 per CU", dict(coop=0, max_waves=4)),
+              ("two wavefronts", dict(coop=1)), ("two wavefronts, 4 per CU", dict(coop=1, max_waves=4))),
+}
+for name, knobs in VARIANTS[os.environ.get("AB", "waves")]:
+    for k, v in {**dict(coop=-1, coop_pack=0, max_waves=0), **knobs}.items():
         ix.knob(k, v)
     for ef in (200, 400, 1000):
         for _ in range(5):
