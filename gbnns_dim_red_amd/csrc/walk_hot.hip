@@ -492,6 +492,9 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     const int lane = lane_id();
     const uint32_t slot = (uint32_t)lane >> 1, half = (uint32_t)lane & 1u;  // lane = 2 * adjacency slot + row half
     const int ef = p.ef;
+#ifdef GBNNS_LIFE_STAMPS   // diagnostic (EXTRA_DEFS=-DGBNNS_LIFE_STAMPS, tools/life_stamps.py): a wavefront's life in three parts, 100 MHz ticks
+    const unsigned long long life0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // R = 1 (QLDS): the query stays in LDS and hot_expand re-reads a lane's four pieces every hop -- 64 registers, 8 wavefronts
     // per SIMD; rows requested after the visited test.  R = 2: the query in registers, speculative row loads (rounds 1-3 layout).
     constexpr bool QLDS = R == 1 && GBNNS_HOT1_QLDS, SPEC = R == 1 ? SPEC1 : true;
@@ -555,6 +558,9 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
     uint32_t pf_node = kInvalidId, pf_val = kInvalidId;    // prefetch 1: the runner-up of the selection
     uint32_t pf2_node = kInvalidId, pf2_val = kInvalidId;  // prefetch 2: the closest new survivor (see below)
     uint32_t pf_valw = kInvalidId, pf2_valw = kInvalidId;  // WIDE: the rows' second halves
+#ifdef GBNNS_LIFE_STAMPS
+    const unsigned long long life1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     while (true) {
         // ---- next node: closest unexpanded entry (ties -> largest id), and the runner-up as prediction
@@ -736,11 +742,26 @@ __device__ __forceinline__ void walk_hot_one(const WalkParams& p, uint32_t qi, u
         }
         return;
     }
+#ifdef GBNNS_LIFE_STAMPS
+    const unsigned long long life2 = __builtin_amdgcn_s_memrealtime();
+#endif
     reg_write_results<R>(p, qi, L, size, hops, dist_calc, edges, lane);
     if (p.rr_db) {
         const int kept = size < p.k ? size : p.k;
         fused_rerank(p, qi, kept, smem, lane, [&](int rank) { return reg_id_at_rank<R>(L, rank); });
     }
+#ifdef GBNNS_LIFE_STAMPS
+    {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long life3 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && p.stamps) {
+            atomicAdd(p.stamps + 0, life1 - life0); atomicAdd(p.stamps + 1, life2 - life1); atomicAdd(p.stamps + 2, life3 - life2);
+            atomicAdd(p.stamps + 3, 1ull);
+            atomicMax(p.stamps + 4, life3 - life0);
+            atomicMax(p.stamps + 5, (1ull << 62) - life0); atomicMax(p.stamps + 6, life0); atomicMax(p.stamps + 7, life3);
+        }
+    }
+#endif
 }
 
 template <bool WIDE = false, int METRIC = 0>
